@@ -1,0 +1,112 @@
+/*
+ * sketchlib_oracle.h -- CPU restatement of bacpop/sketchlib.rust's pairwise
+ * distance path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product (sketchlib.rust_amd/, include/) never links, imports or executes
+ * anything under oracle/.
+ *
+ * Parity pin: the restatement is checked in tests/test_oracle_golden.py
+ * against the reference's own goldens (tests/test_results_correct/
+ * inverted_precluster{,_ani}.stdout, dists_knn_{ca,jaccard,ani}.stdout,
+ * dists_subset.stdout, sketchlib_output_true.txt) -- see DESIGN.md "Oracle".
+ *
+ * All file:line citations are relative to the reference tree
+ * (bacpop/sketchlib.rust v0.3.0).
+ */
+#ifndef SKETCHLIB_ORACLE_H
+#define SKETCHLIB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/sketch/mod.rs:34 */
+#define SKO_BBITS 14
+
+/* dist_type values shared by every driver below */
+#define SKO_COREACC 0 /* DistType::CoreAcc,  distance_matrix.rs:55-61 */
+#define SKO_JACCARD 1 /* DistType::Jaccard(k_idx, k, ani) */
+
+/* ---- jaccard.rs ---- */
+uint32_t sko_samebits(const uint64_t *s1, const uint64_t *s2, uint64_t sketchsize64);
+double sko_jaccard_from_samebits(uint32_t samebits, uint64_t sketchsize64, int has_c, double c1,
+                                 double c2, double completeness_cutoff);
+double sko_jaccard_index(const uint64_t *s1, const uint64_t *s2, uint64_t sketchsize64, int has_c,
+                         double c1, double c2, double completeness_cutoff);
+double sko_ani_pois(double jaccard, double k);
+double sko_completeness_correction(double jaccard, double c1, double c2);
+void sko_simple_linear_regression(double xsum, double ysum, double xysum, double xsquaresum,
+                                  double ysquaresum, double n, float *core, float *acc);
+
+/* A borrowed view of MultiSketch's flat bins (multisketch.rs:22-44,213-219):
+ * word index = sample*sample_stride + k_idx*kmer_stride + chunk*14 + plane,
+ * kmer_stride = sketchsize64*14, sample_stride = kmer_stride*nk. */
+typedef struct {
+    const uint64_t *bins;
+    size_t n_samples;
+    size_t nk;
+    const size_t *kmers;   /* k-mer lengths, ascending as stored in the .skm */
+    uint64_t sketchsize64; /* sketch_size/64 */
+    const double *completeness; /* NULL == Option::None */
+} sko_sketches;
+
+void sko_core_acc_dist(const sko_sketches *ref, const sko_sketches *query, size_t ref_idx,
+                       size_t query_idx, double completeness_cutoff, float *core, float *acc);
+
+/* ---- distance_matrix.rs:11-51 index helpers ---- */
+size_t sko_square_to_condensed(size_t i, size_t j, size_t n);
+size_t sko_calc_row_idx(size_t k, size_t n);
+size_t sko_calc_col_idx(size_t k, size_t i, size_t n);
+
+/* ---- distances/mod.rs drivers.  `threads` stands in for the rayon pool. ---- */
+
+/* mod.rs:58-130.  out: n(n-1)/2 * ncols floats (ncols = 2 CoreAcc, 1 Jaccard). */
+int sko_self_dists_all(const sko_sketches *s, int dist_type, size_t k_idx, int ani,
+                       double completeness_cutoff, int threads, float *out);
+/* mod.rs:227-297.  out: n*n_query*ncols floats, index (i_ref*n_query + j_query)*ncols. */
+int sko_cross_dists_all(const sko_sketches *ref, const sko_sketches *query, int dist_type,
+                        size_t k_idx, int ani, double completeness_cutoff, int threads,
+                        float *out);
+
+/* Sparse output item: SparseJaccard(idx, d0) / SparseCoreAcc(idx, d0, d1)
+ * (distance_matrix.rs:214,243). */
+typedef struct {
+    uint64_t idx;
+    float d0;
+    float d1;
+} sko_sparse;
+
+/* tie_mode: how equal keys are resolved.
+ *   SKO_TIES_RUST_HEAP  -- replay std::collections::BinaryHeap push/pop/
+ *                          into_sorted_vec exactly as mod.rs:41-48 drives it
+ *                          (what the reference binary prints);
+ *   SKO_TIES_CANONICAL  -- keep the knn smallest by (key, index) and emit them in
+ *                          that order.  This is the rule the GPU path implements;
+ *                          it yields the same distance multiset per row.  */
+#define SKO_TIES_RUST_HEAP 0
+#define SKO_TIES_CANONICAL 1
+
+/* mod.rs:133-224.  out: n*knn items, row-major (row i, neighbours ascending). */
+int sko_self_dists_knn(const sko_sketches *s, size_t knn, int dist_type, size_t k_idx, int ani,
+                       double completeness_cutoff, int tie_mode, int threads, sko_sparse *out);
+/* mod.rs:306-395.  Rows = queries, neighbours index refs.  knn is clamped to
+ * min(knn, n_ref) as in :325; returns the clamped knn (or <0 on error). */
+long sko_cross_dists_knn(const sko_sketches *ref, const sko_sketches *query, size_t knn,
+                         int dist_type, size_t k_idx, int ani, double completeness_cutoff,
+                         int tie_mode, int threads, sko_sparse *out);
+
+/* Raw bin-match counts (the value jaccard.rs:15-25 computes and only traces):
+ * self: out[cond(i,j)*nk + k]; cross: out[(i*nq + j)*nk + k]. */
+int sko_self_binmatch(const sko_sketches *s, int threads, uint32_t *out);
+int sko_cross_binmatch(const sko_sketches *ref, const sko_sketches *query, int threads,
+                       uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
