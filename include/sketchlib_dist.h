@@ -1,0 +1,164 @@
+/*
+ * sketchlib_dist.h -- C ABI of the MI355X (gfx950) pairwise-distance engine.
+ *
+ * This is the drop-in boundary for bacpop/sketchlib.rust's `distances` module:
+ * each entry point names the reference function it replaces (file:line relative
+ * to the reference tree, v0.3.0).  Signatures use plain pointers and sizes only,
+ * so the same library binds from Rust (`extern "C"`), C++
+ * (sketchlib.rust_amd/csrc/host) and Python ctypes (sketchlib.rust_amd/capi.py).
+ *
+ * Sketch bins cross the boundary in the reference's own layout -- the `.skd`
+ * byte order, MultiSketch::sketch_bins (src/sketch/multisketch.rs:36-40,
+ * 213-219): little-endian u64,
+ *     word(sample, k_idx, chunk, plane) =
+ *         sample*sample_stride + k_idx*kmer_stride + chunk*14 + plane
+ *     kmer_stride = sketchsize64*14 (BBITS, src/sketch/mod.rs:34),
+ *     sample_stride = kmer_stride*nk.
+ * Any device-side re-layout is internal to the library.
+ *
+ * Error handling: every function returns SKL_OK (0) or a positive SKL_ERR_*;
+ * skl_last_error() returns a thread-local message.  Where the reference
+ * panics (jaccard.rs:70-72, mod.rs:318-323) the ABI returns the matching code
+ * and the same message text.  There is no CPU fallback: without a usable GPU
+ * every compute entry point fails with SKL_ERR_NO_DEVICE.
+ */
+#ifndef SKETCHLIB_DIST_H
+#define SKETCHLIB_DIST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKL_ABI_VERSION 1
+
+/* ---- status codes ---- */
+#define SKL_OK 0
+#define SKL_ERR_INVALID_ARG 1
+#define SKL_ERR_NO_DEVICE 2   /* no HIP device / wrong architecture */
+#define SKL_ERR_HIP 3         /* a HIP runtime call failed */
+#define SKL_ERR_OOM 4
+#define SKL_ERR_KMER_COUNT 5  /* "Need at least two k-mer lengths ..." jaccard.rs:70-72 */
+#define SKL_ERR_EMPTY_DB 6    /* "... database has no loaded samples" mod.rs:318-323 */
+#define SKL_ERR_KMER_NOT_FOUND 7 /* "K-mer size {k} not found in file" mod.rs:28-30 */
+#define SKL_ERR_INCOMPATIBLE 8   /* ref/query differ in k-mers or sketch size */
+
+/* DistType (src/distances/distance_matrix.rs:55-61) */
+#define SKL_DIST_COREACC 0
+#define SKL_DIST_JACCARD 1
+
+typedef struct skl_ctx skl_ctx;           /* one per (host thread, device) */
+typedef struct skl_sketches skl_sketches; /* device-resident MultiSketch bins */
+
+/* Parameters shared by all distance calls.  Mirrors DistType::Jaccard(k_idx, k,
+ * ani) / DistType::CoreAcc plus the completeness_cutoff argument every driver in
+ * src/distances/mod.rs takes. */
+typedef struct {
+    int32_t dist_type;           /* SKL_DIST_COREACC | SKL_DIST_JACCARD */
+    int32_t ani;                 /* Jaccard only: report ANI (jaccard.rs:49-51) */
+    uint64_t k_idx;              /* Jaccard only: index into the k-mer list */
+    double completeness_cutoff;  /* cli.rs:229 default 0.64 */
+} skl_dist_params;
+
+const char *skl_last_error(void);
+int skl_abi_version(void);
+/* Number of visible gfx950 devices (0 if none; never fails). */
+int skl_device_count(void);
+
+/* ---- context ---- */
+int skl_ctx_create(int device, skl_ctx **out);
+int skl_ctx_destroy(skl_ctx *ctx);
+/* Run all subsequent work of this context on a caller-owned hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream).  NULL restores the context's
+ * own stream. */
+int skl_ctx_set_stream(skl_ctx *ctx, void *hip_stream);
+int skl_ctx_synchronize(skl_ctx *ctx);
+/* Pair-kernel timing.  Every dense / binmatch / knn call brackets each launch of the
+ * pair kernel with HIP events recorded on the context's stream.  reset() forgets them;
+ * kernel_ms() synchronises and returns the summed device time and the number of
+ * launches recorded since the last reset (at most 4096 are kept). */
+int skl_ctx_timing_reset(skl_ctx *ctx);
+int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches);
+
+/* ---- sketch slabs: MultiSketch::read_sketch_data / get_sketch_slice
+ *      (src/sketch/multisketch.rs:167-219) ---- */
+/* bins: n_samples*nk*sketchsize64*14 u64 in the reference layout.  `on_device`
+ * != 0 means `bins` is already a device pointer on the context's device. */
+int skl_sketches_create(skl_ctx *ctx, const uint64_t *bins, int on_device, size_t n_samples,
+                        size_t nk, const size_t *kmers, size_t sketchsize64, skl_sketches **out);
+/* Option<&Vec<f64>> completeness vector (src/io.rs:240-324); NULL == None. */
+int skl_sketches_set_completeness(skl_sketches *s, const double *completeness_host);
+int skl_sketches_destroy(skl_sketches *s);
+size_t skl_sketches_n_samples(const skl_sketches *s);
+
+/* set_k (src/distances/mod.rs:25-37): kmer == 0 means Option::None -> CoreAcc. */
+int skl_set_k(const skl_sketches *s, size_t kmer, int ani, double completeness_cutoff,
+              skl_dist_params *out);
+
+/* ---- dense distances ----
+ * `out_on_device` != 0: `out` is a device pointer and the call only enqueues work
+ * on the context's stream; == 0: `out` is host memory and the call returns after
+ * the copy back. */
+
+/* self_dists_all (src/distances/mod.rs:58-130).  out: n(n-1)/2 * ncols f32,
+ * condensed upper triangle, ncols = 2 (core, acc interleaved) or 1. */
+int skl_self_dists_all(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, float *out,
+                       int out_on_device);
+/* Rows [row_begin, row_end) of the same condensed matrix -- the slice
+ * [square_to_condensed(row_begin,row_begin+1), square_to_condensed(row_end,row_end+1))
+ * -- written to out[0..]; the multi-GPU pair-block partition. */
+int skl_self_dists_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                        size_t row_begin, size_t row_end, float *out, int out_on_device);
+/* cross_dists_all (src/distances/mod.rs:227-297).  out: n_ref*n_query*ncols,
+ * index (i_ref*n_query + j_query)*ncols. */
+int skl_cross_dists_all(skl_ctx *ctx, const skl_sketches *ref, const skl_sketches *query,
+                        const skl_dist_params *p, float *out, int out_on_device);
+/* Reference rows [ref_begin, ref_end) of the same matrix. */
+int skl_cross_dists_rows(skl_ctx *ctx, const skl_sketches *ref, const skl_sketches *query,
+                         const skl_dist_params *p, size_t ref_begin, size_t ref_end, float *out,
+                         int out_on_device);
+
+/* ---- sparse k-nearest-neighbour distances ----
+ * Output rows hold `knn` items sorted ascending by (key, neighbour index) where
+ * key = d0 for Jaccard / core for CoreAcc, or 1-ANI for ANI (mod.rs:173-176);
+ * ties resolve to the lowest neighbour index.  out_d1 is written for CoreAcc only
+ * and may be NULL otherwise. */
+
+/* self_dists_knn (src/distances/mod.rs:133-224); requires 1 <= knn < n. */
+int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                       uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device);
+int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                            size_t knn, size_t row_begin, size_t row_end, uint64_t *out_idx,
+                            float *out_d0, float *out_d1, int out_on_device);
+/* cross_dists_knn (src/distances/mod.rs:306-395): rows = queries, neighbours
+ * index refs; knn must already be clamped to <= n_ref (mod.rs:325). */
+int skl_cross_dists_knn(skl_ctx *ctx, const skl_sketches *ref, const skl_sketches *query,
+                        const skl_dist_params *p, size_t knn, uint64_t *out_idx, float *out_d0,
+                        float *out_d1, int out_on_device);
+int skl_cross_dists_knn_rows(skl_ctx *ctx, const skl_sketches *ref, const skl_sketches *query,
+                             const skl_dist_params *p, size_t knn, size_t query_begin,
+                             size_t query_end, uint64_t *out_idx, float *out_d0, float *out_d1,
+                             int out_on_device);
+
+/* ---- raw bin-match counts (`samebits`, src/distances/jaccard.rs:15-25) ----
+ * self: out[cond(i,j)*nk + k]; cross: out[(i_ref*n_query + j_query)*nk + k]. */
+int skl_self_binmatch(skl_ctx *ctx, const skl_sketches *s, uint32_t *out, int out_on_device);
+int skl_cross_binmatch(skl_ctx *ctx, const skl_sketches *ref, const skl_sketches *query,
+                       uint32_t *out, int out_on_device);
+
+/* ---- one-shot forms: host pointers in, host pointers out; the argument lists
+ *      of distances::self_dists_all / cross_dists_all flattened ---- */
+int skl_self_dists_all_host(const uint64_t *bins, size_t n_samples, size_t nk,
+                            const size_t *kmers, size_t sketchsize64,
+                            const skl_dist_params *p, const double *completeness, float *out);
+int skl_cross_dists_all_host(const uint64_t *ref_bins, size_t n_ref, const uint64_t *query_bins,
+                             size_t n_query, size_t nk, const size_t *kmers, size_t sketchsize64,
+                             const skl_dist_params *p, const double *ref_completeness,
+                             const double *query_completeness, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKETCHLIB_DIST_H */

@@ -1,0 +1,321 @@
+"""ctypes binding of include/sketchlib_dist.h.
+
+Used by tests/ and bench.py (and as the model for any other FFI: the Rust binding in
+INTEGRATION.md is the same call sequence).  Host buffers are numpy arrays; device
+buffers are anything with a `data_ptr()` (torch tensors).  Loading fails loudly when
+the in-tree HIP library is missing -- there is no fallback implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import library_path
+
+COREACC = 0
+JACCARD = 1
+
+OK = 0
+ERR_INVALID_ARG = 1
+ERR_NO_DEVICE = 2
+ERR_HIP = 3
+ERR_OOM = 4
+ERR_KMER_COUNT = 5
+ERR_EMPTY_DB = 6
+ERR_KMER_NOT_FOUND = 7
+ERR_INCOMPATIBLE = 8
+
+
+class SklError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[skl error {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class DistParams(C.Structure):
+    _fields_ = [
+        ("dist_type", C.c_int32),
+        ("ani", C.c_int32),
+        ("k_idx", C.c_uint64),
+        ("completeness_cutoff", C.c_double),
+    ]
+
+
+# every symbol include/sketchlib_dist.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIG = [
+    ("skl_last_error", C.c_char_p, []),
+    ("skl_abi_version", C.c_int, []),
+    ("skl_device_count", C.c_int, []),
+    ("skl_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("skl_ctx_destroy", C.c_int, [_P]),
+    ("skl_ctx_set_stream", C.c_int, [_P, _P]),
+    ("skl_ctx_synchronize", C.c_int, [_P]),
+    ("skl_ctx_timing_reset", C.c_int, [_P]),
+    ("skl_ctx_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    ("skl_sketches_create", C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_size_t, _P, C.c_size_t,
+                                      C.POINTER(_P)]),
+    ("skl_sketches_set_completeness", C.c_int, [_P, _P]),
+    ("skl_sketches_destroy", C.c_int, [_P]),
+    ("skl_sketches_n_samples", C.c_size_t, [_P]),
+    ("skl_set_k", C.c_int, [_P, C.c_size_t, C.c_int, C.c_double, C.POINTER(DistParams)]),
+    ("skl_self_dists_all", C.c_int, [_P, _P, C.POINTER(DistParams), _P, C.c_int]),
+    ("skl_self_dists_rows", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, C.c_size_t, _P,
+                                      C.c_int]),
+    ("skl_cross_dists_all", C.c_int, [_P, _P, _P, C.POINTER(DistParams), _P, C.c_int]),
+    ("skl_cross_dists_rows", C.c_int, [_P, _P, _P, C.POINTER(DistParams), C.c_size_t, C.c_size_t,
+                                       _P, C.c_int]),
+    ("skl_self_dists_knn", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, _P, _P, _P,
+                                     C.c_int]),
+    ("skl_self_dists_knn_rows", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, C.c_size_t,
+                                          C.c_size_t, _P, _P, _P, C.c_int]),
+    ("skl_cross_dists_knn", C.c_int, [_P, _P, _P, C.POINTER(DistParams), C.c_size_t, _P, _P, _P,
+                                      C.c_int]),
+    ("skl_cross_dists_knn_rows", C.c_int, [_P, _P, _P, C.POINTER(DistParams), C.c_size_t,
+                                           C.c_size_t, C.c_size_t, _P, _P, _P, C.c_int]),
+    ("skl_self_binmatch", C.c_int, [_P, _P, _P, C.c_int]),
+    ("skl_cross_binmatch", C.c_int, [_P, _P, _P, _P, C.c_int]),
+    ("skl_self_dists_all_host", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, C.c_size_t,
+                                          C.POINTER(DistParams), _P, _P]),
+    ("skl_cross_dists_all_host", C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, _P,
+                                           C.c_size_t, C.POINTER(DistParams), _P, _P, _P]),
+]
+DECLARED_SYMBOLS = [s[0] for s in _SIG]
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C sketchlib.rust_amd/csrc`).  There is no CPU fallback."
+            )
+        L = C.CDLL(path)
+        for name, restype, argtypes in _SIG:
+            fn = getattr(L, name)  # AttributeError if the export is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise SklError(rc, load().skl_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(buf):
+    """(address, on_device) of a numpy array or a device tensor."""
+    if buf is None:
+        return None, 0
+    if isinstance(buf, np.ndarray):
+        return buf.ctypes.data, 0
+    if hasattr(buf, "data_ptr"):
+        return buf.data_ptr(), 1 if buf.is_cuda else 0
+    raise TypeError(f"unsupported buffer type {type(buf)}")
+
+
+def device_count():
+    return load().skl_device_count()
+
+
+class Context:
+    """skl_ctx: one per (thread, device)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = _P()
+        _check(load().skl_ctx_create(device, C.byref(self._h)))
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        """stream: integer hipStream_t handle (torch.cuda.current_stream().cuda_stream) or None."""
+        _check(load().skl_ctx_set_stream(self._h, _P(stream) if stream else None))
+
+    def synchronize(self):
+        _check(load().skl_ctx_synchronize(self._h))
+
+    def timing_reset(self):
+        _check(load().skl_ctx_timing_reset(self._h))
+
+    def kernel_ms(self):
+        """(summed pair-kernel device ms, launches) since the last timing_reset()."""
+        ms = C.c_float()
+        n = C.c_int()
+        _check(load().skl_ctx_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            load().skl_ctx_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- slabs ----
+    def sketches(self, bins, n, kmers, sketchsize64, completeness=None):
+        return Sketches(self, bins, n, kmers, sketchsize64, completeness)
+
+
+class Sketches:
+    """skl_sketches: a MultiSketch's bins resident on the device."""
+
+    def __init__(self, ctx, bins, n, kmers, sketchsize64, completeness=None):
+        self.ctx = ctx
+        self.n = int(n)
+        self.kmers = np.ascontiguousarray(kmers, dtype=np.uintp)
+        self.nk = len(self.kmers)
+        self.ss64 = int(sketchsize64)
+        if isinstance(bins, np.ndarray):
+            bins = np.ascontiguousarray(bins, dtype="<u8").reshape(-1)
+            assert bins.size == self.n * self.nk * self.ss64 * 14, "bins size mismatch"
+        addr, on_dev = _ptr(bins)
+        self._h = _P()
+        _check(load().skl_sketches_create(ctx._h, addr, on_dev, self.n, self.nk,
+                                          self.kmers.ctypes.data, self.ss64, C.byref(self._h)))
+        if completeness is not None:
+            self.set_completeness(completeness)
+
+    def set_completeness(self, completeness):
+        if completeness is None:
+            _check(load().skl_sketches_set_completeness(self._h, None))
+            return
+        comp = np.ascontiguousarray(completeness, dtype=np.float64)
+        assert comp.size == self.n
+        _check(load().skl_sketches_set_completeness(self._h, comp.ctypes.data))
+
+    def set_k(self, kmer=None, ani=False, cutoff=0.64):
+        """distances::set_k (mod.rs:25-37)."""
+        p = DistParams()
+        _check(load().skl_set_k(self._h, 0 if kmer is None else int(kmer), int(ani), cutoff,
+                                C.byref(p)))
+        return p
+
+    def close(self):
+        if self._h:
+            load().skl_sketches_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def params(dist_type=COREACC, k_idx=0, ani=False, cutoff=0.64):
+    return DistParams(dist_type, int(ani), k_idx, cutoff)
+
+
+def ncols(p):
+    return 2 if p.dist_type == COREACC else 1
+
+
+def self_pairs(n, r0=0, r1=None):
+    r1 = n if r1 is None else r1
+    r1 = min(r1, max(n - 1, 0))
+    if r1 <= r0:
+        return 0
+    upto = lambda r: r * n - r * (r + 1) // 2  # noqa: E731
+    return upto(r1) - upto(r0)
+
+
+# ---- dense ----
+
+def self_dists_all(ctx, s, p, out=None):
+    """distances::self_dists_all (mod.rs:58-130) -> [n(n-1)/2, ncols] f32."""
+    n_pairs = self_pairs(s.n)
+    if out is None:
+        out = np.zeros((n_pairs, ncols(p)), dtype=np.float32)
+    addr, dev = _ptr(out)
+    _check(load().skl_self_dists_all(ctx._h, s._h, C.byref(p), addr, dev))
+    return out
+
+
+def self_dists_rows(ctx, s, p, r0, r1, out=None):
+    if out is None:
+        out = np.zeros((self_pairs(s.n, r0, r1), ncols(p)), dtype=np.float32)
+    addr, dev = _ptr(out)
+    _check(load().skl_self_dists_rows(ctx._h, s._h, C.byref(p), r0, r1, addr, dev))
+    return out
+
+
+def cross_dists_all(ctx, r, q, p, out=None):
+    """distances::cross_dists_all (mod.rs:227-297) -> [n_ref, n_query, ncols] f32."""
+    if out is None:
+        out = np.zeros((r.n, q.n, ncols(p)), dtype=np.float32)
+    addr, dev = _ptr(out)
+    _check(load().skl_cross_dists_all(ctx._h, r._h, q._h, C.byref(p), addr, dev))
+    return out
+
+
+def cross_dists_rows(ctx, r, q, p, r0, r1, out=None):
+    if out is None:
+        out = np.zeros((r1 - r0, q.n, ncols(p)), dtype=np.float32)
+    addr, dev = _ptr(out)
+    _check(load().skl_cross_dists_rows(ctx._h, r._h, q._h, C.byref(p), r0, r1, addr, dev))
+    return out
+
+
+# ---- sparse ----
+
+def _knn_out(rows, knn):
+    return (np.zeros((rows, knn), dtype=np.uint64), np.zeros((rows, knn), dtype=np.float32),
+            np.zeros((rows, knn), dtype=np.float32))
+
+
+def self_dists_knn(ctx, s, p, knn, r0=0, r1=None):
+    """distances::self_dists_knn (mod.rs:133-224) -> (idx, d0, d1) each [rows, knn]."""
+    r1 = s.n if r1 is None else r1
+    idx, d0, d1 = _knn_out(r1 - r0, knn)
+    _check(load().skl_self_dists_knn_rows(ctx._h, s._h, C.byref(p), knn, r0, r1, idx.ctypes.data,
+                                          d0.ctypes.data, d1.ctypes.data, 0))
+    return idx, d0, d1
+
+
+def cross_dists_knn(ctx, r, q, p, knn, q0=0, q1=None):
+    """distances::cross_dists_knn (mod.rs:306-395); rows = queries, idx into refs."""
+    q1 = q.n if q1 is None else q1
+    idx, d0, d1 = _knn_out(q1 - q0, knn)
+    _check(load().skl_cross_dists_knn_rows(ctx._h, r._h, q._h, C.byref(p), knn, q0, q1,
+                                           idx.ctypes.data, d0.ctypes.data, d1.ctypes.data, 0))
+    return idx, d0, d1
+
+
+# ---- raw counts ----
+
+def self_binmatch(ctx, s):
+    out = np.zeros((self_pairs(s.n), s.nk), dtype=np.uint32)
+    _check(load().skl_self_binmatch(ctx._h, s._h, out.ctypes.data, 0))
+    return out
+
+
+def cross_binmatch(ctx, r, q):
+    out = np.zeros((r.n, q.n, r.nk), dtype=np.uint32)
+    _check(load().skl_cross_binmatch(ctx._h, r._h, q._h, out.ctypes.data, 0))
+    return out
+
+
+# ---- one-shot host forms ----
+
+def self_dists_all_host(bins, n, kmers, sketchsize64, p, completeness=None):
+    bins = np.ascontiguousarray(bins, dtype="<u8").reshape(-1)
+    kmers = np.ascontiguousarray(kmers, dtype=np.uintp)
+    out = np.zeros((self_pairs(n), ncols(p)), dtype=np.float32)
+    comp = None if completeness is None else np.ascontiguousarray(completeness, dtype=np.float64)
+    _check(load().skl_self_dists_all_host(bins.ctypes.data, n, len(kmers), kmers.ctypes.data,
+                                          sketchsize64, C.byref(p),
+                                          None if comp is None else comp.ctypes.data,
+                                          out.ctypes.data))
+    return out

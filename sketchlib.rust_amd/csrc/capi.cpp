@@ -1,0 +1,848 @@
+// capi.cpp -- implementation of include/sketchlib_dist.h on top of kernels.hip.
+//
+// Host-side responsibilities: device slabs (the MultiSketch bins in the two layouts
+// the pair kernel wants), the samebits -> ln(J) / distance tables (computed with the
+// host libm, i.e. bit-identical to what the reference's f64::ln produces on this
+// machine), banding of large pair spaces through bounded scratch, and mapping the
+// reference's panics to status codes.
+//
+// There is deliberately no CPU compute path here: if HIP cannot run, calls fail.
+#include "../../include/sketchlib_dist.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace skl;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? SKL_ERR_OOM : SKL_ERR_HIP, "%s: %s",   \
+                        #expr, hipGetErrorString(e_));                                     \
+        }                                                                                  \
+    } while (0)
+
+#define SKL_TRY(expr)             \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != SKL_OK) return rc_; \
+    } while (0)
+
+extern "C" const char *skl_last_error(void) { return g_last_error.c_str(); }
+extern "C" int skl_abi_version(void) { return SKL_ABI_VERSION; }
+
+static bool is_gfx950(int dev)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int skl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) ok += is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+
+struct skl_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // grow-only scratch: 0 = dense band, 1 = bin-match counts (unfused core/acc),
+    // 2 = kNN result staging
+    void *scratch[3] = {nullptr, nullptr, nullptr};
+    size_t scratch_bytes[3] = {0, 0, 0};
+    // timing of pair-kernel launches of the last call
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+};
+
+static int ctx_bind(skl_ctx *ctx)
+{
+    if (!ctx) return fail(SKL_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return SKL_OK;
+}
+
+static int ctx_scratch(skl_ctx *ctx, size_t bytes, void **out, int which = 0)
+{
+    void *&buf = ctx->scratch[which];
+    size_t &cap = ctx->scratch_bytes[which];
+    if (bytes > cap) {
+        if (buf) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(buf));
+            buf = nullptr;
+            cap = 0;
+        }
+        HIP_TRY(hipMalloc(&buf, bytes));
+        cap = bytes;
+    }
+    *out = buf;
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_create(int device, skl_ctx **out)
+{
+    if (!out) return fail(SKL_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        return fail(SKL_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
+    }
+    if (device < 0 || device >= n) {
+        return fail(SKL_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    }
+    if (!is_gfx950(device)) {
+        return fail(SKL_ERR_NO_DEVICE, "device %d is not gfx950 (MI355X); kernels are built for gfx950 only",
+                    device);
+    }
+    HIP_TRY(hipSetDevice(device));
+    skl_ctx *ctx = new skl_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(SKL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_destroy(skl_ctx *ctx)
+{
+    if (!ctx) return SKL_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    for (void *buf : ctx->scratch) {
+        if (buf) (void)hipFree(buf);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_set_stream(skl_ctx *ctx, void *hip_stream)
+{
+    SKL_TRY(ctx_bind(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_synchronize(skl_ctx *ctx)
+{
+    SKL_TRY(ctx_bind(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_timing_reset(skl_ctx *ctx)
+{
+    SKL_TRY(ctx_bind(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->events_used = 0;
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!total_ms) return fail(SKL_ERR_INVALID_ARG, "total_ms is null");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float total = 0.f;
+    for (size_t i = 0; i < ctx->events_used; ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ctx->events[i].first, ctx->events[i].second));
+        total += t;
+    }
+    *total_ms = total;
+    if (n_launches) *n_launches = (int)ctx->events_used;
+    return SKL_OK;
+}
+
+// Launch the pair kernel bracketed by HIP events on the context's stream.
+static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int na)
+{
+    constexpr size_t MAX_EVENTS = 4096;
+    if (ctx->events_used >= MAX_EVENTS) {
+        HIP_TRY(launch_pair_kernel(args, mode, na, ctx->stream));
+        return SKL_OK;
+    }
+    if (ctx->events_used == ctx->events.size()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        ctx->events.emplace_back(a, b);
+    }
+    auto &ev = ctx->events[ctx->events_used++];
+    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+    HIP_TRY(launch_pair_kernel(args, mode, na, ctx->stream));
+    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    return SKL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sketch slabs
+// ---------------------------------------------------------------------------
+
+struct skl_sketches {
+    skl_ctx *ctx = nullptr;
+    size_t n = 0, nk = 0, ss64 = 0;
+    std::vector<size_t> kmers;
+    uint64_t *d_rows = nullptr;  // reference layout + A_PAD_ROWS zero rows (scalar operand)
+    uint4 *d_lanes = nullptr;    // lane-interleaved layout (vector operand), built on demand
+    double *d_comp = nullptr;    // completeness or null
+    double *d_ytab = nullptr;    // ln J table [64*ss64+1]
+    double *d_kf = nullptr;      // k-mer lengths as f64 [nk]
+    std::map<std::pair<int, size_t>, float *> d_dtab;  // (jout, k_idx) -> f32 table
+    size_t sample_words() const { return nk * ss64 * BBITS; }
+};
+
+// jaccard.rs:14,26-33 with no completeness: J as a function of samebits alone.
+static double host_jaccard(uint32_t samebits, size_t ss64)
+{
+    const double unionsize = (double)(64u * ss64);
+    const uint32_t maxnbits = (uint32_t)ss64 * 64u;
+    const uint32_t expected = maxnbits >> BBITS;
+    const uint32_t diff = samebits > expected ? samebits - expected : 0u;
+    const double intersize = ((double)diff * (double)maxnbits) / (double)(maxnbits - expected);
+    return intersize / unionsize;
+}
+
+static int ensure_lanes(const skl_sketches *cs)
+{
+    skl_sketches *s = const_cast<skl_sketches *>(cs);
+    if (s->d_lanes || s->n == 0) return SKL_OK;
+    const size_t n_jb = (s->n + 63) / 64;
+    const size_t bytes = n_jb * s->nk * s->ss64 * 7 * 64 * sizeof(uint4);
+    HIP_TRY(hipMalloc((void **)&s->d_lanes, bytes));
+    HIP_TRY(launch_relayout(s->d_rows, s->d_lanes, (uint32_t)s->n, (uint32_t)s->nk,
+                            (uint32_t)s->ss64, s->ctx->stream));
+    return SKL_OK;
+}
+
+static int ensure_ytab(const skl_sketches *cs)
+{
+    skl_sketches *s = const_cast<skl_sketches *>(cs);
+    if (s->d_ytab) return SKL_OK;
+    const size_t m = 64 * s->ss64 + 1;
+    std::vector<double> tab(m);
+    for (size_t b = 0; b < m; ++b) tab[b] = std::log(host_jaccard((uint32_t)b, s->ss64));
+    HIP_TRY(hipMalloc((void **)&s->d_ytab, m * sizeof(double)));
+    HIP_TRY(hipMemcpy(s->d_ytab, tab.data(), m * sizeof(double), hipMemcpyHostToDevice));
+    return SKL_OK;
+}
+
+static int ensure_dtab(const skl_sketches *cs, int jout, size_t k_idx, float **out)
+{
+    skl_sketches *s = const_cast<skl_sketches *>(cs);
+    const size_t key_k = jout == JOUT_DIST ? 0 : k_idx;
+    auto it = s->d_dtab.find({jout, key_k});
+    if (it != s->d_dtab.end()) {
+        *out = it->second;
+        return SKL_OK;
+    }
+    const size_t m = 64 * s->ss64 + 1;
+    const double k = (double)s->kmers[k_idx];
+    std::vector<float> tab(m);
+    for (size_t b = 0; b < m; ++b) {
+        const double j = host_jaccard((uint32_t)b, s->ss64);
+        if (jout == JOUT_DIST) {
+            tab[b] = (float)(1.0 - j);  // mod.rs:99
+        } else {
+            // jaccard.rs:49-51
+            const double ani = std::fmax(0.0, 1.0 + 1.0 / k * std::log((2.0 * j) / (1.0 + j)));
+            tab[b] = jout == JOUT_ANI ? (float)ani : (float)(1.0 - ani);  // mod.rs:97 / :173-176
+        }
+    }
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, m * sizeof(float)));
+    HIP_TRY(hipMemcpy(d, tab.data(), m * sizeof(float), hipMemcpyHostToDevice));
+    s->d_dtab[{jout, key_k}] = d;
+    *out = d;
+    return SKL_OK;
+}
+
+extern "C" int skl_sketches_create(skl_ctx *ctx, const uint64_t *bins, int on_device,
+                                   size_t n_samples, size_t nk, const size_t *kmers,
+                                   size_t sketchsize64, skl_sketches **out)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!out) return fail(SKL_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (nk == 0 || sketchsize64 == 0 || !kmers) {
+        return fail(SKL_ERR_INVALID_ARG, "need at least one k-mer length and a non-zero sketch size");
+    }
+    if (n_samples && !bins) return fail(SKL_ERR_INVALID_ARG, "bins is null");
+    if (n_samples >= (1ull << 31) || sketchsize64 >= (1ull << 25) || nk >= (1ull << 16)) {
+        return fail(SKL_ERR_INVALID_ARG, "dimensions out of range");
+    }
+    skl_sketches *s = new skl_sketches();
+    s->ctx = ctx;
+    s->n = n_samples;
+    s->nk = nk;
+    s->ss64 = sketchsize64;
+    s->kmers.assign(kmers, kmers + nk);
+    const size_t words = s->sample_words();
+    const size_t total = (n_samples + A_PAD_ROWS) * words;
+    hipError_t e = hipMalloc((void **)&s->d_rows, total * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        delete s;
+        return fail(e == hipErrorOutOfMemory ? SKL_ERR_OOM : SKL_ERR_HIP, "hipMalloc(slab %zu B): %s",
+                    total * sizeof(uint64_t), hipGetErrorString(e));
+    }
+    int rc = SKL_OK;
+    do {
+        e = hipMemsetAsync(s->d_rows + n_samples * words, 0, A_PAD_ROWS * words * sizeof(uint64_t),
+                           ctx->stream);
+        if (e != hipSuccess) break;
+        if (n_samples) {
+            e = hipMemcpyAsync(s->d_rows, bins, n_samples * words * sizeof(uint64_t),
+                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               ctx->stream);
+            if (e != hipSuccess) break;
+        }
+        std::vector<double> kf(nk);
+        for (size_t i = 0; i < nk; ++i) kf[i] = (double)kmers[i];
+        e = hipMalloc((void **)&s->d_kf, nk * sizeof(double));
+        if (e != hipSuccess) break;
+        e = hipMemcpy(s->d_kf, kf.data(), nk * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (e != hipSuccess) {
+        rc = fail(SKL_ERR_HIP, "slab upload: %s", hipGetErrorString(e));
+        skl_sketches_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return SKL_OK;
+}
+
+extern "C" int skl_sketches_set_completeness(skl_sketches *s, const double *comp)
+{
+    if (!s) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    SKL_TRY(ctx_bind(s->ctx));
+    if (!comp) {
+        if (s->d_comp) {
+            HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+            HIP_TRY(hipFree(s->d_comp));
+            s->d_comp = nullptr;
+        }
+        return SKL_OK;
+    }
+    if (!s->d_comp) {
+        HIP_TRY(hipMalloc((void **)&s->d_comp, (s->n + A_PAD_ROWS + 64) * sizeof(double)));
+        HIP_TRY(hipMemset(s->d_comp, 0, (s->n + A_PAD_ROWS + 64) * sizeof(double)));
+    }
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    HIP_TRY(hipMemcpy(s->d_comp, comp, s->n * sizeof(double), hipMemcpyHostToDevice));
+    return SKL_OK;
+}
+
+extern "C" int skl_sketches_destroy(skl_sketches *s)
+{
+    if (!s) return SKL_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->d_lanes) (void)hipFree(s->d_lanes);
+    if (s->d_comp) (void)hipFree(s->d_comp);
+    if (s->d_ytab) (void)hipFree(s->d_ytab);
+    if (s->d_kf) (void)hipFree(s->d_kf);
+    for (auto &kv : s->d_dtab) (void)hipFree(kv.second);
+    delete s;
+    return SKL_OK;
+}
+
+extern "C" size_t skl_sketches_n_samples(const skl_sketches *s) { return s ? s->n : 0; }
+
+// mod.rs:25-37
+extern "C" int skl_set_k(const skl_sketches *s, size_t kmer, int ani, double cutoff,
+                         skl_dist_params *out)
+{
+    if (!s || !out) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    out->completeness_cutoff = cutoff;
+    out->k_idx = 0;
+    out->ani = 0;
+    if (kmer == 0) {
+        out->dist_type = SKL_DIST_COREACC;
+        return SKL_OK;
+    }
+    for (size_t i = 0; i < s->nk; ++i) {
+        if (s->kmers[i] == kmer) {
+            out->dist_type = SKL_DIST_JACCARD;
+            out->k_idx = i;
+            out->ani = ani ? 1 : 0;
+            return SKL_OK;
+        }
+    }
+    return fail(SKL_ERR_KMER_NOT_FOUND, "K-mer size %zu not found in file", kmer);
+}
+
+// ---------------------------------------------------------------------------
+// shared launch preparation
+// ---------------------------------------------------------------------------
+
+static int check_params(const skl_sketches *a, const skl_sketches *b, const skl_dist_params *p)
+{
+    if (!a || !b || !p) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (a->ctx != b->ctx) return fail(SKL_ERR_INVALID_ARG, "sketches belong to different contexts");
+    if (a->nk != b->nk || a->ss64 != b->ss64 || a->kmers != b->kmers) {
+        // MultiSketch::is_compatible_with, multisketch.rs:222-226
+        return fail(SKL_ERR_INCOMPATIBLE, "reference and query sketches are not compatible (k-mer lengths / sketch size differ)");
+    }
+    if (p->dist_type == SKL_DIST_COREACC) {
+        if (a->nk < 2) {
+            return fail(SKL_ERR_KMER_COUNT,
+                        "Need at least two k-mer lengths to calculate core/accessory distances");
+        }
+    } else if (p->dist_type == SKL_DIST_JACCARD) {
+        if (p->k_idx >= a->nk) return fail(SKL_ERR_INVALID_ARG, "k_idx %llu out of range", (unsigned long long)p->k_idx);
+    } else {
+        return fail(SKL_ERR_INVALID_ARG, "unknown dist_type %d", p->dist_type);
+    }
+    return SKL_OK;
+}
+
+static bool fused_coreacc_ok(const skl_sketches *s)
+{
+    return s->nk <= (size_t)MAX_FUSED_K && 64 * s->ss64 <= 0xFFFFu;
+}
+
+// Fill the operand / epilogue fields common to every launch.  `rows` is the scalar
+// operand (A), `cols` the lane operand (B).
+static int fill_args(const skl_sketches *rows, const skl_sketches *cols, const skl_dist_params *p,
+                     int mode, int jout, PairArgs *g)
+{
+    memset(g, 0, sizeof *g);
+    SKL_TRY(ensure_lanes(cols));
+    g->A = rows->d_rows;
+    g->B = cols->d_lanes;
+    g->nA = (uint32_t)rows->n;
+    g->nB = (uint32_t)cols->n;
+    g->nk = (uint32_t)rows->nk;
+    g->ss64 = (uint32_t)rows->ss64;
+    g->has_comp = (rows->d_comp && cols->d_comp) ? 1 : 0;  // both Some, jaccard.rs:36
+    g->compA = rows->d_comp;
+    g->compB = cols->d_comp;
+    g->cutoff = p ? p->completeness_cutoff : 0.0;
+    g->tolerance = std::log(2.0 / (double)((rows->ss64 * 64ull) * 64ull));  // jaccard.rs:75
+    g->jout = jout;
+    if (mode == MODE_COUNTS) {
+        g->k_begin = 0;
+        g->k_count = (uint32_t)rows->nk;
+    } else if (mode == MODE_JACCARD) {
+        g->k_begin = (uint32_t)p->k_idx;
+        g->k_count = 1;
+        g->kf[0] = (double)rows->kmers[p->k_idx];
+        if (!g->has_comp) {
+            float *d = nullptr;
+            SKL_TRY(ensure_dtab(rows, jout, p->k_idx, &d));
+            g->dtab = d;
+        }
+    } else {
+        g->k_begin = 0;
+        g->k_count = (uint32_t)rows->nk;
+        for (size_t i = 0; i < rows->nk && i < (size_t)MAX_FUSED_K; ++i) g->kf[i] = (double)rows->kmers[i];
+        SKL_TRY(ensure_ytab(rows));
+        g->ytab = rows->d_ytab;
+    }
+    return SKL_OK;
+}
+
+static uint64_t cond_index(uint64_t i, uint64_t j, uint64_t n)
+{
+    return n * i - ((i * (i + 1)) >> 1) + j - 1 - i;  // distance_matrix.rs:11-14
+}
+
+// Number of pairs in rows [r0, r1) of the condensed triangle of n samples.
+static uint64_t self_rows_pairs(uint64_t r0, uint64_t r1, uint64_t n)
+{
+    if (n < 2) return 0;
+    r1 = std::min<uint64_t>(r1, n - 1);
+    if (r1 <= r0) return 0;
+    auto upto = [n](uint64_t r) { return r * n - r * (r + 1) / 2; };  // pairs with i < r
+    return upto(r1) - upto(r0);
+}
+
+constexpr size_t BAND_BYTES = 512ull << 20;  // scratch bound for host-destined / banded output
+
+// Core of every dense call: rows [r0, r1) of the pair space into `dst` (device).
+// elem_bytes is the output record size per pair.
+static int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
+                      const skl_dist_params *p, int mode, int jout, int self_mode, uint64_t r0,
+                      uint64_t r1, void *dst_dev)
+{
+    const uint64_t n_cols = cols->n;
+    const uint64_t base = self_mode ? cond_index(r0, r0 + 1, n_cols) : r0 * n_cols;
+    const uint64_t pairs = self_mode ? self_rows_pairs(r0, r1, n_cols) : (r1 - r0) * n_cols;
+    if (pairs == 0) return SKL_OK;
+
+    const bool coreacc = mode == MODE_COREACC;
+    if (coreacc && !fused_coreacc_ok(rows)) {
+        // unfused: counts -> scratch2 -> epilogue kernel
+        PairArgs g;
+        SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
+        void *counts = nullptr;
+        SKL_TRY(ctx_scratch(ctx, pairs * rows->nk * sizeof(uint32_t), &counts, 1));
+        g.row_begin = (uint32_t)r0;
+        g.row_end = (uint32_t)r1;
+        g.self_mode = self_mode;
+        g.out_base = base;
+        g.out = counts;
+        const int na = choose_na(r1 - r0, n_cols, self_mode, MODE_COUNTS);
+        SKL_TRY(timed_pair_launch(ctx, g, MODE_COUNTS, na));
+        SKL_TRY(ensure_ytab(rows));
+        EpilogueArgs e;
+        memset(&e, 0, sizeof e);
+        e.counts = (const uint32_t *)counts;
+        e.n_pairs = pairs;
+        e.nk = (uint32_t)rows->nk;
+        e.ss64 = (uint32_t)rows->ss64;
+        e.nA_rows = (uint32_t)rows->n;
+        e.nB_cols = (uint32_t)cols->n;
+        e.row_begin = (uint32_t)r0;
+        e.self_mode = self_mode;
+        e.n_total = (uint32_t)cols->n;
+        e.out_base = base;
+        e.has_comp = g.has_comp;
+        e.ytab = rows->d_ytab;
+        e.compA = rows->d_comp;
+        e.compB = cols->d_comp;
+        e.cutoff = p->completeness_cutoff;
+        e.tolerance = g.tolerance;
+        e.kf = rows->d_kf;
+        e.out = (float *)dst_dev;
+        HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));
+        return SKL_OK;
+    }
+    PairArgs g;
+    SKL_TRY(fill_args(rows, cols, p, mode, jout, &g));
+    g.row_begin = (uint32_t)r0;
+    g.row_end = (uint32_t)r1;
+    g.self_mode = self_mode;
+    g.out_base = base;
+    g.out = dst_dev;
+    const int na = choose_na(r1 - r0, n_cols, self_mode, mode);
+    return timed_pair_launch(ctx, g, mode, na);
+}
+
+static size_t record_bytes(const skl_sketches *s, int mode)
+{
+    if (mode == MODE_COUNTS) return s->nk * sizeof(uint32_t);
+    return mode == MODE_COREACC ? 2 * sizeof(float) : sizeof(float);
+}
+
+// Dense driver: whole row range either straight into a device destination, or banded
+// through scratch and copied back to a host destination.
+static int dense_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
+                      const skl_dist_params *p, int mode, int jout, int self_mode, uint64_t r0,
+                      uint64_t r1, void *out, int out_on_device)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!out) return fail(SKL_ERR_INVALID_ARG, "out is null");
+    const uint64_t n_cols = cols->n;
+    const uint64_t row_limit = self_mode ? (n_cols ? n_cols - 1 : 0) : rows->n;
+    if (r0 > r1 || r1 > (self_mode ? n_cols : rows->n)) {
+        return fail(SKL_ERR_INVALID_ARG, "row range [%llu, %llu) out of bounds", (unsigned long long)r0,
+                    (unsigned long long)r1);
+    }
+    r1 = std::min<uint64_t>(r1, row_limit);
+    if (r1 <= r0 || n_cols == 0) return SKL_OK;
+    const size_t rec = record_bytes(rows, mode);
+    if (out_on_device) {
+        return dense_band(ctx, rows, cols, p, mode, jout, self_mode, r0, r1, out);
+    }
+    // host destination: bands of at most BAND_BYTES
+    const uint64_t first = self_mode ? cond_index(r0, r0 + 1, n_cols) : r0 * n_cols;
+    uint64_t b0 = r0;
+    while (b0 < r1) {
+        uint64_t b1 = b0;
+        uint64_t pairs = 0;
+        while (b1 < r1) {
+            const uint64_t row_pairs = self_mode ? (n_cols - 1 - b1) : n_cols;
+            if (pairs && (pairs + row_pairs) * rec > BAND_BYTES) break;
+            pairs += row_pairs;
+            ++b1;
+        }
+        void *dev = nullptr;
+        SKL_TRY(ctx_scratch(ctx, pairs * rec, &dev, 0));
+        SKL_TRY(dense_band(ctx, rows, cols, p, mode, jout, self_mode, b0, b1, dev));
+        const uint64_t off = (self_mode ? cond_index(b0, b0 + 1, n_cols) : b0 * n_cols) - first;
+        HIP_TRY(hipMemcpyAsync((char *)out + off * rec, dev, pairs * rec, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        b0 = b1;
+    }
+    return SKL_OK;
+}
+
+static int dense_mode(const skl_dist_params *p, int *mode, int *jout)
+{
+    if (p->dist_type == SKL_DIST_COREACC) {
+        *mode = MODE_COREACC;
+        *jout = 0;
+    } else {
+        *mode = MODE_JACCARD;
+        *jout = p->ani ? JOUT_ANI : JOUT_DIST;
+    }
+    return SKL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dense entry points
+// ---------------------------------------------------------------------------
+
+extern "C" int skl_self_dists_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                   size_t row_begin, size_t row_end, float *out, int out_on_device)
+{
+    SKL_TRY(check_params(s, s, p));
+    int mode, jout;
+    dense_mode(p, &mode, &jout);
+    return dense_rows(ctx, s, s, p, mode, jout, 1, row_begin, row_end, out, out_on_device);
+}
+
+extern "C" int skl_self_dists_all(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                  float *out, int out_on_device)
+{
+    if (!s) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    if (s->n < 2) {
+        SKL_TRY(check_params(s, s, p));
+        return SKL_OK;  // empty upper triangle
+    }
+    return skl_self_dists_rows(ctx, s, p, 0, s->n, out, out_on_device);
+}
+
+extern "C" int skl_cross_dists_rows(skl_ctx *ctx, const skl_sketches *ref,
+                                    const skl_sketches *query, const skl_dist_params *p,
+                                    size_t ref_begin, size_t ref_end, float *out,
+                                    int out_on_device)
+{
+    SKL_TRY(check_params(ref, query, p));
+    int mode, jout;
+    dense_mode(p, &mode, &jout);
+    return dense_rows(ctx, ref, query, p, mode, jout, 0, ref_begin, ref_end, out, out_on_device);
+}
+
+extern "C" int skl_cross_dists_all(skl_ctx *ctx, const skl_sketches *ref,
+                                   const skl_sketches *query, const skl_dist_params *p, float *out,
+                                   int out_on_device)
+{
+    if (!ref || !query) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    return skl_cross_dists_rows(ctx, ref, query, p, 0, ref->n, out, out_on_device);
+}
+
+extern "C" int skl_self_binmatch(skl_ctx *ctx, const skl_sketches *s, uint32_t *out,
+                                 int out_on_device)
+{
+    if (!s) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    if (s->n < 2) return SKL_OK;
+    skl_dist_params p = {SKL_DIST_JACCARD, 0, 0, 0.0};
+    return dense_rows(ctx, s, s, &p, MODE_COUNTS, 0, 1, 0, s->n, out, out_on_device);
+}
+
+extern "C" int skl_cross_binmatch(skl_ctx *ctx, const skl_sketches *ref,
+                                  const skl_sketches *query, uint32_t *out, int out_on_device)
+{
+    skl_dist_params p = {SKL_DIST_JACCARD, 0, 0, 0.0};
+    SKL_TRY(check_params(ref, query, &p));
+    return dense_rows(ctx, ref, query, &p, MODE_COUNTS, 0, 0, 0, ref->n, out, out_on_device);
+}
+
+// ---------------------------------------------------------------------------
+// sparse kNN: dense row bands into scratch, then a row-wise top-k kernel
+// ---------------------------------------------------------------------------
+
+static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
+                    const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
+                    uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "output pointers are null");
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    if (coreacc && !out_d1) return fail(SKL_ERR_INVALID_ARG, "out_d1 is required for core/accessory");
+    if (r0 > r1 || r1 > rows->n) return fail(SKL_ERR_INVALID_ARG, "row range out of bounds");
+    const size_t n_cand = cands->n;
+    if (knn == 0 || knn > n_cand - (self_mode ? 1 : 0)) {
+        return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, n_cand - (self_mode ? 1 : 0));
+    }
+    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
+    if (r1 == r0) return SKL_OK;
+
+    const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
+    const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
+    const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
+    size_t band_rows = std::max<size_t>(1, BAND_BYTES / (n_cand * rec));
+    band_rows = std::min(band_rows, r1 - r0);
+
+    // device staging for host-destined results
+    uint64_t *d_idx = out_idx;
+    float *d_d0 = out_d0, *d_d1 = out_d1;
+    const size_t items = (r1 - r0) * knn;
+    void *band = nullptr;
+    if (!out_on_device) {
+        void *stage = nullptr;
+        SKL_TRY(ctx_scratch(ctx, items * (sizeof(uint64_t) + 2 * sizeof(float)), &stage, 2));
+        d_idx = (uint64_t *)stage;
+        d_d0 = (float *)(d_idx + items);
+        d_d1 = d_d0 + items;
+    }
+    SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band, 0));
+
+    for (size_t b0 = r0; b0 < r1; b0 += band_rows) {
+        const size_t b1 = std::min(r1, b0 + band_rows);
+        SKL_TRY(dense_band(ctx, rows, cands, p, mode, jout, 0, b0, b1, band));
+        TopkArgs t;
+        memset(&t, 0, sizeof t);
+        t.keys = (const float *)band;
+        t.rows = (uint32_t)(b1 - b0);
+        t.cols = (uint32_t)n_cand;
+        t.stride2 = coreacc ? 2 : 1;
+        t.knn = (uint32_t)knn;
+        t.self_mode = self_mode;
+        t.row_begin = (uint32_t)b0;
+        t.ani_undo = (!coreacc && p->ani) ? 1 : 0;
+        t.out_idx = d_idx + (b0 - r0) * knn;
+        t.out_d0 = d_d0 + (b0 - r0) * knn;
+        t.out_d1 = coreacc ? d_d1 + (b0 - r0) * knn : nullptr;
+        HIP_TRY(launch_topk(t, ctx->stream));
+    }
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out_idx, d_idx, items * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out_d0, d_d0, items * sizeof(float), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        if (coreacc) {
+            HIP_TRY(hipMemcpyAsync(out_d1, d_d1, items * sizeof(float), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return SKL_OK;
+}
+
+extern "C" int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s,
+                                       const skl_dist_params *p, size_t knn, size_t row_begin,
+                                       size_t row_end, uint64_t *out_idx, float *out_d0,
+                                       float *out_d1, int out_on_device)
+{
+    SKL_TRY(check_params(s, s, p));
+    return knn_rows(ctx, s, s, p, knn, 1, row_begin, row_end, out_idx, out_d0, out_d1,
+                    out_on_device);
+}
+
+extern "C" int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                  size_t knn, uint64_t *out_idx, float *out_d0, float *out_d1,
+                                  int out_on_device)
+{
+    if (!s) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    return skl_self_dists_knn_rows(ctx, s, p, knn, 0, s->n, out_idx, out_d0, out_d1, out_on_device);
+}
+
+extern "C" int skl_cross_dists_knn_rows(skl_ctx *ctx, const skl_sketches *ref,
+                                        const skl_sketches *query, const skl_dist_params *p,
+                                        size_t knn, size_t query_begin, size_t query_end,
+                                        uint64_t *out_idx, float *out_d0, float *out_d1,
+                                        int out_on_device)
+{
+    SKL_TRY(check_params(ref, query, p));
+    if (ref->n == 0) return fail(SKL_ERR_EMPTY_DB, "Reference database has no loaded samples");
+    if (query->n == 0) return fail(SKL_ERR_EMPTY_DB, "Query database has no loaded samples");
+    // rows = queries (scalar operand), candidates = refs (lane operand); samebits and the
+    // completeness factor are symmetric in the pair, so core_acc_dist(ref, query, ri, qi)
+    // (mod.rs:377-385) is computed with the roles swapped.
+    return knn_rows(ctx, query, ref, p, knn, 0, query_begin, query_end, out_idx, out_d0, out_d1,
+                    out_on_device);
+}
+
+extern "C" int skl_cross_dists_knn(skl_ctx *ctx, const skl_sketches *ref,
+                                   const skl_sketches *query, const skl_dist_params *p, size_t knn,
+                                   uint64_t *out_idx, float *out_d0, float *out_d1,
+                                   int out_on_device)
+{
+    if (!ref || !query) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    return skl_cross_dists_knn_rows(ctx, ref, query, p, knn, 0, query->n, out_idx, out_d0, out_d1,
+                                    out_on_device);
+}
+
+// ---------------------------------------------------------------------------
+// one-shot host forms
+// ---------------------------------------------------------------------------
+
+extern "C" int skl_self_dists_all_host(const uint64_t *bins, size_t n_samples, size_t nk,
+                                       const size_t *kmers, size_t sketchsize64,
+                                       const skl_dist_params *p, const double *completeness,
+                                       float *out)
+{
+    skl_ctx *ctx = nullptr;
+    SKL_TRY(skl_ctx_create(0, &ctx));
+    skl_sketches *s = nullptr;
+    int rc = skl_sketches_create(ctx, bins, 0, n_samples, nk, kmers, sketchsize64, &s);
+    if (rc == SKL_OK && completeness) rc = skl_sketches_set_completeness(s, completeness);
+    if (rc == SKL_OK) rc = skl_self_dists_all(ctx, s, p, out, 0);
+    skl_sketches_destroy(s);
+    skl_ctx_destroy(ctx);
+    return rc;
+}
+
+extern "C" int skl_cross_dists_all_host(const uint64_t *ref_bins, size_t n_ref,
+                                        const uint64_t *query_bins, size_t n_query, size_t nk,
+                                        const size_t *kmers, size_t sketchsize64,
+                                        const skl_dist_params *p, const double *ref_completeness,
+                                        const double *query_completeness, float *out)
+{
+    skl_ctx *ctx = nullptr;
+    SKL_TRY(skl_ctx_create(0, &ctx));
+    skl_sketches *r = nullptr, *q = nullptr;
+    int rc = skl_sketches_create(ctx, ref_bins, 0, n_ref, nk, kmers, sketchsize64, &r);
+    if (rc == SKL_OK) rc = skl_sketches_create(ctx, query_bins, 0, n_query, nk, kmers, sketchsize64, &q);
+    if (rc == SKL_OK && ref_completeness) rc = skl_sketches_set_completeness(r, ref_completeness);
+    if (rc == SKL_OK && query_completeness) rc = skl_sketches_set_completeness(q, query_completeness);
+    if (rc == SKL_OK) rc = skl_cross_dists_all(ctx, r, q, p, out, 0);
+    skl_sketches_destroy(q);
+    skl_sketches_destroy(r);
+    skl_ctx_destroy(ctx);
+    return rc;
+}

@@ -1,0 +1,98 @@
+// kernels.h -- internal interface between the C ABI (capi.cpp) and the gfx950
+// device code (kernels.hip).  Not part of the public boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace skl {
+
+constexpr int BBITS = 14;          // src/sketch/mod.rs:34
+constexpr int LANES = 64;          // wavefront width on gfx950
+constexpr int WAVES_PER_WG = 4;    // 256-thread workgroups
+constexpr int MAX_FUSED_K = 6;     // k-mer lengths the fused core/acc epilogue packs (3 x 2 x u16)
+constexpr int A_PAD_ROWS = 64;     // rows the scalar-operand slab is over-allocated by
+
+// What the pair kernel does with the per-(pair,k) mismatch counts.
+enum PairMode : int {
+    MODE_COUNTS = 0,   // store samebits as u32 [pair][k]            (jaccard.rs:15-25)
+    MODE_JACCARD = 1,  // one k: store f32 distance / ANI / kNN key  (mod.rs:83-100)
+    MODE_COREACC = 2,  // all k: fused regression, store (core, acc) (jaccard.rs:61-142)
+};
+
+// How MODE_JACCARD turns J into the stored f32.
+enum JaccardOut : int {
+    JOUT_DIST = 0,     // (1 - J) as f32                    mod.rs:99
+    JOUT_ANI = 1,      // ani_pois(J,k) as f32              mod.rs:97
+    JOUT_ANI_KEY = 2,  // (1 - ani_pois(J,k)) as f32        mod.rs:173-176 (kNN sort key)
+};
+
+struct PairArgs {
+    // operands
+    const uint64_t *A;   // scalar operand: reference layout [nA + pad][nk][ss64][14]
+    const uint4 *B;      // lane operand: [ceil(nB/64)][nk][ss64][7][64] x (2 planes x u64)
+    uint32_t nA, nB;     // valid samples on each side
+    uint32_t nk, ss64;
+    uint32_t k_begin, k_count;
+    // pair space
+    uint32_t row_begin, row_end;  // A rows computed by this launch
+    uint32_t self_mode;           // 1: A == B sample set, only i < j
+    uint32_t a_tiles;             // workgroup tiles along rows
+    uint32_t n_jblocks;           // 64-wide column blocks
+    uint64_t out_base;            // flat index of the first pair of this launch
+    void *out;
+    // epilogue
+    int32_t jout;                 // JaccardOut
+    int32_t has_comp;
+    const double *ytab;           // [64*ss64 + 1] ln(J(samebits)), host libm
+    const float *dtab;            // [64*ss64 + 1] f32 Jaccard-mode output, host libm
+    const double *compA, *compB;  // completeness per sample (device) or null
+    double cutoff;
+    double tolerance;             // ln(2 / (sketch_size * 64))   jaccard.rs:75
+    double kf[MAX_FUSED_K];       // k-mer lengths as f64
+};
+
+// Choose rows-per-wave for a launch of `pairs` pairs.
+int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
+
+hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream);
+
+// reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
+hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint32_t n,
+                           uint32_t nk, uint32_t ss64, hipStream_t stream);
+
+// Unfused core/acc epilogue: counts [pair][nk] u32 -> (core, acc) f32 pairs.
+struct EpilogueArgs {
+    const uint32_t *counts;
+    uint64_t n_pairs;
+    uint32_t nk, ss64;
+    uint32_t nA_rows, nB_cols;  // to recover (i, j) for completeness lookups
+    uint32_t row_begin;
+    uint32_t self_mode;
+    uint32_t n_total;           // n (self mode condensed indexing)
+    uint64_t out_base;
+    int32_t has_comp;
+    const double *ytab;
+    const double *compA, *compB;
+    double cutoff, tolerance;
+    const double *kf;           // device array [nk]
+    float *out;
+};
+hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
+
+// Row-wise top-k over a dense [rows][cols] band of keys (and optional second value).
+struct TopkArgs {
+    const float *keys;      // [rows][cols] or [rows][cols][2] when stride2
+    uint32_t rows, cols;
+    uint32_t stride2;       // 1: plain keys; 2: (core, acc) interleaved, key = core
+    uint32_t knn;
+    uint32_t self_mode;     // skip col == row_begin + row
+    uint32_t row_begin;
+    int32_t ani_undo;       // write 1.0f - key   (mod.rs:183-189)
+    uint64_t *out_idx;      // [rows][knn]
+    float *out_d0, *out_d1;
+};
+hipError_t launch_topk(const TopkArgs &args, hipStream_t stream);
+
+}  // namespace skl

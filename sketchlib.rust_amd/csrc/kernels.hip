@@ -1,0 +1,652 @@
+// kernels.hip -- gfx950 (CDNA4 / MI355X) device code of the pairwise-distance path.
+//
+// What is computed (reference: bacpop/sketchlib.rust v0.3.0):
+//   * bin-match counts            src/distances/jaccard.rs:15-25
+//   * Jaccard / ANI per pair       src/distances/jaccard.rs:26-51, mod.rs:83-100
+//   * core/accessory regression    src/distances/jaccard.rs:61-142
+//   * per-row k nearest neighbours src/distances/mod.rs:41-48,133-224,306-395
+//
+// How it is laid out for the machine (see DESIGN.md "Kernels"):
+//   A sketch is bit-sliced: 14 u64 planes per 64-bin chunk.  A bin matches iff all
+//   14 planes agree, so per (pair, k, chunk) the work is
+//       m = OR_p (a_p ^ b_p);  matches += 64 - popcount(m)
+//   i.e. pure 32-bit integer VALU work (no MFMA shape exists for it).
+//
+//   One wavefront owns NA "row" samples x 64 "column" samples:
+//     * the column sample lives in the lane: its 14 planes of the current chunk are
+//       28 VGPRs, loaded with 7 fully coalesced global_load_dwordx4 per lane from a
+//       lane-interleaved copy of the slab (1 KiB contiguous per wave-instruction);
+//     * the row sample is wave-uniform: its 28 dwords arrive through the scalar
+//       cache with s_load_dwordx16/x8/x4 into SGPRs and feed the VALU as the scalar
+//       operand -- the hardware broadcast path, no LDS traffic and no cross-lane
+//       reduction at all;
+//     * m |= a ^ b is a single v_bitop3_b32 (gfx950 3-input LUT op), so a chunk of
+//       one pair costs 28 bitop3 + 2 v_bcnt_u32_b32 (popcount with fused accumulate).
+//   Counts stay in VGPRs; the Jaccard / regression epilogue runs in the same kernel,
+//   every lane finishing its own pairs.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the regression must not
+// be contracted into FMAs: the reference's f64 arithmetic is unfused).
+#include "kernels.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace skl {
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+
+struct A28 {
+    uint32_t w[28];
+};
+// Constant address space => the compiler emits scalar (SMEM) loads for uniform
+// addresses; the slab is read-only for the lifetime of the launch.
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+
+__device__ __forceinline__ A28 load_row_chunk(const uint64_t *p)
+{
+    const_u32_ptr q = (const_u32_ptr)(uintptr_t)p;
+    A28 r;
+#pragma unroll
+    for (int x = 0; x < 28; ++x) r.w[x] = q[x];
+    return r;
+}
+
+// m | (a ^ b) in one instruction: v_bitop3_b32 with truth table 0xDE for
+// (src0 = a, src1 = m, src2 = b).
+template <bool BITOP3>
+__device__ __forceinline__ uint32_t acc_mismatch(uint32_t m, uint32_t a, uint32_t b)
+{
+    if constexpr (BITOP3) {
+        return __builtin_amdgcn_bitop3_b32(a, m, b, 0xDE);
+    } else {
+        return m | (a ^ b);
+    }
+}
+
+// jaccard.rs:14,26-44 on the device (used when a completeness correction makes the
+// host-built tables inapplicable).
+__device__ __forceinline__ double jaccard_from_samebits_dev(uint32_t samebits, uint32_t ss64,
+                                                            bool has_c, double c1, double c2,
+                                                            double cutoff)
+{
+    const double unionsize = (double)(64u * ss64);
+    const uint32_t maxnbits = ss64 * 64u;
+    const uint32_t expected = maxnbits >> BBITS;
+    const uint32_t diff = samebits > expected ? samebits - expected : 0u;
+    const double intersize = ((double)diff * (double)maxnbits) / (double)(maxnbits - expected);
+    double j = intersize / unionsize;
+    if (has_c) {
+        if (c1 * c2 >= cutoff) {
+            j = j / (c1 * c2 / (c1 + c2 - c1 * c2));  // jaccard.rs:55-57
+            j = fmin(j, 1.0);
+        }
+    }
+    return j;
+}
+
+// jaccard.rs:49-51
+__device__ __forceinline__ double ani_pois_dev(double j, double k)
+{
+    return fmax(0.0, 1.0 + 1.0 / k * log((2.0 * j) / (1.0 + j)));
+}
+
+// jaccard.rs:105-142, operation for operation.
+__device__ __forceinline__ float2 simple_linear_regression_dev(double xsum, double ysum,
+                                                               double xysum, double xsquaresum,
+                                                               double ysquaresum, double n)
+{
+    if (isnan(ysum) || ysum == -INFINITY || n < 3.0) {
+        return make_float2(1.0f, 1.0f);
+    }
+    const double xbar = xsum / n;
+    const double ybar = ysum / n;
+    const double x_diff = xsquaresum - xsum * xsum / n;
+    const double y_diff = ysquaresum - ysum * ysum / n;
+    const double xstddev = sqrt((xsquaresum - xsum * xsum / n) / n);
+    const double ystddev = sqrt((ysquaresum - ysum * ysum / n) / n);
+    const double r = (xysum - xsum * ysum / n) / sqrt(x_diff * y_diff);
+    const double beta = r * ystddev / xstddev;
+    const double alpha = -beta * xbar + ybar;
+    double core = 0.0, acc = 0.0;
+    if (beta < 0.0) {
+        core = 1.0 - exp(beta);
+    } else if (r > 0.0) {
+        core = 1.0;
+    }
+    if (alpha < 0.0) {
+        acc = 1.0 - exp(alpha);
+    }
+    return make_float2((float)core, (float)acc);
+}
+
+// distance_matrix.rs:11-14
+__device__ __forceinline__ uint64_t square_to_condensed_dev(uint64_t i, uint64_t j, uint64_t n)
+{
+    return n * i - ((i * (i + 1)) >> 1) + j - 1 - i;
+}
+
+// ---------------------------------------------------------------------------
+// the pair kernel
+// ---------------------------------------------------------------------------
+
+template <int NA, int MODE, bool BITOP3>
+__global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArgs g)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs, so
+    // blockIdx % 8 labels the XCD; consecutive workgroups of one XCD walk the row
+    // tiles of ONE column block, whose lane-operand slab then stays in that XCD's L2.
+    // Column blocks are dealt to XCDs modulo 8, which also balances the triangle.
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t jb = (slot / g.a_tiles) * 8u + xcd;
+    const uint32_t at = slot % g.a_tiles;
+    if (jb >= g.n_jblocks) return;
+    const uint32_t a0 = g.row_begin + (at * WAVES_PER_WG + wave) * NA;
+    if (a0 >= g.row_end) return;
+    if (g.self_mode && a0 >= jb * 64u + 63u) return;  // no i < j in this wave tile
+    const uint32_t jcol = jb * 64u + lane;
+
+    const size_t kmer_stride = (size_t)g.ss64 * BBITS;
+    const size_t sample_stride = kmer_stride * g.nk;
+    const uint64_t *abase = g.A + (size_t)a0 * sample_stride;
+    const uint32_t last_chunk = g.ss64 - 1u;
+
+    // MODE_COREACC: per pair, the mismatch counts of up to 6 k-mer lengths as a
+    // 96-bit shift register of u16 fields (newest k in the low field of st0).
+    uint32_t st0[NA], st1[NA], st2[NA];
+    if constexpr (MODE == MODE_COREACC) {
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) {
+            st0[ia] = 0;
+            st1[ia] = 0;
+            st2[ia] = 0;
+        }
+    }
+
+    for (uint32_t kk = 0; kk < g.k_count; ++kk) {
+        const uint32_t k = g.k_begin + kk;
+        uint32_t cnt[NA];
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) cnt[ia] = 0;
+
+        const uint4 *bp = g.B + ((size_t)(jb * g.nk + k) * g.ss64) * (7 * LANES) + lane;
+        const uint64_t *ap = abase + (size_t)k * kmer_stride;
+
+        uint4 b[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) b[q] = bp[q * LANES];
+        A28 a_cur = load_row_chunk(ap);
+
+        for (uint32_t c = 0; c <= last_chunk; ++c) {
+            const uint32_t cn = c < last_chunk ? c + 1u : c;
+            // next chunk of the lane operand: in flight under this chunk's VALU work
+            uint4 bn[7];
+            const uint4 *bpn = bp + (size_t)cn * (7 * LANES);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) bn[q] = bpn[q * LANES];
+
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {
+                // First touch of this row's SGPRs: the compiler's s_waitcnt lgkmcnt(0)
+                // lands here, BEFORE the next row's loads are issued (SMEM returns out of
+                // order, so a wait placed after them would wait for them too).
+                uint32_t mlo = a_cur.w[0] ^ b[0].x;
+                uint32_t mhi = a_cur.w[1] ^ b[0].y;
+                __builtin_amdgcn_sched_barrier(0);
+                // next row's chunk (or row 0 of the next chunk): in flight under this
+                // row's 28 VALU ops
+                const A28 a_nxt = (ia + 1 < NA)
+                                      ? load_row_chunk(ap + (size_t)(ia + 1) * sample_stride +
+                                                       (size_t)c * BBITS)
+                                      : load_row_chunk(ap + (size_t)cn * BBITS);
+                __builtin_amdgcn_sched_barrier(0);
+                mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[2], b[0].z);
+                mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[3], b[0].w);
+#pragma unroll
+                for (int q = 1; q < 7; ++q) {
+                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 0], b[q].x);
+                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 1], b[q].y);
+                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 2], b[q].z);
+                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 3], b[q].w);
+                }
+                cnt[ia] += __builtin_popcount(mlo);
+                cnt[ia] += __builtin_popcount(mhi);
+                a_cur = a_nxt;
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) b[q] = bn[q];
+        }
+
+        // ---- per-k epilogue ----
+        const uint32_t maxnbits = g.ss64 * 64u;
+        if constexpr (MODE == MODE_COUNTS) {
+            uint32_t *out = (uint32_t *)g.out;
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {
+                const uint32_t i = a0 + ia;
+                const bool valid = i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
+                if (valid) {
+                    const uint64_t idx = (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB)
+                                                      : (uint64_t)i * g.nB + jcol) -
+                                         g.out_base;
+                    out[idx * g.k_count + kk] = maxnbits - cnt[ia];
+                }
+            }
+        } else if constexpr (MODE == MODE_JACCARD) {
+            float *out = (float *)g.out;
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {
+                const uint32_t i = a0 + ia;
+                const bool valid = i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
+                if (valid) {
+                    const uint32_t same = maxnbits - cnt[ia];
+                    float d;
+                    if (!g.has_comp) {
+                        d = g.dtab[same];
+                    } else {
+                        const double jac = jaccard_from_samebits_dev(
+                            same, g.ss64, true, g.compA[i], g.compB[jcol], g.cutoff);
+                        if (g.jout == JOUT_DIST) {
+                            d = (float)(1.0 - jac);
+                        } else if (g.jout == JOUT_ANI) {
+                            d = (float)ani_pois_dev(jac, g.kf[0]);
+                        } else {
+                            d = (float)(1.0 - ani_pois_dev(jac, g.kf[0]));
+                        }
+                    }
+                    const uint64_t idx = (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB)
+                                                      : (uint64_t)i * g.nB + jcol) -
+                                         g.out_base;
+                    out[idx] = d;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {
+                st2[ia] = __builtin_amdgcn_alignbit(st2[ia], st1[ia], 16);
+                st1[ia] = __builtin_amdgcn_alignbit(st1[ia], st0[ia], 16);
+                st0[ia] = (st0[ia] << 16) | cnt[ia];
+            }
+        }
+    }
+
+    // ---- fused core/accessory regression (jaccard.rs:61-142) ----
+    if constexpr (MODE == MODE_COREACC) {
+        const uint32_t maxnbits = g.ss64 * 64u;
+        float2 *out = (float2 *)g.out;
+        // One body for all NA rows: take slot 0, then rotate the register window.
+#pragma clang loop unroll(disable)
+        for (int r = 0; r < NA; ++r) {
+            const uint32_t i = a0 + (uint32_t)r;
+            const uint32_t s0 = st0[0], s1 = st1[0], s2 = st2[0];
+            const bool valid = i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
+            if (valid) {
+                double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0,
+                       n = 0.0;
+                double c1 = 0.0, c2 = 0.0;
+                if (g.has_comp) {
+                    c1 = g.compA[i];
+                    c2 = g.compB[jcol];
+                }
+                bool alive = true;
+                for (uint32_t t = 0; t < g.k_count; ++t) {
+                    const uint32_t f = g.k_count - 1u - t;  // field holding k index t
+                    const uint32_t word = (f >> 1) == 0u ? s0 : ((f >> 1) == 1u ? s1 : s2);
+                    const uint32_t same = maxnbits - ((word >> ((f & 1u) * 16u)) & 0xFFFFu);
+                    double y;
+                    if (!g.has_comp) {
+                        y = g.ytab[same];
+                    } else {
+                        y = log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff));
+                    }
+                    if (alive) {
+                        if (y < g.tolerance) {
+                            alive = false;  // jaccard.rs:89-91: break
+                        } else {
+                            const double k_fl = g.kf[t];
+                            xsum += k_fl;
+                            ysum += y;
+                            xysum += k_fl * y;
+                            xsquaresum += k_fl * k_fl;
+                            ysquaresum += y * y;
+                            n += 1.0;
+                        }
+                    }
+                }
+                const uint64_t idx = (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB)
+                                                  : (uint64_t)i * g.nB + jcol) -
+                                     g.out_base;
+                out[idx] = simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum,
+                                                        ysquaresum, n);
+            }
+#pragma unroll
+            for (int x = 0; x + 1 < NA; ++x) {
+                st0[x] = st0[x + 1];
+                st1[x] = st1[x + 1];
+                st2[x] = st2[x + 1];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------
+
+int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode)
+{
+    // Enough wave tiles to give every SIMD of the 256 CUs several waves; bigger NA
+    // means fewer lane-operand bytes per pair.
+    const uint64_t pairs = self_mode ? n_rows * n_cols / 2 : n_rows * n_cols;
+    const uint64_t want_waves = 256ull * 4ull * 6ull;
+    const int max_na = mode == MODE_COREACC ? 32 : 32;
+    int na = max_na;
+    while (na > 4 && pairs / ((uint64_t)na * 64ull) < want_waves) na >>= 1;
+    return na;
+}
+
+template <int NA, int MODE>
+static hipError_t launch_t(const PairArgs &args, bool bitop3, dim3 grid, hipStream_t stream)
+{
+    if (bitop3) {
+        hipLaunchKernelGGL((pair_kernel<NA, MODE, true>), grid, dim3(LANES * WAVES_PER_WG), 0,
+                           stream, args);
+    } else {
+        hipLaunchKernelGGL((pair_kernel<NA, MODE, false>), grid, dim3(LANES * WAVES_PER_WG), 0,
+                           stream, args);
+    }
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_m(const PairArgs &args, int na, bool bitop3, dim3 grid,
+                           hipStream_t stream)
+{
+    switch (na) {
+        case 4: return launch_t<4, MODE>(args, bitop3, grid, stream);
+        case 8: return launch_t<8, MODE>(args, bitop3, grid, stream);
+        case 16: return launch_t<16, MODE>(args, bitop3, grid, stream);
+        case 32: return launch_t<32, MODE>(args, bitop3, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pair_kernel(const PairArgs &args_in, int mode, int na, hipStream_t stream)
+{
+    PairArgs args = args_in;
+    if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
+    const uint32_t rows = args.row_end - args.row_begin;
+    const uint32_t rows_per_wg = (uint32_t)na * WAVES_PER_WG;
+    args.a_tiles = (rows + rows_per_wg - 1) / rows_per_wg;
+    args.n_jblocks = (args.nB + 63u) / 64u;
+    const uint64_t n_wg = 8ull * ((args.n_jblocks + 7u) / 8u) * args.a_tiles;
+    if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
+    static const bool bitop3 = [] {
+        const char *e = getenv("SKL_PAIR_VARIANT");
+        return !(e && strcmp(e, "or3") == 0);
+    }();
+    const dim3 grid((unsigned)n_wg);
+    switch (mode) {
+        case MODE_COUNTS: return launch_m<MODE_COUNTS>(args, na, bitop3, grid, stream);
+        case MODE_JACCARD: return launch_m<MODE_JACCARD>(args, na, bitop3, grid, stream);
+        case MODE_COREACC: return launch_m<MODE_COREACC>(args, na, bitop3, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// slab re-layout: reference [sample][k][chunk][plane] -> [jb][k][chunk][q][lane]{2 planes}
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void relayout_kernel(const uint64_t *__restrict__ src,
+                                                       uint4 *__restrict__ dst, uint32_t n,
+                                                       uint32_t nk, uint32_t ss64,
+                                                       uint64_t total)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+        const uint32_t lane = (uint32_t)(o & 63u);
+        uint64_t r = o >> 6;
+        const uint32_t q = (uint32_t)(r % 7u);
+        r /= 7u;
+        const uint32_t c = (uint32_t)(r % ss64);
+        r /= ss64;
+        const uint32_t k = (uint32_t)(r % nk);
+        const uint64_t jb = r / nk;
+        const uint64_t j = jb * 64u + lane;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (j < n) {
+            const uint64_t w = ((j * nk + k) * ss64 + c) * BBITS + 2u * q;
+            const uint64_t p0 = src[w], p1 = src[w + 1];
+            v = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
+        }
+        dst[o] = v;
+    }
+}
+
+hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint32_t n, uint32_t nk,
+                           uint32_t ss64, hipStream_t stream)
+{
+    const uint64_t n_jb = (n + 63u) / 64u;
+    const uint64_t total = n_jb * nk * ss64 * 7ull * 64ull;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 256ull * 32ull) blocks = 256ull * 32ull;
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ref_layout,
+                       lane_layout, n, nk, ss64, total);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// unfused core/acc epilogue (any number of k-mer lengths / any sketch size)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArgs g)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.n_pairs) return;
+    double c1 = 0.0, c2 = 0.0;
+    if (g.has_comp) {
+        // recover (i, j) from the flat index of this launch
+        const uint64_t flat = p + g.out_base;
+        uint64_t i, j;
+        if (g.self_mode) {
+            // invert the condensed index by a row search (rows are short ranges; the
+            // closed form of distance_matrix.rs:46-51 needs an f64 sqrt and a fix-up)
+            const double nn = (double)g.n_total;
+            double guess = nn - 2.0 -
+                           floor(sqrt(-8.0 * (double)flat + 4.0 * nn * (nn - 1.0) - 7.0) / 2.0 -
+                                 0.5);
+            i = (uint64_t)(guess < 0.0 ? 0.0 : guess);
+            if (i > g.n_total - 2ull) i = g.n_total - 2ull;
+            while (i > 0 && square_to_condensed_dev(i, i + 1, g.n_total) > flat) --i;
+            while (i + 2 < g.n_total && square_to_condensed_dev(i + 1, i + 2, g.n_total) <= flat)
+                ++i;
+            j = flat - square_to_condensed_dev(i, i + 1, g.n_total) + i + 1;
+        } else {
+            i = flat / g.nB_cols;
+            j = flat % g.nB_cols;
+        }
+        c1 = g.compA[i];
+        c2 = g.compB[j];
+    }
+    const uint32_t maxnbits = g.ss64 * 64u;
+    double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
+    const uint32_t *cnt = g.counts + p * g.nk;
+    for (uint32_t t = 0; t < g.nk; ++t) {
+        const uint32_t same = cnt[t];
+        double y;
+        if (!g.has_comp) {
+            y = g.ytab[same <= maxnbits ? same : maxnbits];
+        } else {
+            y = log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff));
+        }
+        if (y < g.tolerance) break;
+        const double k_fl = g.kf[t];
+        xsum += k_fl;
+        ysum += y;
+        xysum += k_fl * y;
+        xsquaresum += k_fl * k_fl;
+        ysquaresum += y * y;
+        n += 1.0;
+    }
+    ((float2 *)g.out)[p] =
+        simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
+}
+
+hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream)
+{
+    if (args.n_pairs == 0) return hipSuccess;
+    const uint64_t blocks = (args.n_pairs + 255) / 256;
+    if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(coreacc_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       args);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// row-wise k nearest neighbours over a dense band (mod.rs:41-48 semantics with the
+// canonical tie rule: smallest (key, index) first)
+// ---------------------------------------------------------------------------
+
+constexpr int TOPK_THREADS = 256;
+constexpr int TOPK_MAX = 2048;  // knn upper bound handled on device
+
+__device__ __forceinline__ uint32_t sortable_bits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_remaining, sh_count, sh_taken;
+    __shared__ uint64_t items[TOPK_MAX];  // (sortable key << 32) | col
+
+    const uint32_t row = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const float *keys = g.keys + (size_t)row * g.cols * g.stride2;
+    const uint32_t self_col = g.self_mode ? g.row_begin + row : 0xFFFFFFFFu;
+
+    // ---- radix select: key value of the knn-th smallest ----
+    if (tid == 0) {
+        sh_prefix = 0;
+        sh_remaining = g.knn;
+    }
+    __syncthreads();
+    for (int pass = 3; pass >= 0; --pass) {
+        hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh_prefix;
+        const uint32_t hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << ((pass + 1) * 8));
+        for (uint32_t c = tid; c < g.cols; c += TOPK_THREADS) {
+            if (c == self_col) continue;
+            const uint32_t u = sortable_bits(keys[(size_t)c * g.stride2]);
+            if ((u & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(u >> (pass * 8)) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t rem = sh_remaining, b = 0;
+            for (; b < 256; ++b) {
+                if (hist[b] >= rem) break;
+                rem -= hist[b];
+            }
+            if (b > 255) b = 255;
+            sh_prefix = prefix | (b << (pass * 8));
+            sh_remaining = rem;
+        }
+        __syncthreads();
+    }
+    const uint32_t thresh = sh_prefix;   // exact key bits of the knn-th smallest
+    const uint32_t take_eq = sh_remaining;  // how many == thresh to take, lowest index first
+
+    // ---- collect: everything below the threshold (any order) ----
+    if (tid == 0) {
+        sh_count = 0;
+        sh_taken = 0;
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < g.cols; c += TOPK_THREADS) {
+        if (c == self_col) continue;
+        const uint32_t u = sortable_bits(keys[(size_t)c * g.stride2]);
+        if (u < thresh) {
+            const uint32_t pos = atomicAdd(&sh_count, 1u);
+            items[pos] = ((uint64_t)u << 32) | c;
+        }
+    }
+    __syncthreads();
+    // ---- ties at the threshold: ordered compaction, lowest column first ----
+    const uint32_t n_less = sh_count;
+    for (uint32_t base = 0; base < g.cols && sh_taken < take_eq; base += TOPK_THREADS) {
+        const uint32_t c = base + tid;
+        bool eq = false;
+        if (c < g.cols && c != self_col) {
+            eq = sortable_bits(keys[(size_t)c * g.stride2]) == thresh;
+        }
+        // block-wide exclusive prefix of `eq` via per-wave ballots
+        const uint64_t ballot = __ballot(eq);
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(ballot);
+        __syncthreads();
+        uint32_t before = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) before += wave_cnt[w];
+        const uint32_t taken = sh_taken;
+        if (eq && taken + before < take_eq) {
+            items[n_less + taken + before] = ((uint64_t)thresh << 32) | c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < TOPK_THREADS / 64; ++w) tot += wave_cnt[w];
+            sh_taken = taken + tot;
+        }
+        __syncthreads();
+    }
+
+    // ---- bitonic sort of the knn items by (key, col) ----
+    uint32_t m = 1;
+    while (m < g.knn) m <<= 1;
+    for (uint32_t x = g.knn + tid; x < m; x += TOPK_THREADS) items[x] = ~0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= m; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t x = tid; x < m / 2; x += TOPK_THREADS) {
+                const uint32_t lo = 2 * x - (x & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = items[lo], b = items[hi];
+                if ((a > b) == up) {
+                    items[lo] = b;
+                    items[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t x = tid; x < g.knn; x += TOPK_THREADS) {
+        const uint32_t col = (uint32_t)(items[x] & 0xFFFFFFFFu);
+        const size_t o = (size_t)row * g.knn + x;
+        const float key = keys[(size_t)col * g.stride2];
+        g.out_idx[o] = col;
+        g.out_d0[o] = g.ani_undo ? 1.0f - key : key;
+        if (g.stride2 == 2 && g.out_d1) g.out_d1[o] = keys[(size_t)col * 2 + 1];
+    }
+}
+
+hipError_t launch_topk(const TopkArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0) return hipSuccess;
+    if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace skl
