@@ -40,6 +40,7 @@ struct PairArgs {
     uint32_t self_mode;           // 1: A == B sample set, only i < j
     uint32_t a_tiles;             // workgroup tiles along rows
     uint32_t n_jblocks;           // 64-wide column blocks
+    uint32_t share_rows;          // 1: waves of a workgroup share rows, differ in column block
     uint64_t out_base;            // flat index of the first pair of this launch
     void *out;
     // epilogue

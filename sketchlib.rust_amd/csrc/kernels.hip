@@ -144,10 +144,20 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
     // Column blocks are dealt to XCDs modulo 8, which also balances the triangle.
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t jb = (slot / g.a_tiles) * 8u + xcd;
-    const uint32_t at = slot % g.a_tiles;
+    uint32_t jb, a0;
+    if (g.share_rows) {
+        // the 4 waves share NA rows (scalar-cache reuse) and take 4 adjacent column blocks
+        const uint32_t jg = (slot / g.a_tiles) * 8u + xcd;
+        const uint32_t at = slot % g.a_tiles;
+        jb = jg * WAVES_PER_WG + wave;
+        a0 = g.row_begin + at * NA;
+    } else {
+        // the 4 waves share one column block (vector-L1 reuse) and take 4 row tiles
+        jb = (slot / g.a_tiles) * 8u + xcd;
+        const uint32_t at = slot % g.a_tiles;
+        a0 = g.row_begin + (at * WAVES_PER_WG + wave) * NA;
+    }
     if (jb >= g.n_jblocks) return;
-    const uint32_t a0 = g.row_begin + (at * WAVES_PER_WG + wave) * NA;
     if (a0 >= g.row_end) return;
     if (g.self_mode && a0 >= jb * 64u + 63u) return;  // no i < j in this wave tile
     const uint32_t jcol = jb * 64u + lane;
@@ -343,6 +353,11 @@ int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode)
 {
     // Enough wave tiles to give every SIMD of the 256 CUs several waves; bigger NA
     // means fewer lane-operand bytes per pair.
+    static const int forced = [] {
+        const char *e = getenv("SKL_FORCE_NA");  // tuning knob: 4, 8, 16 or 32
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return forced;
     const uint64_t pairs = self_mode ? n_rows * n_cols / 2 : n_rows * n_cols;
     const uint64_t want_waves = 256ull * 4ull * 6ull;
     const int max_na = mode == MODE_COREACC ? 32 : 32;
@@ -382,10 +397,22 @@ hipError_t launch_pair_kernel(const PairArgs &args_in, int mode, int na, hipStre
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     const uint32_t rows = args.row_end - args.row_begin;
-    const uint32_t rows_per_wg = (uint32_t)na * WAVES_PER_WG;
-    args.a_tiles = (rows + rows_per_wg - 1) / rows_per_wg;
+    static const bool share_rows = [] {
+        const char *e = getenv("SKL_SHARE_ROWS");  // tuning knob
+        return e ? atoi(e) != 0 : true;
+    }();
+    args.share_rows = share_rows ? 1u : 0u;
     args.n_jblocks = (args.nB + 63u) / 64u;
-    const uint64_t n_wg = 8ull * ((args.n_jblocks + 7u) / 8u) * args.a_tiles;
+    uint64_t n_wg;
+    if (share_rows) {
+        args.a_tiles = (rows + (uint32_t)na - 1) / (uint32_t)na;
+        const uint32_t jgroups = (args.n_jblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
+        n_wg = 8ull * ((jgroups + 7u) / 8u) * args.a_tiles;
+    } else {
+        const uint32_t rows_per_wg = (uint32_t)na * WAVES_PER_WG;
+        args.a_tiles = (rows + rows_per_wg - 1) / rows_per_wg;
+        n_wg = 8ull * ((args.n_jblocks + 7u) / 8u) * args.a_tiles;
+    }
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     static const bool bitop3 = [] {
         const char *e = getenv("SKL_PAIR_VARIANT");

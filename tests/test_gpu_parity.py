@@ -64,12 +64,13 @@ def test_unfused_coreacc_many_kmers(oracle, skl, gpu_ctx):
 
 
 def test_random_bins_all_ones(oracle, skl, gpu_ctx):
-    """Set U: J ~ 0 everywhere -> every pair breaks at the first k -> (1, 1)."""
+    """Set U: J ~ 0, so (almost) every pair breaks at the first k -> (1, 1); the few that
+    match a bin at every k regress on noise, identically on both sides."""
     bins = synth.set_u(100, 5, 64)
     o, g = _both(oracle, skl, gpu_ctx, bins, 100, K5, 64)
     got = skl.self_dists_all(gpu_ctx, g, g.set_k())
     assert np.array_equal(got, oracle.self_dists_all(o, threads=8))
-    assert np.all(got == 1.0)
+    assert np.mean(got == 1.0) > 0.9
 
 
 @pytest.mark.parametrize("ani", [False, True])
