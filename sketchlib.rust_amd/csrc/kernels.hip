@@ -132,7 +132,7 @@ __device__ __forceinline__ uint64_t square_to_condensed_dev(uint64_t i, uint64_t
 // the pair kernel
 // ---------------------------------------------------------------------------
 
-template <int NA, int MODE, bool BITOP3>
+template <int NA, int RB, int MODE, bool BITOP3>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArgs g)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -165,72 +165,76 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
     const size_t kmer_stride = (size_t)g.ss64 * BBITS;
     const size_t sample_stride = kmer_stride * g.nk;
     const uint64_t *abase = g.A + (size_t)a0 * sample_stride;
-    const uint32_t last_chunk = g.ss64 - 1u;
 
-    // MODE_COREACC: per pair, the mismatch counts of up to 6 k-mer lengths as a
-    // 96-bit shift register of u16 fields (newest k in the low field of st0).
+    // Per pair, the mismatch counts.  MODE_COREACC keeps up to 6 k-mer lengths as a 96-bit
+    // shift register of u16 fields (st2:st1:st0, newest k in the low field of st0) and
+    // accumulates the current k directly into that low field (counts <= 64*ss64 <= 65535
+    // on this path, so the popcount adds never carry into the neighbouring field).
     uint32_t st0[NA], st1[NA], st2[NA];
-    if constexpr (MODE == MODE_COREACC) {
 #pragma unroll
-        for (int ia = 0; ia < NA; ++ia) {
-            st0[ia] = 0;
-            st1[ia] = 0;
-            st2[ia] = 0;
-        }
+    for (int ia = 0; ia < NA; ++ia) {
+        st0[ia] = 0;
+        st1[ia] = 0;
+        st2[ia] = 0;
     }
 
     for (uint32_t kk = 0; kk < g.k_count; ++kk) {
         const uint32_t k = g.k_begin + kk;
-        uint32_t cnt[NA];
 #pragma unroll
-        for (int ia = 0; ia < NA; ++ia) cnt[ia] = 0;
+        for (int ia = 0; ia < NA; ++ia) {
+            if constexpr (MODE == MODE_COREACC) {
+                st2[ia] = __builtin_amdgcn_alignbit(st2[ia], st1[ia], 16);
+                st1[ia] = __builtin_amdgcn_alignbit(st1[ia], st0[ia], 16);
+                st0[ia] = st0[ia] << 16;
+            } else {
+                st0[ia] = 0;
+            }
+        }
 
         const uint4 *bp = g.B + ((size_t)(jb * g.nk + k) * g.ss64) * (7 * LANES) + lane;
         const uint64_t *ap = abase + (size_t)k * kmer_stride;
 
-        uint4 b[7];
+        for (uint32_t c = 0; c < g.ss64; ++c) {
+            // the lane operand of this chunk: 7 coalesced 16-byte loads per lane.  Not
+            // double-buffered on purpose: VGPRs buy occupancy, and the other waves of the
+            // SIMD cover this wait.
+            uint4 b[7];
+            const uint4 *bpc = bp + (size_t)c * (7 * LANES);
 #pragma unroll
-        for (int q = 0; q < 7; ++q) b[q] = bp[q * LANES];
-        A28 a_cur = load_row_chunk(ap);
-
-        for (uint32_t c = 0; c <= last_chunk; ++c) {
-            const uint32_t cn = c < last_chunk ? c + 1u : c;
-            // next chunk of the lane operand: in flight under this chunk's VALU work
-            uint4 bn[7];
-            const uint4 *bpn = bp + (size_t)cn * (7 * LANES);
-#pragma unroll
-            for (int q = 0; q < 7; ++q) bn[q] = bpn[q * LANES];
+            for (int q = 0; q < 7; ++q) b[q] = bpc[q * LANES];
 
 #pragma unroll
-            for (int ia = 0; ia < NA; ++ia) {
-                // First touch of this row's SGPRs: the compiler's s_waitcnt lgkmcnt(0)
-                // lands here, BEFORE the next row's loads are issued (SMEM returns out of
-                // order, so a wait placed after them would wait for them too).
-                uint32_t mlo = a_cur.w[0] ^ b[0].x;
-                uint32_t mhi = a_cur.w[1] ^ b[0].y;
-                __builtin_amdgcn_sched_barrier(0);
-                // next row's chunk (or row 0 of the next chunk): in flight under this
-                // row's 28 VALU ops
-                const A28 a_nxt = (ia + 1 < NA)
-                                      ? load_row_chunk(ap + (size_t)(ia + 1) * sample_stride +
-                                                       (size_t)c * BBITS)
-                                      : load_row_chunk(ap + (size_t)cn * BBITS);
-                __builtin_amdgcn_sched_barrier(0);
-                mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[2], b[0].z);
-                mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[3], b[0].w);
+            for (int ib = 0; ib < NA / RB; ++ib) {
+                // RB rows per scalar-memory round trip: SMEM returns out of order, so the
+                // only wait is lgkmcnt(0); batching rows amortises that wait and the
+                // resident waves of the SIMD hide it.
+                A28 a[RB];
 #pragma unroll
-                for (int q = 1; q < 7; ++q) {
-                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 0], b[q].x);
-                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 1], b[q].y);
-                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 2], b[q].z);
-                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 3], b[q].w);
+                for (int r = 0; r < RB; ++r) {
+                    a[r] = load_row_chunk(ap + (size_t)(ib * RB + r) * sample_stride +
+                                          (size_t)c * BBITS);
                 }
-                cnt[ia] += __builtin_popcount(mlo);
-                cnt[ia] += __builtin_popcount(mhi);
-                a_cur = a_nxt;
-            }
+                // issue all RB rows' loads first, then compute: keeps the scheduler from
+                // splitting the batch back into one wait per row
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 7; ++q) b[q] = bn[q];
+                for (int r = 0; r < RB; ++r) {
+                    uint32_t mlo = a[r].w[0] ^ b[0].x;
+                    uint32_t mhi = a[r].w[1] ^ b[0].y;
+                    mlo = acc_mismatch<BITOP3>(mlo, a[r].w[2], b[0].z);
+                    mhi = acc_mismatch<BITOP3>(mhi, a[r].w[3], b[0].w);
+#pragma unroll
+                    for (int q = 1; q < 7; ++q) {
+                        mlo = acc_mismatch<BITOP3>(mlo, a[r].w[4 * q + 0], b[q].x);
+                        mhi = acc_mismatch<BITOP3>(mhi, a[r].w[4 * q + 1], b[q].y);
+                        mlo = acc_mismatch<BITOP3>(mlo, a[r].w[4 * q + 2], b[q].z);
+                        mhi = acc_mismatch<BITOP3>(mhi, a[r].w[4 * q + 3], b[q].w);
+                    }
+                    st0[ib * RB + r] += __builtin_popcount(mlo);
+                    st0[ib * RB + r] += __builtin_popcount(mhi);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // ---- per-k epilogue ----
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
                     const uint64_t idx = (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB)
                                                       : (uint64_t)i * g.nB + jcol) -
                                          g.out_base;
-                    out[idx * g.k_count + kk] = maxnbits - cnt[ia];
+                    out[idx * g.k_count + kk] = maxnbits - st0[ia];
                 }
             }
         } else if constexpr (MODE == MODE_JACCARD) {
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
                 const uint32_t i = a0 + ia;
                 const bool valid = i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
                 if (valid) {
-                    const uint32_t same = maxnbits - cnt[ia];
+                    const uint32_t same = maxnbits - st0[ia];
                     float d;
                     if (!g.has_comp) {
                         d = g.dtab[same];
@@ -275,13 +279,6 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
                                          g.out_base;
                     out[idx] = d;
                 }
-            }
-        } else {
-#pragma unroll
-            for (int ia = 0; ia < NA; ++ia) {
-                st2[ia] = __builtin_amdgcn_alignbit(st2[ia], st1[ia], 16);
-                st1[ia] = __builtin_amdgcn_alignbit(st1[ia], st0[ia], 16);
-                st0[ia] = (st0[ia] << 16) | cnt[ia];
             }
         }
     }
@@ -357,24 +354,27 @@ int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode)
         const char *e = getenv("SKL_FORCE_NA");  // tuning knob: 4, 8, 16 or 32
         return e ? atoi(e) : 0;
     }();
-    if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return forced;
+    if (forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 12 || forced == 16) return forced;
     const uint64_t pairs = self_mode ? n_rows * n_cols / 2 : n_rows * n_cols;
     const uint64_t want_waves = 256ull * 4ull * 6ull;
-    const int max_na = mode == MODE_COREACC ? 32 : 32;
-    int na = max_na;
-    while (na > 4 && pairs / ((uint64_t)na * 64ull) < want_waves) na >>= 1;
-    return na;
+    (void)mode;
+    static const int ladder[] = {12, 8, 6, 4, 3};
+    for (int na : ladder) {
+        if (pairs / ((uint64_t)na * 64ull) >= want_waves) return na;
+    }
+    return 3;
 }
 
-template <int NA, int MODE>
+template <int NA, int RB, int MODE>
 static hipError_t launch_t(const PairArgs &args, bool bitop3, dim3 grid, hipStream_t stream)
 {
+    static_assert(NA % RB == 0, "rows per wave must be a multiple of the SMEM batch");
     if (bitop3) {
-        hipLaunchKernelGGL((pair_kernel<NA, MODE, true>), grid, dim3(LANES * WAVES_PER_WG), 0,
+        hipLaunchKernelGGL((pair_kernel<NA, RB, MODE, true>), grid, dim3(LANES * WAVES_PER_WG), 0,
                            stream, args);
     } else {
-        hipLaunchKernelGGL((pair_kernel<NA, MODE, false>), grid, dim3(LANES * WAVES_PER_WG), 0,
-                           stream, args);
+        hipLaunchKernelGGL((pair_kernel<NA, RB, MODE, false>), grid, dim3(LANES * WAVES_PER_WG),
+                           0, stream, args);
     }
     return hipGetLastError();
 }
@@ -384,10 +384,12 @@ static hipError_t launch_m(const PairArgs &args, int na, bool bitop3, dim3 grid,
                            hipStream_t stream)
 {
     switch (na) {
-        case 4: return launch_t<4, MODE>(args, bitop3, grid, stream);
-        case 8: return launch_t<8, MODE>(args, bitop3, grid, stream);
-        case 16: return launch_t<16, MODE>(args, bitop3, grid, stream);
-        case 32: return launch_t<32, MODE>(args, bitop3, grid, stream);
+        case 3: return launch_t<3, 3, MODE>(args, bitop3, grid, stream);
+        case 4: return launch_t<4, 2, MODE>(args, bitop3, grid, stream);
+        case 6: return launch_t<6, 3, MODE>(args, bitop3, grid, stream);
+        case 8: return launch_t<8, 2, MODE>(args, bitop3, grid, stream);
+        case 12: return launch_t<12, 3, MODE>(args, bitop3, grid, stream);
+        case 16: return launch_t<16, 2, MODE>(args, bitop3, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }

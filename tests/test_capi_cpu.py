@@ -1,0 +1,70 @@
+"""CPU-side checks of the product library: it builds, loads, exports every symbol the
+public header declares, and refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "sketchlib_dist.h")
+
+
+def _declared_in_header():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(skl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(skl):
+    import sketchlib.rust_amd as pkg
+
+    declared = _declared_in_header()
+    assert len(declared) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.library_path()], text=True)
+    exported = set(re.findall(r" T (skl_[a-z0-9_]+)", out))
+    missing = [s for s in declared if s not in exported]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    # and the ctypes binding covers the same set
+    assert sorted(skl.DECLARED_SYMBOLS) == declared
+
+
+def test_library_has_gfx950_code_object():
+    import sketchlib.rust_amd as pkg
+
+    pkg.build_library()
+    blob = open(pkg.library_path(), "rb").read()
+    assert b"gfx950" in blob, "no gfx950 code object embedded"
+    assert b"pair_kernel" in blob
+
+
+def test_no_cpu_fallback(skl):
+    if skl.device_count() > 0:
+        pytest.skip("a GPU is present; the refusal path is only reachable without one")
+    with pytest.raises(skl.SklError) as e:
+        skl.Context(0)
+    assert e.value.code == skl.ERR_NO_DEVICE
+    assert "no CPU path" in e.value.message
+    import numpy as np
+
+    p = skl.params()
+    with pytest.raises(skl.SklError) as e:
+        skl.self_dists_all_host(np.zeros(2 * 2 * 14, dtype=np.uint64), 2, [17, 21], 1, p)
+    assert e.value.code == skl.ERR_NO_DEVICE
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may
+    reference it."""
+    pkg_dir = os.path.join(ROOT, "sketchlib.rust_amd")
+    offenders = []
+    for root, _d, files in os.walk(pkg_dir):
+        if "_build" in root or "__pycache__" in root:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                if re.search(r"(from|import)\s+oracle|oracle/|sketchlib_oracle|sko_", text):
+                    offenders.append(os.path.join(root, f))
+    assert not offenders, offenders

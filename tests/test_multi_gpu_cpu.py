@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: row-band partition maths, and a world_size-2 gloo run of the
+gather that assembles the condensed matrix on rank 0."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from sketchlib.rust_amd import multi_gpu
+
+
+@pytest.mark.parametrize("n", [2, 3, 10, 1000, 2829])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_self_band_slices_cover_triangle(n, world):
+    slices = multi_gpu.self_band_slices(n, world)
+    total = n * (n - 1) // 2
+    assert len(slices) == world
+    pos, row = 0, 0
+    for r0, r1, p0, cnt in slices:
+        assert r0 == row and p0 == pos and r1 >= r0
+        # pairs in rows [r0, r1): sum_{i=r0}^{r1-1} (n-1-i)
+        assert cnt == sum(n - 1 - i for i in range(r0, min(r1, n)))
+        pos += cnt
+        row = r1
+    assert pos == total and row == n
+    if n >= 1000:
+        counts = [s[3] for s in slices]
+        assert max(counts) - min(counts) <= 2 * n  # each boundary is within one row of ideal
+
+
+def test_even_row_bounds():
+    assert multi_gpu.even_row_bounds(10, 3) == [0, 3, 6, 10]
+    assert multi_gpu.even_row_bounds(0, 2) == [0, 0, 0]
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from sketchlib.rust_amd import multi_gpu, synth
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, kmers, ss64 = 61, [17, 21, 25], 4
+s = O.Sketches(synth.set_r(n, kmers, ss64, n_clusters=5), n, kmers, ss64)
+ref = torch.from_numpy(O.self_dists_all(s))      # every rank can produce the truth
+slices = multi_gpu.self_band_slices(n, world)
+r0, r1, p0, cnt = slices[rank]
+mine = ref[p0:p0 + cnt].clone()                  # stand-in for this rank's GPU band
+if rank == 0:
+    full = torch.full_like(ref, -1.0)
+    full[p0:p0 + cnt] = mine
+else:
+    full = None
+multi_gpu.gather_to_root(full, mine, slices, rank, world, dist)
+if rank == 0:
+    assert torch.equal(full, ref), "assembled matrix differs"
+    print("GATHER_OK")
+dist.barrier()
+dist.destroy_process_group()
+""" % ROOT
+
+
+def test_gloo_world2_gather(oracle, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "GATHER_OK" in res.stdout
