@@ -30,29 +30,32 @@ print(json.dumps({'n':n,'mode':mode,'kernel_ms':ms/l,'pairs_per_s':pairs/(ms/l/1
 """ % ROOT
 
 
-def run(n, na, variant, mode="coreacc", reps=10):
+def run(n, env_extra, mode="coreacc", reps=10):
     env = dict(os.environ)
-    if na:
-        env["SKL_FORCE_NA"] = str(na)
-    env["SKL_PAIR_VARIANT"] = variant
+    env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, str(n), str(reps), mode], env=env,
                        capture_output=True, text=True)
     line = [x for x in r.stdout.splitlines() if x.startswith("{")]
     if not line:
-        return {"n": n, "na": na, "variant": variant, "error": r.stderr[-300:]}
+        return {"n": n, "env": env_extra, "error": r.stderr[-300:]}
     d = json.loads(line[-1])
-    d.update({"na": na, "variant": variant})
+    d.update(env_extra)
     return d
 
 
 if __name__ == "__main__":
-    ns = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1000", "4000", "16000"])]
-    nas = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["4", "8", "16", "32"])]
-    variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["bitop3", "or3"]
-    modes = sys.argv[4].split(",") if len(sys.argv) > 4 else ["coreacc"]
+    # usage: perf_sweep.py N1,N2 MODE1,MODE2 KEY=v1,v2 KEY2=w1,w2 ...  (cartesian product)
+    import itertools
+
+    ns = [int(x) for x in sys.argv[1].split(",")]
+    modes = sys.argv[2].split(",")
+    keys, vals = [], []
+    for a in sys.argv[3:]:
+        k, v = a.split("=")
+        keys.append(k)
+        vals.append(v.split(","))
     for n in ns:
         for mode in modes:
-            for v in variants:
-                for na in nas:
-                    d = run(n, na, v, mode, reps=20 if n <= 2000 else 5)
-                    print(json.dumps(d), flush=True)
+            for combo in itertools.product(*vals):
+                d = run(n, dict(zip(keys, combo)), mode, reps=20 if n <= 2000 else 5)
+                print(json.dumps(d), flush=True)

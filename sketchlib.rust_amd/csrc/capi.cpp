@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -201,12 +202,33 @@ extern "C" int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches)
     return SKL_OK;
 }
 
+// Two implementations of the same tile computation: rows through LDS broadcast
+// (pair_lds.hip, default) or through the scalar cache (kernels.hip).  SKL_KERNEL=smem
+// selects the latter (kept for A/B measurements).
+static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream)
+{
+    // SKL_KERNEL = smem | lds forces one implementation (A/B measurements); default: the
+    // latency-oriented scalar-cache kernel for small launches, the LDS kernel otherwise.
+    static const int forced = [] {
+        const char *e = getenv("SKL_KERNEL");
+        if (e && strcmp(e, "smem") == 0) return 1;
+        if (e && strcmp(e, "lds") == 0) return 2;
+        return 0;
+    }();
+    const uint64_t rows = args.row_end - args.row_begin;
+    const uint64_t pairs = args.self_mode ? rows * args.nB / 2 : rows * (uint64_t)args.nB;
+    const bool small = pairs < (6ull << 20);  // crossover measured between n=3000 and n=4000
+    if (forced == 1 || (forced == 0 && small)) return launch_pair_kernel(args, mode, na, stream);
+    const int shape = choose_lds_shape(rows, args.nB, args.self_mode, mode);
+    return launch_pair_kernel_lds(args, mode, shape, stream);
+}
+
 // Launch the pair kernel bracketed by HIP events on the context's stream.
 static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int na)
 {
     constexpr size_t MAX_EVENTS = 4096;
     if (ctx->events_used >= MAX_EVENTS) {
-        HIP_TRY(launch_pair_kernel(args, mode, na, ctx->stream));
+        HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream));
         return SKL_OK;
     }
     if (ctx->events_used == ctx->events.size()) {
@@ -217,7 +239,7 @@ static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int n
     }
     auto &ev = ctx->events[ctx->events_used++];
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    HIP_TRY(launch_pair_kernel(args, mode, na, ctx->stream));
+    HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream));
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     return SKL_OK;
 }

@@ -1,0 +1,171 @@
+// device_common.hpp -- device-side helpers shared by the pair kernels: the bin-match
+// primitive and the per-pair epilogues (Jaccard / ANI / core-accessory regression),
+// each a restatement of the reference function it cites.
+#pragma once
+
+#include "kernels.h"
+
+namespace skl {
+
+// m | (a ^ b) in one instruction: v_bitop3_b32 with truth table 0xDE for
+// (src0 = a, src1 = m, src2 = b).
+template <bool BITOP3>
+__device__ __forceinline__ uint32_t acc_mismatch(uint32_t m, uint32_t a, uint32_t b)
+{
+    if constexpr (BITOP3) {
+        return __builtin_amdgcn_bitop3_b32(a, m, b, 0xDE);
+    } else {
+        return m | (a ^ b);
+    }
+}
+
+// jaccard.rs:14,26-44 on the device (used when a completeness correction makes the
+// host-built tables inapplicable).
+__device__ __forceinline__ double jaccard_from_samebits_dev(uint32_t samebits, uint32_t ss64,
+                                                            bool has_c, double c1, double c2,
+                                                            double cutoff)
+{
+    const double unionsize = (double)(64u * ss64);
+    const uint32_t maxnbits = ss64 * 64u;
+    const uint32_t expected = maxnbits >> BBITS;
+    const uint32_t diff = samebits > expected ? samebits - expected : 0u;
+    const double intersize = ((double)diff * (double)maxnbits) / (double)(maxnbits - expected);
+    double j = intersize / unionsize;
+    if (has_c) {
+        if (c1 * c2 >= cutoff) {
+            j = j / (c1 * c2 / (c1 + c2 - c1 * c2));  // jaccard.rs:55-57
+            j = fmin(j, 1.0);
+        }
+    }
+    return j;
+}
+
+// jaccard.rs:49-51
+__device__ __forceinline__ double ani_pois_dev(double j, double k)
+{
+    return fmax(0.0, 1.0 + 1.0 / k * log((2.0 * j) / (1.0 + j)));
+}
+
+// jaccard.rs:105-142, operation for operation.
+__device__ __forceinline__ float2 simple_linear_regression_dev(double xsum, double ysum,
+                                                               double xysum, double xsquaresum,
+                                                               double ysquaresum, double n)
+{
+    if (isnan(ysum) || ysum == -INFINITY || n < 3.0) {
+        return make_float2(1.0f, 1.0f);
+    }
+    const double xbar = xsum / n;
+    const double ybar = ysum / n;
+    const double x_diff = xsquaresum - xsum * xsum / n;
+    const double y_diff = ysquaresum - ysum * ysum / n;
+    const double xstddev = sqrt((xsquaresum - xsum * xsum / n) / n);
+    const double ystddev = sqrt((ysquaresum - ysum * ysum / n) / n);
+    const double r = (xysum - xsum * ysum / n) / sqrt(x_diff * y_diff);
+    const double beta = r * ystddev / xstddev;
+    const double alpha = -beta * xbar + ybar;
+    double core = 0.0, acc = 0.0;
+    if (beta < 0.0) {
+        core = 1.0 - exp(beta);
+    } else if (r > 0.0) {
+        core = 1.0;
+    }
+    if (alpha < 0.0) {
+        acc = 1.0 - exp(alpha);
+    }
+    return make_float2((float)core, (float)acc);
+}
+
+// distance_matrix.rs:11-14
+__device__ __forceinline__ uint64_t square_to_condensed_dev(uint64_t i, uint64_t j, uint64_t n)
+{
+    return n * i - ((i * (i + 1)) >> 1) + j - 1 - i;
+}
+
+
+__device__ __forceinline__ bool pair_valid(const PairArgs &g, uint32_t i, uint32_t jcol)
+{
+    return i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
+}
+
+__device__ __forceinline__ uint64_t pair_out_index(const PairArgs &g, uint32_t i, uint32_t jcol)
+{
+    return (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB) : (uint64_t)i * g.nB + jcol) -
+           g.out_base;
+}
+
+// MODE_COUNTS: samebits of k index kk (jaccard.rs:15-25)
+__device__ __forceinline__ void store_count(const PairArgs &g, uint32_t i, uint32_t jcol,
+                                            uint32_t kk, uint32_t mismatches)
+{
+    if (pair_valid(g, i, jcol)) {
+        ((uint32_t *)g.out)[pair_out_index(g, i, jcol) * g.k_count + kk] =
+            g.ss64 * 64u - mismatches;
+    }
+}
+
+// MODE_JACCARD: mod.rs:83-100 (dense) / :173-176 (kNN key)
+__device__ __forceinline__ void store_jaccard(const PairArgs &g, uint32_t i, uint32_t jcol,
+                                              uint32_t mismatches)
+{
+    if (!pair_valid(g, i, jcol)) return;
+    const uint32_t same = g.ss64 * 64u - mismatches;
+    float d;
+    if (!g.has_comp) {
+        d = g.dtab[same];
+    } else {
+        const double jac =
+            jaccard_from_samebits_dev(same, g.ss64, true, g.compA[i], g.compB[jcol], g.cutoff);
+        if (g.jout == JOUT_DIST) {
+            d = (float)(1.0 - jac);
+        } else if (g.jout == JOUT_ANI) {
+            d = (float)ani_pois_dev(jac, g.kf[0]);
+        } else {
+            d = (float)(1.0 - ani_pois_dev(jac, g.kf[0]));
+        }
+    }
+    ((float *)g.out)[pair_out_index(g, i, jcol)] = d;
+}
+
+// MODE_COREACC: core_acc_dist + simple_linear_regression (jaccard.rs:61-142) from the
+// packed per-k mismatch counts (u16 fields, newest k lowest, s2:s1:s0).
+__device__ __forceinline__ void store_coreacc(const PairArgs &g, uint32_t i, uint32_t jcol,
+                                              uint32_t s0, uint32_t s1, uint32_t s2)
+{
+    if (!pair_valid(g, i, jcol)) return;
+    const uint32_t maxnbits = g.ss64 * 64u;
+    double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
+    double c1 = 0.0, c2 = 0.0;
+    if (g.has_comp) {
+        c1 = g.compA[i];
+        c2 = g.compB[jcol];
+    }
+    bool alive = true;
+    for (uint32_t t = 0; t < g.k_count; ++t) {
+        const uint32_t f = g.k_count - 1u - t;  // field holding k index t
+        const uint32_t word = (f >> 1) == 0u ? s0 : ((f >> 1) == 1u ? s1 : s2);
+        const uint32_t same = maxnbits - ((word >> ((f & 1u) * 16u)) & 0xFFFFu);
+        double y;
+        if (!g.has_comp) {
+            y = g.ytab[same];
+        } else {
+            y = log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff));
+        }
+        if (alive) {
+            if (y < g.tolerance) {
+                alive = false;  // jaccard.rs:89-91: break
+            } else {
+                const double k_fl = g.kf[t];
+                xsum += k_fl;
+                ysum += y;
+                xysum += k_fl * y;
+                xsquaresum += k_fl * k_fl;
+                ysquaresum += y * y;
+                n += 1.0;
+            }
+        }
+    }
+    ((float2 *)g.out)[pair_out_index(g, i, jcol)] =
+        simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
+}
+
+}  // namespace skl

@@ -59,6 +59,11 @@ int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 
 hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream);
 
+// LDS-staged variant (pair_lds.hip).  shape = R*10 + JL: R rows per workgroup tile, JL
+// 64-column blocks per lane; valid shapes: 41, 81, 82, 122, 162.
+hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, hipStream_t stream);
+int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
+
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
 hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint32_t n,
                            uint32_t nk, uint32_t ss64, hipStream_t stream);

@@ -27,7 +27,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the regression must not
 // be contracted into FMAs: the reference's f64 arithmetic is unfused).
-#include "kernels.h"
+#include "device_common.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -54,85 +54,11 @@ __device__ __forceinline__ A28 load_row_chunk(const uint64_t *p)
     return r;
 }
 
-// m | (a ^ b) in one instruction: v_bitop3_b32 with truth table 0xDE for
-// (src0 = a, src1 = m, src2 = b).
-template <bool BITOP3>
-__device__ __forceinline__ uint32_t acc_mismatch(uint32_t m, uint32_t a, uint32_t b)
-{
-    if constexpr (BITOP3) {
-        return __builtin_amdgcn_bitop3_b32(a, m, b, 0xDE);
-    } else {
-        return m | (a ^ b);
-    }
-}
-
-// jaccard.rs:14,26-44 on the device (used when a completeness correction makes the
-// host-built tables inapplicable).
-__device__ __forceinline__ double jaccard_from_samebits_dev(uint32_t samebits, uint32_t ss64,
-                                                            bool has_c, double c1, double c2,
-                                                            double cutoff)
-{
-    const double unionsize = (double)(64u * ss64);
-    const uint32_t maxnbits = ss64 * 64u;
-    const uint32_t expected = maxnbits >> BBITS;
-    const uint32_t diff = samebits > expected ? samebits - expected : 0u;
-    const double intersize = ((double)diff * (double)maxnbits) / (double)(maxnbits - expected);
-    double j = intersize / unionsize;
-    if (has_c) {
-        if (c1 * c2 >= cutoff) {
-            j = j / (c1 * c2 / (c1 + c2 - c1 * c2));  // jaccard.rs:55-57
-            j = fmin(j, 1.0);
-        }
-    }
-    return j;
-}
-
-// jaccard.rs:49-51
-__device__ __forceinline__ double ani_pois_dev(double j, double k)
-{
-    return fmax(0.0, 1.0 + 1.0 / k * log((2.0 * j) / (1.0 + j)));
-}
-
-// jaccard.rs:105-142, operation for operation.
-__device__ __forceinline__ float2 simple_linear_regression_dev(double xsum, double ysum,
-                                                               double xysum, double xsquaresum,
-                                                               double ysquaresum, double n)
-{
-    if (isnan(ysum) || ysum == -INFINITY || n < 3.0) {
-        return make_float2(1.0f, 1.0f);
-    }
-    const double xbar = xsum / n;
-    const double ybar = ysum / n;
-    const double x_diff = xsquaresum - xsum * xsum / n;
-    const double y_diff = ysquaresum - ysum * ysum / n;
-    const double xstddev = sqrt((xsquaresum - xsum * xsum / n) / n);
-    const double ystddev = sqrt((ysquaresum - ysum * ysum / n) / n);
-    const double r = (xysum - xsum * ysum / n) / sqrt(x_diff * y_diff);
-    const double beta = r * ystddev / xstddev;
-    const double alpha = -beta * xbar + ybar;
-    double core = 0.0, acc = 0.0;
-    if (beta < 0.0) {
-        core = 1.0 - exp(beta);
-    } else if (r > 0.0) {
-        core = 1.0;
-    }
-    if (alpha < 0.0) {
-        acc = 1.0 - exp(alpha);
-    }
-    return make_float2((float)core, (float)acc);
-}
-
-// distance_matrix.rs:11-14
-__device__ __forceinline__ uint64_t square_to_condensed_dev(uint64_t i, uint64_t j, uint64_t n)
-{
-    return n * i - ((i * (i + 1)) >> 1) + j - 1 - i;
-}
-
 // ---------------------------------------------------------------------------
 // the pair kernel
 // ---------------------------------------------------------------------------
 
-template <int NA, int RB, int MODE, bool BITOP3>
+template <int NA, int MODE, bool BITOP3>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArgs g)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -142,21 +68,12 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
     // blockIdx % 8 labels the XCD; consecutive workgroups of one XCD walk the row
     // tiles of ONE column block, whose lane-operand slab then stays in that XCD's L2.
     // Column blocks are dealt to XCDs modulo 8, which also balances the triangle.
+    // The 4 waves of a workgroup share the column block and take 4 adjacent row tiles.
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t slot = blockIdx.x >> 3;
-    uint32_t jb, a0;
-    if (g.share_rows) {
-        // the 4 waves share NA rows (scalar-cache reuse) and take 4 adjacent column blocks
-        const uint32_t jg = (slot / g.a_tiles) * 8u + xcd;
-        const uint32_t at = slot % g.a_tiles;
-        jb = jg * WAVES_PER_WG + wave;
-        a0 = g.row_begin + at * NA;
-    } else {
-        // the 4 waves share one column block (vector-L1 reuse) and take 4 row tiles
-        jb = (slot / g.a_tiles) * 8u + xcd;
-        const uint32_t at = slot % g.a_tiles;
-        a0 = g.row_begin + (at * WAVES_PER_WG + wave) * NA;
-    }
+    const uint32_t jb = (slot / g.a_tiles) * 8u + xcd;
+    const uint32_t at = slot % g.a_tiles;
+    const uint32_t a0 = g.row_begin + (at * WAVES_PER_WG + wave) * NA;
     if (jb >= g.n_jblocks) return;
     if (a0 >= g.row_end) return;
     if (g.self_mode && a0 >= jb * 64u + 63u) return;  // no i < j in this wave tile
@@ -165,6 +82,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
     const size_t kmer_stride = (size_t)g.ss64 * BBITS;
     const size_t sample_stride = kmer_stride * g.nk;
     const uint64_t *abase = g.A + (size_t)a0 * sample_stride;
+    const uint32_t last_chunk = g.ss64 - 1u;
 
     // Per pair, the mismatch counts.  MODE_COREACC keeps up to 6 k-mer lengths as a 96-bit
     // shift register of u16 fields (st2:st1:st0, newest k in the low field of st0) and
@@ -194,144 +112,67 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
         const uint4 *bp = g.B + ((size_t)(jb * g.nk + k) * g.ss64) * (7 * LANES) + lane;
         const uint64_t *ap = abase + (size_t)k * kmer_stride;
 
-        for (uint32_t c = 0; c < g.ss64; ++c) {
-            // the lane operand of this chunk: 7 coalesced 16-byte loads per lane.  Not
-            // double-buffered on purpose: VGPRs buy occupancy, and the other waves of the
-            // SIMD cover this wait.
-            uint4 b[7];
-            const uint4 *bpc = bp + (size_t)c * (7 * LANES);
+        uint4 b[7];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) b[q] = bpc[q * LANES];
+        for (int q = 0; q < 7; ++q) b[q] = bp[q * LANES];
+        A28 a_cur = load_row_chunk(ap);
+
+        for (uint32_t c = 0; c <= last_chunk; ++c) {
+            const uint32_t cn = c < last_chunk ? c + 1u : c;
+            // next chunk of the lane operand: in flight under this chunk's VALU work
+            uint4 bn[7];
+            const uint4 *bpn = bp + (size_t)cn * (7 * LANES);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) bn[q] = bpn[q * LANES];
 
 #pragma unroll
-            for (int ib = 0; ib < NA / RB; ++ib) {
-                // RB rows per scalar-memory round trip: SMEM returns out of order, so the
-                // only wait is lgkmcnt(0); batching rows amortises that wait and the
-                // resident waves of the SIMD hide it.
-                A28 a[RB];
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    a[r] = load_row_chunk(ap + (size_t)(ib * RB + r) * sample_stride +
-                                          (size_t)c * BBITS);
-                }
-                // issue all RB rows' loads first, then compute: keeps the scheduler from
-                // splitting the batch back into one wait per row
+            for (int ia = 0; ia < NA; ++ia) {
+                // First touch of this row's SGPRs: the compiler's s_waitcnt lgkmcnt(0)
+                // lands here, BEFORE the next row's loads are issued (SMEM returns out of
+                // order, so a wait placed after them would wait for them too).
+                uint32_t mlo = a_cur.w[0] ^ b[0].x;
+                uint32_t mhi = a_cur.w[1] ^ b[0].y;
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    uint32_t mlo = a[r].w[0] ^ b[0].x;
-                    uint32_t mhi = a[r].w[1] ^ b[0].y;
-                    mlo = acc_mismatch<BITOP3>(mlo, a[r].w[2], b[0].z);
-                    mhi = acc_mismatch<BITOP3>(mhi, a[r].w[3], b[0].w);
-#pragma unroll
-                    for (int q = 1; q < 7; ++q) {
-                        mlo = acc_mismatch<BITOP3>(mlo, a[r].w[4 * q + 0], b[q].x);
-                        mhi = acc_mismatch<BITOP3>(mhi, a[r].w[4 * q + 1], b[q].y);
-                        mlo = acc_mismatch<BITOP3>(mlo, a[r].w[4 * q + 2], b[q].z);
-                        mhi = acc_mismatch<BITOP3>(mhi, a[r].w[4 * q + 3], b[q].w);
-                    }
-                    st0[ib * RB + r] += __builtin_popcount(mlo);
-                    st0[ib * RB + r] += __builtin_popcount(mhi);
-                }
+                // next row's chunk (or row 0 of the next chunk): in flight under this
+                // row's 28 VALU ops
+                const A28 a_nxt = (ia + 1 < NA)
+                                      ? load_row_chunk(ap + (size_t)(ia + 1) * sample_stride +
+                                                       (size_t)c * BBITS)
+                                      : load_row_chunk(ap + (size_t)cn * BBITS);
                 __builtin_amdgcn_sched_barrier(0);
+                mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[2], b[0].z);
+                mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[3], b[0].w);
+#pragma unroll
+                for (int q = 1; q < 7; ++q) {
+                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 0], b[q].x);
+                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 1], b[q].y);
+                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 2], b[q].z);
+                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 3], b[q].w);
+                }
+                st0[ia] += __builtin_popcount(mlo);
+                st0[ia] += __builtin_popcount(mhi);
+                a_cur = a_nxt;
             }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) b[q] = bn[q];
         }
 
         // ---- per-k epilogue ----
-        const uint32_t maxnbits = g.ss64 * 64u;
         if constexpr (MODE == MODE_COUNTS) {
-            uint32_t *out = (uint32_t *)g.out;
 #pragma unroll
-            for (int ia = 0; ia < NA; ++ia) {
-                const uint32_t i = a0 + ia;
-                const bool valid = i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
-                if (valid) {
-                    const uint64_t idx = (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB)
-                                                      : (uint64_t)i * g.nB + jcol) -
-                                         g.out_base;
-                    out[idx * g.k_count + kk] = maxnbits - st0[ia];
-                }
-            }
+            for (int ia = 0; ia < NA; ++ia) store_count(g, a0 + ia, jcol, kk, st0[ia]);
         } else if constexpr (MODE == MODE_JACCARD) {
-            float *out = (float *)g.out;
 #pragma unroll
-            for (int ia = 0; ia < NA; ++ia) {
-                const uint32_t i = a0 + ia;
-                const bool valid = i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
-                if (valid) {
-                    const uint32_t same = maxnbits - st0[ia];
-                    float d;
-                    if (!g.has_comp) {
-                        d = g.dtab[same];
-                    } else {
-                        const double jac = jaccard_from_samebits_dev(
-                            same, g.ss64, true, g.compA[i], g.compB[jcol], g.cutoff);
-                        if (g.jout == JOUT_DIST) {
-                            d = (float)(1.0 - jac);
-                        } else if (g.jout == JOUT_ANI) {
-                            d = (float)ani_pois_dev(jac, g.kf[0]);
-                        } else {
-                            d = (float)(1.0 - ani_pois_dev(jac, g.kf[0]));
-                        }
-                    }
-                    const uint64_t idx = (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB)
-                                                      : (uint64_t)i * g.nB + jcol) -
-                                         g.out_base;
-                    out[idx] = d;
-                }
-            }
+            for (int ia = 0; ia < NA; ++ia) store_jaccard(g, a0 + ia, jcol, st0[ia]);
         }
     }
 
     // ---- fused core/accessory regression (jaccard.rs:61-142) ----
     if constexpr (MODE == MODE_COREACC) {
-        const uint32_t maxnbits = g.ss64 * 64u;
-        float2 *out = (float2 *)g.out;
         // One body for all NA rows: take slot 0, then rotate the register window.
 #pragma clang loop unroll(disable)
         for (int r = 0; r < NA; ++r) {
-            const uint32_t i = a0 + (uint32_t)r;
-            const uint32_t s0 = st0[0], s1 = st1[0], s2 = st2[0];
-            const bool valid = i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
-            if (valid) {
-                double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0,
-                       n = 0.0;
-                double c1 = 0.0, c2 = 0.0;
-                if (g.has_comp) {
-                    c1 = g.compA[i];
-                    c2 = g.compB[jcol];
-                }
-                bool alive = true;
-                for (uint32_t t = 0; t < g.k_count; ++t) {
-                    const uint32_t f = g.k_count - 1u - t;  // field holding k index t
-                    const uint32_t word = (f >> 1) == 0u ? s0 : ((f >> 1) == 1u ? s1 : s2);
-                    const uint32_t same = maxnbits - ((word >> ((f & 1u) * 16u)) & 0xFFFFu);
-                    double y;
-                    if (!g.has_comp) {
-                        y = g.ytab[same];
-                    } else {
-                        y = log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff));
-                    }
-                    if (alive) {
-                        if (y < g.tolerance) {
-                            alive = false;  // jaccard.rs:89-91: break
-                        } else {
-                            const double k_fl = g.kf[t];
-                            xsum += k_fl;
-                            ysum += y;
-                            xysum += k_fl * y;
-                            xsquaresum += k_fl * k_fl;
-                            ysquaresum += y * y;
-                            n += 1.0;
-                        }
-                    }
-                }
-                const uint64_t idx = (g.self_mode ? square_to_condensed_dev(i, jcol, g.nB)
-                                                  : (uint64_t)i * g.nB + jcol) -
-                                     g.out_base;
-                out[idx] = simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum,
-                                                        ysquaresum, n);
-            }
+            store_coreacc(g, a0 + (uint32_t)r, jcol, st0[0], st1[0], st2[0]);
 #pragma unroll
             for (int x = 0; x + 1 < NA; ++x) {
                 st0[x] = st0[x + 1];
@@ -348,33 +189,28 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
 
 int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode)
 {
-    // Enough wave tiles to give every SIMD of the 256 CUs several waves; bigger NA
-    // means fewer lane-operand bytes per pair.
+    (void)mode;
     static const int forced = [] {
-        const char *e = getenv("SKL_FORCE_NA");  // tuning knob: 4, 8, 16 or 32
+        const char *e = getenv("SKL_FORCE_NA");  // tuning knob: 2, 4 or 8
         return e ? atoi(e) : 0;
     }();
-    if (forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 12 || forced == 16) return forced;
+    if (forced == 2 || forced == 4 || forced == 8) return forced;
     const uint64_t pairs = self_mode ? n_rows * n_cols / 2 : n_rows * n_cols;
-    const uint64_t want_waves = 256ull * 4ull * 6ull;
-    (void)mode;
-    static const int ladder[] = {12, 8, 6, 4, 3};
-    for (int na : ladder) {
-        if (pairs / ((uint64_t)na * 64ull) >= want_waves) return na;
-    }
-    return 3;
+    // this kernel serves small launches: aim for >= 2 waves on each of the 1024 SIMDs
+    // (measured on MI355X: NA = 4 beats 2 and 8 from n = 1000 to n = 3000, sweep5.log)
+    if (pairs / (4ull * 64ull) >= 1024) return 4;
+    return 2;
 }
 
-template <int NA, int RB, int MODE>
+template <int NA, int MODE>
 static hipError_t launch_t(const PairArgs &args, bool bitop3, dim3 grid, hipStream_t stream)
 {
-    static_assert(NA % RB == 0, "rows per wave must be a multiple of the SMEM batch");
     if (bitop3) {
-        hipLaunchKernelGGL((pair_kernel<NA, RB, MODE, true>), grid, dim3(LANES * WAVES_PER_WG), 0,
+        hipLaunchKernelGGL((pair_kernel<NA, MODE, true>), grid, dim3(LANES * WAVES_PER_WG), 0,
                            stream, args);
     } else {
-        hipLaunchKernelGGL((pair_kernel<NA, RB, MODE, false>), grid, dim3(LANES * WAVES_PER_WG),
-                           0, stream, args);
+        hipLaunchKernelGGL((pair_kernel<NA, MODE, false>), grid, dim3(LANES * WAVES_PER_WG), 0,
+                           stream, args);
     }
     return hipGetLastError();
 }
@@ -384,12 +220,9 @@ static hipError_t launch_m(const PairArgs &args, int na, bool bitop3, dim3 grid,
                            hipStream_t stream)
 {
     switch (na) {
-        case 3: return launch_t<3, 3, MODE>(args, bitop3, grid, stream);
-        case 4: return launch_t<4, 2, MODE>(args, bitop3, grid, stream);
-        case 6: return launch_t<6, 3, MODE>(args, bitop3, grid, stream);
-        case 8: return launch_t<8, 2, MODE>(args, bitop3, grid, stream);
-        case 12: return launch_t<12, 3, MODE>(args, bitop3, grid, stream);
-        case 16: return launch_t<16, 2, MODE>(args, bitop3, grid, stream);
+        case 2: return launch_t<2, MODE>(args, bitop3, grid, stream);
+        case 4: return launch_t<4, MODE>(args, bitop3, grid, stream);
+        case 8: return launch_t<8, MODE>(args, bitop3, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -399,22 +232,11 @@ hipError_t launch_pair_kernel(const PairArgs &args_in, int mode, int na, hipStre
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     const uint32_t rows = args.row_end - args.row_begin;
-    static const bool share_rows = [] {
-        const char *e = getenv("SKL_SHARE_ROWS");  // tuning knob
-        return e ? atoi(e) != 0 : true;
-    }();
-    args.share_rows = share_rows ? 1u : 0u;
+    args.share_rows = 0;
     args.n_jblocks = (args.nB + 63u) / 64u;
-    uint64_t n_wg;
-    if (share_rows) {
-        args.a_tiles = (rows + (uint32_t)na - 1) / (uint32_t)na;
-        const uint32_t jgroups = (args.n_jblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
-        n_wg = 8ull * ((jgroups + 7u) / 8u) * args.a_tiles;
-    } else {
-        const uint32_t rows_per_wg = (uint32_t)na * WAVES_PER_WG;
-        args.a_tiles = (rows + rows_per_wg - 1) / rows_per_wg;
-        n_wg = 8ull * ((args.n_jblocks + 7u) / 8u) * args.a_tiles;
-    }
+    const uint32_t rows_per_wg = (uint32_t)na * WAVES_PER_WG;
+    args.a_tiles = (rows + rows_per_wg - 1) / rows_per_wg;
+    const uint64_t n_wg = 8ull * ((args.n_jblocks + 7u) / 8u) * args.a_tiles;
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     static const bool bitop3 = [] {
         const char *e = getenv("SKL_PAIR_VARIANT");
