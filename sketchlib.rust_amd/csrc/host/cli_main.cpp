@@ -1,0 +1,307 @@
+// cli_main.cpp -- `sketchlib dist`, the reference's command line for this path
+// (src/cli.rs:185-231, src/lib.rs:303-453) on top of the gfx950 engine.
+//
+// Same positional arguments, flags, defaults, stdout format and exit behaviour
+// (panic -> 101, error -> 1, usage -> 2).  `--threads` is accepted and validated for
+// compatibility (the work runs on the GPU); `--device` is the one addition.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "distances.hpp"
+#include "io.hpp"
+#include "multisketch.hpp"
+
+using namespace skl_host;
+
+namespace {
+
+struct DistArgs {
+    std::string ref_db;
+    std::optional<std::string> query_db, output, subset, ref_completeness_file, query_completeness_file;
+    std::optional<size_t> knn, kmer;
+    bool ani = false;
+    size_t threads = 1;
+    double completeness_cutoff = 0.64;
+    bool verbose = false, quiet = false;
+    int device = 0;
+};
+
+[[noreturn]] void usage_error(const std::string &msg)
+{
+    std::cerr << "error: " << msg << "\n\n"
+              << "Usage: sketchlib dist [OPTIONS] <REF_DB> [QUERY_DB]\n\n"
+              << "For more information, try '--help'.\n";
+    std::exit(2);
+}
+
+void print_help()
+{
+    std::cout <<
+        "Calculate pairwise distances using sketches\n\n"
+        "Usage: sketchlib dist [OPTIONS] <REF_DB> [QUERY_DB]\n\n"
+        "Arguments:\n"
+        "  <REF_DB>    The .skm file used as the reference\n"
+        "  [QUERY_DB]  The .skm file used as the query (omit for ref v ref)\n\n"
+        "Options:\n"
+        "  -o <OUTPUT>                     Output filename (omit to output to stdout)\n"
+        "      --knn <KNN>                 Calculate sparse distances with k nearest-neighbours (ref-vs-ref or ref-vs-query)\n"
+        "      --subset <SUBSET>           Sample names to analyse\n"
+        "  -k <KMER>                       K-mer length (if provided only calculate Jaccard distance)\n"
+        "      --ani                       Calculate ANI rather than Jaccard dists, using Poisson model\n"
+        "      --threads <THREADS>         Number of CPU threads [default: 1]\n"
+        "      --ref-completeness-file <F> File listing reference sample completeness estimates 0.0-1.0\n"
+        "      --query-completeness-file <F> File listing query sample completeness estimates 0.0-1.0\n"
+        "      --completeness-cutoff <C>   minimum completeness product for the correction [default: 0.64]\n"
+        "      --device <D>                GPU to run on [default: 0]\n"
+        "  -v, --verbose                   Show progress messages\n"
+        "      --quiet                     Don't show any messages\n"
+        "  -h, --help                      Print help\n";
+}
+
+size_t parse_usize(const std::string &flag, const std::string &v)
+{
+    char *end = nullptr;
+    if (v.empty() || v[0] == '-') usage_error("invalid value '" + v + "' for '" + flag + "': invalid digit found in string");
+    const unsigned long long x = std::strtoull(v.c_str(), &end, 10);
+    if (end != v.c_str() + v.size()) usage_error("invalid value '" + v + "' for '" + flag + "': invalid digit found in string");
+    return (size_t)x;
+}
+
+DistArgs parse_dist(int argc, char **argv, int first)
+{
+    DistArgs a;
+    std::vector<std::string> positional;
+    for (int i = first; i < argc; ++i) {
+        std::string arg = argv[i];
+        std::optional<std::string> inline_val;
+        if (arg.rfind("--", 0) == 0) {
+            const size_t eq = arg.find('=');
+            if (eq != std::string::npos) {
+                inline_val = arg.substr(eq + 1);
+                arg = arg.substr(0, eq);
+            }
+        }
+        auto value = [&](const std::string &flag) -> std::string {
+            if (inline_val) return *inline_val;
+            if (i + 1 >= argc) usage_error("a value is required for '" + flag + "' but none was supplied");
+            return argv[++i];
+        };
+        if (arg == "-h" || arg == "--help") { print_help(); std::exit(0); }
+        else if (arg == "-v" || arg == "--verbose") a.verbose = true;
+        else if (arg == "--quiet") a.quiet = true;
+        else if (arg == "-o") a.output = value("-o <OUTPUT>");
+        else if (arg == "--knn") a.knn = parse_usize("--knn <KNN>", value("--knn <KNN>"));
+        else if (arg == "--subset") a.subset = value("--subset <SUBSET>");
+        else if (arg == "-k") a.kmer = parse_usize("-k <KMER>", value("-k <KMER>"));
+        else if (arg == "--ani") a.ani = true;
+        else if (arg == "--threads") {
+            const std::string v = value("--threads <THREADS>");
+            char *end = nullptr;
+            const long long t = std::strtoll(v.c_str(), &end, 10);
+            if (v.empty() || end != v.c_str() + v.size()) {
+                usage_error("invalid value '" + v + "' for '--threads <THREADS>': `" + v + "` isn't a valid number of cores");
+            }
+            if (t < 1) usage_error("invalid value '" + v + "' for '--threads <THREADS>': Threads must be one or higher");
+            a.threads = (size_t)t;
+        }
+        else if (arg == "--ref-completeness-file") a.ref_completeness_file = value(arg);
+        else if (arg == "--query-completeness-file") a.query_completeness_file = value(arg);
+        else if (arg == "--completeness-cutoff") {
+            const std::string v = value(arg);
+            char *end = nullptr;
+            a.completeness_cutoff = std::strtod(v.c_str(), &end);
+            if (v.empty() || end != v.c_str() + v.size()) usage_error("invalid value '" + v + "' for '--completeness-cutoff <COMPLETENESS_CUTOFF>': invalid float literal");
+        }
+        else if (arg == "--device") a.device = (int)parse_usize("--device <D>", value(arg));
+        else if (arg.size() > 2 && arg[0] == '-' && arg[1] != '-' && (arg[1] == 'o' || arg[1] == 'k')) {
+            // clap accepts -k21 / -oFILE
+            if (arg[1] == 'o') a.output = arg.substr(2);
+            else a.kmer = parse_usize("-k <KMER>", arg.substr(2));
+        }
+        else if (arg.size() > 1 && arg[0] == '-') usage_error("unexpected argument '" + arg + "' found");
+        else positional.push_back(arg);
+    }
+    if (positional.empty()) usage_error("the following required arguments were not provided:\n  <REF_DB>");
+    if (positional.size() > 2) usage_error("unexpected argument '" + positional[2] + "' found");
+    a.ref_db = positional[0];
+    if (positional.size() == 2) a.query_db = positional[1];
+    if (a.ani && !a.kmer) {  // #[arg(long, requires("kmer"))]
+        usage_error("the following required arguments were not provided:\n  -k <KMER>");
+    }
+    return a;
+}
+
+struct Logger {
+    bool info_on, warn_on;
+    void info(const std::string &m) const { if (info_on) std::cerr << "INFO  [sketchlib] " << m << "\n"; }
+    void warn(const std::string &m) const { if (warn_on) std::cerr << "WARN  [sketchlib] " << m << "\n"; }
+};
+
+int run_dist(const DistArgs &a)
+{
+    // lib.rs:230-237: verbose -> Info, quiet -> Error, default -> Warn
+    const Logger log{a.verbose && !a.quiet, !a.quiet};
+    log.info("Using " + std::to_string(a.threads) + " threads");   // cli.rs:75-86 (host threads unused)
+
+    std::ofstream out_file;
+    std::ostream *os = &std::cout;
+    if (a.output) {
+        out_file.open(*a.output, std::ios::binary);
+        if (!out_file) throw Panic("cannot create output file " + *a.output);
+        os = &out_file;
+    }
+
+    const std::string ref_db_name = strip_sketch_extension(a.ref_db);
+    MultiSketch references;
+    try {
+        references = MultiSketch::load_metadata(ref_db_name);
+    } catch (const std::exception &) {
+        throw Panic("Could not read sketch metadata from " + a.ref_db + ".skm");  // lib.rs:322-323
+    }
+    log.info("Loading sketch data from " + ref_db_name + ".skd");
+    try {
+        if (a.subset) {
+            references.read_sketch_data_block(ref_db_name, read_subset_names(*a.subset));
+        } else {
+            references.read_sketch_data(ref_db_name);
+        }
+    } catch (const std::exception &e) {
+        throw Panic(e.what());
+    }
+    const size_t n = references.number_samples_loaded();
+
+    std::vector<std::string> warnings;
+    std::optional<std::vector<double>> ref_comp;
+    if (a.ref_completeness_file) {
+        ref_comp = read_completeness_file(*a.ref_completeness_file, references, &warnings);
+    }
+
+    DistType dist_type;
+    try {
+        dist_type = distances::set_k(references, a.kmer, a.ani);
+    } catch (const std::exception &e) {
+        throw Panic(std::string("Error setting k size: ") + e.what());  // lib.rs:341-343
+    }
+    log.info(dist_type.describe());
+
+    std::optional<MultiSketch> queries;
+    if (a.query_db) {
+        const std::string query_db_name = strip_sketch_extension(*a.query_db);
+        try {
+            queries = MultiSketch::load_metadata(query_db_name);
+        } catch (const std::exception &) {
+            throw Panic("Could not read sketch metadata from " + *a.query_db + ".skm");
+        }
+        log.info("Loading query sketch data from " + query_db_name + ".skd");
+        queries->read_sketch_data(query_db_name);
+    }
+    std::optional<std::vector<double>> query_comp;
+    if (queries && a.query_completeness_file) {
+        query_comp = read_completeness_file(*a.query_completeness_file, *queries, &warnings);
+    }
+    for (const auto &w : warnings) log.warn(w);
+
+    Device dev(a.device);
+    const std::vector<double> *rc = ref_comp ? &*ref_comp : nullptr;
+    const std::vector<double> *qc = query_comp ? &*query_comp : nullptr;
+    if (!queries) {
+        if (!a.knn) {
+            log.info("Calculating all ref vs ref distances");
+            if (n < 2) {
+                if (dist_type.kind == DistType::CoreAcc && references.kmer_lengths().size() < 2) {
+                    throw Panic("Need at least two k-mer lengths to calculate core/accessory distances");
+                }
+                return 0;  // empty upper triangle
+            }
+            const DistanceMatrix d = distances::self_dists_all(dev, references, n, dist_type, a.quiet, rc,
+                                                               a.completeness_cutoff);
+            log.info("Writing out in long matrix form");
+            d.write(*os);
+        } else {
+            size_t nn = *a.knn;
+            if (nn >= n) {  // lib.rs:379-382
+                log.warn("knn=" + std::to_string(nn) + " is higher than number of samples=" + std::to_string(n));
+                nn = n - 1;
+            }
+            if (nn == 0) throw Panic("chunk size must be non-zero");  // par_chunks_mut(0)
+            log.info("Calculating sparse ref vs ref distances with " + std::to_string(nn) + " nearest neighbours");
+            const SparseDistanceMatrix d = distances::self_dists_knn(dev, references, n, nn, dist_type, a.quiet,
+                                                                     rc, a.completeness_cutoff);
+            log.info("Writing out in sparse matrix form");
+            d.write(*os);
+        }
+    } else {
+        const size_t n_query = queries->number_samples_loaded();
+        if (a.knn) {
+            size_t nn = *a.knn;
+            if (nn > n) {  // lib.rs:411-414
+                log.warn("knn=" + std::to_string(nn) + " is higher than number of reference samples=" + std::to_string(n));
+                nn = n;
+            }
+            log.info("Calculating sparse ref vs query distances with " + std::to_string(nn) + " nearest neighbours");
+            const SparseDistanceMatrix d = distances::cross_dists_knn(dev, references, *queries, n, n_query, nn,
+                                                                      dist_type, a.quiet, rc, qc,
+                                                                      a.completeness_cutoff);
+            log.info("Writing out in sparse matrix form");
+            d.write(*os);
+        } else {
+            log.info("Calculating all ref vs query distances");
+            const DistanceMatrix d = distances::cross_dists_all(dev, references, *queries, n, n_query, dist_type,
+                                                                a.quiet, rc, qc, a.completeness_cutoff);
+            log.info("Writing out in long matrix form");
+            d.write(*os);
+        }
+    }
+    os->flush();
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    const auto start = std::chrono::steady_clock::now();
+    // global flags may precede the subcommand
+    int sub = 1;
+    while (sub < argc && (strcmp(argv[sub], "-v") == 0 || strcmp(argv[sub], "--verbose") == 0 ||
+                          strcmp(argv[sub], "--quiet") == 0)) {
+        ++sub;
+    }
+    if (sub >= argc || strcmp(argv[sub], "-h") == 0 || strcmp(argv[sub], "--help") == 0) {
+        std::cout << "Usage: sketchlib [OPTIONS] <COMMAND>\n\nCommands:\n"
+                     "  dist  Calculate pairwise distances using sketches\n\n"
+                     "(this build provides the GPU `dist` path only)\n";
+        return sub >= argc ? 2 : 0;
+    }
+    if (strcmp(argv[sub], "dist") != 0) {
+        std::cerr << "error: unrecognized subcommand '" << argv[sub]
+                  << "' (this build provides `dist` only)\n";
+        return 2;
+    }
+    DistArgs args = parse_dist(argc, argv, sub + 1);
+    for (int i = 1; i < sub; ++i) {
+        if (strcmp(argv[i], "--quiet") == 0) args.quiet = true;
+        else args.verbose = true;
+    }
+    try {
+        const int rc = run_dist(args);
+        if (args.verbose && !args.quiet) {
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+            std::cerr << "INFO  [sketchlib] Complete in " << s << "s\n";  // lib.rs:949-957
+        }
+        return rc;
+    } catch (const Panic &p) {
+        std::cerr << "thread 'main' panicked:\n" << p.what() << "\n";
+        return 101;
+    } catch (const std::exception &e) {
+        std::cerr << "Error: " << e.what() << "\n";
+        return 1;
+    }
+}

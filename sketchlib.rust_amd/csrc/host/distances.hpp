@@ -1,0 +1,66 @@
+// distances.hpp -- C++ mirror of the reference's `distances` module API
+// (src/distances/mod.rs): same function names, argument meaning and error behaviour,
+// implemented by calling the gfx950 engine through the C ABI (include/sketchlib_dist.h).
+#pragma once
+
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "distance_matrix.hpp"
+#include "multisketch.hpp"
+
+struct skl_ctx;
+
+namespace skl_host {
+
+// What a Rust panic is in the reference (exit code 101 in the CLI).
+struct Panic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// One GPU context (skl_ctx) -- the stand-in for the reference's global rayon pool.
+class Device {
+  public:
+    explicit Device(int device = 0);
+    ~Device();
+    Device(const Device &) = delete;
+    Device &operator=(const Device &) = delete;
+    skl_ctx *ctx() const { return ctx_; }
+
+  private:
+    skl_ctx *ctx_ = nullptr;
+};
+
+namespace distances {
+
+// mod.rs:25-37.  Throws std::runtime_error("K-mer size {k} not found in file").
+DistType set_k(const MultiSketch &sketches, std::optional<size_t> kmer, bool ani);
+
+// mod.rs:58-130
+DistanceMatrix self_dists_all(Device &dev, const MultiSketch &sketches, size_t n, const DistType &dist_type,
+                              bool quiet, const std::vector<double> *completeness_vec,
+                              double completeness_cutoff);
+// mod.rs:133-224
+SparseDistanceMatrix self_dists_knn(Device &dev, const MultiSketch &sketches, size_t n, size_t knn,
+                                    const DistType &dist_type, bool quiet,
+                                    const std::vector<double> *completeness_vec,
+                                    double completeness_cutoff);
+// mod.rs:227-297
+DistanceMatrix cross_dists_all(Device &dev, const MultiSketch &ref_sketches,
+                               const MultiSketch &query_sketches, size_t n, size_t n_query,
+                               const DistType &dist_type, bool quiet,
+                               const std::vector<double> *ref_completeness_vec,
+                               const std::vector<double> *query_completeness_vec,
+                               double completeness_cutoff);
+// mod.rs:306-395
+SparseDistanceMatrix cross_dists_knn(Device &dev, const MultiSketch &ref_sketches,
+                                     const MultiSketch &query_sketches, size_t n, size_t n_query,
+                                     size_t knn, const DistType &dist_type, bool quiet,
+                                     const std::vector<double> *ref_completeness_vec,
+                                     const std::vector<double> *query_completeness_vec,
+                                     double completeness_cutoff);
+
+}  // namespace distances
+}  // namespace skl_host

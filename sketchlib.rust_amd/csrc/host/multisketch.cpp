@@ -1,0 +1,225 @@
+#include "multisketch.hpp"
+
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+#include "cbor.hpp"
+#include "snappy_frame.hpp"
+
+namespace skl_host {
+
+static std::vector<uint8_t> read_file(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    f.seekg(0);
+    std::vector<uint8_t> buf((size_t)n);
+    if (n > 0) f.read((char *)buf.data(), n);
+    if (!f) throw std::runtime_error("cannot read " + path);
+    return buf;
+}
+
+MultiSketch::MultiSketch(std::vector<SketchMeta> meta, uint64_t sketch_size_bins,
+                         std::vector<size_t> kmers, std::string version)
+{
+    // MultiSketch::new, multisketch.rs:50-77
+    sketch_size = sketch_size_bins;
+    sketchsize64 = sketch_size_bins / 64;
+    kmer_lengths_ = std::move(kmers);
+    sketch_metadata_ = std::move(meta);
+    for (size_t i = 0; i < sketch_metadata_.size(); ++i) {
+        if (!sketch_metadata_[i].index) sketch_metadata_[i].index = i;
+        name_map_[sketch_metadata_[i].name] = (size_t)*sketch_metadata_[i].index;
+        name_map_order_.emplace_back(sketch_metadata_[i].name, (size_t)*sketch_metadata_[i].index);
+    }
+    bin_stride_ = 1;
+    kmer_stride_ = (size_t)(sketchsize64 * BBITS);
+    sample_stride_ = kmer_stride_ * kmer_lengths_.size();
+    sketch_version_ = std::move(version);
+    hash_type_ = "DNA";
+}
+
+MultiSketch MultiSketch::load_metadata(const std::string &file_prefix)
+{
+    const std::string filename = file_prefix + ".skm";
+    const CborValue root = cbor_decode(snappy_frame_decode(read_file(filename)));
+    if (root.kind != CborValue::MAP) throw std::runtime_error(filename + ": not a CBOR map");
+    auto need = [&](const char *key) -> const CborValue & {
+        const CborValue *v = root.get(key);
+        if (!v) throw std::runtime_error(filename + ": missing field " + key);
+        return *v;
+    };
+    MultiSketch m;
+    m.sketch_size = need("sketch_size").as_u64("sketch_size");
+    if (const CborValue *v = root.get("sketchsize64")) m.sketchsize64 = v->as_u64("sketchsize64");  // #[serde(default)]
+    for (const auto &k : need("kmer_lengths").arr) m.kmer_lengths_.push_back((size_t)k.as_u64("kmer_lengths"));
+    for (const auto &s : need("sketch_metadata").arr) {
+        SketchMeta sm;
+        if (const CborValue *v = s.get("name")) sm.name = v->s;
+        if (const CborValue *v = s.get("index")) {
+            if (v->kind == CborValue::UINT) sm.index = v->u;
+        }
+        if (const CborValue *v = s.get("rc")) sm.rc = v->b;
+        if (const CborValue *v = s.get("reads")) sm.reads = v->b;
+        if (const CborValue *v = s.get("seq_length")) sm.seq_length = v->as_u64("seq_length");
+        if (const CborValue *v = s.get("densified")) sm.densified = v->b;
+        if (const CborValue *v = s.get("acgt")) {
+            for (size_t i = 0; i < 4 && i < v->arr.size(); ++i) sm.acgt[i] = v->arr[i].as_u64("acgt");
+        }
+        if (const CborValue *v = s.get("non_acgt")) sm.non_acgt = v->as_u64("non_acgt");
+        m.sketch_metadata_.push_back(std::move(sm));
+    }
+    for (const auto &kv : need("name_map").map) {
+        m.name_map_[kv.first.s] = (size_t)kv.second.as_u64("name_map");
+        m.name_map_order_.emplace_back(kv.first.s, (size_t)kv.second.u);
+    }
+    m.bin_stride_ = (size_t)need("bin_stride").as_u64("bin_stride");
+    m.kmer_stride_ = (size_t)need("kmer_stride").as_u64("kmer_stride");
+    m.sample_stride_ = (size_t)need("sample_stride").as_u64("sample_stride");
+    m.sketch_version_ = need("sketch_version").s;
+    const CborValue &ht = need("hash_type");
+    if (ht.kind == CborValue::TEXT) {
+        m.hash_type_ = ht.s;
+    } else if (ht.kind == CborValue::MAP && !ht.map.empty()) {
+        m.hash_type_ = ht.map[0].first.s + ":" + ht.map[0].second.s;  // {"AA": "Level1"}
+    }
+    // For backwards compatibility (field added in v0.2.0), multisketch.rs:96-100
+    if (m.sketchsize64 == 0) {
+        m.sketchsize64 = m.sketch_size;
+        m.sketch_size *= 64;
+    }
+    return m;
+}
+
+void MultiSketch::save_metadata(const std::string &file_prefix) const
+{
+    CborValue root = CborValue::object();
+    root.put("sketch_size", CborValue::uint(sketch_size));
+    root.put("sketchsize64", CborValue::uint(sketchsize64));
+    CborValue ks = CborValue::array();
+    for (size_t k : kmer_lengths_) ks.arr.push_back(CborValue::uint(k));
+    root.put("kmer_lengths", ks);
+    CborValue metas = CborValue::array();
+    for (const auto &s : sketch_metadata_) {
+        CborValue o = CborValue::object();
+        o.put("name", CborValue::text(s.name));
+        o.put("index", s.index ? CborValue::uint(*s.index) : CborValue::null());
+        o.put("rc", CborValue::boolean(s.rc));
+        o.put("reads", CborValue::boolean(s.reads));
+        o.put("seq_length", CborValue::uint(s.seq_length));
+        o.put("densified", CborValue::boolean(s.densified));
+        CborValue acgt = CborValue::array();
+        for (uint64_t c : s.acgt) acgt.arr.push_back(CborValue::uint(c));
+        o.put("acgt", acgt);
+        o.put("non_acgt", CborValue::uint(s.non_acgt));
+        metas.arr.push_back(std::move(o));
+    }
+    root.put("sketch_metadata", metas);
+    CborValue nm = CborValue::object();
+    for (const auto &kv : name_map_order_) nm.put(kv.first, CborValue::uint(kv.second));
+    root.put("name_map", nm);
+    root.put("bin_stride", CborValue::uint(bin_stride_));
+    root.put("kmer_stride", CborValue::uint(kmer_stride_));
+    root.put("sample_stride", CborValue::uint(sample_stride_));
+    root.put("sketch_version", CborValue::text(sketch_version_));
+    const size_t colon = hash_type_.find(':');
+    if (colon == std::string::npos) {
+        root.put("hash_type", CborValue::text(hash_type_));
+    } else {
+        CborValue o = CborValue::object();
+        o.put(hash_type_.substr(0, colon), CborValue::text(hash_type_.substr(colon + 1)));
+        root.put("hash_type", o);
+    }
+    const std::vector<uint8_t> framed = snappy_frame_encode(cbor_encode(root));
+    std::ofstream f(file_prefix + ".skm", std::ios::binary);
+    if (!f) throw std::runtime_error("cannot create " + file_prefix + ".skm");
+    f.write((const char *)framed.data(), (std::streamsize)framed.size());
+}
+
+void MultiSketch::write_sketch_data(const std::string &file_prefix, const uint64_t *bins, size_t n_words)
+{
+    std::ofstream f(file_prefix + ".skd", std::ios::binary);
+    if (!f) throw std::runtime_error("cannot create " + file_prefix + ".skd");
+    f.write((const char *)bins, (std::streamsize)(n_words * sizeof(uint64_t)));  // little-endian host
+}
+
+void MultiSketch::read_sketch_data(const std::string &file_prefix)
+{
+    // read_all_from_skd streams the whole file (sketch_datafile.rs:159-168)
+    const std::vector<uint8_t> raw = read_file(file_prefix + ".skd");
+    sketch_bins_.resize(raw.size() / sizeof(uint64_t));
+    memcpy(sketch_bins_.data(), raw.data(), sketch_bins_.size() * sizeof(uint64_t));
+    block_reindex_.reset();
+}
+
+void MultiSketch::read_sketch_data_block(const std::string &file_prefix,
+                                         const std::vector<std::string> &names)
+{
+    std::vector<size_t> block_reindex, read_indices;
+    for (const auto &name : names) {
+        auto it = name_map_.find(name);
+        if (it == name_map_.end()) {
+            throw std::runtime_error("Could not find requested sample " + name + " in sketch metadata");
+        }
+        const size_t sketch_idx = it->second;
+        read_indices.push_back((size_t)sketch_metadata_.at(sketch_idx).index.value_or(sketch_idx));
+        block_reindex.push_back(sketch_idx);
+    }
+    std::ifstream f(file_prefix + ".skd", std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + file_prefix + ".skd");
+    sketch_bins_.assign(sample_stride_ * read_indices.size(), 0);
+    for (size_t i = 0; i < read_indices.size(); ++i) {
+        f.seekg((std::streamoff)(read_indices[i] * sample_stride_ * sizeof(uint64_t)));
+        f.read((char *)(sketch_bins_.data() + i * sample_stride_),
+               (std::streamsize)(sample_stride_ * sizeof(uint64_t)));
+        if (!f) throw std::runtime_error(file_prefix + ".skd is shorter than its metadata says");
+    }
+    block_reindex_ = std::move(block_reindex);
+}
+
+size_t MultiSketch::number_samples_loaded() const
+{
+    return block_reindex_ ? block_reindex_->size() : sketch_metadata_.size();
+}
+
+std::optional<size_t> MultiSketch::get_k_idx(size_t k) const
+{
+    for (size_t i = 0; i < kmer_lengths_.size(); ++i) {
+        if (kmer_lengths_[i] == k) return i;
+    }
+    return std::nullopt;
+}
+
+const std::string &MultiSketch::sketch_name(size_t index) const
+{
+    return block_reindex_ ? sketch_metadata_.at((*block_reindex_).at(index)).name
+                          : sketch_metadata_.at(index).name;
+}
+
+std::optional<size_t> MultiSketch::get_sample_index(const std::string &name) const
+{
+    if (block_reindex_) {
+        for (size_t logical = 0; logical < block_reindex_->size(); ++logical) {
+            if (sketch_metadata_[(*block_reindex_)[logical]].name == name) return logical;
+        }
+        return std::nullopt;
+    }
+    auto it = name_map_.find(name);
+    if (it == name_map_.end()) return std::nullopt;
+    return it->second;
+}
+
+const uint64_t *MultiSketch::get_sketch_slice(size_t sketch_idx, size_t k_idx) const
+{
+    return sketch_bins_.data() + sketch_idx * sample_stride_ + k_idx * kmer_stride_;
+}
+
+bool MultiSketch::is_compatible_with(const MultiSketch &o) const
+{
+    return kmer_lengths_ == o.kmer_lengths_ && sketch_size == o.sketch_size && hash_type_ == o.hash_type_;
+}
+
+}  // namespace skl_host

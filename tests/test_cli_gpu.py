@@ -1,0 +1,78 @@
+"""`sketchlib dist` (C++ host + HIP engine) against the reference's CLI goldens and the
+oracle, in the style of the reference's own tests/distance.rs / tests/inverted.rs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REF_FIXTURES, ROOT
+from helpers import FIXTURE_NAMES, load_fixture_bins, rust_f32
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build", "sketchlib")
+
+
+def run(*args):
+    res = subprocess.run([CLI, "dist", *args], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return res.stdout
+
+
+@pytest.mark.parametrize("flags,golden", [((), "inverted_precluster.stdout"),
+                                          (("--ani",), "inverted_precluster_ani.stdout")])
+def test_sketches3_knn1_reference_stdout(gpu_ctx, flags, golden):
+    out = run(os.path.join(REF_FIXTURES, "sketches3"), "-k", "21", "--knn", "1", *flags)
+    expected = open(os.path.join(REF_FIXTURES, golden)).read()
+    assert sorted(out.splitlines()) == sorted(expected.splitlines())
+
+
+def test_dense_self_text_matches_oracle(oracle, gpu_ctx):
+    bins, n, kmers, ss64 = load_fixture_bins("sketches2")
+    o = oracle.Sketches(bins, n, kmers, ss64)
+    d = oracle.self_dists_all(o, oracle.JACCARD, 0).ravel()
+    lines, x = [], 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            lines.append(f"{FIXTURE_NAMES[i]}\t{FIXTURE_NAMES[j]}\t{rust_f32(d[x])}")
+            x += 1
+    assert run(os.path.join(REF_FIXTURES, "sketches2.skm"), "-k", "31") == "\n".join(lines) + "\n"
+
+
+def test_legacy_db_coreacc_text(gpu_ctx):
+    out = run(os.path.join(REF_FIXTURES, "legacy_db"))
+    assert out == "R6.fa.gz\tTIGR4.fa.gz\t0.02203464\t0\n"
+
+
+def test_subset_order_follows_file(gpu_ctx, oracle, tmp_path):
+    """--subset: rows/names follow the subset file order (tests/distance.rs:690-721)."""
+    sub = tmp_path / "subset.txt"
+    sub.write_text("TIGR4.fa.gz\n14412_3#82.contigs_velvet.fa.gz\nR6.fa.gz\n")
+    out = run(os.path.join(REF_FIXTURES, "sketches1"), "-k", "31", "--subset", str(sub))
+    names = [l.split("\t")[:2] for l in out.splitlines()]
+    assert names == [["TIGR4.fa.gz", "14412_3#82.contigs_velvet.fa.gz"], ["TIGR4.fa.gz", "R6.fa.gz"],
+                     ["14412_3#82.contigs_velvet.fa.gz", "R6.fa.gz"]]
+    vals = [l.split("\t")[2] for l in out.splitlines()]
+    assert vals == ["1", "0.33789062", "1"]   # App. A: (0,3)=1, (2,3)=0.33789062, (0,2)=1
+
+
+def test_cross_query_and_output_file(gpu_ctx, oracle, tmp_path):
+    out_file = tmp_path / "d.txt"
+    db = os.path.join(REF_FIXTURES, "sketches1")
+    subprocess.check_call([CLI, "dist", db, db, "-k", "31", "-o", str(out_file)])
+    lines = out_file.read_text().splitlines()
+    assert len(lines) == 16 and lines[0].split("\t")[2] == "0"      # ref vs itself: 1 - J = 0
+    assert lines[1] == "14412_3#82.contigs_velvet.fa.gz\t14412_3#84.contigs_velvet.fa.gz\t0.4169922"
+    # cross kNN: 4 query rows x knn
+    out = run(db, db, "-k", "31", "--knn", "2", "--ani")
+    rows = out.splitlines()
+    assert len(rows) == 8 and rows[0].split("\t")[:2] == [FIXTURE_NAMES[0], FIXTURE_NAMES[0]]
+    assert rows[0].split("\t")[2] == "1"                            # ANI of a genome with itself
+
+
+def test_knn_clamped_like_reference(gpu_ctx):
+    """lib.rs:379-382: self kNN >= n is clamped to n - 1."""
+    out = run(os.path.join(REF_FIXTURES, "sketches1"), "-k", "31", "--knn", "50")
+    rows = out.splitlines()
+    # 4 rows x 3 neighbours, minus padding-suppressed lines (none here: col != row always)
+    assert len(rows) == 12

@@ -1,0 +1,140 @@
+"""The reference's on-disk layout (.skm snappy-framed CBOR, .skd raw LE u64) through the
+C++ host layer, without a GPU: parsing the committed fixtures (incl. the pre-0.2.0
+legacy_db rule, multisketch.rs:96-100 / tests/sketch.rs:145), write -> read round trips,
+and an independent Python decode of what the C++ writer emits."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REF_FIXTURES, ROOT
+from helpers import FIXTURE_DBS, FIXTURE_NAMES
+
+BUILD = os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build")
+DBTOOL = os.path.join(BUILD, "skl_dbtool")
+CLI = os.path.join(BUILD, "sketchlib")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built(skl):
+    assert os.path.exists(DBTOOL) and os.path.exists(CLI)
+
+
+def _info(prefix):
+    out = subprocess.check_output([DBTOOL, "info", prefix], text=True)
+    d, samples = {}, []
+    for line in out.splitlines():
+        parts = line.split("\t")
+        if parts[0] == "sample":
+            samples.append(parts[1:])
+        else:
+            d[parts[0]] = parts[1]
+    return d, samples
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURE_DBS))
+def test_skm_fields(name):
+    n, kmers, ss64 = FIXTURE_DBS[name]
+    d, samples = _info(os.path.join(REF_FIXTURES, name))
+    assert int(d["sketchsize64"]) == ss64
+    assert int(d["sketch_size"]) == ss64 * 64          # legacy: sketch_size *= 64
+    assert [int(k) for k in d["kmer_lengths"].split(",")] == kmers
+    assert int(d["n_samples"]) == n == len(samples)
+    assert int(d["kmer_stride"]) == ss64 * 14
+    assert int(d["sample_stride"]) == ss64 * 14 * len(kmers)
+    assert d["hash_type"] == "DNA"
+    names = [s[1] for s in samples]
+    assert names == (FIXTURE_NAMES if n == 4 else ["R6.fa.gz", "TIGR4.fa.gz"])
+    assert [int(s[2]) for s in samples] == list(range(n))   # .skd block positions
+
+
+def test_legacy_version_string():
+    d, _ = _info(os.path.join(REF_FIXTURES, "legacy_db.skm"))  # prefix given with extension
+    assert d["sketch_version"] == "0.1.3"
+
+
+def test_get_sketch_slice_matches_skd_bytes():
+    prefix = os.path.join(REF_FIXTURES, "legacy_db")
+    raw = np.fromfile(prefix + ".skd", dtype="<u8")
+    out = subprocess.check_output([DBTOOL, "slice", prefix, "1", "2"], text=True)
+    words = np.array([int(x) for x in out.split()], dtype=np.uint64)
+    kmer_stride, sample_stride = 28, 84
+    assert np.array_equal(words, raw[1 * sample_stride + 2 * kmer_stride:][:kmer_stride])
+
+
+def _py_unframe(data):
+    """Independent check of the writer: snappy frame with uncompressed chunks + masked CRC32C."""
+    import struct
+    assert data[:10] == b"\xff\x06\x00\x00sNaPpY"
+    i, out = 10, b""
+    table = []
+    for n in range(256):
+        c = n
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        table.append(c)
+
+    def crc32c(b):
+        c = 0xFFFFFFFF
+        for x in b:
+            c = table[(c ^ x) & 0xFF] ^ (c >> 8)
+        return c ^ 0xFFFFFFFF
+
+    while i < len(data):
+        t = data[i]
+        ln = int.from_bytes(data[i + 1:i + 4], "little")
+        body = data[i + 4:i + 4 + ln]
+        i += 4 + ln
+        assert t == 0x01, "writer emits uncompressed chunks"
+        crc = struct.unpack("<I", body[:4])[0]
+        payload = body[4:]
+        c = crc32c(payload)
+        assert crc == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+        out += payload
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURE_DBS))
+def test_roundtrip_write_read(tmp_path, name):
+    src = os.path.join(REF_FIXTURES, name)
+    dst = str(tmp_path / "copy")
+    subprocess.check_call([DBTOOL, "roundtrip", src, dst])
+    assert open(dst + ".skd", "rb").read() == open(src + ".skd", "rb").read()
+    a, sa = _info(src)
+    b, sb = _info(dst)
+    assert a == b and sa == sb
+    cbor = _py_unframe(open(dst + ".skm", "rb").read())
+    assert cbor[0] >> 5 == 5 and b"sketch_metadata" in cbor and b"name_map" in cbor
+
+
+def test_corrupt_skm_is_rejected(tmp_path):
+    data = bytearray(open(os.path.join(REF_FIXTURES, "sketches1.skm"), "rb").read())
+    data[40] ^= 0xFF
+    bad = tmp_path / "bad.skm"
+    bad.write_bytes(bytes(data))
+    res = subprocess.run([DBTOOL, "info", str(bad)], capture_output=True, text=True)
+    assert res.returncode == 1 and "Error:" in res.stderr
+
+
+def test_cli_usage_errors():
+    db = os.path.join(REF_FIXTURES, "sketches3")
+    res = subprocess.run([CLI, "dist", db, "--ani"], capture_output=True, text=True)
+    assert res.returncode == 2 and "-k <KMER>" in res.stderr       # --ani requires -k (cli.rs:211-213)
+    res = subprocess.run([CLI, "dist", db, "--threads", "0"], capture_output=True, text=True)
+    assert res.returncode == 2 and "Threads must be one or higher" in res.stderr   # cli.rs:63-73
+    res = subprocess.run([CLI, "dist"], capture_output=True, text=True)
+    assert res.returncode == 2 and "<REF_DB>" in res.stderr
+    res = subprocess.run([CLI, "dist", "/nonexistent/db"], capture_output=True, text=True)
+    assert res.returncode == 101 and "Could not read sketch metadata" in res.stderr   # lib.rs:322-323
+    res = subprocess.run([CLI, "dist", db, "-k", "33"], capture_output=True, text=True)
+    assert res.returncode == 101 and "K-mer size 33 not found in file" in res.stderr   # lib.rs:341-343
+
+
+def test_cli_rejects_percent_completeness(tmp_path):
+    """tests/distance.rs:619-623: percentages are an error mentioning [0.0, 1.0]."""
+    comp = tmp_path / "comp.txt"
+    comp.write_text("R6.fa.gz\t95.0\nTIGR4.fa.gz\t0.9\n")
+    res = subprocess.run([CLI, "dist", os.path.join(REF_FIXTURES, "sketches3"), "-k", "21",
+                          "--ref-completeness-file", str(comp)], capture_output=True, text=True)
+    assert res.returncode == 1 and "[0.0, 1.0]" in res.stderr and "R6.fa.gz: 95" in res.stderr
