@@ -63,11 +63,19 @@ def test_cross_query_and_output_file(gpu_ctx, oracle, tmp_path):
     lines = out_file.read_text().splitlines()
     assert len(lines) == 16 and lines[0].split("\t")[2] == "0"      # ref vs itself: 1 - J = 0
     assert lines[1] == "14412_3#82.contigs_velvet.fa.gz\t14412_3#84.contigs_velvet.fa.gz\t0.4169922"
-    # cross kNN: 4 query rows x knn
+    # cross kNN, 4 query rows x knn=2 in ANI mode.  The genome's own ref entry has ANI 1.0
+    # and the same name, which the reference's Display treats as padding and suppresses
+    # (distance_matrix.rs:379-381) -- so only the second neighbour of each row prints.
     out = run(db, db, "-k", "31", "--knn", "2", "--ani")
-    rows = out.splitlines()
-    assert len(rows) == 8 and rows[0].split("\t")[:2] == [FIXTURE_NAMES[0], FIXTURE_NAMES[0]]
-    assert rows[0].split("\t")[2] == "1"                            # ANI of a genome with itself
+    rows = [l.split("\t") for l in out.splitlines()]
+    assert [r[:2] for r in rows] == [[FIXTURE_NAMES[0], FIXTURE_NAMES[1]], [FIXTURE_NAMES[1], FIXTURE_NAMES[0]],
+                                     [FIXTURE_NAMES[2], FIXTURE_NAMES[3]], [FIXTURE_NAMES[3], FIXTURE_NAMES[2]]]
+    assert [r[2] for r in rows] == ["0.9901376", "0.9901376", "0.99266887", "0.99266887"]
+    # Jaccard distances: the self entry (distance 0 < 1) is printed
+    out = run(db, db, "-k", "31", "--knn", "2")
+    rows = [l.split("\t") for l in out.splitlines()]
+    assert len(rows) == 8 and rows[0] == [FIXTURE_NAMES[0], FIXTURE_NAMES[0], "0"]
+    assert rows[1] == [FIXTURE_NAMES[0], FIXTURE_NAMES[1], "0.4169922"]
 
 
 def test_knn_clamped_like_reference(gpu_ctx):
