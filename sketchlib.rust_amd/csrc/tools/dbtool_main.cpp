@@ -2,12 +2,14 @@
 //   skl_dbtool info <prefix>            dump the .skm fields (one `key<TAB>value` per line)
 //   skl_dbtool roundtrip <in> <out>     load <in>.skm/.skd and write them back as <out>.*
 //   skl_dbtool slice <prefix> <i> <k>   print the u64 words of get_sketch_slice(i, k_idx)
+//   skl_dbtool make <prefix> <bins> <k1,k2,..> <name>...  write <prefix>.skm for an existing .skd
 // Used by the test-suite to pin the file-format code without a GPU, and to write
 // synthetic databases in the reference's on-disk layout.
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "../host/io.hpp"
 #include "../host/multisketch.hpp"
@@ -52,7 +54,33 @@ int main(int argc, char **argv)
             for (size_t w = 0; w < m.kmer_stride(); ++w) std::cout << p[w] << "\n";
             return 0;
         }
-        std::cerr << "usage: skl_dbtool info|roundtrip|slice ...\n";
+        if (argc >= 6 && std::string(argv[1]) == "make") {
+            // make <prefix> <sketch_size_bins> <k1,k2,...> <name>...: write <prefix>.skm for an
+            // existing <prefix>.skd whose sample blocks are in the order of the names
+            const std::string prefix = strip_sketch_extension(argv[2]);
+            const uint64_t bins = strtoull(argv[3], nullptr, 10);
+            std::vector<size_t> kmers;
+            std::string ks = argv[4];
+            size_t pos = 0;
+            while (pos <= ks.size()) {
+                const size_t comma = ks.find(',', pos);
+                const std::string tok = ks.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                if (!tok.empty()) kmers.push_back((size_t)strtoull(tok.c_str(), nullptr, 10));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
+            std::vector<SketchMeta> meta;
+            for (int i = 5; i < argc; ++i) {
+                SketchMeta sm;
+                sm.name = argv[i];
+                sm.index = (uint64_t)(i - 5);
+                meta.push_back(sm);
+            }
+            MultiSketch m(std::move(meta), bins, kmers);
+            m.save_metadata(prefix);
+            return 0;
+        }
+        std::cerr << "usage: skl_dbtool info|roundtrip|slice|make ...\n";
         return 2;
     } catch (const std::exception &e) {
         std::cerr << "Error: " << e.what() << "\n";

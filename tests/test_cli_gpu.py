@@ -84,3 +84,29 @@ def test_knn_clamped_like_reference(gpu_ctx):
     rows = out.splitlines()
     # 4 rows x 3 neighbours, minus padding-suppressed lines (none here: col != row always)
     assert len(rows) == 12
+
+
+# ---- the reference's own CLI tests over the 4-genome, 4-k database ----
+GEN_DB = os.path.join(os.path.dirname(REF_FIXTURES), "generated", "sketch_db_4k")
+
+
+@pytest.mark.parametrize("flags,golden", [
+    (("--knn", "1"), "dists_knn_ca.stdout"),                         # tests/distance.rs:293-302
+    (("--knn", "1", "-k", "21"), "dists_knn_jaccard.stdout"),        # :304-315
+    (("--knn", "1", "-k", "21", "--ani"), "dists_knn_ani.stdout"),   # :317-328
+])
+def test_knn_dists_exact_stdout(gpu_ctx, flags, golden):
+    assert run(GEN_DB, "-v", *flags) == open(os.path.join(REF_FIXTURES, golden)).read()
+
+
+def test_subset_dists_exact_stdout(gpu_ctx):
+    """tests/distance.rs:690-721"""
+    out = run(GEN_DB, "--subset", os.path.join(REF_FIXTURES, "subset.txt"))
+    assert out == open(os.path.join(REF_FIXTURES, "dists_subset.stdout")).read()
+
+
+def test_completeness_file_all_ones_is_identity(gpu_ctx):
+    """completeness.txt lists 1.0 for every genome: the corrected output equals the plain one."""
+    plain = run(GEN_DB)
+    comp = run(GEN_DB, "--ref-completeness-file", os.path.join(REF_FIXTURES, "completeness.txt"))
+    assert plain == comp

@@ -136,3 +136,55 @@ def test_knn_tie_modes_agree_on_distances(oracle):
     assert np.all(np.diff(b["d0"], axis=1) >= 0)
     # heap order is ascending too (into_sorted_vec)
     assert np.all(np.diff(a["d0"], axis=1) >= 0)
+
+
+# ---------------------------------------------------------------------------
+# The reference's exact-text goldens over the 4-genome, 4-k database
+# (tests/distance.rs:270-328 knn_dists, :690-721 subset_dists).  The database is
+# regenerated from the reference's FASTA by oracle/sketcher.py, itself pinned bit-exactly
+# on sketches{1,2,3}.skd -- see tests/golden/make_generated_fixtures.py.
+# ---------------------------------------------------------------------------
+GEN = os.path.join(os.path.dirname(REF_FIXTURES), "generated")
+K4 = [17, 21, 25, 29]
+
+
+def _db4(oracle, subset=None):
+    bins = np.fromfile(os.path.join(GEN, "sketch_db_4k.skd"), dtype="<u8").reshape(4, -1)
+    names = list(FIXTURE_NAMES)
+    if subset is not None:
+        bins = bins[[names.index(s) for s in subset]]
+        names = subset
+    return oracle.Sketches(bins, len(names), K4, 157), names
+
+
+@pytest.mark.parametrize("dist,golden", [("coreacc", "dists_knn_ca.stdout"),
+                                         ("jaccard", "dists_knn_jaccard.stdout"),
+                                         ("ani", "dists_knn_ani.stdout")])
+def test_knn_goldens_exact_text(oracle, dist, golden):
+    s, names = _db4(oracle)
+    if dist == "coreacc":
+        text = _knn_text(oracle, s, names, 1, oracle.COREACC, 0, False)
+    else:
+        text = _knn_text(oracle, s, names, 1, oracle.JACCARD, 1, dist == "ani")
+    assert text == open(os.path.join(REF_FIXTURES, golden)).read()
+
+
+def test_subset_golden_exact_text(oracle):
+    subset = open(os.path.join(REF_FIXTURES, "subset.txt")).read().split()
+    s, names = _db4(oracle, subset)
+    d = oracle.self_dists_all(s)
+    lines, x = [], 0
+    for i in range(len(names)):
+        for j in range(i + 1, len(names)):
+            lines.append(f"{names[i]}\t{names[j]}\t{rust_f32(d[x][0])}\t{rust_f32(d[x][1])}")
+            x += 1
+    assert "\n".join(lines) + "\n" == open(os.path.join(REF_FIXTURES, "dists_subset.stdout")).read()
+
+
+def test_db4_samebits_appendix_a(oracle):
+    s, _ = _db4(oracle)
+    bm = oracle.self_binmatch(s)
+    assert bm[0].tolist() == [6811, 6547, 6310, 6127]      # (0,1)
+    assert bm[5].tolist() == [7167, 6871, 6623, 6342]      # (2,3)
+    assert bm[4].tolist() == [7, 1, 1, 3]                  # (1,3): regression on noise
+    assert bm[1].tolist() == [12, 0, 1, 0]                 # (0,2): early break
