@@ -19,6 +19,19 @@ __device__ __forceinline__ uint32_t acc_mismatch(uint32_t m, uint32_t a, uint32_
     }
 }
 
+// Same function with the operands placed for the register file (all-VGPR form used by the
+// LDS kernel): src0 = row dword, src1 = column dword, src2 = accumulator; truth table
+// (F0 ^ CC) | AA = 0xBE.  Measured on MI355X (scripts/microbench/vgpr_banks.hip):
+// v_bitop3_b32 issues at half rate exactly when src0 and src1 come from the same VGPR bank
+// (register index mod 4); src2 and the destination are free.  The column slab stores each
+// plane as (hi, lo), so the dword that pairs with the row's even-register component always
+// sits in an odd register and vice versa (128-bit VGPR tuples are even-aligned on gfx950):
+// the conflict cannot occur, whatever the register allocator does.
+__device__ __forceinline__ uint32_t acc_mismatch_vvv(uint32_t m, uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, m, 0xBE);
+}
+
 // jaccard.rs:14,26-44 on the device (used when a completeness correction makes the
 // host-built tables inapplicable).
 __device__ __forceinline__ double jaccard_from_samebits_dev(uint32_t samebits, uint32_t ss64,

@@ -60,7 +60,7 @@ int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream);
 
 // LDS-staged variant (pair_lds.hip).  shape = R*10 + JL: R rows per workgroup tile, JL
-// 64-column blocks per lane; valid shapes: 41, 81, 82, 122, 162.
+// 64-column blocks per lane; valid shapes: 41, 81, 82, 162.
 hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, hipStream_t stream);
 int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 

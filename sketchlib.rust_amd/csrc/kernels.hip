@@ -130,8 +130,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
                 // First touch of this row's SGPRs: the compiler's s_waitcnt lgkmcnt(0)
                 // lands here, BEFORE the next row's loads are issued (SMEM returns out of
                 // order, so a wait placed after them would wait for them too).
-                uint32_t mlo = a_cur.w[0] ^ b[0].x;
-                uint32_t mhi = a_cur.w[1] ^ b[0].y;
+                uint32_t mlo = a_cur.w[0] ^ b[0].y;
+                uint32_t mhi = a_cur.w[1] ^ b[0].x;
                 __builtin_amdgcn_sched_barrier(0);
                 // next row's chunk (or row 0 of the next chunk): in flight under this
                 // row's 28 VALU ops
@@ -140,14 +140,14 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
                                                        (size_t)c * BBITS)
                                       : load_row_chunk(ap + (size_t)cn * BBITS);
                 __builtin_amdgcn_sched_barrier(0);
-                mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[2], b[0].z);
-                mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[3], b[0].w);
+                mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[2], b[0].w);
+                mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[3], b[0].z);
 #pragma unroll
                 for (int q = 1; q < 7; ++q) {
-                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 0], b[q].x);
-                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 1], b[q].y);
-                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 2], b[q].z);
-                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 3], b[q].w);
+                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 0], b[q].y);
+                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 1], b[q].x);
+                    mlo = acc_mismatch<BITOP3>(mlo, a_cur.w[4 * q + 2], b[q].w);
+                    mhi = acc_mismatch<BITOP3>(mhi, a_cur.w[4 * q + 3], b[q].z);
                 }
                 st0[ia] += __builtin_popcount(mlo);
                 st0[ia] += __builtin_popcount(mhi);
@@ -252,7 +252,7 @@ hipError_t launch_pair_kernel(const PairArgs &args_in, int mode, int na, hipStre
 }
 
 // ---------------------------------------------------------------------------
-// slab re-layout: reference [sample][k][chunk][plane] -> [jb][k][chunk][q][lane]{2 planes}
+// slab re-layout: reference [sample][k][chunk][plane] -> [jb][k][chunk][q][lane]{2 planes, hi:lo}
 // ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void relayout_kernel(const uint64_t *__restrict__ src,
@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256) void relayout_kernel(const uint64_t *__restric
         if (j < n) {
             const uint64_t w = ((j * nk + k) * ss64 + c) * BBITS + 2u * q;
             const uint64_t p0 = src[w], p1 = src[w + 1];
-            v = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
+            // (hi, lo) order inside each plane: see "VGPR banks" in pair_lds.hip -- the dword
+            // that meets row-operand component .x (even register) sits in .y (odd register)
+            v = make_uint4((uint32_t)(p0 >> 32), (uint32_t)p0, (uint32_t)(p1 >> 32), (uint32_t)p1);
         }
         dst[o] = v;
     }

@@ -18,6 +18,8 @@
 //     + 2 v_bcnt (popcount fused with the accumulate).
 // LDS traffic: 28 LDS cycles per wave-row-step against JL x ~87 VALU cycles, so JL = 2
 // keeps the LDS pipe at ~2/3 of the VALU time and the kernel VALU-bound.
+// Template flag ADB ("ahead"): rolling one-row prefetch of the row registers (default);
+// false = read, wait, compute per row (kept for A/B measurements).
 #include "device_common.hpp"
 
 #include <cstdlib>
@@ -27,10 +29,10 @@ namespace skl {
 constexpr int STAGE_CHUNKS = 8;  // chunks per LDS stage
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <int R, int JL, int MODE, bool ADB>
+template <int R, int JL, int MODE, bool ADB, int ORD, int ABL = 0>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const PairArgs g)
 {
-    constexpr int S = STAGE_CHUNKS;
+    constexpr int S = R > 16 ? STAGE_CHUNKS / 2 : STAGE_CHUNKS;
     constexpr int PIECES = R * S * 7;                     // 16-byte pieces per stage
     constexpr int PPT = (PIECES + 255) / 256;             // pieces per thread
     constexpr int P = R * JL;                             // pairs per lane
@@ -137,6 +139,11 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
                 uint4 b[JL][7];
 #pragma unroll
                 for (int j = 0; j < JL; ++j) {
+                    if ((ABL & 2) && c > 0) {  // timing-only ablation: reuse stale registers
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) asm volatile("" : "=v"(b[j][q]));
+                        continue;
+                    }
                     const uint32_t jb = (jb0 + j) < g.n_jblocks ? (jb0 + j) : (g.n_jblocks - 1u);
                     const uint4 *bp =
                         g.B + (((size_t)jb * g.nk + k) * g.ss64 + (c0 + c)) * (7 * LANES) + lane;
@@ -144,55 +151,58 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
                     for (int q = 0; q < 7; ++q) b[j][q] = bp[q * LANES];
                 }
                 const uint4 *rows = &lds_rows[buf][(size_t)c * R * 7];
-                uint4 a[2][7];
+                // Row operand: 7 uniform-address ds_read_b128 per row put the row's 14 planes
+                // into 28 VGPRs of every lane.  Rolling prefetch with no extra registers: the
+                // read of row r+1's plane pair q is issued right after row r's last use of
+                // a[q] (LDS returns in order, so the counted lgkmcnt the compiler inserts
+                // before each use is exact).  Prefetch distance: most of one row's VALU work.
+                uint4 a[7];
                 if constexpr (ADB) {
 #pragma unroll
-                    for (int q = 0; q < 7; ++q) a[0][q] = rows[q];
+                    for (int q = 0; q < 7; ++q) a[q] = rows[q];
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    // row r's 7 broadcast reads (uniform address).  ADB: row r+1 is read
-                    // one step ahead; the scheduling barriers keep the compiler from
-                    // hoisting every row's reads to the top (>200 VGPRs otherwise).
-                    constexpr int unused = 0;
-                    (void)unused;
-                    const int cur = ADB ? (r & 1) : 0;
-                    if constexpr (ADB) {
-                        if (r + 1 < R) {
+                    if constexpr (!ADB) {
 #pragma unroll
-                            for (int q = 0; q < 7; ++q) a[cur ^ 1][q] = rows[(r + 1) * 7 + q];
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) a[0][q] = rows[r * 7 + q];
+                        for (int q = 0; q < 7; ++q) a[q] = rows[r * 7 + q];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    uint32_t mlo[JL], mhi[JL];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+#pragma unroll
+                        for (int j = 0; j < JL; ++j) {
+                            // b is stored (hi, lo) per plane: .y/.w are the low halves
+                            if (q == 0) {
+                                mlo[j] = a[0].x ^ b[j][0].y;
+                                mhi[j] = a[0].y ^ b[j][0].x;
+                            } else {
+                                mlo[j] = ORD ? acc_mismatch_vvv(mlo[j], a[q].x, b[j][q].y)
+                                             : acc_mismatch<true>(mlo[j], a[q].x, b[j][q].y);
+                                mhi[j] = ORD ? acc_mismatch_vvv(mhi[j], a[q].y, b[j][q].x)
+                                             : acc_mismatch<true>(mhi[j], a[q].y, b[j][q].x);
+                            }
+                            mlo[j] = ORD ? acc_mismatch_vvv(mlo[j], a[q].z, b[j][q].w)
+                                         : acc_mismatch<true>(mlo[j], a[q].z, b[j][q].w);
+                            mhi[j] = ORD ? acc_mismatch_vvv(mhi[j], a[q].w, b[j][q].z)
+                                         : acc_mismatch<true>(mhi[j], a[q].w, b[j][q].z);
+                        }
+                        if constexpr (ADB) {
+                            // a[q] is dead for this row: start fetching the next row's
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (r + 1 < R && !(ABL & 1)) a[q] = rows[(r + 1) * 7 + q];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < JL; ++j) {
-                        // VGPR banks (measured, scripts/microbench/vgpr_banks.hip): v_bitop3_b32
-                        // drops to half rate when src0 sits in the accumulator's bank.  128-bit
-                        // load results are even-aligned tuples, so .x/.z are in even registers
-                        // and .y/.w in odd ones; keeping the two accumulators as ONE aligned
-                        // 64-bit pair and accumulating the even-register planes into its odd
-                        // half (and vice versa) makes the conflict impossible.
-                        u32x2 m;
-                        m.y = a[cur][0].x ^ b[j][0].x;  // low halves of the planes
-                        m.x = a[cur][0].y ^ b[j][0].y;  // high halves
-                        asm volatile("" : "+v"(m));
-                        m.y = acc_mismatch<true>(m.y, a[cur][0].z, b[j][0].z);
-                        m.x = acc_mismatch<true>(m.x, a[cur][0].w, b[j][0].w);
-#pragma unroll
-                        for (int q = 1; q < 7; ++q) {
-                            m.y = acc_mismatch<true>(m.y, a[cur][q].x, b[j][q].x);
-                            m.x = acc_mismatch<true>(m.x, a[cur][q].y, b[j][q].y);
-                            m.y = acc_mismatch<true>(m.y, a[cur][q].z, b[j][q].z);
-                            m.x = acc_mismatch<true>(m.x, a[cur][q].w, b[j][q].w);
-                        }
-                        asm volatile("" : "+v"(m));
-                        cnt[r * JL + j] += __builtin_popcount(m.y);
-                        cnt[r * JL + j] += __builtin_popcount(m.x);
+                        // popcount with the add fused (v_bcnt_u32_b32 d, m, d): hipcc otherwise
+                        // emits two bcnt + one add3 -- three half-rate ops instead of two
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[j]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[j]));
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!ADB) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -256,21 +266,21 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
     }
 }
 
-template <int R, int JL, bool ADB>
-static hipError_t launch_rja(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
+template <int R, int JL, bool ADB, int ORD>
+static hipError_t launch_rjao(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
 {
     const dim3 block(LANES * WAVES_PER_WG);
     switch (mode) {
         case MODE_COUNTS:
-            hipLaunchKernelGGL((pair_kernel_lds<R, JL, MODE_COUNTS, ADB>), grid, block, 0, stream,
+            hipLaunchKernelGGL((pair_kernel_lds<R, JL, MODE_COUNTS, ADB, ORD>), grid, block, 0, stream,
                                args);
             break;
         case MODE_JACCARD:
-            hipLaunchKernelGGL((pair_kernel_lds<R, JL, MODE_JACCARD, ADB>), grid, block, 0, stream,
+            hipLaunchKernelGGL((pair_kernel_lds<R, JL, MODE_JACCARD, ADB, ORD>), grid, block, 0, stream,
                                args);
             break;
         case MODE_COREACC:
-            hipLaunchKernelGGL((pair_kernel_lds<R, JL, MODE_COREACC, ADB>), grid, block, 0, stream,
+            hipLaunchKernelGGL((pair_kernel_lds<R, JL, MODE_COREACC, ADB, ORD>), grid, block, 0, stream,
                                args);
             break;
         default: return hipErrorInvalidValue;
@@ -281,12 +291,9 @@ static hipError_t launch_rja(const PairArgs &args, int mode, dim3 grid, hipStrea
 template <int R, int JL>
 static hipError_t launch_rj(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
 {
-    static const bool adb = [] {
-        const char *e = getenv("SKL_LDS_ADB");  // tuning knob: double-buffer the row reads
-        return e ? atoi(e) != 0 : true;
-    }();
-    return adb ? launch_rja<R, JL, true>(args, mode, grid, stream)
-               : launch_rja<R, JL, false>(args, mode, grid, stream);
+    // ADB = true (rolling row prefetch), ORD = 1 (accumulator in src2): the A/B runs that
+    // chose them are in profiles/r01_kernel_sweeps.jsonl
+    return launch_rjao<R, JL, true, 1>(args, mode, grid, stream);
 }
 
 // shape: rows R and columns-per-lane JL, encoded as R*10 + JL
@@ -303,11 +310,21 @@ hipError_t launch_pair_kernel_lds(const PairArgs &args_in, int mode, int shape, 
     const uint64_t n_wg = 8ull * ((jgroups + 7u) / 8u) * args.a_tiles;
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);
+    static const int abl = [] {
+        const char *e = getenv("SKL_LDS_ABLATE");  // timing-only: 1 no row re-reads, 2 no column reloads
+        return e ? atoi(e) : 0;
+    }();
+    if (abl && shape == 162 && mode == MODE_COREACC) {
+        const dim3 block(LANES * WAVES_PER_WG);
+        if (abl == 1) hipLaunchKernelGGL((pair_kernel_lds<16, 2, MODE_COREACC, true, 1, 1>), grid, block, 0, stream, args);
+        else if (abl == 2) hipLaunchKernelGGL((pair_kernel_lds<16, 2, MODE_COREACC, true, 1, 2>), grid, block, 0, stream, args);
+        else hipLaunchKernelGGL((pair_kernel_lds<16, 2, MODE_COREACC, true, 1, 3>), grid, block, 0, stream, args);
+        return hipGetLastError();
+    }
     switch (shape) {
         case 41: return launch_rj<4, 1>(args, mode, grid, stream);
         case 81: return launch_rj<8, 1>(args, mode, grid, stream);
         case 82: return launch_rj<8, 2>(args, mode, grid, stream);
-        case 122: return launch_rj<12, 2>(args, mode, grid, stream);
         case 162: return launch_rj<16, 2>(args, mode, grid, stream);
         default: return hipErrorInvalidValue;
     }
