@@ -45,17 +45,28 @@ def algorithmic_bytes_per_pair(nk, ss64, ncols):
     return 2 * nk * ss64 * 14 * 8 + 4 * ncols
 
 
-def cpu_baseline(n, kmers, ss64, dataset):
-    """The oracle (CPU restatement of the reference's rayon path) on the same workload,
-    all host cores, best of 3."""
-    import numpy as np
-
+def cpu_baseline(kmers, ss64, dataset):
+    """The oracle (CPU restatement of the reference's rayon path: 1000-pair chunks over the
+    condensed triangle, src/distances/mod.rs:20,69-76) on all host cores, on a bounded
+    sample of the same workload: the sample size is chosen from a short calibration run so
+    that one repetition is ~10 core-seconds of CPU work; best of 3."""
     from oracle import oracle as O
     from sketchlib.rust_amd import synth
 
     cores = os.cpu_count() or 1
-    bins = synth.set_u(n, len(kmers), ss64) if dataset == "U" else synth.set_r(n, kmers, ss64)
-    s = O.Sketches(bins, n, kmers, ss64)
+
+    def make(n):
+        bins = synth.set_u(n, len(kmers), ss64) if dataset == "U" else synth.set_r(n, kmers, ss64)
+        return O.Sketches(bins, n, kmers, ss64)
+
+    # calibration: single-thread rate on a small slice
+    s = make(200)
+    t0 = time.perf_counter()
+    O.self_dists_all(s, O.COREACC, threads=1)
+    per_core = (200 * 199 // 2) / (time.perf_counter() - t0)
+    target_pairs = per_core * 10.0            # ~10 core-seconds per repetition
+    n = max(BASE_N, min(6000, n_for_pairs(int(target_pairs))))
+    s = make(n)
     pairs = n * (n - 1) // 2
     best = float("inf")
     for _ in range(3):
@@ -67,8 +78,10 @@ def cpu_baseline(n, kmers, ss64, dataset):
         "unit": "pairs/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"full N=1 workload: n={n} Set {dataset}, {pairs} pairs, self_dists_all core/acc, "
-                  f"1000-pair chunks over {cores} threads, best of 3 ({best:.3f} s)",
+        "sample": f"n={n} Set {dataset} slice of the workload ({pairs} pairs, same sketch shape), "
+                  f"self_dists_all core/acc, 1000-pair chunks over {cores} threads, best of 3 "
+                  f"({best:.3f} s wall = {best * cores:.1f} core-s per repetition; "
+                  f"single-thread calibration {per_core:.3g} pairs/s)",
     }
 
 
@@ -174,11 +187,13 @@ def main():
         b_pair = algorithmic_bytes_per_pair(nk, SS64, ncols)
         avg_kernel_s = (kernel_ms / 1e3) / max(launches, 1)
         achieved_gbs = (b_pair * my_pairs / avg_kernel_s) / 1e9 if avg_kernel_s > 0 else 0.0
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE): profiles/pmc_traffic.json
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"n{n}_set{args.dataset}_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"n{n}_set{args.dataset}_world{world}")
             except Exception:
                 traffic = None
         out = {
@@ -225,7 +240,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, KMERS, SS64, args.dataset)
+            out["cpu_baseline"] = cpu_baseline(KMERS, SS64, args.dataset)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
