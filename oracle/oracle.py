@@ -71,6 +71,9 @@ def lib():
         L.sko_self_dists_all.restype = C.c_int
         L.sko_self_dists_all.argtypes = [P, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_int,
                                          C.c_void_p]
+        L.sko_self_dists_all_repeat.restype = C.c_int
+        L.sko_self_dists_all_repeat.argtypes = [P, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_int,
+                                                C.c_int, C.c_void_p]
         L.sko_cross_dists_all.restype = C.c_int
         L.sko_cross_dists_all.argtypes = [P, P, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_int,
                                           C.c_void_p]
@@ -80,6 +83,8 @@ def lib():
         L.sko_cross_dists_knn.restype = C.c_long
         L.sko_cross_dists_knn.argtypes = [P, P, C.c_size_t, C.c_int, C.c_size_t, C.c_int,
                                           C.c_double, C.c_int, C.c_int, C.c_void_p]
+        L.sko_core_acc_dist.restype = None
+        L.sko_core_acc_dist.argtypes = [P, P, C.c_size_t, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p]
         L.sko_self_binmatch.restype = C.c_int
         L.sko_self_binmatch.argtypes = [P, C.c_int, C.c_void_p]
         L.sko_cross_binmatch.restype = C.c_int
@@ -126,6 +131,17 @@ def self_dists_all(s, dist_type=COREACC, k_idx=0, ani=False, cutoff=0.64, thread
     return out.reshape(n_pairs, ncols(dist_type))
 
 
+def self_dists_all_repeat(s, repeat, dist_type=COREACC, k_idx=0, ani=False, cutoff=0.64, threads=1):
+    """`repeat` passes inside one thread pool (timing helper for bench.py)."""
+    n_pairs = s.n * (s.n - 1) // 2
+    out = np.zeros(n_pairs * ncols(dist_type), dtype=np.float32)
+    rc = lib().sko_self_dists_all_repeat(s.ref, dist_type, k_idx, int(ani), cutoff, threads, repeat,
+                                         out.ctypes.data)
+    if rc:
+        raise ValueError(f"oracle self_dists_all_repeat failed rc={rc}")
+    return out.reshape(n_pairs, ncols(dist_type))
+
+
 def cross_dists_all(r, q, dist_type=COREACC, k_idx=0, ani=False, cutoff=0.64, threads=1):
     out = np.zeros(r.n * q.n * ncols(dist_type), dtype=np.float32)
     rc = lib().sko_cross_dists_all(r.ref, q.ref, dist_type, k_idx, int(ani), cutoff, threads,
@@ -167,6 +183,14 @@ def cross_binmatch(r, q, threads=1):
     out = np.zeros(r.n * q.n * r.nk, dtype=np.uint32)
     lib().sko_cross_binmatch(r.ref, q.ref, threads, out.ctypes.data)
     return out.reshape(r.n, q.n, r.nk)
+
+
+def core_acc_pair(r, q, i, j, cutoff=0.64):
+    """jaccard.rs:61-101 for one (ref i, query j) pair."""
+    core = C.c_float()
+    acc = C.c_float()
+    lib().sko_core_acc_dist(r.ref, q.ref, i, j, cutoff, C.byref(core), C.byref(acc))
+    return core.value, acc.value
 
 
 def regression(xsum, ysum, xysum, xsq, ysq, n):

@@ -297,6 +297,33 @@ static int check_coreacc(const sko_sketches *s, int dist_type, size_t k_idx)
     return 0;
 }
 
+/* Benchmark helper: the same computation `repeat` times inside one thread pool (chunk
+ * indices wrap), so that a short workload can be timed without paying thread start-up
+ * per pass.  Results are simply overwritten each pass. */
+typedef struct {
+    const dense_job *job;
+    size_t n_chunks;
+} repeat_job;
+
+static void self_chunk_wrapped(void *ctx, size_t chunk_idx)
+{
+    const repeat_job *r = (const repeat_job *)ctx;
+    self_chunk((void *)r->job, chunk_idx % r->n_chunks);
+}
+
+int sko_self_dists_all_repeat(const sko_sketches *s, int dist_type, size_t k_idx, int ani,
+                              double cutoff, int threads, int repeat, float *out)
+{
+    int rc = check_coreacc(s, dist_type, k_idx);
+    if (rc) return rc;
+    if (s->n_samples < 2 || repeat < 1) return 0;
+    dense_job job = {s, NULL, dist_type, k_idx, ani, cutoff, out, NULL,
+                     s->n_samples * (s->n_samples - 1) / 2};
+    repeat_job r = {&job, (job.n_dist + CHUNK_SIZE - 1) / CHUNK_SIZE};
+    run_chunks(self_chunk_wrapped, &r, r.n_chunks * (size_t)repeat, threads);
+    return 0;
+}
+
 int sko_self_dists_all(const sko_sketches *s, int dist_type, size_t k_idx, int ani, double cutoff,
                        int threads, float *out)
 {

@@ -68,6 +68,9 @@ size_t sko_calc_col_idx(size_t k, size_t i, size_t n);
 /* mod.rs:58-130.  out: n(n-1)/2 * ncols floats (ncols = 2 CoreAcc, 1 Jaccard). */
 int sko_self_dists_all(const sko_sketches *s, int dist_type, size_t k_idx, int ani,
                        double completeness_cutoff, int threads, float *out);
+/* Timing helper for bench.py: `repeat` passes of sko_self_dists_all inside one thread pool. */
+int sko_self_dists_all_repeat(const sko_sketches *s, int dist_type, size_t k_idx, int ani,
+                              double completeness_cutoff, int threads, int repeat, float *out);
 /* mod.rs:227-297.  out: n*n_query*ncols floats, index (i_ref*n_query + j_query)*ncols. */
 int sko_cross_dists_all(const sko_sketches *ref, const sko_sketches *query, int dist_type,
                         size_t k_idx, int ani, double completeness_cutoff, int threads,
