@@ -96,6 +96,13 @@ def load():
                 f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C sketchlib.rust_amd/csrc`).  There is no CPU fallback."
             )
+        # If torch is going to share this process (device tensors, torch.distributed), let it
+        # load ITS HIP runtime first: two different libamdhip64 copies in one process leave
+        # the second one without devices ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(path)
         for name, restype, argtypes in _SIG:
             fn = getattr(L, name)  # AttributeError if the export is missing

@@ -207,18 +207,30 @@ extern "C" int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches)
 // selects the latter (kept for A/B measurements).
 static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream)
 {
-    // SKL_KERNEL = smem | lds forces one implementation (A/B measurements); default: the
-    // latency-oriented scalar-cache kernel for small launches, the LDS kernel otherwise.
+    // Three implementations of the same tile computation, chosen by launch size:
+    //   ksplit (pair_ksplit.hip)  small launches: chunks split over the 4 waves of a workgroup
+    //   lds    (pair_lds.hip)     large launches: R x 256/512 tiles, rows broadcast from LDS
+    //   smem   (kernels.hip)      rows through the scalar cache; kept for A/B measurements
+    // SKL_KERNEL = ksplit | lds | smem forces one.
     static const int forced = [] {
         const char *e = getenv("SKL_KERNEL");
         if (e && strcmp(e, "smem") == 0) return 1;
         if (e && strcmp(e, "lds") == 0) return 2;
+        if (e && strcmp(e, "ksplit") == 0) return 3;
         return 0;
+    }();
+    static const int forced_rows = [] {
+        const char *e = getenv("SKL_KSPLIT_ROWS");  // tuning knob: 4 or 8
+        return e ? atoi(e) : 0;
     }();
     const uint64_t rows = args.row_end - args.row_begin;
     const uint64_t pairs = args.self_mode ? rows * args.nB / 2 : rows * (uint64_t)args.nB;
     const bool small = pairs < (6ull << 20);  // crossover measured between n=3000 and n=4000
-    if (forced == 1 || (forced == 0 && small)) return launch_pair_kernel(args, mode, na, stream);
+    if (forced == 1) return launch_pair_kernel(args, mode, na, stream);
+    if (forced == 3 || (forced == 0 && small)) {
+        int r = forced_rows ? forced_rows : 4;  // 4 beats 8 from n = 1000 to n = 3000 (sweep 14)
+        return launch_pair_kernel_ksplit(args, mode, r, stream);
+    }
     const int shape = choose_lds_shape(rows, args.nB, args.self_mode, mode);
     return launch_pair_kernel_lds(args, mode, shape, stream);
 }

@@ -62,6 +62,9 @@ hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_
 // LDS-staged variant (pair_lds.hip).  shape = R*10 + JL: R rows per workgroup tile, JL
 // 64-column blocks per lane; valid shapes: 41, 81, 82, 162.
 hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, hipStream_t stream);
+// K-split variant for small launches (pair_ksplit.hip): rows_per_tile in {4, 8}.
+hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_per_tile,
+                                     hipStream_t stream);
 int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
