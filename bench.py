@@ -163,6 +163,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.kernel_ms()
+    kernel_name = ctx.last_kernel()
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -224,7 +225,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "skl::pair_kernel<NA, MODE_COREACC>",
+                "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_pair": b_pair,
                 "pairs_per_launch": my_pairs,

@@ -81,6 +81,9 @@ int skl_ctx_synchronize(skl_ctx *ctx);
  * launches recorded since the last reset (at most 4096 are kept). */
 int skl_ctx_timing_reset(skl_ctx *ctx);
 int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches);
+/* Name (with tile shape) of the pair kernel the last call dispatched, e.g.
+ * "pair_kernel_ksplit<R=4>" -- for benchmark reports.  Valid until the next call. */
+const char *skl_ctx_last_kernel(skl_ctx *ctx);
 
 /* ---- sketch slabs: MultiSketch::read_sketch_data / get_sketch_slice
  *      (src/sketch/multisketch.rs:167-219) ---- */

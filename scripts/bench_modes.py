@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Throughput of the other modes of the path on one MI355X (reduced-size stand-ins for
+BASELINE configs 3-5; inputs resident in HBM, synthetic Set U):
+  dense self at n = 50 000 (slice of cfg 3), dense cross 100k x 10k (cfg 4 / 10),
+  self kNN-50 at n = 40 000 and cross kNN-50 100k refs x 4k queries (cfg 5 scaled down).
+Prints one JSON line per mode."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from sketchlib.rust_amd import capi, synth  # noqa: E402
+
+dev = torch.device("cuda", 0)
+ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+
+
+def timed(fn, reps=2):
+    fn()
+    torch.cuda.synchronize()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    ms, launches = ctx.kernel_ms()
+    return wall, ms / reps
+
+
+def main():
+    which = sys.argv[1:] or ["self50k", "cross", "selfknn", "crossknn"]
+    if "self50k" in which:
+        n, K = 50000, [15, 19, 23, 27, 31]
+        sk = ctx.sketches(synth.set_u_device(n, 5, 64, dev), n, K, 64)
+        pairs = n * (n - 1) // 2
+        out = torch.empty((pairs, 2), dtype=torch.float32, device=dev)
+        wall, kms = timed(lambda: capi.self_dists_all(ctx, sk, sk.set_k(), out=out), reps=1)
+        print(json.dumps({"mode": "dense self core/acc", "n": n, "sketchsize64": 64, "pairs": pairs,
+                          "wall_s": wall, "pair_kernel_ms": kms, "pairs_per_s": pairs / wall}), flush=True)
+        del out
+        sk.close()
+    K4 = [13, 17, 21, 25, 29]
+    if "cross" in which:
+        nr, nq = 100000, 10000
+        r = ctx.sketches(synth.set_u_device(nr, 5, 32, dev), nr, K4, 32)
+        q = ctx.sketches(synth.set_u_device(nq, 5, 32, dev, first_sample=10 ** 7), nq, K4, 32)
+        out = torch.empty((nr, nq, 2), dtype=torch.float32, device=dev)
+        wall, kms = timed(lambda: capi.cross_dists_all(ctx, r, q, r.set_k(), out=out), reps=1)
+        print(json.dumps({"mode": "dense cross core/acc", "n_ref": nr, "n_query": nq, "sketchsize64": 32,
+                          "pairs": nr * nq, "wall_s": wall, "pair_kernel_ms": kms,
+                          "pairs_per_s": nr * nq / wall}), flush=True)
+        del out
+        r.close()
+        q.close()
+    if "selfknn" in which:
+        n = 40000
+        sk = ctx.sketches(synth.set_u_device(n, 5, 32, dev), n, K4, 32)
+        for label, p in [("core/acc", sk.set_k()), ("jaccard k=21", sk.set_k(21))]:
+            t0 = time.perf_counter()
+            idx, d0, d1 = capi.self_dists_knn(ctx, sk, p, 50)
+            wall = time.perf_counter() - t0
+            print(json.dumps({"mode": f"self kNN-50 {label}", "n": n, "sketchsize64": 32, "pairs": n * (n - 1),
+                              "wall_s": wall, "pairs_per_s": n * (n - 1) / wall,
+                              "rows_per_s": n / wall}), flush=True)
+        sk.close()
+    if "crossknn" in which:
+        nr, nq = 100000, 4000
+        r = ctx.sketches(synth.set_u_device(nr, 5, 32, dev), nr, K4, 32)
+        q = ctx.sketches(synth.set_u_device(nq, 5, 32, dev, first_sample=10 ** 7), nq, K4, 32)
+        t0 = time.perf_counter()
+        idx, d0, d1 = capi.cross_dists_knn(ctx, r, q, r.set_k(), 50)
+        wall = time.perf_counter() - t0
+        print(json.dumps({"mode": "cross kNN-50 core/acc", "n_ref": nr, "n_query": nq, "sketchsize64": 32,
+                          "pairs": nr * nq, "wall_s": wall, "pairs_per_s": nr * nq / wall}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

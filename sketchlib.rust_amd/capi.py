@@ -54,6 +54,7 @@ _SIG = [
     ("skl_ctx_synchronize", C.c_int, [_P]),
     ("skl_ctx_timing_reset", C.c_int, [_P]),
     ("skl_ctx_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    ("skl_ctx_last_kernel", C.c_char_p, [_P]),
     ("skl_sketches_create", C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_size_t, _P, C.c_size_t,
                                       C.POINTER(_P)]),
     ("skl_sketches_set_completeness", C.c_int, [_P, _P]),
@@ -158,6 +159,9 @@ class Context:
         n = C.c_int()
         _check(load().skl_ctx_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def last_kernel(self):
+        return load().skl_ctx_last_kernel(self._h).decode()
 
     def close(self):
         if self._h:

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -77,6 +79,14 @@ extern "C" int skl_device_count(void)
 }
 
 // ---------------------------------------------------------------------------
+// handle registry: destroy calls in any order (and twice) must be harmless -- a binding's
+// finalisers run in arbitrary order at interpreter shutdown.
+// ---------------------------------------------------------------------------
+
+static std::mutex g_registry_mutex;
+static std::set<const void *> g_live_ctx, g_live_sketches;
+
+// ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
 
@@ -91,6 +101,8 @@ struct skl_ctx {
     // timing of pair-kernel launches of the last call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    std::string last_kernel;
+    std::set<skl_sketches *> sketches;  // slabs created on this context
 };
 
 static int ctx_bind(skl_ctx *ctx)
@@ -142,15 +154,26 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
         return fail(SKL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        g_live_ctx.insert(ctx);
+    }
     *out = ctx;
     return SKL_OK;
 }
 
+static void free_sketches_locked(skl_sketches *s);
+
 extern "C" int skl_ctx_destroy(skl_ctx *ctx)
 {
     if (!ctx) return SKL_OK;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    if (!g_live_ctx.erase(ctx)) return SKL_OK;  // already destroyed
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    // slabs die with their context; their handles become inert
+    const std::set<skl_sketches *> owned = ctx->sketches;
+    for (skl_sketches *s : owned) free_sketches_locked(s);
     for (auto &ev : ctx->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -177,6 +200,8 @@ extern "C" int skl_ctx_synchronize(skl_ctx *ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SKL_OK;
 }
+
+extern "C" const char *skl_ctx_last_kernel(skl_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
 
 extern "C" int skl_ctx_timing_reset(skl_ctx *ctx)
 {
@@ -205,8 +230,11 @@ extern "C" int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches)
 // Two implementations of the same tile computation: rows through LDS broadcast
 // (pair_lds.hip, default) or through the scalar cache (kernels.hip).  SKL_KERNEL=smem
 // selects the latter (kept for A/B measurements).
-static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream)
+static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream,
+                                       std::string *name)
 {
+    static const char *mode_names[] = {"COUNTS", "JACCARD", "COREACC"};
+    const std::string m = mode_names[mode];
     // Three implementations of the same tile computation, chosen by launch size:
     //   ksplit (pair_ksplit.hip)  small launches: chunks split over the 4 waves of a workgroup
     //   lds    (pair_lds.hip)     large launches: R x 256/512 tiles, rows broadcast from LDS
@@ -226,12 +254,19 @@ static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, h
     const uint64_t rows = args.row_end - args.row_begin;
     const uint64_t pairs = args.self_mode ? rows * args.nB / 2 : rows * (uint64_t)args.nB;
     const bool small = pairs < (6ull << 20);  // crossover measured between n=3000 and n=4000
-    if (forced == 1) return launch_pair_kernel(args, mode, na, stream);
+    if (forced == 1) {
+        *name = "skl::pair_kernel<NA=" + std::to_string(na) + ", " + m + "> (scalar-cache rows)";
+        return launch_pair_kernel(args, mode, na, stream);
+    }
     if (forced == 3 || (forced == 0 && small)) {
         int r = forced_rows ? forced_rows : 4;  // 4 beats 8 from n = 1000 to n = 3000 (sweep 14)
+        *name = "skl::pair_kernel_ksplit<R=" + std::to_string(r) + ", " + m + "> (" + std::to_string(r) +
+                "x64 tiles, chunks split over 4 waves)";
         return launch_pair_kernel_ksplit(args, mode, r, stream);
     }
     const int shape = choose_lds_shape(rows, args.nB, args.self_mode, mode);
+    *name = "skl::pair_kernel_lds<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(shape % 10) +
+            ", " + m + "> (" + std::to_string(shape / 10) + "x" + std::to_string((shape % 10) * 256) + " tiles)";
     return launch_pair_kernel_lds(args, mode, shape, stream);
 }
 
@@ -240,7 +275,7 @@ static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int n
 {
     constexpr size_t MAX_EVENTS = 4096;
     if (ctx->events_used >= MAX_EVENTS) {
-        HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream));
+        HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel));
         return SKL_OK;
     }
     if (ctx->events_used == ctx->events.size()) {
@@ -251,7 +286,7 @@ static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int n
     }
     auto &ev = ctx->events[ctx->events_used++];
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream));
+    HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel));
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     return SKL_OK;
 }
@@ -354,6 +389,11 @@ extern "C" int skl_sketches_create(skl_ctx *ctx, const uint64_t *bins, int on_de
     }
     skl_sketches *s = new skl_sketches();
     s->ctx = ctx;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        g_live_sketches.insert(s);
+        ctx->sketches.insert(s);
+    }
     s->n = n_samples;
     s->nk = nk;
     s->ss64 = sketchsize64;
@@ -362,7 +402,7 @@ extern "C" int skl_sketches_create(skl_ctx *ctx, const uint64_t *bins, int on_de
     const size_t total = (n_samples + A_PAD_ROWS) * words;
     hipError_t e = hipMalloc((void **)&s->d_rows, total * sizeof(uint64_t));
     if (e != hipSuccess) {
-        delete s;
+        skl_sketches_destroy(s);
         return fail(e == hipErrorOutOfMemory ? SKL_ERR_OOM : SKL_ERR_HIP, "hipMalloc(slab %zu B): %s",
                     total * sizeof(uint64_t), hipGetErrorString(e));
     }
@@ -415,9 +455,10 @@ extern "C" int skl_sketches_set_completeness(skl_sketches *s, const double *comp
     return SKL_OK;
 }
 
-extern "C" int skl_sketches_destroy(skl_sketches *s)
+static void free_sketches_locked(skl_sketches *s)
 {
-    if (!s) return SKL_OK;
+    if (!g_live_sketches.erase(s)) return;
+    s->ctx->sketches.erase(s);
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->d_rows) (void)hipFree(s->d_rows);
@@ -427,6 +468,13 @@ extern "C" int skl_sketches_destroy(skl_sketches *s)
     if (s->d_kf) (void)hipFree(s->d_kf);
     for (auto &kv : s->d_dtab) (void)hipFree(kv.second);
     delete s;
+}
+
+extern "C" int skl_sketches_destroy(skl_sketches *s)
+{
+    if (!s) return SKL_OK;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    free_sketches_locked(s);  // no-op if the handle (or its context) is already gone
     return SKL_OK;
 }
 
