@@ -20,6 +20,18 @@
 
 namespace skl {
 
+// 16 bytes per lane, global -> LDS, no VGPR destination (global_load_lds_dwordx4).  The
+// builtin only exists in the device pass; the host pass needs the kernel body to parse.
+__device__ __forceinline__ void skl_dma16(const void *src, void *lds_wave_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+#else
+    (void)src;
+    (void)lds_wave_base;
+#endif
+}
+
 template <int R, int MODE, int S, bool BPF>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const PairArgs g)
 {
@@ -61,8 +73,11 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
         st2[x] = 0;
     }
 
-    uint4 stage_reg[PPT];
-#define SKL_STAGE_LOAD(T)                                                                    \
+    // Row staging: global -> LDS DMA (global_load_lds_dwordx4), no VGPR round trip.  Each
+    // wave-instruction writes 64 x 16 B linearly at a wave-uniform LDS base; the source
+    // address is per lane, so piece p = (chunk*R + row)*7 + plane_pair lands at LDS slot p.
+    // Pieces past the end re-load an early piece into the unused tail (same bytes, harmless).
+#define SKL_STAGE_DMA(T, BUF)                                                                \
     do {                                                                                     \
         const uint32_t k_ = g.k_begin + (T) / stages_per_k;                                  \
         const uint32_t c0_ = ((T) % stages_per_k) * S;                                       \
@@ -75,16 +90,11 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
             const uint64_t *src_ = g.A + (size_t)(a0 + r_) * sample_stride +                 \
                                    (size_t)k_ * kmer_stride + (size_t)(c0_ + c_) * BBITS +   \
                                    2u * q_;                                                  \
-            stage_reg[u] = *(const uint4 *)src_;                                             \
+            skl_dma16(src_, &lds_rows[BUF][u * 256u + wave * 64u]);                          \
         }                                                                                    \
     } while (0)
-#define SKL_STAGE_STORE(BUF)                                                                 \
-    do {                                                                                     \
-        _Pragma("unroll") for (int u = 0; u < PPT; ++u) lds_rows[BUF][tid + u * 256u] = stage_reg[u]; \
-    } while (0)
 
-    SKL_STAGE_LOAD(0u);
-    SKL_STAGE_STORE(0);
+    SKL_STAGE_DMA(0u, 0);
     // first column chunk of this wave
     uint4 b_nxt[7];
     if constexpr (BPF) {
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
         const uint32_t k = g.k_begin + kk;
         const uint32_t c0 = (t % stages_per_k) * S;
         const bool have_next = t + 1 < n_stages;
-        if (have_next) SKL_STAGE_LOAD(t + 1);
+        if (have_next) SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
 
         const uint32_t c_end = (g.ss64 - c0) < (uint32_t)S ? (g.ss64 - c0) : (uint32_t)S;
         for (uint32_t c = wave; c < c_end; c += WAVES_PER_WG) {   // this wave's chunks
@@ -155,7 +165,6 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
             }
         }
 
-        if (have_next) SKL_STAGE_STORE(buf ^ 1u);
 
         const bool k_done = (t % stages_per_k) == stages_per_k - 1u;
         if (k_done) {
@@ -189,8 +198,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
             // after these reads: no extra barrier needed.
         }
     }
-#undef SKL_STAGE_LOAD
-#undef SKL_STAGE_STORE
+#undef SKL_STAGE_DMA
 
     if constexpr (MODE == MODE_COREACC) {
 #pragma unroll

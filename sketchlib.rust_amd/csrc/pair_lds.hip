@@ -26,6 +26,18 @@
 
 namespace skl {
 
+// 16 bytes per lane, global -> LDS, no VGPR destination (global_load_lds_dwordx4).  The
+// builtin only exists in the device pass; the host pass needs the kernel body to parse.
+__device__ __forceinline__ void skl_dma16(const void *src, void *lds_wave_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+#else
+    (void)src;
+    (void)lds_wave_base;
+#endif
+}
+
 constexpr int STAGE_CHUNKS = 8;  // chunks per LDS stage
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -72,14 +84,16 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
     for (int x = 0; x < P; ++x) cnt[x] = 0;
 
     // this thread's share of a stage: global -> registers (early), registers -> LDS (late)
-    uint4 stage_reg[PPT];
-#define SKL_STAGE_LOAD(T)                                                                    \
+    // Row staging: global -> LDS DMA (global_load_lds_dwordx4), no VGPR round trip.  Each
+    // wave-instruction writes 64 x 16 B linearly at a wave-uniform LDS base; the source
+    // address is per lane, so piece p = (chunk*R + row)*7 + plane_pair lands at LDS slot p.
+    // Pieces past the end re-load an early piece into the unused tail (same bytes, harmless).
+#define SKL_STAGE_DMA(T, BUF)                                                                \
     do {                                                                                     \
         const uint32_t k_ = g.k_begin + (T) / stages_per_k;                                  \
         const uint32_t c0_ = ((T) % stages_per_k) * S;                                       \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u)                                      \
         {                                                                                    \
-            /* pieces past the end re-load an early piece (same bytes, harmless) */          \
             const uint32_t pp_ = tid + u * 256u;                                             \
             const uint32_t p_ = pp_ < (uint32_t)PIECES ? pp_ : pp_ - (uint32_t)PIECES;       \
             const uint32_t q_ = p_ % 7u, rc_ = p_ / 7u;                                      \
@@ -87,21 +101,11 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
             const uint64_t *src_ = g.A + (size_t)(a0 + r_) * sample_stride +                 \
                                    (size_t)k_ * kmer_stride + (size_t)(c0_ + c_) * BBITS +   \
                                    2u * q_;                                                  \
-            stage_reg[u] = *(const uint4 *)src_;                                             \
-        }                                                                                    \
-    } while (0)
-#define SKL_STAGE_STORE(BUF)                                                                 \
-    do {                                                                                     \
-        _Pragma("unroll") for (int u = 0; u < PPT; ++u)                                      \
-        {                                                                                    \
-            const uint32_t pp_ = tid + u * 256u;                                             \
-            /* duplicates land in the unused tail of the buffer */                           \
-            lds_rows[BUF][pp_] = stage_reg[u];                                               \
+            skl_dma16(src_, &lds_rows[BUF][u * 256u + wave * 64u]);                          \
         }                                                                                    \
     } while (0)
 
-    SKL_STAGE_LOAD(0u);
-    SKL_STAGE_STORE(0);
+    SKL_STAGE_DMA(0u, 0);
     __syncthreads();
 
     for (uint32_t t = 0; t < n_stages; ++t) {
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
         const uint32_t k = g.k_begin + kk;
         const uint32_t c0 = (t % stages_per_k) * S;
         const bool have_next = t + 1 < n_stages;
-        if (have_next) SKL_STAGE_LOAD(t + 1);  // in flight under this stage's VALU work
+        if (have_next) SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
 
         if (c0 == 0 && active) {
             // start of a k-mer length
@@ -207,7 +211,6 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
             }
         }
 
-        if (have_next) SKL_STAGE_STORE(buf ^ 1u);
         __syncthreads();
 
         // ---- per-k epilogue ----
@@ -228,8 +231,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
             }
         }
     }
-#undef SKL_STAGE_LOAD
-#undef SKL_STAGE_STORE
+#undef SKL_STAGE_DMA
 
     if constexpr (MODE == MODE_COREACC) {
         if (active) {
