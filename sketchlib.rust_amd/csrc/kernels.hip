@@ -71,7 +71,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
     // The 4 waves of a workgroup share the column block and take 4 adjacent row tiles.
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t jb = (slot / g.a_tiles) * 8u + xcd;
+    const uint32_t gseq = slot / g.a_tiles;
+    const uint32_t jb = gseq * 8u + ((gseq & 1u) ? 7u - xcd : xcd);  // boustrophedon deal
     const uint32_t at = slot % g.a_tiles;
     const uint32_t a0 = g.row_begin + (at * WAVES_PER_WG + wave) * NA;
     if (jb >= g.n_jblocks) return;

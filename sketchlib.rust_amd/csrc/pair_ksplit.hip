@@ -49,7 +49,9 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
 
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t jb = (slot / g.a_tiles) * 8u + xcd;   // 64-wide column block
+    // boustrophedon deal of column blocks to XCDs (see pair_lds.hip): balances the triangle
+    const uint32_t gseq = slot / g.a_tiles;
+    const uint32_t jb = gseq * 8u + ((gseq & 1u) ? 7u - xcd : xcd);   // 64-wide column block
     const uint32_t at = slot % g.a_tiles;
     const uint32_t a0 = g.row_begin + at * R;
     if (jb >= g.n_jblocks) return;

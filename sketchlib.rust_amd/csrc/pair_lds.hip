@@ -59,7 +59,11 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
     // column group, whose lane-operand slab stays in that XCD's L2.
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t jg = (slot / g.a_tiles) * 8u + xcd;  // column group: 4*JL blocks
+    // column groups are dealt to the XCDs boustrophedon (0..7, 7..0, ...): in self mode the work
+    // of a column group grows with its index, and a plain modulo deal left the last XCD with
+    // up to 2.4x the rows of the first one on small grids
+    const uint32_t gseq = slot / g.a_tiles;
+    const uint32_t jg = gseq * 8u + ((gseq & 1u) ? 7u - xcd : xcd);  // column group: 4*JL blocks
     const uint32_t at = slot % g.a_tiles;
     const uint32_t jb0 = (jg * WAVES_PER_WG + wave) * JL;  // this wave's first column block
     const uint32_t a0 = g.row_begin + at * R;
