@@ -107,8 +107,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # SKL_BENCH_BACKEND=gloo is a debugging aid: it lets N ranks share fewer GPUs (RCCL
+        # refuses two ranks on one device) so that the partition / gather / timing logic can
+        # be exercised on a 1-GPU box; the gather is then staged through host memory.
+        backend = os.environ.get("SKL_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     if rank == 0:
         pkg.build_library()
@@ -143,10 +151,23 @@ def main():
         full = None
         local = torch.zeros((my_pairs, 2), dtype=torch.float32, device=device)
 
+    host_staged = dist is not None and dist.get_backend() != "nccl"
+
     def step():
         capi.self_dists_rows(ctx, sk, p, r0, r1, out=local)
         if dist is not None and not args.no_gather:
-            multi_gpu.gather_to_root(full, local, slices, rank, world, dist)
+            if host_staged:  # gloo debugging path
+                torch.cuda.synchronize(device)
+                if rank == 0:
+                    full_h = torch.empty((total_pairs, 2), dtype=torch.float32)
+                    multi_gpu.gather_to_root(full_h, None, slices, rank, world, dist)
+                    for w in range(1, world):
+                        a, cnt = slices[w][2], slices[w][3]
+                        full[a:a + cnt].copy_(full_h[a:a + cnt])
+                else:
+                    multi_gpu.gather_to_root(None, local.cpu(), slices, rank, world, dist)
+            else:
+                multi_gpu.gather_to_root(full, local, slices, rank, world, dist)
 
     def fence():
         if dist is not None:
@@ -175,6 +196,12 @@ def main():
     if rank == 0:
         checksum = float(full.double().sum().item())
         assert bool(torch.isfinite(full).all()), "non-finite distances"
+        if world > 1 and not args.no_gather:
+            # the assembled matrix must equal the one rank 0 computes alone (not timed)
+            whole = torch.empty_like(full)
+            capi.self_dists_all(ctx, sk, p, out=whole)
+            torch.cuda.synchronize(device)
+            assert torch.equal(whole, full), "gathered matrix differs from the single-rank result"
 
     if rank == 0:
         ncols = 2
