@@ -2,8 +2,9 @@
 // (src/cli.rs:185-231, src/lib.rs:303-453) on top of the gfx950 engine.
 //
 // Same positional arguments, flags, defaults, stdout format and exit behaviour
-// (panic -> 101, error -> 1, usage -> 2).  `--threads` is accepted and validated for
-// compatibility (the work runs on the GPU); `--device` is the one addition.
+// (panic -> 101, error -> 1, usage -> 2).  `--threads` (default 1, as in the reference) sets
+// the host threads that format the dense text output; the distances themselves run on the
+// GPU.  `--device` is the one addition.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -223,7 +224,7 @@ int run_dist(const DistArgs &a)
             const DistanceMatrix d = distances::self_dists_all(dev, references, n, dist_type, a.quiet, rc,
                                                                a.completeness_cutoff);
             log.info("Writing out in long matrix form");
-            d.write(*os);
+            d.write(*os, a.threads);
         } else {
             size_t nn = *a.knn;
             if (nn >= n) {  // lib.rs:379-382
@@ -256,7 +257,7 @@ int run_dist(const DistArgs &a)
             const DistanceMatrix d = distances::cross_dists_all(dev, references, *queries, n, n_query, dist_type,
                                                                 a.quiet, rc, qc, a.completeness_cutoff);
             log.info("Writing out in long matrix form");
-            d.write(*os);
+            d.write(*os, a.threads);
         }
     }
     os->flush();

@@ -42,7 +42,10 @@ class DistanceMatrix {
     std::vector<std::string> ref_names;
     std::optional<std::vector<std::string>> query_names;
 
-    void write(std::ostream &os) const;
+    // The reference's Display impl (distance_matrix.rs:175-209).  `threads` > 1 formats row
+    // blocks concurrently into per-thread buffers and writes them in order -- the reference
+    // formats single-threaded, which dwarfs the GPU time at large n.
+    void write(std::ostream &os, size_t threads = 1) const;
 };
 
 struct SparseJaccard {   // distance_matrix.rs:214

@@ -110,3 +110,34 @@ def test_completeness_file_all_ones_is_identity(gpu_ctx):
     plain = run(GEN_DB)
     comp = run(GEN_DB, "--ref-completeness-file", os.path.join(REF_FIXTURES, "completeness.txt"))
     assert plain == comp
+
+
+def _write_db(tmp_path, name, bins, kmers, ss64):
+    """A database in the reference's on-disk layout: .skd = raw LE u64, .skm via skl_dbtool."""
+    dbtool = os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build", "skl_dbtool")
+    prefix = str(tmp_path / name)
+    bins.astype("<u8").tofile(prefix + ".skd")
+    names = [f"sample_{i:04d}" for i in range(bins.shape[0])]
+    subprocess.check_call([dbtool, "make", prefix, str(ss64 * 64), ",".join(map(str, kmers)), *names])
+    return prefix, names
+
+
+def test_synthetic_db_dense_text_and_parallel_formatting(gpu_ctx, oracle, tmp_path):
+    from sketchlib.rust_amd import synth
+
+    kmers, ss64, n = [15, 19, 23, 27, 31], 64, 300
+    bins = synth.set_r(n, kmers, ss64, n_clusters=12)
+    prefix, names = _write_db(tmp_path, "synth", bins, kmers, ss64)
+    d = oracle.self_dists_all(oracle.Sketches(bins, n, kmers, ss64), threads=8)
+    lines, x = [], 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            lines.append(f"{names[i]}\t{names[j]}\t{rust_f32(d[x][0])}\t{rust_f32(d[x][1])}")
+            x += 1
+    expected = "\n".join(lines) + "\n"
+    assert run(prefix) == expected
+    assert run(prefix, "--threads", "7") == expected          # row blocks formatted concurrently
+    # cross mode, parallel formatting
+    one = run(prefix, prefix, "-k", "23", "--threads", "1")
+    assert run(prefix, prefix, "-k", "23", "--threads", "5") == one
+    assert len(one.splitlines()) == n * n
