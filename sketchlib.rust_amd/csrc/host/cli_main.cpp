@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <algorithm>
 #include <iostream>
 #include <optional>
 #include <string>
@@ -18,6 +19,7 @@
 #include "distances.hpp"
 #include "io.hpp"
 #include "multisketch.hpp"
+#include "sketch.hpp"
 
 using namespace skl_host;
 
@@ -34,10 +36,12 @@ struct DistArgs {
     int device = 0;
 };
 
+const char *g_usage = "sketchlib dist [OPTIONS] <REF_DB> [QUERY_DB]";
+
 [[noreturn]] void usage_error(const std::string &msg)
 {
     std::cerr << "error: " << msg << "\n\n"
-              << "Usage: sketchlib dist [OPTIONS] <REF_DB> [QUERY_DB]\n\n"
+              << "Usage: " << g_usage << "\n\n"
               << "For more information, try '--help'.\n";
     std::exit(2);
 }
@@ -264,6 +268,79 @@ int run_dist(const DistArgs &a)
     return 0;
 }
 
+// ---- `sketchlib sketch` (src/cli.rs:121-183, src/lib.rs:242-301), DNA assemblies ----
+struct SketchArgs {
+    std::vector<std::string> seq_files;
+    std::optional<std::string> file_list, output;
+    std::vector<size_t> k_vals, k_seq;
+    uint64_t sketch_size = 1000;   // DEFAULT_SKETCHSIZE, cli.rs:17
+    bool single_strand = false;
+    size_t threads = 1;
+    bool verbose = false, quiet = false;
+};
+
+std::vector<size_t> parse_list(const std::string &flag, const std::string &v)
+{
+    std::vector<size_t> out;
+    size_t pos = 0;
+    while (pos <= v.size()) {
+        const size_t comma = v.find(',', pos);
+        const std::string tok = v.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        out.push_back(parse_usize(flag, tok));
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+    }
+    return out;
+}
+
+int run_sketch(int argc, char **argv, int first, bool verbose, bool quiet)
+{
+    g_usage = "sketchlib sketch [OPTIONS] -o <OUTPUT> <--k-vals <K_VALS>|--k-seq <K_SEQ>> <SEQ_FILES|-f <FILE_LIST>>";
+    SketchArgs a;
+    a.verbose = verbose;
+    a.quiet = quiet;
+    for (int i = first; i < argc; ++i) {
+        std::string arg = argv[i];
+        auto value = [&](const std::string &flag) -> std::string {
+            if (i + 1 >= argc) usage_error("a value is required for '" + flag + "' but none was supplied");
+            return argv[++i];
+        };
+        if (arg == "-v" || arg == "--verbose") a.verbose = true;
+        else if (arg == "--quiet") a.quiet = true;
+        else if (arg == "-f") a.file_list = value("-f <FILE_LIST>");
+        else if (arg == "-o") a.output = value("-o <OUTPUT>");
+        else if (arg == "-k" || arg == "--k-vals") a.k_vals = parse_list("--k-vals <K_VALS>", value(arg));
+        else if (arg == "--k-seq") a.k_seq = parse_list("--k-seq <K_SEQ>", value(arg));
+        else if (arg == "-s" || arg == "--sketch-size") a.sketch_size = parse_usize("--sketch-size <SKETCH_SIZE>", value(arg));
+        else if (arg == "--single-strand") a.single_strand = true;
+        else if (arg == "--threads") a.threads = std::max<size_t>(1, parse_usize("--threads <THREADS>", value(arg)));
+        else if (arg == "--seq-type") {
+            const std::string v = value(arg);
+            if (v != "dna") { std::cerr << "error: this build sketches DNA assemblies only (--seq-type " << v << ")\n"; return 2; }
+        }
+        else if (arg == "--min-count" || arg == "--min-qual" || arg == "--level") (void)value(arg);
+        else if (arg.size() > 1 && arg[0] == '-') usage_error("unexpected argument '" + arg + "' found");
+        else a.seq_files.push_back(arg);
+    }
+    if (!a.output) usage_error("the following required arguments were not provided:\n  -o <OUTPUT>");
+    if (a.seq_files.empty() == !a.file_list.has_value()) {
+        usage_error("exactly one of <SEQ_FILES>... or -f <FILE_LIST> must be given");
+    }
+    if (a.k_vals.empty() == a.k_seq.empty()) usage_error("exactly one of --k-vals or --k-seq must be given");
+    const Logger log{a.verbose && !a.quiet, !a.quiet};
+    const std::vector<InputFastx> inputs = a.file_list ? read_rfile(*a.file_list) : read_input_fastas(a.seq_files);
+    log.info("Parsed " + std::to_string(inputs.size()) + " samples in input list");
+    const std::vector<size_t> kmers = parse_kmers(a.k_vals, a.k_seq);
+    const uint64_t bins = (a.sketch_size + 63) / 64 * 64;
+    log.info("Running sketching: sketch_size:" + std::to_string(bins) + " threads:" + std::to_string(a.threads));
+    try {
+        sketch_files(*a.output, inputs, kmers, a.sketch_size, !a.single_strand, a.threads);
+    } catch (const std::exception &e) {
+        throw Panic(e.what());   // the reference panics on unreadable / empty input
+    }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -277,13 +354,29 @@ int main(int argc, char **argv)
     }
     if (sub >= argc || strcmp(argv[sub], "-h") == 0 || strcmp(argv[sub], "--help") == 0) {
         std::cout << "Usage: sketchlib [OPTIONS] <COMMAND>\n\nCommands:\n"
-                     "  dist  Calculate pairwise distances using sketches\n\n"
-                     "(this build provides the GPU `dist` path only)\n";
+                     "  sketch  Create sketches from input data (DNA assemblies, CPU)\n"
+                     "  dist    Calculate pairwise distances using sketches (GPU)\n";
         return sub >= argc ? 2 : 0;
+    }
+    if (strcmp(argv[sub], "sketch") == 0) {
+        bool verbose = false, quiet = false;
+        for (int i = 1; i < sub; ++i) {
+            if (strcmp(argv[i], "--quiet") == 0) quiet = true;
+            else verbose = true;
+        }
+        try {
+            return run_sketch(argc, argv, sub + 1, verbose, quiet);
+        } catch (const Panic &p) {
+            std::cerr << "thread 'main' panicked:\n" << p.what() << "\n";
+            return 101;
+        } catch (const std::exception &e) {
+            std::cerr << "Error: " << e.what() << "\n";
+            return 1;
+        }
     }
     if (strcmp(argv[sub], "dist") != 0) {
         std::cerr << "error: unrecognized subcommand '" << argv[sub]
-                  << "' (this build provides `dist` only)\n";
+                  << "' (this build provides `sketch` (DNA assemblies, CPU) and `dist` (GPU))\n";
         return 2;
     }
     DistArgs args = parse_dist(argc, argv, sub + 1);

@@ -141,3 +141,20 @@ def test_synthetic_db_dense_text_and_parallel_formatting(gpu_ctx, oracle, tmp_pa
     one = run(prefix, prefix, "-k", "23", "--threads", "1")
     assert run(prefix, prefix, "-k", "23", "--threads", "5") == one
     assert len(one.splitlines()) == n * n
+
+
+def test_sketch_then_dist_like_reference_knn_dists(gpu_ctx, tmp_path):
+    """tests/distance.rs:270-328 end to end: sketch the four genomes, then the three kNN runs."""
+    db = str(tmp_path / "sketch_db")
+    subprocess.check_call([CLI, "sketch", "-o", db, "-v", "--k-seq", "17,31,4", "-s", "10000", "-f", "rfile.txt"],
+                          cwd=REF_FIXTURES, stderr=subprocess.DEVNULL)
+    for flags, golden in [(("--knn", "1"), "dists_knn_ca.stdout"),
+                          (("--knn", "1", "-k", "21"), "dists_knn_jaccard.stdout"),
+                          (("--knn", "1", "-k", "21", "--ani"), "dists_knn_ani.stdout")]:
+        assert run(db, "-v", *flags) == open(os.path.join(REF_FIXTURES, golden)).read()
+    # tests/distance.rs dense_distances (test 1): two short sequences, k=5 -> Jaccard 0.7538061
+    short = str(tmp_path / "short")
+    subprocess.check_call([CLI, "sketch", "-o", short, "-k", "5", "-s", "1000", "short_sequence.fa",
+                           "short_sequence_SNP.fa"], cwd=REF_FIXTURES)
+    val = float(run(short, "-k", "5").split()[-1])
+    assert abs(round(val, 3) - round(0.7538061, 3)) <= 0.05   # the reference's own tolerance
