@@ -152,9 +152,34 @@ def test_sketch_then_dist_like_reference_knn_dists(gpu_ctx, tmp_path):
                           (("--knn", "1", "-k", "21"), "dists_knn_jaccard.stdout"),
                           (("--knn", "1", "-k", "21", "--ani"), "dists_knn_ani.stdout")]:
         assert run(db, "-v", *flags) == open(os.path.join(REF_FIXTURES, golden)).read()
-    # tests/distance.rs dense_distances (test 1): two short sequences, k=5 -> Jaccard 0.7538061
-    short = str(tmp_path / "short")
-    subprocess.check_call([CLI, "sketch", "-o", short, "-k", "5", "-s", "1000", "short_sequence.fa",
-                           "short_sequence_SNP.fa"], cwd=REF_FIXTURES)
-    val = float(run(short, "-k", "5").split()[-1])
-    assert abs(round(val, 3) - round(0.7538061, 3)) <= 0.05   # the reference's own tolerance
+
+
+def test_dense_distances_like_reference(gpu_ctx, tmp_path):
+    """tests/distance.rs:80-266 `dense_distances`: sketch -> cross dist, compared with the
+    pp-sketchlib numbers of sketchlib_output_true.txt under the reference's tolerance
+    (round to 3 dp, |diff| <= 0.05)."""
+    truth = {}
+    for line in open(os.path.join(REF_FIXTURES, "sketchlib_output_true.txt")):
+        key, val = line.split(": ")
+        truth[key] = [float(x) for x in val.strip().strip("[]").split(",")]
+
+    def close(a, b):
+        return abs(round(a, 3) - round(b, 3)) <= 0.05
+
+    def sk(name, *args):
+        out = str(tmp_path / name)
+        subprocess.check_call([CLI, "sketch", "-o", out, *args], cwd=REF_FIXTURES)
+        return out
+
+    # test 1: one short sequence vs the same with one SNP, k = 3
+    a = sk("t1a", "--k-vals", "3", "short_sequence.fa")
+    b = sk("t1b", "--k-vals", "3", "short_sequence_SNP.fa")
+    assert close(float(run(a, b, "-k", "3").split()[-1]), truth["short_sequence_jaccard_dists_3"][0])
+    # test 2: whole genome vs the same with one 3.6 kb contig removed, k = 17
+    a = sk("t2a", "--k-vals", "17", "14412_3#82.contigs_velvet.fa.gz")
+    b = sk("t2b", "--k-vals", "17", "14412_3#82.contigs_velvet_removed_block.fa.gz")
+    assert close(float(run(a, b, "-k", "17").split()[-1]), truth["whole_genome_block_removed"][0])
+    # test 3: four genomes, k = 31, s = 10000, self mode
+    c = sk("t3", "--k-vals", "31", "-s", "10000", *FIXTURE_NAMES)
+    got = [float(l.split()[-1]) for l in run(c, "-k", "31").splitlines()]
+    assert len(got) == 6 and all(close(x, y) for x, y in zip(got, truth["multiple_genomes"]))
