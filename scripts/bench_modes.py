@@ -32,8 +32,52 @@ def timed(fn, reps=2):
     return wall, ms / reps
 
 
+def full_size(which):
+    """BASELINE configs 3-5 at FULL size on ONE MI355X (they are specified for 8)."""
+    K5, K4 = [15, 19, 23, 27, 31], [13, 17, 21, 25, 29]
+    if "cfg3" in which:
+        n = 100000
+        sk = ctx.sketches(synth.set_u_device(n, 5, 64, dev), n, K5, 64)
+        pairs = n * (n - 1) // 2
+        out = torch.empty((pairs, 2), dtype=torch.float32, device=dev)
+        wall, kms = timed(lambda: capi.self_dists_all(ctx, sk, sk.set_k(), out=out), reps=1)
+        print(json.dumps({"mode": "cfg3 FULL: dense self core/acc, 1 GPU", "n": n, "sketchsize64": 64,
+                          "pairs": pairs, "output_GB": pairs * 8 / 1e9, "wall_s": wall,
+                          "pair_kernel_ms": kms, "pairs_per_s": pairs / wall,
+                          "checksum": float(out[:10 ** 7].double().sum().item())}), flush=True)
+        del out
+        sk.close()
+        torch.cuda.empty_cache()
+    if "cfg4" in which:
+        nr, nq = 1000000, 10000
+        r = ctx.sketches(synth.set_u_device(nr, 5, 32, dev), nr, K4, 32)
+        q = ctx.sketches(synth.set_u_device(nq, 5, 32, dev, first_sample=10 ** 7), nq, K4, 32)
+        out = torch.empty((nr, nq, 2), dtype=torch.float32, device=dev)
+        wall, kms = timed(lambda: capi.cross_dists_all(ctx, r, q, r.set_k(), out=out), reps=1)
+        print(json.dumps({"mode": "cfg4 FULL: dense cross core/acc 1M x 10k, 1 GPU", "sketchsize64": 32,
+                          "pairs": nr * nq, "output_GB": nr * nq * 8 / 1e9, "wall_s": wall,
+                          "pair_kernel_ms": kms, "pairs_per_s": nr * nq / wall}), flush=True)
+        del out
+        r.close()
+        q.close()
+        torch.cuda.empty_cache()
+    if "cfg5q" in which:
+        nr, nq = 1000000, 100000   # 1/10 of cfg 5's query rows
+        r = ctx.sketches(synth.set_u_device(nr, 5, 32, dev), nr, K4, 32)
+        q = ctx.sketches(synth.set_u_device(nq, 5, 32, dev, first_sample=10 ** 7), nq, K4, 32)
+        t0 = time.perf_counter()
+        idx, d0, d1 = capi.cross_dists_knn(ctx, r, q, r.set_k(21), 50)
+        wall = time.perf_counter() - t0
+        print(json.dumps({"mode": "cfg5 / 10: kNN-50 (Jaccard k=21), 1M refs x 100k query rows, 1 GPU",
+                          "sketchsize64": 32, "pairs": nr * nq, "wall_s": wall,
+                          "pairs_per_s": nr * nq / wall, "rows_per_s": nq / wall}), flush=True)
+
+
 def main():
     which = sys.argv[1:] or ["self50k", "cross", "selfknn", "crossknn"]
+    if any(w.startswith("cfg") for w in which):
+        full_size(which)
+        return
     if "self50k" in which:
         n, K = 50000, [15, 19, 23, 27, 31]
         sk = ctx.sketches(synth.set_u_device(n, 5, 64, dev), n, K, 64)

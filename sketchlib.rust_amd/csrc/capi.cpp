@@ -796,7 +796,14 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
     const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
     const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
-    size_t band_rows = std::max<size_t>(1, BAND_BYTES / (n_cand * rec));
+    // the key band lives only on the device: take up to a quarter of the free HBM (<= 8 GiB)
+    // so that the row-wise top-k kernel has thousands of rows (= workgroups) per launch
+    size_t free_b = 0, total_b = 0;
+    size_t band_bytes = BAND_BYTES;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        band_bytes = std::max(band_bytes, std::min<size_t>(free_b / 4, 8ull << 30));
+    }
+    size_t band_rows = std::max<size_t>(1, band_bytes / (n_cand * rec));
     band_rows = std::min(band_rows, r1 - r0);
 
     // device staging for host-destined results

@@ -33,7 +33,7 @@ struct DistArgs {
     size_t threads = 1;
     double completeness_cutoff = 0.64;
     bool verbose = false, quiet = false;
-    int device = 0;
+    std::vector<int> devices = {0};   // --device D | --devices a,b,.. | --gpus N
 };
 
 const char *g_usage = "sketchlib dist [OPTIONS] <REF_DB> [QUERY_DB]";
@@ -65,6 +65,8 @@ void print_help()
         "      --query-completeness-file <F> File listing query sample completeness estimates 0.0-1.0\n"
         "      --completeness-cutoff <C>   minimum completeness product for the correction [default: 0.64]\n"
         "      --device <D>                GPU to run on [default: 0]\n"
+        "      --gpus <N>                  Split the pair space over GPUs 0..N-1 (row bands)\n"
+        "      --devices <LIST>            Same, with an explicit comma separated device list\n"
         "  -v, --verbose                   Show progress messages\n"
         "      --quiet                     Don't show any messages\n"
         "  -h, --help                      Print help\n";
@@ -124,7 +126,24 @@ DistArgs parse_dist(int argc, char **argv, int first)
             a.completeness_cutoff = std::strtod(v.c_str(), &end);
             if (v.empty() || end != v.c_str() + v.size()) usage_error("invalid value '" + v + "' for '--completeness-cutoff <COMPLETENESS_CUTOFF>': invalid float literal");
         }
-        else if (arg == "--device") a.device = (int)parse_usize("--device <D>", value(arg));
+        else if (arg == "--device") a.devices = {(int)parse_usize("--device <D>", value(arg))};
+        else if (arg == "--gpus") {
+            const size_t ngpu = parse_usize("--gpus <N>", value(arg));
+            if (ngpu < 1) usage_error("invalid value for '--gpus <N>': must be one or higher");
+            a.devices.clear();
+            for (size_t d = 0; d < ngpu; ++d) a.devices.push_back((int)d);
+        }
+        else if (arg == "--devices") {
+            a.devices.clear();
+            const std::string v = value(arg);
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                const size_t comma = v.find(',', pos);
+                a.devices.push_back((int)parse_usize("--devices <LIST>", v.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos)));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
+        }
         else if (arg.size() > 2 && arg[0] == '-' && arg[1] != '-' && (arg[1] == 'o' || arg[1] == 'k')) {
             // clap accepts -k21 / -oFILE
             if (arg[1] == 'o') a.output = arg.substr(2);
@@ -213,7 +232,8 @@ int run_dist(const DistArgs &a)
     }
     for (const auto &w : warnings) log.warn(w);
 
-    Device dev(a.device);
+    DeviceSet dev(a.devices);
+    if (a.devices.size() > 1) log.info("Using " + std::to_string(a.devices.size()) + " GPU contexts (row-band partition)");
     const std::vector<double> *rc = ref_comp ? &*ref_comp : nullptr;
     const std::vector<double> *qc = query_comp ? &*query_comp : nullptr;
     if (!queries) {

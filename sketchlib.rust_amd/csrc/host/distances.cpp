@@ -1,6 +1,8 @@
 #include "distances.hpp"
 
+#include <exception>
 #include <string>
+#include <thread>
 
 #include "../../../include/sketchlib_dist.h"
 
@@ -17,6 +19,12 @@ static void check(int rc)
 
 Device::Device(int device) { check(skl_ctx_create(device, &ctx_)); }
 Device::~Device() { skl_ctx_destroy(ctx_); }
+
+DeviceSet::DeviceSet(const std::vector<int> &devices)
+{
+    if (devices.empty()) throw std::runtime_error("no devices given");
+    for (int d : devices) devs_.push_back(std::make_unique<Device>(d));
+}
 
 namespace {
 // RAII for a device-resident MultiSketch
@@ -152,6 +160,179 @@ SparseDistanceMatrix cross_dists_knn(Device &dev, const MultiSketch &ref_sketche
     Slab r(dev, ref_sketches, ref_completeness_vec);
     Slab q(dev, query_sketches, query_completeness_vec);
     SparseDistanceMatrix out = run_knn(dev, r.h, q.h, n_query, knn, dist_type, completeness_cutoff);
+    out.ref_names = sketch_names(ref_sketches);
+    out.query_names = sketch_names(query_sketches);
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// several devices: contiguous row bands, one host thread per device
+// ---------------------------------------------------------------------------
+
+namespace {
+// rows [0, n) of the condensed triangle split into `parts` bands of ~equal pair count
+std::vector<size_t> self_row_bounds(size_t n, size_t parts)
+{
+    const size_t total = n * (n - 1) / 2;
+    std::vector<size_t> b = {0};
+    size_t row = 0, acc = 0;
+    for (size_t w = 1; w < parts; ++w) {
+        const size_t target = (total * w + parts - 1) / parts;
+        while (row < n && acc < target) {
+            acc += n - 1 - row;
+            ++row;
+        }
+        b.push_back(row);
+    }
+    b.push_back(n);
+    return b;
+}
+
+std::vector<size_t> even_bounds(size_t rows, size_t parts)
+{
+    std::vector<size_t> b;
+    for (size_t w = 0; w <= parts; ++w) b.push_back(rows * w / parts);
+    return b;
+}
+
+// run fn(device index) on one thread per device; rethrow the first failure
+template <class F>
+void for_each_device(DeviceSet &devs, F fn)
+{
+    std::vector<std::exception_ptr> errs(devs.size());
+    std::vector<std::thread> pool;
+    for (size_t d = 0; d < devs.size(); ++d) {
+        pool.emplace_back([&, d] {
+            try {
+                fn(d);
+            } catch (...) {
+                errs[d] = std::current_exception();
+            }
+        });
+    }
+    for (auto &t : pool) t.join();
+    for (auto &e : errs) {
+        if (e) std::rethrow_exception(e);
+    }
+}
+}  // namespace
+
+DistanceMatrix self_dists_all(DeviceSet &devs, const MultiSketch &sketches, size_t n, const DistType &dist_type,
+                              bool quiet, const std::vector<double> *completeness_vec,
+                              double completeness_cutoff)
+{
+    if (devs.size() == 1) return self_dists_all(devs[0], sketches, n, dist_type, quiet, completeness_vec, completeness_cutoff);
+    DistanceMatrix out;
+    out.jaccard = dist_type;
+    out.ref_names = sketch_names(sketches);
+    out.n_distances = n * (n - 1) / 2;
+    const size_t ncols = dist_type.n_dist_cols();
+    out.distances.assign(out.n_distances * ncols, 0.0f);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    const std::vector<size_t> b = self_row_bounds(n, devs.size());
+    for_each_device(devs, [&](size_t d) {
+        if (b[d + 1] <= b[d]) return;
+        Slab s(devs[d], sketches, completeness_vec);
+        const size_t first = b[d] + 1 < n ? square_to_condensed(b[d], b[d] + 1, n) : out.n_distances;
+        check(skl_self_dists_rows(devs[d].ctx(), s.h, &p, b[d], b[d + 1], out.distances.data() + first * ncols, 0));
+    });
+    return out;
+}
+
+DistanceMatrix cross_dists_all(DeviceSet &devs, const MultiSketch &ref_sketches,
+                               const MultiSketch &query_sketches, size_t n, size_t n_query,
+                               const DistType &dist_type, bool quiet,
+                               const std::vector<double> *ref_completeness_vec,
+                               const std::vector<double> *query_completeness_vec,
+                               double completeness_cutoff)
+{
+    if (devs.size() == 1) {
+        return cross_dists_all(devs[0], ref_sketches, query_sketches, n, n_query, dist_type, quiet,
+                               ref_completeness_vec, query_completeness_vec, completeness_cutoff);
+    }
+    DistanceMatrix out;
+    out.jaccard = dist_type;
+    out.ref_names = sketch_names(ref_sketches);
+    out.query_names = sketch_names(query_sketches);
+    out.n_distances = n * n_query;
+    const size_t ncols = dist_type.n_dist_cols();
+    out.distances.assign(out.n_distances * ncols, 0.0f);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    const std::vector<size_t> b = even_bounds(n, devs.size());
+    for_each_device(devs, [&](size_t d) {
+        if (b[d + 1] <= b[d]) return;
+        Slab r(devs[d], ref_sketches, ref_completeness_vec);
+        Slab q(devs[d], query_sketches, query_completeness_vec);
+        check(skl_cross_dists_rows(devs[d].ctx(), r.h, q.h, &p, b[d], b[d + 1],
+                                   out.distances.data() + b[d] * n_query * ncols, 0));
+    });
+    return out;
+}
+
+static SparseDistanceMatrix assemble_knn(const DistType &dist_type, size_t knn, const std::vector<uint64_t> &idx,
+                                         const std::vector<float> &d0, const std::vector<float> &d1)
+{
+    SparseDistanceMatrix out;
+    out.jaccard = dist_type;
+    out.knn = knn;
+    out.n_distances = idx.size();
+    if (dist_type.kind == DistType::CoreAcc) {
+        out.coreacc_dists.resize(idx.size());
+        for (size_t i = 0; i < idx.size(); ++i) out.coreacc_dists[i] = {(size_t)idx[i], d0[i], d1[i]};
+    } else {
+        out.jaccard_dists.resize(idx.size());
+        for (size_t i = 0; i < idx.size(); ++i) out.jaccard_dists[i] = {(size_t)idx[i], d0[i]};
+    }
+    return out;
+}
+
+SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches, size_t n, size_t knn,
+                                    const DistType &dist_type, bool quiet,
+                                    const std::vector<double> *completeness_vec,
+                                    double completeness_cutoff)
+{
+    if (devs.size() == 1) return self_dists_knn(devs[0], sketches, n, knn, dist_type, quiet, completeness_vec, completeness_cutoff);
+    std::vector<uint64_t> idx(n * knn);
+    std::vector<float> d0(n * knn), d1(n * knn);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    const std::vector<size_t> b = even_bounds(n, devs.size());
+    for_each_device(devs, [&](size_t d) {
+        if (b[d + 1] <= b[d]) return;
+        Slab s(devs[d], sketches, completeness_vec);
+        check(skl_self_dists_knn_rows(devs[d].ctx(), s.h, &p, knn, b[d], b[d + 1], idx.data() + b[d] * knn,
+                                      d0.data() + b[d] * knn, d1.data() + b[d] * knn, 0));
+    });
+    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
+    out.ref_names = sketch_names(sketches);
+    return out;
+}
+
+SparseDistanceMatrix cross_dists_knn(DeviceSet &devs, const MultiSketch &ref_sketches,
+                                     const MultiSketch &query_sketches, size_t n, size_t n_query,
+                                     size_t knn, const DistType &dist_type, bool quiet,
+                                     const std::vector<double> *ref_completeness_vec,
+                                     const std::vector<double> *query_completeness_vec,
+                                     double completeness_cutoff)
+{
+    if (devs.size() == 1) {
+        return cross_dists_knn(devs[0], ref_sketches, query_sketches, n, n_query, knn, dist_type, quiet,
+                               ref_completeness_vec, query_completeness_vec, completeness_cutoff);
+    }
+    if (n == 0) throw Panic("Reference database has no loaded samples");
+    if (n_query == 0) throw Panic("Query database has no loaded samples");
+    knn = std::min(knn, n);
+    std::vector<uint64_t> idx(n_query * knn);
+    std::vector<float> d0(n_query * knn), d1(n_query * knn);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    const std::vector<size_t> b = even_bounds(n_query, devs.size());
+    for_each_device(devs, [&](size_t d) {
+        if (b[d + 1] <= b[d]) return;
+        Slab r(devs[d], ref_sketches, ref_completeness_vec);
+        Slab q(devs[d], query_sketches, query_completeness_vec);
+        check(skl_cross_dists_knn_rows(devs[d].ctx(), r.h, q.h, &p, knn, b[d], b[d + 1], idx.data() + b[d] * knn,
+                                       d0.data() + b[d] * knn, d1.data() + b[d] * knn, 0));
+    });
+    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
     out.ref_names = sketch_names(ref_sketches);
     out.query_names = sketch_names(query_sketches);
     return out;

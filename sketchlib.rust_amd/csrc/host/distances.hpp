@@ -3,6 +3,7 @@
 // implemented by calling the gfx950 engine through the C ABI (include/sketchlib_dist.h).
 #pragma once
 
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -33,7 +34,43 @@ class Device {
     skl_ctx *ctx_ = nullptr;
 };
 
+// Several GPUs of one node driven from one process: one host thread and one context per
+// device, every device holding the whole slab, the pair space split into contiguous row
+// bands whose results are copied straight into the right offsets of the host output (the
+// bands are contiguous slices of the reference's output arrays, so no exchange is needed).
+// The same device may be listed more than once (used by the tests on a 1-GPU box).
+class DeviceSet {
+  public:
+    explicit DeviceSet(const std::vector<int> &devices);
+    size_t size() const { return devs_.size(); }
+    Device &operator[](size_t i) { return *devs_[i]; }
+
+  private:
+    std::vector<std::unique_ptr<Device>> devs_;
+};
+
 namespace distances {
+
+// Multi-GPU forms of the dense / sparse drivers (same results as the single-device ones).
+DistanceMatrix self_dists_all(DeviceSet &devs, const MultiSketch &sketches, size_t n, const DistType &dist_type,
+                              bool quiet, const std::vector<double> *completeness_vec,
+                              double completeness_cutoff);
+DistanceMatrix cross_dists_all(DeviceSet &devs, const MultiSketch &ref_sketches,
+                               const MultiSketch &query_sketches, size_t n, size_t n_query,
+                               const DistType &dist_type, bool quiet,
+                               const std::vector<double> *ref_completeness_vec,
+                               const std::vector<double> *query_completeness_vec,
+                               double completeness_cutoff);
+SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches, size_t n, size_t knn,
+                                    const DistType &dist_type, bool quiet,
+                                    const std::vector<double> *completeness_vec,
+                                    double completeness_cutoff);
+SparseDistanceMatrix cross_dists_knn(DeviceSet &devs, const MultiSketch &ref_sketches,
+                                     const MultiSketch &query_sketches, size_t n, size_t n_query,
+                                     size_t knn, const DistType &dist_type, bool quiet,
+                                     const std::vector<double> *ref_completeness_vec,
+                                     const std::vector<double> *query_completeness_vec,
+                                     double completeness_cutoff);
 
 // mod.rs:25-37.  Throws std::runtime_error("K-mer size {k} not found in file").
 DistType set_k(const MultiSketch &sketches, std::optional<size_t> kmer, bool ani);

@@ -183,3 +183,25 @@ def test_dense_distances_like_reference(gpu_ctx, tmp_path):
     c = sk("t3", "--k-vals", "31", "-s", "10000", *FIXTURE_NAMES)
     got = [float(l.split()[-1]) for l in run(c, "-k", "31").splitlines()]
     assert len(got) == 6 and all(close(x, y) for x, y in zip(got, truth["multiple_genomes"]))
+
+
+@pytest.mark.parametrize("flags", [(), ("-k", "21"), ("--knn", "2"), ("--knn", "3", "-k", "25", "--ani")])
+def test_multi_context_row_bands_equal_single(gpu_ctx, flags):
+    """--devices a,b,c: one host thread + one context per entry, contiguous row bands copied
+    straight into the host output.  On this 1-GPU box the same device is listed three times,
+    which exercises the partition / assembly code; results must equal the single-context run."""
+    one = run(GEN_DB, *flags)
+    assert run(GEN_DB, *flags, "--devices", "0,0,0") == one
+    assert run(GEN_DB, GEN_DB, *flags, "--devices", "0,0") == run(GEN_DB, GEN_DB, *flags)
+
+
+def test_multi_context_synthetic(gpu_ctx, tmp_path):
+    from sketchlib.rust_amd import synth
+
+    kmers, ss64, n = [15, 19, 23, 27, 31], 16, 257
+    prefix, _ = _write_db(tmp_path, "m", synth.set_r(n, kmers, ss64, n_clusters=9), kmers, ss64)
+    one = run(prefix)
+    assert run(prefix, "--devices", "0,0,0,0,0", "--threads", "3") == one
+    assert run(prefix, "--gpus", "1") == one
+    knn = run(prefix, "--knn", "10")
+    assert run(prefix, "--knn", "10", "--devices", "0,0,0") == knn
