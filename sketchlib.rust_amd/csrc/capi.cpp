@@ -102,6 +102,7 @@ struct skl_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     std::string last_kernel;
+    TileScratch tile_scratch;           // device table of the balanced tile enumeration
     std::set<skl_sketches *> sketches;  // slabs created on this context
 };
 
@@ -181,6 +182,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     for (void *buf : ctx->scratch) {
         if (buf) (void)hipFree(buf);
     }
+    if (ctx->tile_scratch.d_prefix) (void)hipFree(ctx->tile_scratch.d_prefix);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SKL_OK;
@@ -231,7 +233,7 @@ extern "C" int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches)
 // (pair_lds.hip, default) or through the scalar cache (kernels.hip).  SKL_KERNEL=smem
 // selects the latter (kept for A/B measurements).
 static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream,
-                                       std::string *name)
+                                       std::string *name, TileScratch &tiles)
 {
     static const char *mode_names[] = {"COUNTS", "JACCARD", "COREACC"};
     const std::string m = mode_names[mode];
@@ -253,21 +255,21 @@ static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, h
     }();
     const uint64_t rows = args.row_end - args.row_begin;
     const uint64_t pairs = args.self_mode ? rows * args.nB / 2 : rows * (uint64_t)args.nB;
-    const bool small = pairs < (6ull << 20);  // crossover measured between n=3000 and n=4000
+    const bool small = pairs < (8ull << 20);  // ksplit<8> leads below n ~ 4000, lds<16,2> above (sweeps 21/22)
     if (forced == 1) {
         *name = "skl::pair_kernel<NA=" + std::to_string(na) + ", " + m + "> (scalar-cache rows)";
         return launch_pair_kernel(args, mode, na, stream);
     }
     if (forced == 3 || (forced == 0 && small)) {
-        int r = forced_rows ? forced_rows : 4;  // 4 beats 8 from n = 1000 to n = 3000 (sweep 14)
+        int r = forced_rows ? forced_rows : 8;  // 8 >= 4 from n = 1000 up once XCDs are balanced (sweep 18)
         *name = "skl::pair_kernel_ksplit<R=" + std::to_string(r) + ", " + m + "> (" + std::to_string(r) +
                 "x64 tiles, chunks split over 4 waves)";
-        return launch_pair_kernel_ksplit(args, mode, r, stream);
+        return launch_pair_kernel_ksplit(args, mode, r, tiles, stream);
     }
     const int shape = choose_lds_shape(rows, args.nB, args.self_mode, mode);
     *name = "skl::pair_kernel_lds<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(shape % 10) +
             ", " + m + "> (" + std::to_string(shape / 10) + "x" + std::to_string((shape % 10) * 256) + " tiles)";
-    return launch_pair_kernel_lds(args, mode, shape, stream);
+    return launch_pair_kernel_lds(args, mode, shape, tiles, stream);
 }
 
 // Launch the pair kernel bracketed by HIP events on the context's stream.
@@ -275,7 +277,7 @@ static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int n
 {
     constexpr size_t MAX_EVENTS = 4096;
     if (ctx->events_used >= MAX_EVENTS) {
-        HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel));
+        HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel, ctx->tile_scratch));
         return SKL_OK;
     }
     if (ctx->events_used == ctx->events.size()) {
@@ -286,7 +288,7 @@ static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int n
     }
     auto &ev = ctx->events[ctx->events_used++];
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel));
+    HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel, ctx->tile_scratch));
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     return SKL_OK;
 }

@@ -95,6 +95,33 @@ __device__ __forceinline__ uint64_t square_to_condensed_dev(uint64_t i, uint64_t
 }
 
 
+// Balanced, XCD-aware tile lookup.  Workgroups are dealt round-robin to the 8 XCDs, so
+// blockIdx % 8 labels the XCD (MI355X_MICROARCH.md); XCD x takes tiles
+// [x*tiles_per_xcd, (x+1)*tiles_per_xcd) of the column-group-major numbering of the ACTIVE
+// tiles: every XCD gets the same number of (equal-cost) tiles, and the tiles of one XCD
+// share at most ceil(groups/8)+1 column groups, whose lane slab then stays in its L2.
+// Returns false when this workgroup has no tile.
+__device__ __forceinline__ bool lookup_tile(const PairArgs &g, uint32_t &group, uint32_t &row_tile)
+{
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    if (slot >= g.tiles_per_xcd) return false;
+    const uint32_t t = xcd * g.tiles_per_xcd + slot;
+    if (t >= g.n_active_tiles) return false;
+    if (!g.self_mode) {
+        group = t / g.a_tiles;
+        row_tile = t - group * g.a_tiles;
+        return true;
+    }
+    uint32_t lo = 0, hi = g.n_groups;  // largest lo with prefix[lo] <= t
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g.tile_prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    group = lo;
+    row_tile = t - g.tile_prefix[lo];
+    return true;
+}
+
 __device__ __forceinline__ bool pair_valid(const PairArgs &g, uint32_t i, uint32_t jcol)
 {
     return i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);

@@ -6,6 +6,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace skl {
 
 constexpr int BBITS = 14;          // src/sketch/mod.rs:34
@@ -41,6 +43,12 @@ struct PairArgs {
     uint32_t a_tiles;             // workgroup tiles along rows
     uint32_t n_jblocks;           // 64-wide column blocks
     uint32_t share_rows;          // 1: waves of a workgroup share rows, differ in column block
+    // balanced tile enumeration (pair_lds / pair_ksplit): active tiles are numbered column
+    // group by column group and each XCD takes one contiguous eighth of the numbering
+    uint32_t n_active_tiles;
+    uint32_t tiles_per_xcd;       // ceil(n_active_tiles / 8)
+    uint32_t n_groups;            // column groups
+    const uint32_t *tile_prefix;  // [n_groups + 1] first tile number of each group (self mode)
     uint64_t out_base;            // flat index of the first pair of this launch
     void *out;
     // epilogue
@@ -59,12 +67,26 @@ int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 
 hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream);
 
+// Device buffer the launchers may use for the tile-prefix table (owned by the context).
+struct TileScratch {
+    uint32_t *d_prefix = nullptr;
+    size_t capacity = 0;           // entries
+    uint64_t cached_key[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+};
+
+// Fills n_active_tiles / tiles_per_xcd / n_groups / tile_prefix of `args` for tiles of
+// rows_per_tile x cols_per_group; uploads the prefix table (self mode) on `stream`.
+// Returns the grid size (0 = nothing to do).
+hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_group,
+                      TileScratch &scratch, hipStream_t stream, uint64_t *grid_out);
+
 // LDS-staged variant (pair_lds.hip).  shape = R*10 + JL: R rows per workgroup tile, JL
 // 64-column blocks per lane; valid shapes: 41, 81, 82, 162.
-hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, hipStream_t stream);
+hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, TileScratch &scratch,
+                                  hipStream_t stream);
 // K-split variant for small launches (pair_ksplit.hip): rows_per_tile in {4, 8}.
 hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_per_tile,
-                                     hipStream_t stream);
+                                     TileScratch &scratch, hipStream_t stream);
 int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)

@@ -29,6 +29,7 @@
 // be contracted into FMAs: the reference's f64 arithmetic is unfused).
 #include "device_common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -250,6 +251,62 @@ hipError_t launch_pair_kernel(const PairArgs &args_in, int mode, int na, hipStre
         case MODE_COREACC: return launch_m<MODE_COREACC>(args, na, bitop3, grid, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+// ---------------------------------------------------------------------------
+// balanced tile enumeration (host side of device_common.hpp::lookup_tile)
+// ---------------------------------------------------------------------------
+
+hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_group,
+                      TileScratch &scratch, hipStream_t stream, uint64_t *grid_out)
+{
+    *grid_out = 0;
+    const uint32_t rows = args.row_end - args.row_begin;
+    args.a_tiles = (rows + rows_per_tile - 1) / rows_per_tile;
+    args.n_jblocks = (args.nB + 63u) / 64u;
+    args.n_groups = (args.nB + cols_per_group - 1) / cols_per_group;
+    args.tile_prefix = nullptr;
+    uint64_t total;
+    if (!args.self_mode) {
+        total = (uint64_t)args.a_tiles * args.n_groups;
+    } else {
+        // group g is needed by the row tiles with a0 < (g+1)*W - 1 (some i < j exists)
+        std::vector<uint32_t> prefix(args.n_groups + 1);
+        total = 0;
+        for (uint32_t gi = 0; gi < args.n_groups; ++gi) {
+            prefix[gi] = (uint32_t)total;
+            const uint64_t last_col = (uint64_t)(gi + 1) * cols_per_group - 1;
+            const uint32_t lim = (uint32_t)std::min<uint64_t>(args.row_end, last_col);
+            total += lim > args.row_begin ? (lim - args.row_begin + rows_per_tile - 1) / rows_per_tile : 0u;
+        }
+        prefix[args.n_groups] = (uint32_t)total;
+        if (total >= (1ull << 32)) return hipErrorInvalidValue;
+        const uint64_t key[4] = {((uint64_t)args.row_begin << 32) | args.row_end, args.nB,
+                                 ((uint64_t)rows_per_tile << 32) | cols_per_group, total};
+        if (prefix.size() > scratch.capacity) {
+            if (scratch.d_prefix) (void)hipFree(scratch.d_prefix);
+            scratch.capacity = 0;
+            const size_t cap = std::max<size_t>(prefix.size(), 4096);
+            const hipError_t e = hipMalloc((void **)&scratch.d_prefix, cap * sizeof(uint32_t));
+            if (e != hipSuccess) return e;
+            scratch.capacity = cap;
+            scratch.cached_key[0] = ~0ull;
+        }
+        if (memcmp(key, scratch.cached_key, sizeof key) != 0) {
+            // pageable source: the runtime stages it before returning, so `prefix` may die
+            const hipError_t e = hipMemcpyAsync(scratch.d_prefix, prefix.data(), prefix.size() * sizeof(uint32_t),
+                                                hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+            memcpy(scratch.cached_key, key, sizeof key);
+        }
+        args.tile_prefix = scratch.d_prefix;
+    }
+    if (total == 0) return hipSuccess;
+    if (total >= (1ull << 31)) return hipErrorInvalidValue;
+    args.n_active_tiles = (uint32_t)total;
+    args.tiles_per_xcd = (uint32_t)((total + 7) / 8);
+    *grid_out = 8ull * args.tiles_per_xcd;
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------

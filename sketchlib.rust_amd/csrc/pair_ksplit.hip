@@ -47,12 +47,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t slot = blockIdx.x >> 3;
-    // boustrophedon deal of column blocks to XCDs (see pair_lds.hip): balances the triangle
-    const uint32_t gseq = slot / g.a_tiles;
-    const uint32_t jb = gseq * 8u + ((gseq & 1u) ? 7u - xcd : xcd);   // 64-wide column block
-    const uint32_t at = slot % g.a_tiles;
+    uint32_t jb, at;  // 64-wide column block, row tile
+    if (!lookup_tile(g, jb, at)) return;
     const uint32_t a0 = g.row_begin + at * R;
     if (jb >= g.n_jblocks) return;
     if (a0 >= g.row_end) return;
@@ -239,19 +235,19 @@ static hipError_t launch_r(const PairArgs &args, int mode, dim3 grid, hipStream_
 }
 
 hipError_t launch_pair_kernel_ksplit(const PairArgs &args_in, int mode, int rows_per_tile,
-                                     hipStream_t stream)
+                                     TileScratch &scratch, hipStream_t stream)
 {
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
-    const uint32_t rows = args.row_end - args.row_begin;
-    args.a_tiles = (rows + (uint32_t)rows_per_tile - 1) / (uint32_t)rows_per_tile;
-    args.n_jblocks = (args.nB + 63u) / 64u;
-    const uint64_t n_wg = 8ull * ((args.n_jblocks + 7u) / 8u) * args.a_tiles;
-    if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
+    uint64_t n_wg = 0;
+    const hipError_t pe = plan_tiles(args, (uint32_t)rows_per_tile, 64u, scratch, stream, &n_wg);
+    if (pe != hipSuccess) return pe;
+    if (n_wg == 0) return hipSuccess;
     const dim3 grid((unsigned)n_wg);
     switch (rows_per_tile) {
         case 4: return launch_r<4>(args, mode, grid, stream);
         case 8: return launch_r<8>(args, mode, grid, stream);
+        case 16: return launch_r<16>(args, mode, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }

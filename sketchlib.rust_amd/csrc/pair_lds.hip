@@ -55,16 +55,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware mapping (see kernels.hip): workgroups of one XCD walk the row tiles of one
-    // column group, whose lane-operand slab stays in that XCD's L2.
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t slot = blockIdx.x >> 3;
-    // column groups are dealt to the XCDs boustrophedon (0..7, 7..0, ...): in self mode the work
-    // of a column group grows with its index, and a plain modulo deal left the last XCD with
-    // up to 2.4x the rows of the first one on small grids
-    const uint32_t gseq = slot / g.a_tiles;
-    const uint32_t jg = gseq * 8u + ((gseq & 1u) ? 7u - xcd : xcd);  // column group: 4*JL blocks
-    const uint32_t at = slot % g.a_tiles;
+    uint32_t jg, at;  // column group (4*JL blocks of 64), row tile
+    if (!lookup_tile(g, jg, at)) return;
     const uint32_t jb0 = (jg * WAVES_PER_WG + wave) * JL;  // this wave's first column block
     const uint32_t a0 = g.row_begin + at * R;
     if (jg * WAVES_PER_WG * JL >= g.n_jblocks) return;     // whole workgroup out of range
@@ -303,18 +295,16 @@ static hipError_t launch_rj(const PairArgs &args, int mode, dim3 grid, hipStream
 }
 
 // shape: rows R and columns-per-lane JL, encoded as R*10 + JL
-hipError_t launch_pair_kernel_lds(const PairArgs &args_in, int mode, int shape, hipStream_t stream)
+hipError_t launch_pair_kernel_lds(const PairArgs &args_in, int mode, int shape, TileScratch &scratch,
+                                  hipStream_t stream)
 {
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     const int R = shape / 10, JL = shape % 10;
-    const uint32_t rows = args.row_end - args.row_begin;
-    args.a_tiles = (rows + (uint32_t)R - 1) / (uint32_t)R;
-    args.n_jblocks = (args.nB + 63u) / 64u;
-    const uint32_t blocks_per_group = WAVES_PER_WG * (uint32_t)JL;
-    const uint32_t jgroups = (args.n_jblocks + blocks_per_group - 1) / blocks_per_group;
-    const uint64_t n_wg = 8ull * ((jgroups + 7u) / 8u) * args.a_tiles;
-    if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
+    uint64_t n_wg = 0;
+    const hipError_t pe = plan_tiles(args, (uint32_t)R, WAVES_PER_WG * (uint32_t)JL * 64u, scratch, stream, &n_wg);
+    if (pe != hipSuccess) return pe;
+    if (n_wg == 0) return hipSuccess;
     const dim3 grid((unsigned)n_wg);
     static const int abl = [] {
         const char *e = getenv("SKL_LDS_ABLATE");  // timing-only: 1 no row re-reads, 2 no column reloads
@@ -345,8 +335,11 @@ int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode)
     if (forced) return forced;
     const uint64_t pairs = self_mode ? n_rows * n_cols / 2 : n_rows * n_cols;
     (void)mode;
-    // measured on MI355X (gpurun sweeps 4/5): 8x256 tiles up to ~24M pairs, 16x512 beyond
-    return pairs < (24ull << 20) ? 81 : 162;
+    // with the balanced tile enumeration the 16x512 tile is at least as fast as 8x256 from
+    // ~8M pairs up (profiles/r01_kernel_sweeps.jsonl, sweeps 21/22); smaller launches go
+    // to pair_ksplit.hip
+    (void)pairs;
+    return 162;
 }
 
 }  // namespace skl
