@@ -806,6 +806,11 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         band_bytes = std::max(band_bytes, std::min<size_t>(free_b / 4, 8ull << 30));
     }
     size_t band_rows = std::max<size_t>(1, band_bytes / (n_cand * rec));
+    static const size_t forced_band_rows = [] {
+        const char *e = getenv("SKL_KNN_BAND_ROWS");  // test knob: force several bands
+        return e ? (size_t)atoll(e) : (size_t)0;
+    }();
+    if (forced_band_rows) band_rows = forced_band_rows;
     band_rows = std::min(band_rows, r1 - r0);
 
     // device staging for host-destined results
