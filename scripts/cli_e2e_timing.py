@@ -23,6 +23,7 @@ with tempfile.TemporaryDirectory() as tmp:
     for threads in (1, 8, 32):
         out = os.path.join(tmp, "out.txt")
         t0 = time.perf_counter()
-        subprocess.check_call([os.path.join(BUILD, "sketchlib"), "dist", prefix, "-o", out, "--threads", str(threads)])
+        subprocess.check_call([os.path.join(BUILD, "sketchlib"), "dist", prefix, "-o", out, "--threads", str(threads)],
+                              env={**os.environ, "SKL_CLI_TIMING": "1"})
         wall = time.perf_counter() - t0
         print(f"n={n} pairs={n*(n-1)//2} threads={threads} wall={wall:.2f}s out={os.path.getsize(out)/1e6:.0f} MB", flush=True)

@@ -12,6 +12,7 @@
 #include <fstream>
 #include <algorithm>
 #include <iostream>
+#include <memory>
 #include <optional>
 #include <string>
 #include <vector>
@@ -34,6 +35,13 @@ struct DistArgs {
     double completeness_cutoff = 0.64;
     bool verbose = false, quiet = false;
     std::vector<int> devices = {0};   // --device D | --devices a,b,.. | --gpus N
+    size_t band_bytes = 256ull << 20;  // --band-mb: host memory per streamed output band
+    size_t band() const
+    {
+        // finer-than-MB override, for tests that want many bands on a small database
+        if (const char *e = std::getenv("SKL_DIST_BAND_BYTES")) return std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+        return band_bytes;
+    }
 };
 
 const char *g_usage = "sketchlib dist [OPTIONS] <REF_DB> [QUERY_DB]";
@@ -65,6 +73,7 @@ void print_help()
         "      --query-completeness-file <F> File listing query sample completeness estimates 0.0-1.0\n"
         "      --completeness-cutoff <C>   minimum completeness product for the correction [default: 0.64]\n"
         "      --device <D>                GPU to run on [default: 0]\n"
+        "      --band-mb <MB>              Host memory per streamed dense output band [default: 256]\n"
         "      --gpus <N>                  Split the pair space over GPUs 0..N-1 (row bands)\n"
         "      --devices <LIST>            Same, with an explicit comma separated device list\n"
         "  -v, --verbose                   Show progress messages\n"
@@ -127,6 +136,7 @@ DistArgs parse_dist(int argc, char **argv, int first)
             if (v.empty() || end != v.c_str() + v.size()) usage_error("invalid value '" + v + "' for '--completeness-cutoff <COMPLETENESS_CUTOFF>': invalid float literal");
         }
         else if (arg == "--device") a.devices = {(int)parse_usize("--device <D>", value(arg))};
+        else if (arg == "--band-mb") a.band_bytes = std::max<size_t>(1, parse_usize("--band-mb <MB>", value(arg))) << 20;
         else if (arg == "--gpus") {
             const size_t ngpu = parse_usize("--gpus <N>", value(arg));
             if (ngpu < 1) usage_error("invalid value for '--gpus <N>': must be one or higher");
@@ -170,17 +180,31 @@ struct Logger {
 
 int run_dist(const DistArgs &a)
 {
+    const bool timing = std::getenv("SKL_CLI_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_loaded = 0, t_device = 0;
     // lib.rs:230-237: verbose -> Info, quiet -> Error, default -> Warn
     const Logger log{a.verbose && !a.quiet, !a.quiet};
     log.info("Using " + std::to_string(a.threads) + " threads");   // cli.rs:75-86 (host threads unused)
 
+    // dense listings go through a TextSink (regular file: blocks written at offsets from all
+    // formatting threads); sparse listings are small and use the plain stream
     std::ofstream out_file;
     std::ostream *os = &std::cout;
-    if (a.output) {
+    std::unique_ptr<TextSink> sink;
+    if (a.output && !a.knn) {
+        try {
+            sink = std::make_unique<FileSink>(*a.output);
+        } catch (const std::exception &e) {
+            throw Panic(e.what());
+        }
+    } else if (a.output) {
         out_file.open(*a.output, std::ios::binary);
         if (!out_file) throw Panic("cannot create output file " + *a.output);
         os = &out_file;
     }
+    if (!sink) sink = std::make_unique<StreamSink>(*os);
 
     const std::string ref_db_name = strip_sketch_extension(a.ref_db);
     MultiSketch references;
@@ -232,7 +256,9 @@ int run_dist(const DistArgs &a)
     }
     for (const auto &w : warnings) log.warn(w);
 
+    t_loaded = since_start();
     DeviceSet dev(a.devices);
+    t_device = since_start();
     if (a.devices.size() > 1) log.info("Using " + std::to_string(a.devices.size()) + " GPU contexts (row-band partition)");
     const std::vector<double> *rc = ref_comp ? &*ref_comp : nullptr;
     const std::vector<double> *qc = query_comp ? &*query_comp : nullptr;
@@ -245,10 +271,17 @@ int run_dist(const DistArgs &a)
                 }
                 return 0;  // empty upper triangle
             }
-            const DistanceMatrix d = distances::self_dists_all(dev, references, n, dist_type, a.quiet, rc,
-                                                               a.completeness_cutoff);
-            log.info("Writing out in long matrix form");
-            d.write(*os, a.threads);
+            if (a.devices.size() == 1) {
+                // one device: stream row bands (compute band i+1 while band i is written)
+                log.info("Writing out in long matrix form");
+                distances::self_dists_all_streamed(dev[0], references, n, dist_type, rc, a.completeness_cutoff,
+                                                   *sink, a.threads, a.band());
+            } else {
+                const DistanceMatrix d = distances::self_dists_all(dev, references, n, dist_type, a.quiet, rc,
+                                                                   a.completeness_cutoff);
+                log.info("Writing out in long matrix form");
+                d.write_rows(*sink, 0, n, d.distances.data(), a.threads);
+            }
         } else {
             size_t nn = *a.knn;
             if (nn >= n) {  // lib.rs:379-382
@@ -278,13 +311,24 @@ int run_dist(const DistArgs &a)
             d.write(*os);
         } else {
             log.info("Calculating all ref vs query distances");
-            const DistanceMatrix d = distances::cross_dists_all(dev, references, *queries, n, n_query, dist_type,
-                                                                a.quiet, rc, qc, a.completeness_cutoff);
-            log.info("Writing out in long matrix form");
-            d.write(*os, a.threads);
+            if (a.devices.size() == 1) {
+                log.info("Writing out in long matrix form");
+                distances::cross_dists_all_streamed(dev[0], references, *queries, n, n_query, dist_type, rc, qc,
+                                                    a.completeness_cutoff, *sink, a.threads, a.band());
+            } else {
+                const DistanceMatrix d = distances::cross_dists_all(dev, references, *queries, n, n_query, dist_type,
+                                                                    a.quiet, rc, qc, a.completeness_cutoff);
+                log.info("Writing out in long matrix form");
+                d.write_rows(*sink, 0, n, d.distances.data(), a.threads);
+            }
         }
     }
     os->flush();
+    if (timing) {
+        const OutputTiming &t = output_timing();
+        std::fprintf(stderr, "TIMING load=%.3fs device_init=%.3fs dist+output=%.3fs (gpu_wait=%.3fs format=%.3fs sink=%.3fs)\n",
+                     t_loaded, t_device - t_loaded, since_start() - t_device, t.wait_s, t.format_s, t.sink_s);
+    }
     return 0;
 }
 

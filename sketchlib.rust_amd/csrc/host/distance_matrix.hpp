@@ -33,6 +33,44 @@ struct DistType {
 // Rust's `{}` for f32: shortest digits that round-trip, positional notation.
 std::string format_f32(float v);
 
+// Wall-clock split of the dense text path (seconds), reported by `sketchlib dist` when
+// SKL_CLI_TIMING is set: time formatting blocks, time handing them to the sink, time the
+// writer waited for the GPU band.
+struct OutputTiming {
+    double format_s = 0, sink_s = 0, wait_s = 0;
+};
+OutputTiming &output_timing();
+
+// Where formatted text blocks go.  A stream takes them one after the other; a regular file
+// takes them at computed offsets from several threads at once (page-cache copies of a multi-GB
+// listing are otherwise the serial tail of `sketchlib dist -o`).
+class TextSink {
+  public:
+    virtual ~TextSink() = default;
+    // Called once per text block, in output order, one caller at a time.  Returns a token
+    // for finish().
+    virtual uint64_t begin(const char *p, size_t len) = 0;
+    // Called after begin() for the same block, from any thread, in any order.
+    virtual void finish(uint64_t /*token*/, const char * /*p*/, size_t /*len*/) {}
+};
+class StreamSink : public TextSink {
+  public:
+    explicit StreamSink(std::ostream &os) : os_(os) {}
+    uint64_t begin(const char *p, size_t len) override;
+  private:
+    std::ostream &os_;
+};
+class FileSink : public TextSink {
+  public:
+    explicit FileSink(const std::string &path);   // throws std::runtime_error if it cannot be created
+    ~FileSink() override;
+    uint64_t begin(const char *p, size_t len) override;
+    void finish(uint64_t token, const char *p, size_t len) override;
+  private:
+    int fd_ = -1;
+    uint64_t offset_ = 0;
+};
+
 // DistanceMatrix, distance_matrix.rs:120-209
 class DistanceMatrix {
   public:
@@ -46,6 +84,10 @@ class DistanceMatrix {
     // blocks concurrently into per-thread buffers and writes them in order -- the reference
     // formats single-threaded, which dwarfs the GPU time at large n.
     void write(std::ostream &os, size_t threads = 1) const;
+
+    // Streaming form: write reference rows [r0, r1) whose distances start at `band`
+    // (the slice of the full matrix that skl_*_dists_rows produces for that row range).
+    void write_rows(TextSink &sink, size_t r0, size_t r1, const float *band, size_t threads) const;
 };
 
 struct SparseJaccard {   // distance_matrix.rs:214

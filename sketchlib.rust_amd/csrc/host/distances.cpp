@@ -1,6 +1,8 @@
 #include "distances.hpp"
 
+#include <chrono>
 #include <exception>
+#include <ostream>
 #include <string>
 #include <thread>
 
@@ -336,6 +338,102 @@ SparseDistanceMatrix cross_dists_knn(DeviceSet &devs, const MultiSketch &ref_ske
     out.ref_names = sketch_names(ref_sketches);
     out.query_names = sketch_names(query_sketches);
     return out;
+}
+
+// ---------------------------------------------------------------------------
+// streaming dense drivers
+// ---------------------------------------------------------------------------
+
+namespace {
+// Compute bands [b[i], b[i+1]) one after the other; while band i is formatted and written,
+// band i+1 is already being computed (one helper thread drives the GPU call).
+template <class Compute>
+void stream_bands(const DistanceMatrix &shape, const std::vector<size_t> &b, size_t max_band_floats,
+                  Compute compute, TextSink &sink, size_t threads)
+{
+    std::vector<float> buf[2];
+    buf[0].resize(max_band_floats);
+    buf[1].resize(max_band_floats);
+    std::exception_ptr err;
+    auto launch = [&](size_t i) {
+        return std::thread([&, i] {
+            try {
+                compute(b[i], b[i + 1], buf[i & 1].data());
+            } catch (...) {
+                err = std::current_exception();
+            }
+        });
+    };
+    const size_t n_bands = b.size() - 1;
+    if (n_bands == 0) return;
+    std::thread worker = launch(0);
+    for (size_t i = 0; i < n_bands; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        worker.join();
+        output_timing().wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (err) std::rethrow_exception(err);
+        if (i + 1 < n_bands) worker = launch(i + 1);
+        shape.write_rows(sink, b[i], b[i + 1], buf[i & 1].data(), threads);
+    }
+}
+}  // namespace
+
+void self_dists_all_streamed(Device &dev, const MultiSketch &sketches, size_t n, const DistType &dist_type,
+                             const std::vector<double> *completeness_vec, double completeness_cutoff,
+                             TextSink &sink, size_t threads, size_t band_bytes)
+{
+    if (n < 2) return;
+    DistanceMatrix shape;   // names + type only; no n^2 storage
+    shape.jaccard = dist_type;
+    shape.ref_names = sketch_names(sketches);
+    shape.n_distances = n * (n - 1) / 2;
+    const size_t ncols = dist_type.n_dist_cols();
+    const size_t band_pairs = std::max<size_t>(n, band_bytes / (ncols * sizeof(float)));
+    std::vector<size_t> b = {0};
+    size_t acc = 0, max_pairs = 0;
+    for (size_t i = 0; i + 1 < n; ++i) {
+        const size_t row = n - 1 - i;
+        if (acc && acc + row > band_pairs) {
+            b.push_back(i);
+            max_pairs = std::max(max_pairs, acc);
+            acc = 0;
+        }
+        acc += row;
+    }
+    b.push_back(n);
+    max_pairs = std::max(max_pairs, acc);
+    Slab s(dev, sketches, completeness_vec);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    stream_bands(shape, b, max_pairs * ncols,
+                 [&](size_t r0, size_t r1, float *out) { check(skl_self_dists_rows(dev.ctx(), s.h, &p, r0, r1, out, 0)); },
+                 sink, threads);
+}
+
+void cross_dists_all_streamed(Device &dev, const MultiSketch &ref_sketches, const MultiSketch &query_sketches,
+                              size_t n, size_t n_query, const DistType &dist_type,
+                              const std::vector<double> *ref_completeness_vec,
+                              const std::vector<double> *query_completeness_vec, double completeness_cutoff,
+                              TextSink &sink, size_t threads, size_t band_bytes)
+{
+    if (n == 0 || n_query == 0) return;
+    DistanceMatrix shape;
+    shape.jaccard = dist_type;
+    shape.ref_names = sketch_names(ref_sketches);
+    shape.query_names = sketch_names(query_sketches);
+    shape.n_distances = n * n_query;
+    const size_t ncols = dist_type.n_dist_cols();
+    const size_t rows_per_band = std::max<size_t>(1, band_bytes / (n_query * ncols * sizeof(float)));
+    std::vector<size_t> b;
+    for (size_t r = 0; r < n; r += rows_per_band) b.push_back(r);
+    b.push_back(n);
+    Slab r(dev, ref_sketches, ref_completeness_vec);
+    Slab q(dev, query_sketches, query_completeness_vec);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    stream_bands(shape, b, std::min(rows_per_band, n) * n_query * ncols,
+                 [&](size_t r0, size_t r1, float *out) {
+                     check(skl_cross_dists_rows(dev.ctx(), r.h, q.h, &p, r0, r1, out, 0));
+                 },
+                 sink, threads);
 }
 
 }  // namespace distances

@@ -3,6 +3,7 @@
 // implemented by calling the gfx950 engine through the C ABI (include/sketchlib_dist.h).
 #pragma once
 
+#include <iosfwd>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -71,6 +72,20 @@ SparseDistanceMatrix cross_dists_knn(DeviceSet &devs, const MultiSketch &ref_ske
                                      const std::vector<double> *ref_completeness_vec,
                                      const std::vector<double> *query_completeness_vec,
                                      double completeness_cutoff);
+
+// Streaming dense drivers (the reference muses about it at mod.rs:50-55):
+// the matrix is produced in row bands of at most `band_bytes`, each band is written as text
+// as soon as it is back on the host while the GPU computes the next one -- bounded host
+// memory instead of n(n-1)/2 records, and formatting overlapped with compute.  Output is
+// byte-identical to DistanceMatrix::write of the whole matrix.
+void self_dists_all_streamed(Device &dev, const MultiSketch &sketches, size_t n, const DistType &dist_type,
+                             const std::vector<double> *completeness_vec, double completeness_cutoff,
+                             TextSink &sink, size_t threads, size_t band_bytes);
+void cross_dists_all_streamed(Device &dev, const MultiSketch &ref_sketches, const MultiSketch &query_sketches,
+                              size_t n, size_t n_query, const DistType &dist_type,
+                              const std::vector<double> *ref_completeness_vec,
+                              const std::vector<double> *query_completeness_vec, double completeness_cutoff,
+                              TextSink &sink, size_t threads, size_t band_bytes);
 
 // mod.rs:25-37.  Throws std::runtime_error("K-mer size {k} not found in file").
 DistType set_k(const MultiSketch &sketches, std::optional<size_t> kmer, bool ani);

@@ -3,14 +3,22 @@
 //   skl_dbtool roundtrip <in> <out>     load <in>.skm/.skd and write them back as <out>.*
 //   skl_dbtool slice <prefix> <i> <k>   print the u64 words of get_sketch_slice(i, k_idx)
 //   skl_dbtool make <prefix> <bins> <k1,k2,..> <name>...  write <prefix>.skm for an existing .skd
+//   skl_dbtool format <self|cross> <coreacc|jaccard> <n> <nq> <threads> <band_rows> <dists.f32> [out]
+//                                       print a raw f32 distance array as the dense long-form text
+//                                       (names s0,s1,.. / q0,q1,..), in row bands of <band_rows> rows,
+//                                       to stdout or (block-parallel) to <out>
 // Used by the test-suite to pin the file-format code without a GPU, and to write
 // synthetic databases in the reference's on-disk layout.
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
+#include <fstream>
+
+#include "../host/distance_matrix.hpp"
 #include "../host/io.hpp"
 #include "../host/multisketch.hpp"
 
@@ -52,6 +60,35 @@ int main(int argc, char **argv)
             m.read_sketch_data(prefix);
             const uint64_t *p = m.get_sketch_slice((size_t)atoll(argv[3]), (size_t)atoll(argv[4]));
             for (size_t w = 0; w < m.kmer_stride(); ++w) std::cout << p[w] << "\n";
+            return 0;
+        }
+        if (argc >= 9 && std::string(argv[1]) == "format") {
+            const bool cross = std::string(argv[2]) == "cross";
+            DistanceMatrix m;
+            m.jaccard.kind = std::string(argv[3]) == "coreacc" ? DistType::CoreAcc : DistType::Jaccard;
+            const size_t n = strtoull(argv[4], nullptr, 10), nq = strtoull(argv[5], nullptr, 10);
+            const size_t threads = strtoull(argv[6], nullptr, 10), band_rows = strtoull(argv[7], nullptr, 10);
+            for (size_t i = 0; i < n; ++i) m.ref_names.push_back("s" + std::to_string(i));
+            if (cross) {
+                m.query_names.emplace();
+                for (size_t i = 0; i < nq; ++i) m.query_names->push_back("q" + std::to_string(i));
+            }
+            std::ifstream f(argv[8], std::ios::binary);
+            f.seekg(0, std::ios::end);
+            const size_t bytes = (size_t)f.tellg();
+            f.seekg(0);
+            m.distances.resize(bytes / sizeof(float));
+            f.read(reinterpret_cast<char *>(m.distances.data()), (std::streamsize)bytes);
+            const size_t ncols = m.jaccard.n_dist_cols();
+            m.n_distances = m.distances.size() / ncols;
+            std::unique_ptr<TextSink> sink;
+            if (argc >= 10) sink = std::make_unique<FileSink>(argv[9]);
+            else sink = std::make_unique<StreamSink>(std::cout);
+            for (size_t r0 = 0; r0 < n; r0 += band_rows) {
+                const size_t first = cross ? r0 * nq : (r0 + 1 < n ? square_to_condensed(r0, r0 + 1, n) : 0);
+                m.write_rows(*sink, r0, std::min(n, r0 + band_rows), m.distances.data() + first * ncols, threads);
+            }
+            std::cout.flush();
             return 0;
         }
         if (argc >= 6 && std::string(argv[1]) == "make") {

@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 CLI = os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build", "sketchlib")
 
 
-def run(*args):
-    res = subprocess.run([CLI, "dist", *args], capture_output=True, text=True)
+def run(*args, env=None):
+    res = subprocess.run([CLI, "dist", *args], capture_output=True, text=True,
+                         env=None if env is None else {**os.environ, **env})
     assert res.returncode == 0, res.stderr
     return res.stdout
 
@@ -141,6 +142,18 @@ def test_synthetic_db_dense_text_and_parallel_formatting(gpu_ctx, oracle, tmp_pa
     one = run(prefix, prefix, "-k", "23", "--threads", "1")
     assert run(prefix, prefix, "-k", "23", "--threads", "5") == one
     assert len(one.splitlines()) == n * n
+    # streamed output: many small row bands (compute of band i+1 overlaps the write of band i)
+    for band in ("1", "4096", "100000"):
+        env = {"SKL_DIST_BAND_BYTES": band}
+        assert run(prefix, "--threads", "3", env=env) == expected
+        assert run(prefix, prefix, "-k", "23", "--threads", "3", env=env) == one
+    assert run(prefix, "-k", "19", env={"SKL_DIST_BAND_BYTES": "777"}) == run(prefix, "-k", "19")
+    assert run(prefix, "--band-mb", "1") == expected
+    # -o <file>: blocks are written at offsets from all formatting threads
+    out_file = tmp_path / "dense.txt"
+    for env in (None, {"SKL_DIST_BAND_BYTES": "50000"}):
+        assert run(prefix, "-o", str(out_file), "--threads", "6", env=env) == ""
+        assert out_file.read_text() == expected
 
 
 def test_sketch_then_dist_like_reference_knn_dists(gpu_ctx, tmp_path):
