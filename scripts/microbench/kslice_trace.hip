@@ -1,0 +1,129 @@
+// Per-wave timeline of pair_kernel_kslice on the BASELINE configs[1] shape (n genomes, 5
+// k-mer lengths, sketchsize64 = 64): when does every wave start / get its first rows /
+// finish streaming / finish, and on which CU.  Answers "where does the time of a 0.17 ms
+// launch go": dispatch ramp, rounds, tail.  (Measurement tool, not product code.)
+// Build: see scripts/microbench/build.sh
+#define SKL_TRACE 1
+// distinct symbol names: the product library exports the untraced kernel under the original ones
+#define pair_kernel_kslice pair_kernel_kslice_traced
+#define launch_pair_kernel_kslice launch_pair_kernel_kslice_traced
+#define kslice_supported kslice_supported_traced
+#include "../../sketchlib.rust_amd/csrc/pair_kslice.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <vector>
+
+using namespace skl;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    const uint32_t n = argc > 1 ? atoi(argv[1]) : 1000;
+    const int shape = argc > 2 ? atoi(argv[2]) : 162;
+    const uint32_t nk = 5, ss64 = 64;
+    const size_t sample_words = (size_t)nk * ss64 * BBITS;
+    std::vector<uint64_t> h((size_t)(n + A_PAD_ROWS) * sample_words, 0);
+    std::mt19937_64 rng(1);
+    for (size_t i = 0; i < (size_t)n * sample_words; ++i) h[i] = rng();
+    uint64_t *dA;
+    uint4 *dB;
+    CK(hipMalloc(&dA, h.size() * 8));
+    CK(hipMemcpy(dA, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    const size_t n_jb = (n + 63) / 64;
+    CK(hipMalloc(&dB, n_jb * nk * ss64 * 7 * 64 * sizeof(uint4)));
+    fprintf(stderr, "relayout\n");
+    CK(launch_relayout(dA, dB, n, nk, ss64, 0));
+    CK(hipDeviceSynchronize());
+    fprintf(stderr, "relayout done\n");
+    const uint64_t pairs = (uint64_t)n * (n - 1) / 2;
+    uint32_t *dOut;
+    CK(hipMalloc(&dOut, pairs * nk * 4));
+    PairArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = dA; g.B = dB; g.nA = n; g.nB = n; g.nk = nk; g.ss64 = ss64;
+    g.k_begin = 0; g.k_count = nk; g.row_begin = 0; g.row_end = n - 1; g.self_mode = 1;
+    g.out_base = 0; g.out = dOut; g.cnt_pair_stride = 1; g.cnt_k_stride = pairs;
+    uint64_t *dTrace;
+    CK(hipMalloc(&dTrace, (5u << 16) * 8));
+    CK(hipMemset(dTrace, 0, (5u << 16) * 8));
+    g.dtab = (const float *)dTrace;
+    TileScratch ts;
+    fprintf(stderr, "launch\n");
+    for (int i = 0; i < 3; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, ts, 0));
+    CK(hipDeviceSynchronize());
+    fprintf(stderr, "warm done\n");
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, ts, 0));
+    hipEventRecord(e1);
+    CK(hipDeviceSynchronize());
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const int R = shape / 10, JL = shape % 10;
+    PairArgs gp = g; uint64_t n_wg = 0;
+    CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
+    n_wg *= nk;
+    const int wpw = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
+    const size_t n_waves = n_wg * wpw;
+    fprintf(stderr, "n_wg %llu\n", (unsigned long long)n_wg);
+    std::vector<uint64_t> tr(n_waves * 5);
+    CK(hipMemcpy(tr.data(), dTrace, tr.size() * 8, hipMemcpyDeviceToHost));
+    // 100 MHz ticks -> us
+    uint64_t t_min = ~0ull, t_max = 0;
+    size_t active = 0;
+    for (size_t w = 0; w < n_waves; ++w) {
+        const uint64_t *r = &tr[w * 5];
+        if (r[3] == 0 || r[0] == 0) continue;   // wave exited early (no tile)
+        ++active;
+        t_min = std::min(t_min, r[0]);
+        t_max = std::max(t_max, r[3]);
+    }
+    printf("n=%u shape=%d workgroups=%llu waves=%zu (with work: %zu) event time %.1f us, trace span %.1f us\n", n, shape,
+           (unsigned long long)n_wg, n_waves, active, ms * 1e3, (t_max - t_min) / 100.0);
+    std::vector<double> start, wait0, stream, tail, total;
+    std::map<uint64_t, int> per_cu;   // (xcc, se, cu) -> waves
+    for (size_t w = 0; w < n_waves; ++w) {
+        const uint64_t *r = &tr[w * 5];
+        if (r[3] == 0 || r[0] == 0) continue;
+        start.push_back((r[0] - t_min) / 100.0);
+        wait0.push_back((r[1] - r[0]) / 100.0);
+        stream.push_back((r[2] - r[1]) / 100.0);
+        tail.push_back((r[3] - r[2]) / 100.0);
+        total.push_back((r[3] - r[0]) / 100.0);
+        const uint32_t hw = (uint32_t)r[4], xcc = (uint32_t)(r[4] >> 32) & 0xF;
+        const uint32_t cu = (hw >> 8) & 0xF, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;
+        per_cu[((uint64_t)xcc << 16) | (se << 8) | (sh << 4) | cu]++;
+    }
+    if (start.empty()) { printf("no trace records\n"); return 1; }
+    auto stats = [](std::vector<double> v, const char *name) {
+        std::sort(v.begin(), v.end());
+        double sum = 0; for (double x : v) sum += x;
+        printf("  %-28s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f  mean %7.2f us\n", name, v.front(),
+               v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), sum / v.size());
+    };
+    stats(start, "start after first wave");
+    stats(wait0, "wait for first rows (DMA)");
+    stats(stream, "streaming chunks");
+    stats(tail, "reduce + store");
+    stats(total, "wave lifetime");
+    // concurrency over time
+    const double span = (t_max - t_min) / 100.0;
+    const int bins = 20;
+    printf("  waves in flight per %.1f us bin:", span / bins);
+    for (int b = 0; b < bins; ++b) {
+        const double t = (b + 0.5) * span / bins;
+        size_t c = 0;
+        for (size_t i = 0; i < start.size(); ++i) c += (start[i] <= t && start[i] + total[i] > t);
+        printf(" %zu", c);
+    }
+    printf("\n  CUs used: %zu; waves per CU min/max:", per_cu.size());
+    int mn = 1 << 30, mx = 0;
+    for (auto &kv : per_cu) { mn = std::min(mn, kv.second); mx = std::max(mx, kv.second); }
+    printf(" %d / %d\n", mn, mx);
+    return 0;
+}

@@ -24,9 +24,11 @@ pairs=n*(n-1)//2
 out=torch.zeros((pairs, 2 if mode=='coreacc' else 1),dtype=torch.float32,device=dev)
 for _ in range(2): capi.self_dists_all(ctx,sk,p,out=out)
 ctx.timing_reset()
+torch.cuda.synchronize(); t0=time.perf_counter()
 for _ in range(reps): capi.self_dists_all(ctx,sk,p,out=out)
+torch.cuda.synchronize(); step_ms=(time.perf_counter()-t0)*1e3/reps
 ms,l=ctx.kernel_ms()
-print(json.dumps({'n':n,'mode':mode,'kernel_ms':ms/l,'pairs_per_s':pairs/(ms/l/1e3)}))
+print(json.dumps({'n':n,'mode':mode,'kernel_ms':ms/l,'step_ms':step_ms,'pairs_per_s':pairs/(step_ms/1e3),'kernel':ctx.last_kernel().split(' (')[0]}))
 """ % ROOT
 
 
@@ -57,5 +59,5 @@ if __name__ == "__main__":
     for n in ns:
         for mode in modes:
             for combo in itertools.product(*vals):
-                d = run(n, dict(zip(keys, combo)), mode, reps=20 if n <= 2000 else 5)
+                d = run(n, dict(zip(keys, combo)), mode, reps=200 if n <= 2000 else 5)
                 print(json.dumps(d), flush=True)

@@ -229,6 +229,24 @@ extern "C" int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches)
     return SKL_OK;
 }
 
+static long long env_int(const char *name, long long dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+}
+
+// SKL_KERNEL = smem | lds | ksplit | kslice forces one implementation (0: dispatcher's choice)
+static int forced_kernel()
+{
+    const char *e = getenv("SKL_KERNEL");
+    if (!e) return 0;
+    if (strcmp(e, "smem") == 0) return 1;
+    if (strcmp(e, "lds") == 0) return 2;
+    if (strcmp(e, "ksplit") == 0) return 3;
+    if (strcmp(e, "kslice") == 0) return 4;
+    return 0;
+}
+
 // Two implementations of the same tile computation: rows through LDS broadcast
 // (pair_lds.hip, default) or through the scalar cache (kernels.hip).  SKL_KERNEL=smem
 // selects the latter (kept for A/B measurements).
@@ -242,25 +260,33 @@ static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, h
     //   lds    (pair_lds.hip)     large launches: R x 256/512 tiles, rows broadcast from LDS
     //   smem   (kernels.hip)      rows through the scalar cache; kept for A/B measurements
     // SKL_KERNEL = ksplit | lds | smem forces one.
-    static const int forced = [] {
-        const char *e = getenv("SKL_KERNEL");
-        if (e && strcmp(e, "smem") == 0) return 1;
-        if (e && strcmp(e, "lds") == 0) return 2;
-        if (e && strcmp(e, "ksplit") == 0) return 3;
-        return 0;
-    }();
-    static const int forced_rows = [] {
-        const char *e = getenv("SKL_KSPLIT_ROWS");  // tuning knob: 4 or 8
-        return e ? atoi(e) : 0;
-    }();
+    // (tuning knobs are read on every call so an A/B run can interleave variants in one
+    // process: scripts/ab_sweep.py)
+    const int forced = forced_kernel();
+    const int forced_kslice_shape = env_int("SKL_KSLICE_SHAPE", 0);  // 81, 82, 161, 162
+    const int forced_rows = env_int("SKL_KSPLIT_ROWS", 0);           // 4 or 8
     const uint64_t rows = args.row_end - args.row_begin;
     const uint64_t pairs = args.self_mode ? rows * args.nB / 2 : rows * (uint64_t)args.nB;
-    const bool small = pairs < (8ull << 20);  // ksplit<8> leads below n ~ 4000, lds<16,2> above (sweeps 21/22)
+    const bool small = pairs < (8ull << 20);
     if (forced == 1) {
         *name = "skl::pair_kernel<NA=" + std::to_string(na) + ", " + m + "> (scalar-cache rows)";
         return launch_pair_kernel(args, mode, na, stream);
     }
-    if (forced == 3 || (forced == 0 && small)) {
+    // SKL_KERNEL=kslice (or no override): the chunk-split kernel, k-sliced for small launches
+    // (core/acc then arrives here as MODE_COUNTS from dense_band), all-k fused otherwise.
+    if (forced == 0 || forced == 4) {
+        // single-k Jaccard: the sliced and the all-k form are the same work, the sliced one
+        // compiles to fewer registers
+        const bool sliced = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
+        if (kslice_supported(args, mode, sliced)) {
+            const int shape = forced_kslice_shape ? forced_kslice_shape : 162;
+            *name = "skl::pair_kernel_kslice<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(shape % 10) +
+                    ", " + m + (sliced ? ", k-sliced" : ", all k") + "> (" + std::to_string(shape / 10) + "x" +
+                    std::to_string((shape % 10) * 64) + " tiles, chunks split over 4 waves)";
+            return launch_pair_kernel_kslice(args, mode, shape, sliced, tiles, stream);
+        }
+    }
+    if (forced == 3 || (forced != 2 && small)) {
         int r = forced_rows ? forced_rows : 8;  // 8 >= 4 from n = 1000 up once XCDs are balanced (sweep 18)
         *name = "skl::pair_kernel_ksplit<R=" + std::to_string(r) + ", " + m + "> (" + std::to_string(r) +
                 "x64 tiles, chunks split over 4 waves)";
@@ -557,6 +583,8 @@ static int fill_args(const skl_sketches *rows, const skl_sketches *cols, const s
     if (mode == MODE_COUNTS) {
         g->k_begin = 0;
         g->k_count = (uint32_t)rows->nk;
+        g->cnt_pair_stride = rows->nk;   // [pair][k] records
+        g->cnt_k_stride = 1;
     } else if (mode == MODE_JACCARD) {
         g->k_begin = (uint32_t)p->k_idx;
         g->k_count = 1;
@@ -574,6 +602,17 @@ static int fill_args(const skl_sketches *rows, const skl_sketches *cols, const s
         g->ytab = rows->d_ytab;
     }
     return SKL_OK;
+}
+
+// Launch-size rule shared with dispatch_pair_kernel: core/acc launches below this many pairs
+// run k-sliced (counts + epilogue kernel), larger ones as one fused kernel.
+constexpr long long SLICED_MAX_PAIRS = 32ll << 20;   // n ~ 8000 all-vs-all: equal there (scripts/ab_sweep.py)
+static bool coreacc_runs_sliced(const skl_sketches *s, uint64_t pairs)
+{
+    const int forced = forced_kernel();
+    if (s->ss64 > 1023 || (forced != 0 && forced != 4)) return false;   // another kernel forced: never slice
+    const long long limit = env_int("SKL_SLICED_MAX_PAIRS", SLICED_MAX_PAIRS);
+    return pairs < (uint64_t)limit;
 }
 
 static uint64_t cond_index(uint64_t i, uint64_t j, uint64_t n)
@@ -605,12 +644,20 @@ static int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches
     if (pairs == 0) return SKL_OK;
 
     const bool coreacc = mode == MODE_COREACC;
-    if (coreacc && !fused_coreacc_ok(rows)) {
+    // Small core/acc launches run as (tile, k) workgroups producing counts + the epilogue
+    // kernel (pair_kslice.hip): 5x the workgroups of the fused kernel and two columns per lane.
+    const bool sliced = coreacc && coreacc_runs_sliced(rows, pairs);
+    if (coreacc && (sliced || !fused_coreacc_ok(rows))) {
         // unfused: counts -> scratch2 -> epilogue kernel
         PairArgs g;
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
         void *counts = nullptr;
         SKL_TRY(ctx_scratch(ctx, pairs * rows->nk * sizeof(uint32_t), &counts, 1));
+        if (sliced) {   // k-major scratch: coalesced stores from the (tile, k) workgroups
+            g.cnt_pair_stride = 1;
+            g.cnt_k_stride = pairs;
+            g.k_sliced = 1;
+        }
         g.row_begin = (uint32_t)r0;
         g.row_end = (uint32_t)r1;
         g.self_mode = self_mode;
@@ -622,6 +669,8 @@ static int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches
         EpilogueArgs e;
         memset(&e, 0, sizeof e);
         e.counts = (const uint32_t *)counts;
+        e.pair_stride = g.cnt_pair_stride;
+        e.k_stride = g.cnt_k_stride;
         e.n_pairs = pairs;
         e.nk = (uint32_t)rows->nk;
         e.ss64 = (uint32_t)rows->ss64;

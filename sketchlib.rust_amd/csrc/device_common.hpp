@@ -101,9 +101,9 @@ __device__ __forceinline__ uint64_t square_to_condensed_dev(uint64_t i, uint64_t
 // tiles: every XCD gets the same number of (equal-cost) tiles, and the tiles of one XCD
 // share at most ceil(groups/8)+1 column groups, whose lane slab then stays in its L2.
 // Returns false when this workgroup has no tile.
-__device__ __forceinline__ bool lookup_tile(const PairArgs &g, uint32_t &group, uint32_t &row_tile)
+__device__ __forceinline__ bool lookup_tile_at(const PairArgs &g, uint32_t xcd, uint32_t slot,
+                                               uint32_t &group, uint32_t &row_tile)
 {
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     if (slot >= g.tiles_per_xcd) return false;
     const uint32_t t = xcd * g.tiles_per_xcd + slot;
     if (t >= g.n_active_tiles) return false;
@@ -122,6 +122,11 @@ __device__ __forceinline__ bool lookup_tile(const PairArgs &g, uint32_t &group, 
     return true;
 }
 
+__device__ __forceinline__ bool lookup_tile(const PairArgs &g, uint32_t &group, uint32_t &row_tile)
+{
+    return lookup_tile_at(g, blockIdx.x & 7u, blockIdx.x >> 3, group, row_tile);
+}
+
 __device__ __forceinline__ bool pair_valid(const PairArgs &g, uint32_t i, uint32_t jcol)
 {
     return i < g.row_end && jcol < g.nB && (!g.self_mode || i < jcol);
@@ -138,7 +143,7 @@ __device__ __forceinline__ void store_count(const PairArgs &g, uint32_t i, uint3
                                             uint32_t kk, uint32_t mismatches)
 {
     if (pair_valid(g, i, jcol)) {
-        ((uint32_t *)g.out)[pair_out_index(g, i, jcol) * g.k_count + kk] =
+        ((uint32_t *)g.out)[pair_out_index(g, i, jcol) * g.cnt_pair_stride + kk * g.cnt_k_stride] =
             g.ss64 * 64u - mismatches;
     }
 }

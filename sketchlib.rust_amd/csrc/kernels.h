@@ -51,6 +51,10 @@ struct PairArgs {
     const uint32_t *tile_prefix;  // [n_groups + 1] first tile number of each group (self mode)
     uint64_t out_base;            // flat index of the first pair of this launch
     void *out;
+    // MODE_COUNTS record layout: count of (pair p, k index kk) at out[p*cnt_pair_stride + kk*cnt_k_stride]
+    // ([pair][k] for the public bin-match calls, k-major for the internal counts scratch)
+    uint64_t cnt_pair_stride, cnt_k_stride;
+    uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
     // epilogue
     int32_t jout;                 // JaccardOut
     int32_t has_comp;
@@ -87,6 +91,13 @@ hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, Til
 // K-split variant for small launches (pair_ksplit.hip): rows_per_tile in {4, 8}.
 hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_per_tile,
                                      TileScratch &scratch, hipStream_t stream);
+// Chunk-split kernel (pair_kslice.hip): R x 64*JL tiles, the 4 waves of a workgroup split the
+// chunks.  k_sliced = one workgroup per (tile, k-mer length), MODE_COUNTS / MODE_JACCARD only;
+// otherwise one workgroup walks all k-mer lengths and runs the fused epilogue.
+// shape = R*10 + JL in {81, 82, 161, 162}.
+hipError_t launch_pair_kernel_kslice(const PairArgs &args, int mode, int shape, bool k_sliced,
+                                     TileScratch &scratch, hipStream_t stream);
+bool kslice_supported(const PairArgs &args, int mode, bool k_sliced);
 int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
@@ -95,7 +106,8 @@ hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint3
 
 // Unfused core/acc epilogue: counts [pair][nk] u32 -> (core, acc) f32 pairs.
 struct EpilogueArgs {
-    const uint32_t *counts;
+    const uint32_t *counts;     // count of (pair p, k t) at counts[p*pair_stride + t*k_stride]
+    uint64_t pair_stride, k_stride;
     uint64_t n_pairs;
     uint32_t nk, ss64;
     uint32_t nA_rows, nB_cols;  // to recover (i, j) for completeness lookups

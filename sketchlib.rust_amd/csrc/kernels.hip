@@ -389,9 +389,9 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
     }
     const uint32_t maxnbits = g.ss64 * 64u;
     double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
-    const uint32_t *cnt = g.counts + p * g.nk;
+    const uint32_t *cnt = g.counts + p * g.pair_stride;
     for (uint32_t t = 0; t < g.nk; ++t) {
-        const uint32_t same = cnt[t];
+        const uint32_t same = cnt[t * g.k_stride];
         double y;
         if (!g.has_comp) {
             y = g.ytab[same <= maxnbits ? same : maxnbits];

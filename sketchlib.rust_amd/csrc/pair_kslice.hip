@@ -1,0 +1,320 @@
+// pair_kslice.hip -- the chunk-split pair kernel (gfx950): the default kernel of the path.
+//
+// Measured on MI355X (scripts/microbench/lds_bcast.hip): one CU returns ~0.39 wave-level
+// ds_read_b128 per ns, broadcast or not, against ~3.4 wave-level v_bitop3 per ns over its
+// 4 SIMDs.  A row read of 7 x b128 feeds JL x 28 v_bitop3, so with one column per lane the
+// LDS pipe caps a kernel at ~46 % of the VALU rate; two columns per lane lift the cap to
+// ~92 %.  The workgroup tile is therefore R rows x 128 columns, every lane owning 2 columns,
+// and the 4 waves of the workgroup split the CHUNK axis of that one tile:
+//
+//   * wave w takes chunk pairs {2w, 2w+1} + 8t of every k-mer length and stages the rows of
+//     its own chunks into a private, double-buffered LDS region (global_load_lds DMA): no
+//     other wave reads them, so waves never wait for each other while streaming;
+//   * at the end of a k-mer length the 4 partial counts per pair are summed through LDS
+//     (u16 pairs, written into the row buffer the wave has just finished with) and wave w
+//     keeps the totals of packed pair slots x = w (mod 4), finishing those pairs itself.
+//
+// Two workgroup shapes of the same code (template flag KSL):
+//   * KSL = false: one workgroup walks all k-mer lengths of its tile and runs the fused
+//     epilogue (counts / Jaccard / core-accessory regression).  Large launches.
+//   * KSL = true ("k-sliced"): one workgroup = one (tile, k-mer length); counts or single-k
+//     Jaccard only.  BASELINE.json's 1 000-genome configuration has too few tiles to fill
+//     256 CUs; slicing the k axis gives 5x the workgroups, and core/accessory launches of
+//     that size run MODE_COUNTS into a k-major scratch array followed by
+//     coreacc_epilogue_kernel (kernels.hip) -- 28 bytes per pair of extra traffic.
+//
+// Per (row, column, chunk) the instruction stream is 2 v_xor + 26 v_bitop3 (all-VGPR,
+// bank-conflict-free, see device_common.hpp) + 2 fused v_bcnt.
+// Wave timelines of this kernel: scripts/microbench/kslice_trace.hip.
+#include "device_common.hpp"
+
+#include <cstdlib>
+
+namespace skl {
+
+__device__ __forceinline__ void skl_dma16_ks(const void *src, void *lds_wave_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+#else
+    (void)src;
+    (void)lds_wave_base;
+#endif
+}
+
+#ifdef SKL_TRACE
+// scripts/microbench/kslice_trace.hip: per-wave timeline (100 MHz wall clock) + hardware id;
+// the trace buffer rides in the dtab field (unused by MODE_COUNTS)
+#define skl_trace ((uint64_t *)g.dtab)
+#define SKL_TRACE_MARK(SLOT)                                                                  \
+    do {                                                                                      \
+        if (lane == 0) skl_trace[((size_t)blockIdx.x * WAVES_PER_WG + wave) * 5u + (SLOT)] = wall_clock64(); \
+    } while (0)
+#else
+#define SKL_TRACE_MARK(SLOT) do { } while (0)
+#endif
+
+template <int R, int JL, int MODE, bool KSL>
+__global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const PairArgs g)
+{
+    constexpr int W = WAVES_PER_WG;
+    constexpr int CH = 2;                         // chunks per wave per stage
+    constexpr int PIECES = R * CH * 7;            // 16-byte pieces per wave-stage
+    constexpr int PPL = (PIECES + LANES - 1) / LANES;   // DMA instructions per wave-stage
+    constexpr int P = R * JL;                     // pairs per lane
+    constexpr int PX = P / 2;                     // packed (2 x u16) partial counts per lane
+    constexpr int SLOTS = PX / W;                 // packed slots finished by each wave
+    static_assert(P % 2 == 0 && PX % W == 0, "packed slots must split over the waves");
+    static_assert(PPL * LANES - PIECES < PIECES, "tail pieces wrap at most once");
+    static_assert(PPL * LANES * 16 >= PX * LANES * 4, "the reduction words fit one row buffer");
+    static_assert(!KSL || MODE != MODE_COREACC, "k-sliced core/acc runs COUNTS + the epilogue kernel");
+    __shared__ uint4 lds_rows[W][2][PPL * LANES];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SKL_TRACE
+    if (lane == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        skl_trace[((size_t)blockIdx.x * W + wave) * 5u + 4] = ((uint64_t)xcc << 32) | hw;
+    }
+#endif
+    SKL_TRACE_MARK(0);
+
+    // blockIdx -> (XCD, tile slot on that XCD[, k-mer length]): the k slices of a tile are
+    // neighbours in the per-XCD order
+    const uint32_t xcd = blockIdx.x & 7u, s_idx = blockIdx.x >> 3;
+    const uint32_t slot = KSL ? s_idx / g.k_count : s_idx;
+    const uint32_t kk0 = KSL ? s_idx - slot * g.k_count : 0u;   // first k index of this workgroup
+    const uint32_t nkk = KSL ? 1u : g.k_count;                  // k-mer lengths it walks
+    uint32_t jg, at;  // column group (JL blocks of 64), row tile
+    if (!lookup_tile_at(g, xcd, slot, jg, at)) return;
+    const uint32_t jb0 = jg * JL;
+    const uint32_t a0 = g.row_begin + at * R;
+    if (jb0 >= g.n_jblocks) return;
+    if (a0 >= g.row_end) return;
+    if (g.self_mode && a0 >= (jg + 1u) * JL * 64u - 1u) return;   // tile entirely on/below the diagonal
+
+    const size_t kmer_stride = (size_t)g.ss64 * BBITS;
+    const size_t sample_stride = kmer_stride * g.nk;
+    // wave w owns chunks w*CH + i + ts*(W*CH), i < CH, of every k-mer length
+    const uint32_t stages_per_k = (g.ss64 + W * CH - 1) / (W * CH);
+    const uint32_t n_stages = stages_per_k * nkk;
+
+    uint32_t cnt[P];   // this wave's partial mismatch counts of the current k (its chunks only)
+#pragma unroll
+    for (int x = 0; x < P; ++x) cnt[x] = 0;
+    // MODE_COREACC: totals of this wave's packed slots, one word per k-mer length (two u16
+    // fields per word: the slot's two pairs).  Private (scratch) memory on purpose: written
+    // once per k-mer length, read once at the end, and 24 registers cheaper.
+    volatile uint32_t hist[(MODE == MODE_COREACC) ? SLOTS * MAX_FUSED_K : 1];
+
+    // Row staging: global -> LDS DMA (global_load_lds_dwordx4): piece p = (chunk*R + row)*7 + q
+    // of this wave's stage lands at slot p of the wave's buffer.  Chunks past the end of the
+    // sketch are clamped to the last one and never used.
+#define SKL_STAGE_DMA(T, BUF)                                                                \
+    do {                                                                                     \
+        const uint32_t k_ = g.k_begin + kk0 + (T) / stages_per_k;                            \
+        const uint32_t c0_ = ((T) % stages_per_k) * (W * CH) + wave * CH;                    \
+        _Pragma("unroll") for (int u = 0; u < PPL; ++u)                                      \
+        {                                                                                    \
+            const uint32_t pp_ = lane + u * 64u;                                             \
+            const uint32_t p_ = pp_ < (uint32_t)PIECES ? pp_ : pp_ - (uint32_t)PIECES;       \
+            const uint32_t q_ = p_ % 7u, rc_ = p_ / 7u;                                      \
+            const uint32_t r_ = rc_ % R, c_ = rc_ / R;                                       \
+            const uint32_t cc_ = (c0_ + c_) < g.ss64 ? (c0_ + c_) : (g.ss64 - 1u);           \
+            const uint64_t *src_ = g.A + (size_t)(a0 + r_) * sample_stride +                 \
+                                   (size_t)k_ * kmer_stride + (size_t)cc_ * BBITS + 2u * q_; \
+            skl_dma16_ks(src_, &lds_rows[wave][BUF][u * 64u]);                               \
+        }                                                                                    \
+    } while (0)
+
+    SKL_STAGE_DMA(0u, 0);
+
+    uint32_t t = 0;   // flat stage counter (k-mer lengths x stages)
+    for (uint32_t kl = 0; kl < nkk; ++kl) {
+        const uint32_t kk = kk0 + kl;
+        const uint32_t k = g.k_begin + kk;
+        for (uint32_t ts = 0; ts < stages_per_k; ++ts, ++t) {
+            const uint32_t buf = t & 1u;
+            const uint32_t c0 = ts * (W * CH) + wave * CH;
+            // this wave's DMA of stage t has landed (nothing else of this wave is in flight)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0) SKL_TRACE_MARK(1);
+            if (t + 1 < n_stages) SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
+
+            for (uint32_t ci = 0; ci < (uint32_t)CH && c0 + ci < g.ss64; ++ci) {
+                uint4 b[JL][7];
+#pragma unroll
+                for (int j = 0; j < JL; ++j) {
+                    const uint32_t jb = (jb0 + j) < g.n_jblocks ? (jb0 + j) : (g.n_jblocks - 1u);
+                    const uint4 *bp = g.B + (((size_t)jb * g.nk + k) * g.ss64 + (c0 + ci)) * (7 * LANES) + lane;
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) b[j][q] = bp[q * LANES];
+                }
+                const uint4 *rows = &lds_rows[wave][buf][(size_t)ci * R * 7];
+                uint4 a[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) a[q] = rows[q];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    uint32_t mlo[JL], mhi[JL];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+#pragma unroll
+                        for (int j = 0; j < JL; ++j) {
+                            // b is stored (hi, lo) per plane: see device_common.hpp "VGPR banks"
+                            if (q == 0) {
+                                mlo[j] = a[0].x ^ b[j][0].y;
+                                mhi[j] = a[0].y ^ b[j][0].x;
+                            } else {
+                                mlo[j] = acc_mismatch_vvv(mlo[j], a[q].x, b[j][q].y);
+                                mhi[j] = acc_mismatch_vvv(mhi[j], a[q].y, b[j][q].x);
+                            }
+                            mlo[j] = acc_mismatch_vvv(mlo[j], a[q].z, b[j][q].w);
+                            mhi[j] = acc_mismatch_vvv(mhi[j], a[q].w, b[j][q].z);
+                        }
+                        // rolling prefetch of the next row's plane pair (no extra registers)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (r + 1 < R) a[q] = rows[(r + 1) * 7 + q];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < JL; ++j) {
+                        // popcount with the add fused (v_bcnt_u32_b32 d, m, d)
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[j]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[j]));
+                    }
+                }
+            }
+        }
+
+        // ---- end of a k-mer length: sum the 4 partial counts per pair through LDS ----
+        if (kl + 1 == nkk) SKL_TRACE_MARK(2);
+        // The buffer this wave consumed last is dead (the next stage was prefetched into the
+        // other one), so every wave publishes into its own: [wave][buf][PX][LANES] words.
+        const uint32_t dead = (t - 1u) & 1u;
+        uint32_t *red = reinterpret_cast<uint32_t *>(&lds_rows[0][0][0]);
+        constexpr uint32_t BUF_WORDS = PPL * LANES * 4u;
+#pragma unroll
+        for (int x = 0; x < PX; ++x) {
+            red[((uint32_t)wave * 2u + dead) * BUF_WORDS + (uint32_t)x * LANES + lane] =
+                cnt[2 * x] | (cnt[2 * x + 1] << 16);
+            cnt[2 * x] = 0;
+            cnt[2 * x + 1] = 0;
+        }
+        __syncthreads();
+        // wave w finishes packed slots x = w (mod 4); fields stay below 2^16 (ss64 <= 1023)
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const uint32_t x = (uint32_t)i * W + wave;
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) total += red[((uint32_t)w * 2u + dead) * BUF_WORDS + x * LANES + lane];
+            if constexpr (MODE == MODE_COREACC) {
+                hist[i * MAX_FUSED_K + kl] = total;
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t pair = 2u * x + h;
+                    const uint32_t r = pair / JL, j = pair % JL;
+                    const uint32_t mism = h ? (total >> 16) : (total & 0xFFFFu);
+                    if constexpr (MODE == MODE_COUNTS) {
+                        store_count(g, a0 + r, (jb0 + j) * 64u + lane, kk, mism);
+                    } else {
+                        store_jaccard(g, a0 + r, (jb0 + j) * 64u + lane, mism);
+                    }
+                }
+            }
+        }
+        // the next stage's DMA of every wave goes into the buffer just read: fence the reads
+        if (kl + 1 < nkk) __syncthreads();
+    }
+#undef SKL_STAGE_DMA
+
+    if constexpr (MODE == MODE_COREACC) {
+        // store_coreacc() takes u16 fields, newest k lowest, as s2:s1:s0
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < SLOTS; ++i) {
+            const uint32_t x = (uint32_t)i * W + wave;
+            uint32_t word[MAX_FUSED_K];   // word[f]: totals of the k-mer length f steps from the newest
+#pragma unroll
+            for (int f = 0; f < MAX_FUSED_K; ++f) {
+                word[f] = (uint32_t)f < nkk ? hist[i * MAX_FUSED_K + (nkk - 1u - f)] : 0u;
+            }
+#pragma clang loop unroll(disable)
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t pair = 2u * x + h;
+                const uint32_t r = pair / JL, j = pair % JL;
+                const uint32_t sh = h * 16u;
+                const uint32_t s0 = ((word[0] >> sh) & 0xFFFFu) | (((word[1] >> sh) & 0xFFFFu) << 16);
+                const uint32_t s1 = ((word[2] >> sh) & 0xFFFFu) | (((word[3] >> sh) & 0xFFFFu) << 16);
+                const uint32_t s2 = ((word[4] >> sh) & 0xFFFFu) | (((word[5] >> sh) & 0xFFFFu) << 16);
+                store_coreacc(g, a0 + r, (jb0 + j) * 64u + lane, s0, s1, s2);
+            }
+        }
+    }
+    SKL_TRACE_MARK(3);
+}
+
+template <int R, int JL, bool KSL>
+static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
+{
+    const dim3 block(LANES * WAVES_PER_WG);
+    switch (mode) {
+        case MODE_COUNTS:
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL>), grid, block, 0, stream, args);
+            break;
+        case MODE_JACCARD:
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, KSL>), grid, block, 0, stream, args);
+            break;
+        case MODE_COREACC:
+            if constexpr (!KSL) {
+                hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COREACC, false>), grid, block, 0, stream, args);
+                break;
+            }
+            return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
+{
+    if (args.ss64 > 1023u || args.k_count < 1u) return false;   // u16 count fields
+    if (mode == MODE_COREACC) return !k_sliced && args.k_count <= (uint32_t)MAX_FUSED_K;
+    return mode == MODE_COUNTS || mode == MODE_JACCARD;
+}
+
+// shape = R*10 + JL; valid: 81, 82, 161, 162
+hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shape, bool k_sliced,
+                                     TileScratch &scratch, hipStream_t stream)
+{
+    PairArgs args = args_in;
+    if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
+    if (!kslice_supported(args, mode, k_sliced)) return hipErrorInvalidValue;
+    const int R = shape / 10, JL = shape % 10;
+    uint64_t n_wg = 0;
+    const hipError_t pe = plan_tiles(args, (uint32_t)R, (uint32_t)JL * 64u, scratch, stream, &n_wg);
+    if (pe != hipSuccess) return pe;
+    if (n_wg == 0) return hipSuccess;
+    if (k_sliced) n_wg *= args.k_count;
+    if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)n_wg);
+#define SKL_SHAPE(SH, RR, JJ)                                                                  \
+    case SH:                                                                                   \
+        return k_sliced ? launch_rjk<RR, JJ, true>(args, mode, grid, stream)                   \
+                        : launch_rjk<RR, JJ, false>(args, mode, grid, stream);
+    switch (shape) {
+        SKL_SHAPE(81, 8, 1)
+        SKL_SHAPE(82, 8, 2)
+        SKL_SHAPE(161, 16, 1)
+        SKL_SHAPE(162, 16, 2)
+        default: return hipErrorInvalidValue;
+    }
+#undef SKL_SHAPE
+}
+
+}  // namespace skl

@@ -328,10 +328,8 @@ hipError_t launch_pair_kernel_lds(const PairArgs &args_in, int mode, int shape, 
 
 int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode)
 {
-    static const int forced = [] {
-        const char *e = getenv("SKL_LDS_SHAPE");  // tuning knob: 41, 81, 82, 122, 162
-        return e ? atoi(e) : 0;
-    }();
+    const char *e = getenv("SKL_LDS_SHAPE");  // tuning knob: 41, 81, 82, 162 (read per call)
+    const int forced = e ? atoi(e) : 0;
     if (forced) return forced;
     const uint64_t pairs = self_mode ? n_rows * n_cols / 2 : n_rows * n_cols;
     (void)mode;

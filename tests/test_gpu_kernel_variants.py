@@ -1,0 +1,83 @@
+"""Every pair-kernel implementation the library ships, not only the one the dispatcher picks:
+the chunk-split kernel in both forms (k-sliced + epilogue kernel, all-k fused) and its tile
+shapes, and the A/B kernels kept behind SKL_KERNEL (lds, ksplit, smem).  The knobs are read
+once per process, so each variant runs in a child process; results must equal the oracle
+bit for bit (counts, Jaccard f32, regression outputs without completeness correction)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from sketchlib.rust_amd import capi, synth
+from oracle import oracle
+expect = sys.argv[1]
+kmers, ss64 = [15, 19, 23, 27, 31], 64
+n, nq = 413, 150
+bins = synth.set_r(n, kmers, ss64, n_clusters=9)
+qb = synth.set_r(nq, kmers, ss64, n_clusters=9, first_sample=1000)
+ctx = capi.Context(0)
+g, o = ctx.sketches(bins, n, kmers, ss64), oracle.Sketches(bins, n, kmers, ss64)
+gq, oq = ctx.sketches(qb, nq, kmers, ss64), oracle.Sketches(qb, nq, kmers, ss64)
+# core/accessory, self and cross
+got = capi.self_dists_all(ctx, g, g.set_k())
+assert expect in ctx.last_kernel(), ctx.last_kernel()
+assert np.array_equal(got, oracle.self_dists_all(o, threads=8)), "self coreacc"
+got = capi.cross_dists_all(ctx, g, gq, g.set_k())
+assert np.array_equal(got, oracle.cross_dists_all(o, oq, threads=8)), "cross coreacc"
+# single-k Jaccard and ANI
+for ani in (False, True):
+    got = capi.self_dists_all(ctx, g, g.set_k(23, ani=ani))
+    assert np.array_equal(got, oracle.self_dists_all(o, oracle.JACCARD, 2, ani, threads=8)), "jaccard"
+# raw bin-match counts
+assert np.array_equal(capi.self_binmatch(ctx, g), oracle.self_binmatch(o, threads=8)), "self counts"
+assert np.array_equal(capi.cross_binmatch(ctx, g, gq), oracle.cross_binmatch(o, oq, threads=8)), "cross counts"
+# completeness correction (device-side ln; tolerance: north_star's 1e-6).  The regression takes the
+# k-mer lengths before the first one with no matching bin (jaccard.rs:89-91).  Pairs whose bin-match
+# count is the same at every one of those have a flat fit: y_diff is pure rounding noise and the
+# 0-or-1 outcome of jaccard.rs:128-133 depends on the last bit of the platform's ln (DESIGN.md
+# "Parity bar") -- they are compared on the accessory distance only.
+comp = np.linspace(0.7, 1.0, n)
+g.set_completeness(comp)
+oc = oracle.Sketches(bins, n, kmers, ss64, completeness=comp)
+got = capi.self_dists_all(ctx, g, g.set_k())
+ref = oracle.self_dists_all(oc, threads=8)
+counts = oracle.self_binmatch(o, threads=8)
+used = np.cumprod(counts > 0, axis=1).astype(bool)            # prefix before the first zero count
+flat = (used.sum(axis=1) >= 3) & ((counts == counts[:, :1]) | ~used).all(axis=1) & (counts[:, 0] < 64 * ss64)
+assert flat.mean() < 0.02
+assert np.allclose(got[~flat], ref[~flat], rtol=0, atol=1e-6), "completeness"
+assert np.allclose(got[flat, 1], ref[flat, 1], rtol=0, atol=1e-6), "completeness (flat fits, accessory)"
+core_flat = got[flat, 0].astype(np.float64)
+agree = np.abs(core_flat - ref[flat, 0]) <= 1e-6
+assert (agree | (np.minimum(np.abs(core_flat), np.abs(core_flat - 1.0)) <= 1e-6)).all(), "flat fits: core is 0 or 1"
+print("VARIANT_OK", ctx.last_kernel())
+""" % {"root": ROOT}
+
+VARIANTS = [
+    ({}, "k-sliced"),                                              # dispatcher's choice at this size
+    ({"SKL_SLICED_MAX_PAIRS": "0"}, "all k"),                      # all-k fused form
+    ({"SKL_KSLICE_SHAPE": "82"}, "R=8, JL=2"),
+    ({"SKL_KSLICE_SHAPE": "81", "SKL_SLICED_MAX_PAIRS": "0"}, "R=8, JL=1"),
+    ({"SKL_KSLICE_SHAPE": "161"}, "R=16, JL=1"),
+    ({"SKL_KERNEL": "lds"}, "pair_kernel_lds"),
+    ({"SKL_KERNEL": "lds", "SKL_LDS_SHAPE": "82"}, "pair_kernel_lds"),
+    ({"SKL_KERNEL": "ksplit"}, "pair_kernel_ksplit"),
+    ({"SKL_KERNEL": "smem"}, "pair_kernel<"),
+]
+
+
+@pytest.mark.parametrize("env,expect", VARIANTS, ids=[",".join(f"{k}={v}" for k, v in e.items()) or "default"
+                                                      for e, _ in VARIANTS])
+def test_kernel_variant_parity(gpu_ctx, env, expect):
+    res = subprocess.run([sys.executable, "-c", CHILD, expect], env={**os.environ, **env}, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and "VARIANT_OK" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
