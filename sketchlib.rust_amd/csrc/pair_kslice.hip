@@ -32,13 +32,35 @@
 
 namespace skl {
 
-__device__ __forceinline__ void skl_dma16_ks(const void *src, void *lds_wave_base)
+// 16 bytes per lane, global -> LDS, no VGPR destination (global_load_lds_dwordx4): lane l's
+// 16 bytes land at LDS byte address m0 + 16*l.  Issued through inline asm ON PURPOSE: the
+// compiler treats the builtin form as an LDS write it cannot disambiguate and puts
+// `s_waitcnt vmcnt(0)` in front of every later LDS read -- which also waits for the NEXT
+// stage's DMA and the column prefetch, i.e. exposes their full latency once per chunk.
+// Hidden from its bookkeeping, the ordering is ours: the explicit counted vmcnt wait at the
+// top of each stage (VMEM returns in order).  Hidden VMEM ops can only make the compiler's
+// own counted waits stricter, never laxer, and the issue points below keep every hidden op
+// OLDER than the column loads in flight, so they stay exact.
+__device__ __forceinline__ void skl_dma16_ks(const void *src, uint32_t lds_byte_addr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr))
+                 : "memory");   // m0 is reserved (cannot be listed); nothing else in this kernel uses it
 #else
     (void)src;
-    (void)lds_wave_base;
+    (void)lds_byte_addr;
+#endif
+}
+
+__device__ __forceinline__ uint32_t skl_lds_addr(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+#else
+    (void)p;
+    return 0;
 #endif
 }
 
@@ -54,7 +76,7 @@ __device__ __forceinline__ void skl_dma16_ks(const void *src, void *lds_wave_bas
 #define SKL_TRACE_MARK(SLOT) do { } while (0)
 #endif
 
-template <int R, int JL, int MODE, bool KSL>
+template <int R, int JL, int MODE, bool KSL, int ABL = 0>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const PairArgs g)
 {
     constexpr int W = WAVES_PER_WG;
@@ -127,33 +149,87 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
             const uint32_t cc_ = (c0_ + c_) < g.ss64 ? (c0_ + c_) : (g.ss64 - 1u);           \
             const uint64_t *src_ = g.A + (size_t)(a0 + r_) * sample_stride +                 \
                                    (size_t)k_ * kmer_stride + (size_t)cc_ * BBITS + 2u * q_; \
-            skl_dma16_ks(src_, &lds_rows[wave][BUF][u * 64u]);                               \
+            skl_dma16_ks(src_, lds_base + (((uint32_t)wave * 2u + (BUF)) * (PPL * LANES) + u * 64u) * 16u); \
         }                                                                                    \
     } while (0)
 
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(skl_lds_addr(&lds_rows[0][0][0]));
     SKL_STAGE_DMA(0u, 0);
+
+    // Next valid chunk of this wave after (kl, ts, ci) in its walk over k-mer lengths, stages
+    // and chunks (wave-uniform scalar code); false when the walk is over.
+    auto next_chunk = [&](uint32_t kl_, uint32_t ts_, int ci_, uint32_t &k_out, uint32_t &c_out) {
+        for (;;) {
+            if (++ci_ >= CH) {
+                ci_ = 0;
+                if (++ts_ >= stages_per_k) {
+                    ts_ = 0;
+                    ++kl_;
+                }
+            }
+            if (kl_ >= nkk) return false;
+            const uint32_t c_ = ts_ * (W * CH) + wave * CH + (uint32_t)ci_;
+            if (c_ < g.ss64) {
+                k_out = g.k_begin + kk0 + kl_;
+                c_out = c_;
+                return true;
+            }
+        }
+    };
+    auto column_ptr = [&](int j, uint32_t k_, uint32_t c_) {
+        const uint32_t jb = (jb0 + j) < g.n_jblocks ? (jb0 + j) : (g.n_jblocks - 1u);   // clamped, never stored
+        return g.B + (((size_t)jb * g.nk + k_) * g.ss64 + c_) * (7 * LANES) + lane;
+    };
+
+    // Column operand: 2 x 7 x 16 B per lane and chunk, always ONE CHUNK AHEAD with no extra
+    // registers: during the last row of a chunk every b[j][q] is re-loaded with the next
+    // chunk's data right after its last use (the first of them gets most of a row of lead,
+    // the loads return in order, and the compiler's counted vmcnt before each use is exact).
+    uint4 b[JL][7];
+    {
+        uint32_t k1 = g.k_begin + kk0, c1 = 0;
+        next_chunk(0u, 0u, -1, k1, c1);
+#pragma unroll
+        for (int j = 0; j < JL; ++j) {
+            const uint4 *bp = column_ptr(j, k1, c1);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) b[j][q] = bp[q * LANES];
+        }
+    }
+    uint32_t b_younger = 1;   // chunks' worth of column loads (JL*7 each) issued after the newest row DMA
 
     uint32_t t = 0;   // flat stage counter (k-mer lengths x stages)
     for (uint32_t kl = 0; kl < nkk; ++kl) {
         const uint32_t kk = kk0 + kl;
-        const uint32_t k = g.k_begin + kk;
         for (uint32_t ts = 0; ts < stages_per_k; ++ts, ++t) {
             const uint32_t buf = t & 1u;
             const uint32_t c0 = ts * (W * CH) + wave * CH;
-            // this wave's DMA of stage t has landed (nothing else of this wave is in flight)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // This wave's DMA of stage t must have landed.  VMEM returns in order, so it is
+            // enough that only the younger column loads may still be in flight.
+            if (b_younger == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (b_younger == 1) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JL * 7) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * JL * 7) : "memory");
+            }
             if (t == 0) SKL_TRACE_MARK(1);
-            if (t + 1 < n_stages) SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
+            // The next stage's rows are requested after row 0 of this stage's first chunk (all
+            // column registers consumed once, so no column load is in flight then); a stage
+            // in which this wave has no chunk requests them here.
+            const bool want_dma = t + 1 < n_stages;
+            if (want_dma && c0 >= g.ss64) {
+                SKL_STAGE_DMA(t + 1, buf ^ 1u);
+                b_younger = 0;
+            }
 
             for (uint32_t ci = 0; ci < (uint32_t)CH && c0 + ci < g.ss64; ++ci) {
-                uint4 b[JL][7];
+                // where the columns of the next chunk are (the current ones again if none follows)
+                uint32_t kn = g.k_begin + kk, cn = c0 + ci;
+                next_chunk(kl, ts, (int)ci, kn, cn);
+                const uint4 *bn[JL];
 #pragma unroll
-                for (int j = 0; j < JL; ++j) {
-                    const uint32_t jb = (jb0 + j) < g.n_jblocks ? (jb0 + j) : (g.n_jblocks - 1u);
-                    const uint4 *bp = g.B + (((size_t)jb * g.nk + k) * g.ss64 + (c0 + ci)) * (7 * LANES) + lane;
-#pragma unroll
-                    for (int q = 0; q < 7; ++q) b[j][q] = bp[q * LANES];
-                }
+                for (int j = 0; j < JL; ++j) bn[j] = column_ptr(j, kn, cn);
                 const uint4 *rows = &lds_rows[wave][buf][(size_t)ci * R * 7];
                 uint4 a[7];
 #pragma unroll
@@ -178,7 +254,17 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
                         }
                         // rolling prefetch of the next row's plane pair (no extra registers)
                         __builtin_amdgcn_sched_barrier(0);
-                        if (r + 1 < R) a[q] = rows[(r + 1) * 7 + q];
+                        if constexpr (ABL & 1) {   // timing-only: no re-read, but opaque to CSE
+                            asm volatile("" : "+v"(a[q].x), "+v"(a[q].y), "+v"(a[q].z), "+v"(a[q].w));
+                        } else {
+                            if (r + 1 < R) a[q] = rows[(r + 1) * 7 + q];
+                        }
+                        if constexpr (!(ABL & 2)) {
+                            if (r == R - 1) {   // last use of b[.][q] in this chunk: fetch the next chunk's
+#pragma unroll
+                                for (int j = 0; j < JL; ++j) b[j][q] = bn[j][q * LANES];
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -187,7 +273,12 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
                         asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[j]));
                         asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[j]));
                     }
+                    if (r == 0 && ci == 0 && want_dma) {
+                        SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
+                        b_younger = 0;
+                    }
                 }
+                if constexpr (!(ABL & 2)) ++b_younger;
             }
         }
 
@@ -303,6 +394,18 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (k_sliced) n_wg *= args.k_count;
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);
+    // timing-only ablations of the sliced COUNTS kernel (outputs wrong by construction):
+    // SKL_KSLICE_ABLATE = 1 no row re-reads from LDS, 2 no column reloads, 3 both
+    if (const char *e = getenv("SKL_KSLICE_ABLATE")) {
+        const int abl = atoi(e);
+        if (abl && shape == 162 && k_sliced && mode == MODE_COUNTS) {
+            const dim3 block(LANES * WAVES_PER_WG);
+            if (abl == 1) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 1>), grid, block, 0, stream, args);
+            else if (abl == 2) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 2>), grid, block, 0, stream, args);
+            else hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 3>), grid, block, 0, stream, args);
+            return hipGetLastError();
+        }
+    }
 #define SKL_SHAPE(SH, RR, JJ)                                                                  \
     case SH:                                                                                   \
         return k_sliced ? launch_rjk<RR, JJ, true>(args, mode, grid, stream)                   \
