@@ -5,9 +5,9 @@ cd "$(dirname "$0")"
 mkdir -p _build
 CSRC=../../sketchlib.rust_amd/csrc
 for t in valu_rates vgpr_banks lds_bcast; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $t.hip -o _build/$t 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value $t.hip -o _build/$t
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I../../include -I$CSRC \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Wno-unused-value -I../../include -I$CSRC \
   kslice_trace.hip -L$CSRC/_build -lsketchlib_dist_hip -Wl,-rpath,'$ORIGIN/../../../sketchlib.rust_amd/csrc/_build' \
-  -o _build/kslice_trace 2>/dev/null
+  -o _build/kslice_trace
 ls _build

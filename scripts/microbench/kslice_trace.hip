@@ -54,13 +54,13 @@ int main(int argc, char **argv)
     g.dtab = (const float *)dTrace;
     TileScratch ts;
     fprintf(stderr, "launch\n");
-    for (int i = 0; i < 3; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, ts, 0));
+    for (int i = 0; i < 3; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ts, 0));
     CK(hipDeviceSynchronize());
     fprintf(stderr, "warm done\n");
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, ts, 0));
+    CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ts, 0));
     hipEventRecord(e1);
     CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -111,6 +111,65 @@ int main(int argc, char **argv)
     stats(stream, "streaming chunks");
     stats(tail, "reduce + store");
     stats(total, "wave lifetime");
+    // who is slow?  streaming time of first-round waves by XCD, by k-mer length, by wave-in-workgroup
+    {
+        std::map<int, std::pair<double, int>> by_xcc, by_k, by_wave, by_se;
+        const int wpw_ = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
+        for (size_t w = 0; w < n_waves; ++w) {
+            const uint64_t *r = &tr[w * 5];
+            if (r[3] == 0 || r[0] == 0) continue;
+            if ((r[0] - t_min) / 100.0 > 10.0) continue;   // first round only
+            const double st = (r[2] - r[1]) / 100.0;
+            const uint32_t hw = (uint32_t)r[4], xcc = (uint32_t)(r[4] >> 32) & 0xF;
+            const size_t wg = w / wpw_;
+            auto add = [&](std::map<int, std::pair<double, int>> &m, int key) { m[key].first += st; m[key].second++; };
+            add(by_xcc, (int)xcc);
+            add(by_k, (int)((wg >> 3) % nk));
+            add(by_wave, (int)(w % wpw_));
+            add(by_se, (int)((hw >> 13) & 0x7));
+        }
+        auto show = [](const char *name, std::map<int, std::pair<double, int>> &m) {
+            printf("  first-round streaming us by %s:", name);
+            for (auto &kv : m) printf(" %d:%.1f(n=%d)", kv.first, kv.second.first / kv.second.second, kv.second.second);
+            printf("\n");
+        };
+        // per-CU means of first-round streaming time, and the spread inside one workgroup
+        {
+            std::map<uint64_t, std::pair<double, int>> cu;
+            std::map<size_t, std::pair<double, double>> wgmm;
+            std::vector<double> first;
+            for (size_t w = 0; w < n_waves; ++w) {
+                const uint64_t *r = &tr[w * 5];
+                if (r[3] == 0 || r[0] == 0) continue;
+                if ((r[0] - t_min) / 100.0 > 10.0) continue;
+                const double st = (r[2] - r[1]) / 100.0;
+                first.push_back(st);
+                const uint32_t hw = (uint32_t)r[4], xcc = (uint32_t)(r[4] >> 32) & 0xF;
+                const uint64_t key = ((uint64_t)xcc << 16) | (hw & 0xFF00);   // XCC + SE/SH/CU bits
+                cu[key].first += st;
+                cu[key].second++;
+                auto &mm = wgmm[w / wpw_];
+                if (mm.first == 0) mm = {st, st};
+                mm.first = std::min(mm.first, st);
+                mm.second = std::max(mm.second, st);
+            }
+            std::sort(first.begin(), first.end());
+            printf("  first-round streaming: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f\n", first.front(),
+                   first[first.size() / 10], first[first.size() / 2], first[first.size() * 9 / 10], first.back());
+            std::vector<double> cum;
+            for (auto &kv : cu) cum.push_back(kv.second.first / kv.second.second);
+            std::sort(cum.begin(), cum.end());
+            printf("  per-CU mean (n=%zu CUs): min %.1f p10 %.1f median %.1f p90 %.1f max %.1f\n", cum.size(), cum.front(),
+                   cum[cum.size() / 10], cum[cum.size() / 2], cum[cum.size() * 9 / 10], cum.back());
+            double spread = 0;
+            for (auto &kv : wgmm) spread += kv.second.second - kv.second.first;
+            printf("  mean (max - min) inside a workgroup: %.2f us\n", spread / wgmm.size());
+        }
+        show("XCD", by_xcc);
+        show("k index", by_k);
+        show("wave in workgroup", by_wave);
+        show("shader engine", by_se);
+    }
     // concurrency over time
     const double span = (t_max - t_min) / 100.0;
     const int bins = 20;
