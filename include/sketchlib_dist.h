@@ -74,6 +74,12 @@ int skl_ctx_destroy(skl_ctx *ctx);
  * (e.g. torch.cuda.current_stream().cuda_stream).  NULL restores the context's
  * own stream. */
 int skl_ctx_set_stream(skl_ctx *ctx, void *hip_stream);
+/* Run on the device's (legacy) default stream -- hipStream_t 0, which is what
+ * torch.cuda.current_stream().cuda_stream is unless the caller entered a stream context.
+ * The context's own stream is non-blocking, i.e. NOT ordered with work queued on the default
+ * stream; a caller that fills or reads buffers with default-stream work and does not
+ * synchronise explicitly wants this. */
+int skl_ctx_use_default_stream(skl_ctx *ctx);
 int skl_ctx_synchronize(skl_ctx *ctx);
 /* Pair-kernel timing.  Every dense / binmatch / knn call brackets each launch of the
  * pair kernel with HIP events recorded on the context's stream.  reset() forgets them;

@@ -42,7 +42,10 @@ def lib_of(v):
     if path not in _LIBS:
         L = C.CDLL(path)
         for name, restype, argtypes in capi._SIG:
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:      # an older build without a newer entry point
+                continue
             fn.restype, fn.argtypes = restype, argtypes
         _LIBS[path] = L
     return _LIBS[path]

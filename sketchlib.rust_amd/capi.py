@@ -51,6 +51,7 @@ _SIG = [
     ("skl_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("skl_ctx_destroy", C.c_int, [_P]),
     ("skl_ctx_set_stream", C.c_int, [_P, _P]),
+    ("skl_ctx_use_default_stream", C.c_int, [_P]),
     ("skl_ctx_synchronize", C.c_int, [_P]),
     ("skl_ctx_timing_reset", C.c_int, [_P]),
     ("skl_ctx_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
@@ -144,8 +145,14 @@ class Context:
             self.set_stream(stream)
 
     def set_stream(self, stream):
-        """stream: integer hipStream_t handle (torch.cuda.current_stream().cuda_stream) or None."""
-        _check(load().skl_ctx_set_stream(self._h, _P(stream) if stream else None))
+        """stream: integer hipStream_t handle (torch.cuda.current_stream().cuda_stream): 0 is
+        the device's default stream; None restores the context's own (non-blocking) stream."""
+        if stream is None:
+            _check(load().skl_ctx_set_stream(self._h, None))
+        elif int(stream) == 0:
+            _check(load().skl_ctx_use_default_stream(self._h))
+        else:
+            _check(load().skl_ctx_set_stream(self._h, _P(stream)))
 
     def synchronize(self):
         _check(load().skl_ctx_synchronize(self._h))

@@ -183,6 +183,8 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
         if (buf) (void)hipFree(buf);
     }
     if (ctx->tile_scratch.d_prefix) (void)hipFree(ctx->tile_scratch.d_prefix);
+    if (ctx->tile_scratch.h_staging) (void)hipHostFree(ctx->tile_scratch.h_staging);
+    if (ctx->tile_scratch.staged) (void)hipEventDestroy(ctx->tile_scratch.staged);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SKL_OK;
@@ -193,6 +195,14 @@ extern "C" int skl_ctx_set_stream(skl_ctx *ctx, void *hip_stream)
     SKL_TRY(ctx_bind(ctx));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_use_default_stream(skl_ctx *ctx)
+{
+    SKL_TRY(ctx_bind(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = nullptr;   // the legacy default stream: ordered with every blocking stream
     return SKL_OK;
 }
 

@@ -74,6 +74,8 @@ hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_
 // Device buffer the launchers may use for the tile-prefix table (owned by the context).
 struct TileScratch {
     uint32_t *d_prefix = nullptr;
+    uint32_t *h_staging = nullptr; // pinned host copy the upload reads from
+    hipEvent_t staged = nullptr;   // recorded after each upload: h_staging may be rewritten once it fired
     size_t capacity = 0;           // entries
     uint64_t cached_key[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 };

@@ -284,18 +284,35 @@ hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_
         const uint64_t key[4] = {((uint64_t)args.row_begin << 32) | args.row_end, args.nB,
                                  ((uint64_t)rows_per_tile << 32) | cols_per_group, total};
         if (prefix.size() > scratch.capacity) {
-            if (scratch.d_prefix) (void)hipFree(scratch.d_prefix);
+            if (scratch.d_prefix) (void)hipFree(scratch.d_prefix);          // (synchronises the device)
+            if (scratch.h_staging) (void)hipHostFree(scratch.h_staging);
+            scratch.d_prefix = nullptr;
+            scratch.h_staging = nullptr;
             scratch.capacity = 0;
             const size_t cap = std::max<size_t>(prefix.size(), 4096);
-            const hipError_t e = hipMalloc((void **)&scratch.d_prefix, cap * sizeof(uint32_t));
+            hipError_t e = hipMalloc((void **)&scratch.d_prefix, cap * sizeof(uint32_t));
             if (e != hipSuccess) return e;
+            e = hipHostMalloc((void **)&scratch.h_staging, cap * sizeof(uint32_t), hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            if (!scratch.staged) {
+                e = hipEventCreateWithFlags(&scratch.staged, hipEventDisableTiming);
+                if (e != hipSuccess) return e;
+            }
             scratch.capacity = cap;
             scratch.cached_key[0] = ~0ull;
         }
         if (memcmp(key, scratch.cached_key, sizeof key) != 0) {
-            // pageable source: the runtime stages it before returning, so `prefix` may die
-            const hipError_t e = hipMemcpyAsync(scratch.d_prefix, prefix.data(), prefix.size() * sizeof(uint32_t),
-                                                hipMemcpyHostToDevice, stream);
+            // The upload is asynchronous on `stream`: it reads a PINNED staging buffer owned by the
+            // context (never a local that dies with this call), which is rewritten only after
+            // the previous upload has fired its event; the device table itself is ordered with
+            // the kernels that read it by the stream.
+            hipError_t e = hipEventSynchronize(scratch.staged);
+            if (e != hipSuccess) return e;
+            memcpy(scratch.h_staging, prefix.data(), prefix.size() * sizeof(uint32_t));
+            e = hipMemcpyAsync(scratch.d_prefix, scratch.h_staging, prefix.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+            e = hipEventRecord(scratch.staged, stream);
             if (e != hipSuccess) return e;
             memcpy(scratch.cached_key, key, sizeof key);
         }

@@ -113,3 +113,37 @@ def test_large_launch_spot_checks(oracle, skl, gpu_ctx, n):
     r0 = oracle.Sketches(bins[:1], 1, K5, SS64)
     exp = oracle.cross_dists_all(r0, o, oracle.JACCARD, 3, threads=8)[0, 1:, 0]
     assert np.array_equal(dj[:, 0], exp)
+
+
+def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx, monkeypatch):
+    """4.5e8 pairs into a NaN-filled device buffer, alternating the kernel implementations and
+    their tile shapes on one context: every launch must write every pair, and all of them the
+    same values.  (A per-launch tile table that was uploaded from a dying host buffer once left
+    0.6 % of a 5e9-pair launch unwritten when two tile shapes alternated; the table is now a
+    closed form evaluated on the device.)"""
+    import torch
+
+    n = 30000
+    dev = torch.device("cuda", 0)
+    # the NaN fill is torch work on the default stream: run the context there too
+    gpu_ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    g = gpu_ctx.sketches(synth.set_u_device(n, 5, SS64, dev), n, K5, SS64)
+    pairs = n * (n - 1) // 2
+    first = None
+    for env in ({}, {"SKL_KERNEL": "lds"}, {"SKL_SLICED_MAX_PAIRS": "100000000000"}, {"SKL_KERNEL": "ksplit"},
+                {"SKL_KERNEL": "lds", "SKL_LDS_SHAPE": "82"}, {}):
+        for k in ("SKL_KERNEL", "SKL_SLICED_MAX_PAIRS", "SKL_LDS_SHAPE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = torch.full((pairs, 2), float("nan"), dtype=torch.float32, device=dev)
+        skl.self_dists_all(gpu_ctx, g, g.set_k(), out=out)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(out).any().item()), (env, gpu_ctx.last_kernel())
+        if first is None:
+            first = out
+        else:
+            assert bool((out == first).all().item()), (env, gpu_ctx.last_kernel())
+            del out
+    g.close()
+    gpu_ctx.set_stream(None)
