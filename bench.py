@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 KMERS = [15, 19, 23, 27, 31]
 SS64 = 64
 BASE_N = 1000
+VALU_SLOTS_PER_NS = 0.85  # full-rate wave-instructions per ns per SIMD, measured (profiles/r01_valu_rates_microbench.txt)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -258,6 +259,17 @@ def main():
                 "pairs_per_launch": my_pairs,
                 "note": "no-reuse streaming model (SURVEY 8d): frac > 1 measures on-chip operand reuse; "
                         "the binding resource of the tiled kernel is 32-bit VALU (see DESIGN.md)",
+                # Secondary ceiling, the one that actually binds: VALU issue slots.  Per (pair, k,
+                # 64-bin chunk) the kernel needs 28 full-rate (v_xor/v_bitop3) + 2 half-rate (v_bcnt)
+                # instructions = 32 slots; one SIMD issues 0.85 wave-slots/ns at >= 2 waves
+                # (scripts/microbench/valu_rates.hip, measured), 1024 SIMDs x 64 lanes.
+                "valu": {
+                    "slots_per_pair": 32 * nk * SS64,
+                    "peak_pairs_per_s": VALU_SLOTS_PER_NS * 1e9 * 1024 * 64 / (32 * nk * SS64),
+                    "achieved_pairs_per_s": my_pairs / avg_kernel_s if avg_kernel_s > 0 else 0.0,
+                    "frac": (my_pairs / avg_kernel_s) / (VALU_SLOTS_PER_NS * 1e9 * 1024 * 64 / (32 * nk * SS64))
+                    if avg_kernel_s > 0 else 0.0,
+                },
             },
         }
         if world == 1 and not args.no_cpu_baseline:

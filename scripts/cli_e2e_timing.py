@@ -20,6 +20,12 @@ with tempfile.TemporaryDirectory() as tmp:
     synth.set_u(n, 5, ss64).astype("<u8").tofile(prefix + ".skd")
     subprocess.check_call([os.path.join(BUILD, "skl_dbtool"), "make", prefix, str(ss64 * 64),
                            ",".join(map(str, kmers)), *[f"s{i}" for i in range(n)]])
+    out = os.path.join(tmp, "out.npy")
+    t0 = time.perf_counter()
+    subprocess.check_call([os.path.join(BUILD, "sketchlib"), "dist", prefix, "-o", out, "--npy"],
+                          env={**os.environ, "SKL_CLI_TIMING": "1"})
+    print(f"n={n} pairs={n*(n-1)//2} --npy wall={time.perf_counter() - t0:.2f}s out={os.path.getsize(out)/1e6:.0f} MB", flush=True)
+    os.remove(out)
     for threads in (1, 8, 32):
         out = os.path.join(tmp, "out.txt")
         t0 = time.perf_counter()

@@ -35,6 +35,7 @@ struct DistArgs {
     double completeness_cutoff = 0.64;
     bool verbose = false, quiet = false;
     std::vector<int> devices = {0};   // --device D | --devices a,b,.. | --gpus N
+    bool npy = false;                  // --npy: dense output as a NumPy .npy array instead of text
     size_t band_bytes = 256ull << 20;  // --band-mb: host memory per streamed output band
     size_t band() const
     {
@@ -73,6 +74,8 @@ void print_help()
         "      --query-completeness-file <F> File listing query sample completeness estimates 0.0-1.0\n"
         "      --completeness-cutoff <C>   minimum completeness product for the correction [default: 0.64]\n"
         "      --device <D>                GPU to run on [default: 0]\n"
+        "      --npy                       Dense output as a NumPy .npy array (f32, one row per pair in the\n"
+        "                                  order of the text lines) instead of text; needs -o\n"
         "      --band-mb <MB>              Host memory per streamed dense output band [default: 256]\n"
         "      --gpus <N>                  Split the pair space over GPUs 0..N-1 (row bands)\n"
         "      --devices <LIST>            Same, with an explicit comma separated device list\n"
@@ -136,6 +139,7 @@ DistArgs parse_dist(int argc, char **argv, int first)
             if (v.empty() || end != v.c_str() + v.size()) usage_error("invalid value '" + v + "' for '--completeness-cutoff <COMPLETENESS_CUTOFF>': invalid float literal");
         }
         else if (arg == "--device") a.devices = {(int)parse_usize("--device <D>", value(arg))};
+        else if (arg == "--npy") a.npy = true;
         else if (arg == "--band-mb") a.band_bytes = std::max<size_t>(1, parse_usize("--band-mb <MB>", value(arg))) << 20;
         else if (arg == "--gpus") {
             const size_t ngpu = parse_usize("--gpus <N>", value(arg));
@@ -178,8 +182,25 @@ struct Logger {
     void warn(const std::string &m) const { if (warn_on) std::cerr << "WARN  [sketchlib] " << m << "\n"; }
 };
 
+// A dense matrix held whole in memory (multi-device path): text or .npy.
+void write_whole(const DistanceMatrix &d, TextSink &sink, size_t n, const DistArgs &a)
+{
+    if (!a.npy) {
+        d.write_rows(sink, 0, n, d.distances.data(), a.threads);
+        return;
+    }
+    const std::string h = distances::npy_header(d.n_distances, d.jaccard.n_dist_cols());
+    sink.finish(sink.begin(h.data(), h.size()), h.data(), h.size());
+    const char *bytes = reinterpret_cast<const char *>(d.distances.data());
+    const size_t len = d.distances.size() * sizeof(float);
+    sink.finish(sink.begin(bytes, len), bytes, len);
+}
+
 int run_dist(const DistArgs &a)
 {
+    if (a.npy && (!a.output || a.knn)) {
+        usage_error("--npy needs -o <file> and a dense (no --knn) output");
+    }
     const bool timing = std::getenv("SKL_CLI_TIMING") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
@@ -275,12 +296,12 @@ int run_dist(const DistArgs &a)
                 // one device: stream row bands (compute band i+1 while band i is written)
                 log.info("Writing out in long matrix form");
                 distances::self_dists_all_streamed(dev[0], references, n, dist_type, rc, a.completeness_cutoff,
-                                                   *sink, a.threads, a.band());
+                                                   *sink, a.threads, a.band(), a.npy);
             } else {
                 const DistanceMatrix d = distances::self_dists_all(dev, references, n, dist_type, a.quiet, rc,
                                                                    a.completeness_cutoff);
                 log.info("Writing out in long matrix form");
-                d.write_rows(*sink, 0, n, d.distances.data(), a.threads);
+                write_whole(d, *sink, n, a);
             }
         } else {
             size_t nn = *a.knn;
@@ -314,12 +335,12 @@ int run_dist(const DistArgs &a)
             if (a.devices.size() == 1) {
                 log.info("Writing out in long matrix form");
                 distances::cross_dists_all_streamed(dev[0], references, *queries, n, n_query, dist_type, rc, qc,
-                                                    a.completeness_cutoff, *sink, a.threads, a.band());
+                                                    a.completeness_cutoff, *sink, a.threads, a.band(), a.npy);
             } else {
                 const DistanceMatrix d = distances::cross_dists_all(dev, references, *queries, n, n_query, dist_type,
                                                                     a.quiet, rc, qc, a.completeness_cutoff);
                 log.info("Writing out in long matrix form");
-                d.write_rows(*sink, 0, n, d.distances.data(), a.threads);
+                write_whole(d, *sink, n, a);
             }
         }
     }

@@ -349,8 +349,21 @@ namespace {
 // band i+1 is already being computed (one helper thread drives the GPU call).
 template <class Compute>
 void stream_bands(const DistanceMatrix &shape, const std::vector<size_t> &b, size_t max_band_floats,
-                  Compute compute, TextSink &sink, size_t threads)
+                  Compute compute, TextSink &sink, size_t threads, bool npy)
 {
+    const size_t ncols = shape.jaccard.n_dist_cols();
+    const size_t n_rows = shape.ref_names.size();
+    auto band_floats = [&](size_t r0, size_t r1) {
+        if (shape.query_names) return (r1 - r0) * shape.query_names->size() * ncols;
+        r1 = std::min(r1, n_rows ? n_rows - 1 : 0);
+        if (r1 <= r0) return (size_t)0;
+        auto upto = [&](size_t r) { return r * n_rows - r * (r + 1) / 2; };   // pairs with i < r
+        return (upto(r1) - upto(r0)) * ncols;
+    };
+    if (npy) {
+        const std::string h = npy_header(shape.n_distances, ncols);
+        sink.finish(sink.begin(h.data(), h.size()), h.data(), h.size());
+    }
     std::vector<float> buf[2];
     buf[0].resize(max_band_floats);
     buf[1].resize(max_band_floats);
@@ -373,14 +386,40 @@ void stream_bands(const DistanceMatrix &shape, const std::vector<size_t> &b, siz
         output_timing().wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (err) std::rethrow_exception(err);
         if (i + 1 < n_bands) worker = launch(i + 1);
-        shape.write_rows(sink, b[i], b[i + 1], buf[i & 1].data(), threads);
+        if (npy) {
+            const char *bytes = reinterpret_cast<const char *>(buf[i & 1].data());
+            const size_t len = band_floats(b[i], b[i + 1]) * sizeof(float);
+            const auto t1 = std::chrono::steady_clock::now();
+            sink.finish(sink.begin(bytes, len), bytes, len);
+            output_timing().sink_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        } else {
+            shape.write_rows(sink, b[i], b[i + 1], buf[i & 1].data(), threads);
+        }
     }
 }
+
 }  // namespace
+
+std::string npy_header(size_t rows, size_t cols)
+{
+    std::string dict = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(rows) + ", " +
+                       std::to_string(cols) + "), }";
+    // magic(6) + version(2) + header length(2) + dict + padding + '\n' must be a multiple of 64
+    size_t total = 10 + dict.size() + 1;
+    const size_t pad = (64 - total % 64) % 64;
+    dict.append(pad, ' ');
+    dict.push_back('\n');
+    std::string h("\x93NUMPY", 6);
+    h.push_back('\x01');
+    h.push_back('\x00');
+    h.push_back((char)(dict.size() & 0xFF));
+    h.push_back((char)((dict.size() >> 8) & 0xFF));
+    return h + dict;
+}
 
 void self_dists_all_streamed(Device &dev, const MultiSketch &sketches, size_t n, const DistType &dist_type,
                              const std::vector<double> *completeness_vec, double completeness_cutoff,
-                             TextSink &sink, size_t threads, size_t band_bytes)
+                             TextSink &sink, size_t threads, size_t band_bytes, bool npy)
 {
     if (n < 2) return;
     DistanceMatrix shape;   // names + type only; no n^2 storage
@@ -406,14 +445,14 @@ void self_dists_all_streamed(Device &dev, const MultiSketch &sketches, size_t n,
     const skl_dist_params p = to_params(dist_type, completeness_cutoff);
     stream_bands(shape, b, max_pairs * ncols,
                  [&](size_t r0, size_t r1, float *out) { check(skl_self_dists_rows(dev.ctx(), s.h, &p, r0, r1, out, 0)); },
-                 sink, threads);
+                 sink, threads, npy);
 }
 
 void cross_dists_all_streamed(Device &dev, const MultiSketch &ref_sketches, const MultiSketch &query_sketches,
                               size_t n, size_t n_query, const DistType &dist_type,
                               const std::vector<double> *ref_completeness_vec,
                               const std::vector<double> *query_completeness_vec, double completeness_cutoff,
-                              TextSink &sink, size_t threads, size_t band_bytes)
+                              TextSink &sink, size_t threads, size_t band_bytes, bool npy)
 {
     if (n == 0 || n_query == 0) return;
     DistanceMatrix shape;
@@ -433,7 +472,7 @@ void cross_dists_all_streamed(Device &dev, const MultiSketch &ref_sketches, cons
                  [&](size_t r0, size_t r1, float *out) {
                      check(skl_cross_dists_rows(dev.ctx(), r.h, q.h, &p, r0, r1, out, 0));
                  },
-                 sink, threads);
+                 sink, threads, npy);
 }
 
 }  // namespace distances

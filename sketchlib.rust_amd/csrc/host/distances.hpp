@@ -78,14 +78,18 @@ SparseDistanceMatrix cross_dists_knn(DeviceSet &devs, const MultiSketch &ref_ske
 // as soon as it is back on the host while the GPU computes the next one -- bounded host
 // memory instead of n(n-1)/2 records, and formatting overlapped with compute.  Output is
 // byte-identical to DistanceMatrix::write of the whole matrix.
+// `npy` = write the matrix as a NumPy .npy v1.0 array instead of text: '<f4', C order, shape
+// (n_pairs, ncols), rows in the same (condensed / ref-major) order as the text lines.
 void self_dists_all_streamed(Device &dev, const MultiSketch &sketches, size_t n, const DistType &dist_type,
                              const std::vector<double> *completeness_vec, double completeness_cutoff,
-                             TextSink &sink, size_t threads, size_t band_bytes);
+                             TextSink &sink, size_t threads, size_t band_bytes, bool npy = false);
 void cross_dists_all_streamed(Device &dev, const MultiSketch &ref_sketches, const MultiSketch &query_sketches,
                               size_t n, size_t n_query, const DistType &dist_type,
                               const std::vector<double> *ref_completeness_vec,
                               const std::vector<double> *query_completeness_vec, double completeness_cutoff,
-                              TextSink &sink, size_t threads, size_t band_bytes);
+                              TextSink &sink, size_t threads, size_t band_bytes, bool npy = false);
+// The .npy v1.0 header of a (rows, cols) little-endian f32 array.
+std::string npy_header(size_t rows, size_t cols);
 
 // mod.rs:25-37.  Throws std::runtime_error("K-mer size {k} not found in file").
 DistType set_k(const MultiSketch &sketches, std::optional<size_t> kmer, bool ani);

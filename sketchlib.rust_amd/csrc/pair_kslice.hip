@@ -223,7 +223,12 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
                 b_younger = 0;
             }
 
-            for (uint32_t ci = 0; ci < (uint32_t)CH && c0 + ci < g.ss64; ++ci) {
+            // (unrolled: the column loads issued in the last row of chunk 0 and their first use
+            // in chunk 1 are then straight-line code, and the compiler's waits on them are counted
+            // instead of the vmcnt(0) it falls back to across a loop back-edge)
+#pragma unroll
+            for (uint32_t ci = 0; ci < (uint32_t)CH; ++ci) {
+                if (c0 + ci >= g.ss64) break;
                 // where the columns of the next chunk are (the current ones again if none follows)
                 uint32_t kn = g.k_begin + kk, cn = c0 + ci;
                 next_chunk(kl, ts, (int)ci, kn, cn);

@@ -149,6 +149,18 @@ def test_synthetic_db_dense_text_and_parallel_formatting(gpu_ctx, oracle, tmp_pa
         assert run(prefix, prefix, "-k", "23", "--threads", "3", env=env) == one
     assert run(prefix, "-k", "19", env={"SKL_DIST_BAND_BYTES": "777"}) == run(prefix, "-k", "19")
     assert run(prefix, "--band-mb", "1") == expected
+    # --npy: the same numbers as a NumPy array (streamed in bands, and from the multi-context path)
+    npy = tmp_path / "dense.npy"
+    for extra, env in (((), None), ((), {"SKL_DIST_BAND_BYTES": "40000"}), (("--devices", "0,0"), None)):
+        assert run(prefix, "-o", str(npy), "--npy", *extra, env=env) == ""
+        arr = np.load(npy)
+        assert arr.dtype == np.float32 and arr.shape == d.shape and np.array_equal(arr, d)
+    assert run(prefix, prefix, "-k", "23", "-o", str(npy), "--npy", env={"SKL_DIST_BAND_BYTES": "100000"}) == ""
+    arr = np.load(npy)
+    assert arr.shape == (n * n, 1)
+    assert [rust_f32(x) for x in arr[:50, 0]] == [l.split("\t")[2] for l in one.splitlines()[:50]]
+    res = subprocess.run([CLI, "dist", prefix, "--npy"], capture_output=True, text=True)
+    assert res.returncode == 2 and "--npy needs -o" in res.stderr
     # -o <file>: blocks are written at offsets from all formatting threads
     out_file = tmp_path / "dense.txt"
     for env in (None, {"SKL_DIST_BAND_BYTES": "50000"}):
