@@ -141,6 +141,17 @@ int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_param
 int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
                             size_t knn, size_t row_begin, size_t row_end, uint64_t *out_idx,
                             float *out_d0, float *out_d1, int out_on_device);
+/* Candidate-list form of skl_self_dists_knn: the device half of self_dists_knn_precluster
+ * (src/distances/mod.rs:399-553).  Row i is compared only with the samples
+ * cand[row_offsets[i] .. row_offsets[i+1]) (ascending sample ids, i itself excluded) -- what
+ * Inverted::any_shared_bins (src/inverted.rs:259-268) returns for it.  Single-k Jaccard / ANI
+ * only (the reference's CoreAcc arm is unimplemented!(), mod.rs:549-551).  Output as
+ * skl_self_dists_knn, rows of fewer than knn candidates padded with (i, 1.0) (mod.rs:535-546).
+ * All pointers are host pointers. */
+int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                  size_t knn, const uint64_t *row_offsets, const uint32_t *cand,
+                                  uint64_t *out_idx, float *out_d0);
+
 /* cross_dists_knn (src/distances/mod.rs:306-395): rows = queries, neighbours
  * index refs; knn must already be clamped to <= n_ref (mod.rs:325). */
 int skl_cross_dists_knn(skl_ctx *ctx, const skl_sketches *ref, const skl_sketches *query,

@@ -83,6 +83,12 @@ def lib():
         L.sko_cross_dists_knn.restype = C.c_long
         L.sko_cross_dists_knn.argtypes = [P, P, C.c_size_t, C.c_int, C.c_size_t, C.c_int,
                                           C.c_double, C.c_int, C.c_int, C.c_void_p]
+        L.sko_self_dists_knn_precluster.restype = C.c_int
+        L.sko_self_dists_knn_precluster.argtypes = [P, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                    C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                    C.c_int, C.c_void_p]
+        L.sko_prefilter_pair_count.restype = C.c_uint64
+        L.sko_prefilter_pair_count.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         L.sko_core_acc_dist.restype = None
         L.sko_core_acc_dist.argtypes = [P, P, C.c_size_t, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p]
         L.sko_self_binmatch.restype = C.c_int
@@ -170,6 +176,28 @@ def cross_dists_knn(r, q, knn, dist_type=COREACC, k_idx=0, ani=False, cutoff=0.6
     if rc < 0:
         raise ValueError(f"oracle cross_dists_knn failed rc={rc}")
     return out.reshape(q.n, knn_eff)
+
+
+RETAIN_NONE, RETAIN_SINGLETON, RETAIN_BRUTEFORCE = 0, 1, 2
+
+
+def self_dists_knn_precluster(s, skq, knn, k_idx=0, ani=False, cutoff=0.64, ski_of_skd=None,
+                              retain=RETAIN_NONE, ties=TIES_CANONICAL, threads=1):
+    """mod.rs:399-553.  skq: [n, sketch_size] u16 bins in index order."""
+    skq = np.ascontiguousarray(skq, dtype=np.uint16)
+    assert skq.shape[0] == s.n
+    lookup = np.arange(s.n, dtype=np.uintp) if ski_of_skd is None else np.ascontiguousarray(ski_of_skd, dtype=np.uintp)
+    out = np.zeros(s.n * knn, dtype=SPARSE_DTYPE)
+    rc = lib().sko_self_dists_knn_precluster(s.ref, skq.ctypes.data, skq.shape[1], lookup.ctypes.data, knn,
+                                             k_idx, int(ani), cutoff, retain, ties, threads, out.ctypes.data)
+    if rc:
+        raise ValueError(f"oracle self_dists_knn_precluster failed rc={rc}")
+    return out.reshape(s.n, knn)
+
+
+def prefilter_pair_count(skq):
+    skq = np.ascontiguousarray(skq, dtype=np.uint16)
+    return int(lib().sko_prefilter_pair_count(skq.ctypes.data, skq.shape[0], skq.shape[1]))
 
 
 def self_binmatch(s, threads=1):

@@ -151,3 +151,19 @@ def sketch_files(paths, kmers, sketch_size, rc=True):
         codes, offsets = read_fasta_bases(p)
         rows.append(sketch_sequence(codes, offsets, sorted(kmers), sketch_size, rc))
     return np.stack(rows)
+
+
+def inverted_sketch_files(paths, k, sketch_size, rc=True):
+    """Inverted::sketch_files_inverted (src/inverted.rs:303-395) for single-file samples:
+    get_signs_no_densify with num_bins = sketch_size (NOT rounded up to 64), densify_bin, then
+    `as u16` (the low 16 bits of the sign).  [n_samples, sketch_size] uint16 = the .skq rows."""
+    bin_size = -(-SIGN_MOD // sketch_size)
+    rows = []
+    for p in paths:
+        codes, offsets = read_fasta_bases(p)
+        h = kmer_hashes(codes, offsets, k, rc) % np.uint64(SIGN_MOD)
+        signs = np.full(sketch_size, U64_MAX, dtype=np.uint64)
+        np.minimum.at(signs, (h // np.uint64(bin_size)).astype(np.int64), h)
+        densify_bin(signs)
+        rows.append((signs & np.uint64(0xFFFF)).astype(np.uint16))
+    return np.stack(rows)

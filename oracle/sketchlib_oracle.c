@@ -583,3 +583,131 @@ long sko_cross_dists_knn(const sko_sketches *ref, const sko_sketches *query, siz
     run_chunks(knn_row, &job, query->n_samples, threads);
     return (long)knn;
 }
+
+/* ---- mod.rs:399-553: self_dists_knn_precluster ----
+ * Inverted::any_shared_bins (src/inverted.rs:259-268) restated without the index: sample j
+ * (ski order) is a candidate of the query sketch iff some bin position holds the same u16
+ * value in both -- exactly the union of index[bin][value] over the bins.  Candidates are
+ * visited in ascending ski order, as RoaringBitmap::iter yields them. */
+typedef struct {
+    const sko_sketches *s;
+    const uint16_t *skq;          /* [n][skq_stride], ski order */
+    size_t skq_stride;
+    const size_t *ski_of_skd;     /* skq_index_lookup: skd index -> ski index */
+    const size_t *skd_of_ski;     /* skd_index_from_ski */
+    size_t knn, k_idx;
+    int ani;
+    double cutoff;
+    int retain_mode, tie_mode;
+    sko_sparse *out;
+} pre_job;
+
+static float pre_key(const pre_job *job, size_t i, size_t j)
+{
+    const sko_sketches *s = job->s;
+    int has_c = s->completeness != NULL;
+    double c1 = has_c ? s->completeness[i] : 0.0, c2 = has_c ? s->completeness[j] : 0.0;
+    double jac = sko_jaccard_index(get_sketch_slice(s, i, job->k_idx), get_sketch_slice(s, j, job->k_idx),
+                                   s->sketchsize64, has_c, c1, c2, job->cutoff);
+    double k_f64 = (double)s->kmers[job->k_idx];
+    return job->ani ? (float)(1.0 - sko_ani_pois(jac, k_f64)) : (float)(1.0 - jac);
+}
+
+static size_t pre_collect(const pre_job *job, size_t i, int brute, sko_sparse *all, heap_t *heap)
+{
+    const size_t n = job->s->n_samples;
+    const size_t ski_i = job->ski_of_skd[i];
+    const uint16_t *qi = job->skq + ski_i * job->skq_stride;
+    size_t n_all = 0;
+    for (size_t c = 0; c < n; ++c) {
+        size_t skd_j;
+        if (brute) {                       /* mod.rs:500-523: j over skd order, skip i */
+            if (c == i) continue;
+            skd_j = c;
+        } else {                           /* mod.rs:455-485: j over ski order, skip self */
+            if (c == ski_i) continue;
+            const uint16_t *qj = job->skq + c * job->skq_stride;
+            int shared = 0;
+            for (size_t b = 0; b < job->skq_stride && !shared; ++b) shared = qi[b] == qj[b];
+            if (!shared) continue;
+            skd_j = job->skd_of_ski[c];
+        }
+        sko_sparse item;
+        item.idx = skd_j;
+        item.d0 = pre_key(job, i, skd_j);
+        item.d1 = 0.0f;
+        if (all) all[n_all] = item; else push_heap(heap, item, job->knn);
+        ++n_all;
+    }
+    return n_all;
+}
+
+static void pre_row(void *ctx, size_t i)
+{
+    const pre_job *job = (const pre_job *)ctx;
+    const size_t n = job->s->n_samples, knn = job->knn;
+    sko_sparse *dst = job->out + i * knn;
+    sko_sparse *all = NULL;
+    heap_t heap;
+    heap.len = 0;
+    heap.data = NULL;
+    if (job->tie_mode == SKO_TIES_CANONICAL) all = (sko_sparse *)malloc(sizeof(sko_sparse) * (n ? n : 1));
+    else heap.data = (sko_sparse *)malloc(sizeof(sko_sparse) * (knn + 1));
+    size_t found = pre_collect(job, i, 0, all, &heap);
+    if (found == 0 && job->retain_mode == 1) {          /* Singleton, mod.rs:489-497 */
+        dst[0].idx = i; dst[0].d0 = 0.0f; dst[0].d1 = 0.0f;
+        for (size_t t = 1; t < knn; ++t) { dst[t].idx = i; dst[t].d0 = 1.0f; dst[t].d1 = 0.0f; }
+        free(all); free(heap.data);
+        return;
+    }
+    if (found == 0 && job->retain_mode == 2) {          /* Bruteforce, mod.rs:498-525 */
+        heap.len = 0;
+        found = pre_collect(job, i, 1, all, &heap);
+    }
+    size_t got;
+    if (all) {
+        qsort(all, found, sizeof(sko_sparse), canon_cmp);
+        got = found < knn ? found : knn;
+        for (size_t t = 0; t < got; ++t) dst[t] = all[t];
+        free(all);
+    } else {
+        heap_into_sorted(&heap);
+        got = heap.len;
+        for (size_t t = 0; t < got; ++t) dst[t] = heap.data[t];
+        free(heap.data);
+    }
+    if (job->ani) for (size_t t = 0; t < got; ++t) dst[t].d0 = 1.0f - dst[t].d0;   /* mod.rs:529-534 */
+    for (size_t t = got; t < knn; ++t) { dst[t].idx = i; dst[t].d0 = 1.0f; dst[t].d1 = 0.0f; }  /* :535-546 */
+}
+
+int sko_self_dists_knn_precluster(const sko_sketches *s, const uint16_t *skq, size_t skq_stride,
+                                  const size_t *ski_of_skd, size_t knn, size_t k_idx, int ani,
+                                  double cutoff, int retain_mode, int tie_mode, int threads,
+                                  sko_sparse *out)
+{
+    if (k_idx >= s->nk) return -2;
+    if (knn == 0 || knn >= s->n_samples) return -3; /* caller clamps, lib.rs:737-740 */
+    size_t n = s->n_samples;
+    size_t *skd_of_ski = (size_t *)calloc(n ? n : 1, sizeof(size_t));
+    for (size_t i = 0; i < n; ++i) skd_of_ski[ski_of_skd[i]] = i;   /* mod.rs:436-439 */
+    pre_job job = {s, skq, skq_stride, ski_of_skd, skd_of_ski, knn, k_idx, ani, cutoff, retain_mode, tie_mode, out};
+    run_chunks(pre_row, &job, n, threads);
+    free(skd_of_ski);
+    return 0;
+}
+
+/* `sketchlib inverted precluster --count` (src/lib.rs:700-712, inverted.rs:271-300): pairs that
+ * share at least one bin. */
+uint64_t sko_prefilter_pair_count(const uint16_t *skq, size_t n, size_t skq_stride)
+{
+    uint64_t count = 0;
+    for (size_t i = 0; i < n; ++i) {
+        for (size_t j = i + 1; j < n; ++j) {
+            const uint16_t *a = skq + i * skq_stride, *b = skq + j * skq_stride;
+            for (size_t x = 0; x < skq_stride; ++x) {
+                if (a[x] == b[x]) { ++count; break; }
+            }
+        }
+    }
+    return count;
+}

@@ -103,6 +103,19 @@ long sko_cross_dists_knn(const sko_sketches *ref, const sko_sketches *query, siz
                          int dist_type, size_t k_idx, int ani, double completeness_cutoff,
                          int tie_mode, int threads, sko_sparse *out);
 
+/* mod.rs:399-553, self_dists_knn_precluster (single-k Jaccard / ANI only).  `skq` holds the
+ * u16 bins of the inverted index's samples ([n][skq_stride], index order); ski_of_skd[i] is
+ * the index-order position of .skd sample i (skq_index_lookup).  Candidates of a row are the
+ * samples sharing at least one bin with it (inverted.rs:259-268).  retain_mode: 0 none,
+ * 1 singleton, 2 bruteforce (RetainUnmatched, mod.rs:487-527).  Rows are padded with
+ * (i, 1.0) (mod.rs:535-546).  out: n*knn items. */
+int sko_self_dists_knn_precluster(const sko_sketches *s, const uint16_t *skq, size_t skq_stride,
+                                  const size_t *ski_of_skd, size_t knn, size_t k_idx, int ani,
+                                  double completeness_cutoff, int retain_mode, int tie_mode,
+                                  int threads, sko_sparse *out);
+/* Number of sample pairs sharing at least one bin (`precluster --count`, lib.rs:700-712). */
+uint64_t sko_prefilter_pair_count(const uint16_t *skq, size_t n, size_t skq_stride);
+
 /* Raw bin-match counts (the value jaccard.rs:15-25 computes and only traces):
  * self: out[cond(i,j)*nk + k]; cross: out[(i*nq + j)*nk + k]. */
 int sko_self_binmatch(const sko_sketches *s, int threads, uint32_t *out);

@@ -76,6 +76,7 @@ _SIG = [
                                       C.c_int]),
     ("skl_cross_dists_knn_rows", C.c_int, [_P, _P, _P, C.POINTER(DistParams), C.c_size_t,
                                            C.c_size_t, C.c_size_t, _P, _P, _P, C.c_int]),
+    ("skl_self_dists_knn_candidates", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, _P, _P, _P, _P]),
     ("skl_self_binmatch", C.c_int, [_P, _P, _P, C.c_int]),
     ("skl_cross_binmatch", C.c_int, [_P, _P, _P, _P, C.c_int]),
     ("skl_self_dists_all_host", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, C.c_size_t,
@@ -309,6 +310,19 @@ def cross_dists_knn(ctx, r, q, p, knn, q0=0, q1=None):
     _check(load().skl_cross_dists_knn_rows(ctx._h, r._h, q._h, C.byref(p), knn, q0, q1,
                                            idx.ctypes.data, d0.ctypes.data, d1.ctypes.data, 0))
     return idx, d0, d1
+
+
+def self_dists_knn_candidates(ctx, s, p, knn, row_offsets, cand):
+    """Candidate-list kNN (device half of self_dists_knn_precluster, mod.rs:399-553): row i is
+    compared with cand[row_offsets[i]:row_offsets[i+1]] only (ascending ids, i excluded)."""
+    row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+    cand = np.ascontiguousarray(cand, dtype=np.uint32)
+    assert row_offsets.size == s.n + 1 and int(row_offsets[-1]) == cand.size
+    idx, d0, _ = _knn_out(s.n, knn)
+    _check(load().skl_self_dists_knn_candidates(ctx._h, s._h, C.byref(p), knn, row_offsets.ctypes.data,
+                                                cand.ctypes.data if cand.size else None, idx.ctypes.data,
+                                                d0.ctypes.data))
+    return idx, d0
 
 
 # ---- raw counts ----

@@ -936,6 +936,89 @@ extern "C" int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl
     return skl_self_dists_knn_rows(ctx, s, p, knn, 0, s->n, out_idx, out_d0, out_d1, out_on_device);
 }
 
+// Candidate-list kNN: the device half of the reference's self_dists_knn_precluster
+// (src/distances/mod.rs:399-553).  Host pointers in, host pointers out.
+extern "C" int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                             size_t knn, const uint64_t *row_offsets, const uint32_t *cand,
+                                             uint64_t *out_idx, float *out_d0)
+{
+    SKL_TRY(check_params(s, s, p));
+    SKL_TRY(ctx_bind(ctx));
+    if (p->dist_type != SKL_DIST_JACCARD) {
+        return fail(SKL_ERR_INVALID_ARG, "Prefilter only available for single k-mer distances");  // mod.rs:549-551
+    }
+    if (!row_offsets || !out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    const size_t n = s->n;
+    if (n == 0) return SKL_OK;
+    if (knn == 0 || knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, 2048]", knn);
+    const uint64_t total = row_offsets[n];
+    if (total && !cand) return fail(SKL_ERR_INVALID_ARG, "cand is null");
+    // 64-candidate work items, row by row
+    std::vector<uint32_t> work_row;
+    std::vector<uint64_t> work_start;
+    for (size_t i = 0; i < n; ++i) {
+        if (row_offsets[i + 1] < row_offsets[i]) return fail(SKL_ERR_INVALID_ARG, "row_offsets must not decrease");
+        for (uint64_t c0 = row_offsets[i]; c0 < row_offsets[i + 1]; c0 += 64) {
+            work_row.push_back((uint32_t)i);
+            work_start.push_back(c0);
+        }
+    }
+    for (uint64_t x = 0; x < total; ++x) {
+        if (cand[x] >= n) return fail(SKL_ERR_INVALID_ARG, "candidate id %u out of range", cand[x]);
+    }
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } d_off, d_cand, d_wrow, d_wstart, d_keys, d_idx, d_d0;
+    auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(&b.p, std::max<size_t>(bytes, 16)));
+        if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SKL_OK;
+    };
+    SKL_TRY(upload(d_off, row_offsets, (n + 1) * sizeof(uint64_t)));
+    SKL_TRY(upload(d_cand, cand, total * sizeof(uint32_t)));
+    SKL_TRY(upload(d_wrow, work_row.data(), work_row.size() * sizeof(uint32_t)));
+    SKL_TRY(upload(d_wstart, work_start.data(), work_start.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&d_keys.p, std::max<size_t>(total * sizeof(float), 16)));
+    HIP_TRY(hipMalloc(&d_idx.p, n * knn * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&d_d0.p, n * knn * sizeof(float)));
+    // the uploads read pageable host memory: make sure they are done before the vectors die
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+    PairArgs g;
+    SKL_TRY(fill_args(s, s, p, MODE_JACCARD, p->ani ? JOUT_ANI_KEY : JOUT_DIST, &g));
+    CandArgs c;
+    memset(&c, 0, sizeof c);
+    c.row_offsets = (const uint64_t *)d_off.p;
+    c.cand = (const uint32_t *)d_cand.p;
+    c.work_row = (const uint32_t *)d_wrow.p;
+    c.work_start = (const uint64_t *)d_wstart.p;
+    c.n_work = work_row.size();
+    c.keys = (float *)d_keys.p;
+    HIP_TRY(launch_pair_cand(c, g, ctx->stream));
+    ctx->last_kernel = "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)";
+    TopkArgs t;
+    memset(&t, 0, sizeof t);
+    t.keys = (const float *)d_keys.p;
+    t.rows = (uint32_t)n;
+    t.cols = 0;
+    t.stride2 = 1;
+    t.knn = (uint32_t)knn;
+    t.self_mode = 0;
+    t.row_begin = 0;
+    t.ani_undo = p->ani ? 1 : 0;
+    t.out_idx = (uint64_t *)d_idx.p;
+    t.out_d0 = (float *)d_d0.p;
+    t.out_d1 = nullptr;
+    t.row_offsets = (const uint64_t *)d_off.p;
+    t.col_ids = (const uint32_t *)d_cand.p;
+    HIP_TRY(launch_topk(t, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_idx, d_idx.p, n * knn * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_d0, d_d0.p, n * knn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
 extern "C" int skl_cross_dists_knn_rows(skl_ctx *ctx, const skl_sketches *ref,
                                         const skl_sketches *query, const skl_dist_params *p,
                                         size_t knn, size_t query_begin, size_t query_end,

@@ -149,26 +149,23 @@ __device__ __forceinline__ void store_count(const PairArgs &g, uint32_t i, uint3
 }
 
 // MODE_JACCARD: mod.rs:83-100 (dense) / :173-176 (kNN key)
+__device__ __forceinline__ float jaccard_out_value(const PairArgs &g, uint32_t i, uint32_t jcol,
+                                                   uint32_t mismatches)
+{
+    const uint32_t same = g.ss64 * 64u - mismatches;
+    if (!g.has_comp) return g.dtab[same];
+    const double jac =
+        jaccard_from_samebits_dev(same, g.ss64, true, g.compA[i], g.compB[jcol], g.cutoff);
+    if (g.jout == JOUT_DIST) return (float)(1.0 - jac);
+    if (g.jout == JOUT_ANI) return (float)ani_pois_dev(jac, g.kf[0]);
+    return (float)(1.0 - ani_pois_dev(jac, g.kf[0]));
+}
+
 __device__ __forceinline__ void store_jaccard(const PairArgs &g, uint32_t i, uint32_t jcol,
                                               uint32_t mismatches)
 {
     if (!pair_valid(g, i, jcol)) return;
-    const uint32_t same = g.ss64 * 64u - mismatches;
-    float d;
-    if (!g.has_comp) {
-        d = g.dtab[same];
-    } else {
-        const double jac =
-            jaccard_from_samebits_dev(same, g.ss64, true, g.compA[i], g.compB[jcol], g.cutoff);
-        if (g.jout == JOUT_DIST) {
-            d = (float)(1.0 - jac);
-        } else if (g.jout == JOUT_ANI) {
-            d = (float)ani_pois_dev(jac, g.kf[0]);
-        } else {
-            d = (float)(1.0 - ani_pois_dev(jac, g.kf[0]));
-        }
-    }
-    ((float *)g.out)[pair_out_index(g, i, jcol)] = d;
+    ((float *)g.out)[pair_out_index(g, i, jcol)] = jaccard_out_value(g, i, jcol, mismatches);
 }
 
 // MODE_COREACC: core_acc_dist + simple_linear_regression (jaccard.rs:61-142) from the

@@ -127,6 +127,17 @@ struct EpilogueArgs {
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
 
 // Row-wise top-k over a dense [rows][cols] band of keys (and optional second value).
+// Candidate-list pair kernel (pair_cand.hip): row i against cand[row_offsets[i] .. row_offsets[i+1]).
+struct CandArgs {
+    const uint64_t *row_offsets;  // [n_rows + 1]
+    const uint32_t *cand;         // candidate sample ids (ascending inside a row)
+    const uint32_t *work_row;     // [n_work] row of each 64-candidate work item
+    const uint64_t *work_start;   // [n_work] first candidate position of the work item
+    uint64_t n_work;
+    float *keys;                  // [n_candidates] MODE_JACCARD output per candidate
+};
+hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream);
+
 struct TopkArgs {
     const float *keys;      // [rows][cols] or [rows][cols][2] when stride2
     uint32_t rows, cols;
@@ -137,6 +148,11 @@ struct TopkArgs {
     int32_t ani_undo;       // write 1.0f - key   (mod.rs:183-189)
     uint64_t *out_idx;      // [rows][knn]
     float *out_d0, *out_d1;
+    // Ragged form (candidate lists): row r owns keys[row_offsets[r] .. row_offsets[r+1]) and
+    // col_ids maps a position to the sample id written to out_idx; rows with fewer than knn
+    // candidates are padded with (row id, 1.0f) as mod.rs:535-546 does.  Null = dense form.
+    const uint64_t *row_offsets;
+    const uint32_t *col_ids;
 };
 hipError_t launch_topk(const TopkArgs &args, hipStream_t stream);
 

@@ -460,13 +460,26 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
 
     const uint32_t row = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    const float *keys = g.keys + (size_t)row * g.cols * g.stride2;
+    const bool ragged = g.row_offsets != nullptr;
+    const uint64_t row_base = ragged ? g.row_offsets[row] : (uint64_t)row * g.cols;
+    const uint32_t n_cols = ragged ? (uint32_t)(g.row_offsets[row + 1] - row_base) : g.cols;
+    const uint32_t knn_eff = ragged ? (n_cols < g.knn ? n_cols : g.knn) : g.knn;
+    const float *keys = g.keys + row_base * g.stride2;
     const uint32_t self_col = g.self_mode ? g.row_begin + row : 0xFFFFFFFFu;
+    if (ragged) {
+        // padding entries (fewer candidates than knn): (this row, 1.0)
+        for (uint32_t x = knn_eff + tid; x < g.knn; x += TOPK_THREADS) {
+            const size_t o = (size_t)row * g.knn + x;
+            g.out_idx[o] = g.row_begin + row;
+            g.out_d0[o] = 1.0f;
+        }
+        if (knn_eff == 0) return;
+    }
 
     // ---- radix select: key value of the knn-th smallest ----
     if (tid == 0) {
         sh_prefix = 0;
-        sh_remaining = g.knn;
+        sh_remaining = knn_eff;
     }
     __syncthreads();
     for (int pass = 3; pass >= 0; --pass) {
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
         __syncthreads();
         const uint32_t prefix = sh_prefix;
         const uint32_t hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << ((pass + 1) * 8));
-        for (uint32_t c = tid; c < g.cols; c += TOPK_THREADS) {
+        for (uint32_t c = tid; c < n_cols; c += TOPK_THREADS) {
             if (c == self_col) continue;
             const uint32_t u = sortable_bits(keys[(size_t)c * g.stride2]);
             if ((u & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(u >> (pass * 8)) & 0xFFu], 1u);
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
         sh_taken = 0;
     }
     __syncthreads();
-    for (uint32_t c = tid; c < g.cols; c += TOPK_THREADS) {
+    for (uint32_t c = tid; c < n_cols; c += TOPK_THREADS) {
         if (c == self_col) continue;
         const uint32_t u = sortable_bits(keys[(size_t)c * g.stride2]);
         if (u < thresh) {
@@ -512,10 +525,10 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
     __syncthreads();
     // ---- ties at the threshold: ordered compaction, lowest column first ----
     const uint32_t n_less = sh_count;
-    for (uint32_t base = 0; base < g.cols && sh_taken < take_eq; base += TOPK_THREADS) {
+    for (uint32_t base = 0; base < n_cols && sh_taken < take_eq; base += TOPK_THREADS) {
         const uint32_t c = base + tid;
         bool eq = false;
-        if (c < g.cols && c != self_col) {
+        if (c < n_cols && c != self_col) {
             eq = sortable_bits(keys[(size_t)c * g.stride2]) == thresh;
         }
         // block-wide exclusive prefix of `eq` via per-wave ballots
@@ -541,8 +554,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
 
     // ---- bitonic sort of the knn items by (key, col) ----
     uint32_t m = 1;
-    while (m < g.knn) m <<= 1;
-    for (uint32_t x = g.knn + tid; x < m; x += TOPK_THREADS) items[x] = ~0ull;
+    while (m < knn_eff) m <<= 1;
+    for (uint32_t x = knn_eff + tid; x < m; x += TOPK_THREADS) items[x] = ~0ull;
     __syncthreads();
     for (uint32_t size = 2; size <= m; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -559,11 +572,11 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
             __syncthreads();
         }
     }
-    for (uint32_t x = tid; x < g.knn; x += TOPK_THREADS) {
+    for (uint32_t x = tid; x < knn_eff; x += TOPK_THREADS) {
         const uint32_t col = (uint32_t)(items[x] & 0xFFFFFFFFu);
         const size_t o = (size_t)row * g.knn + x;
         const float key = keys[(size_t)col * g.stride2];
-        g.out_idx[o] = col;
+        g.out_idx[o] = g.col_ids ? g.col_ids[row_base + col] : col;
         g.out_d0[o] = g.ani_undo ? 1.0f - key : key;
         if (g.stride2 == 2 && g.out_d1) g.out_d1[o] = keys[(size_t)col * 2 + 1];
     }

@@ -1,0 +1,72 @@
+// pair_cand.hip -- distances for an explicit candidate list (gfx950).
+//
+// The reference's `self_dists_knn_precluster` (src/distances/mod.rs:399-553) computes, for
+// every sample i, the single-k Jaccard / ANI key against the samples an inverted index
+// returns for it (any shared bin), instead of against all n.  The pair space is then a
+// ragged list: row_offsets[i] .. row_offsets[i+1] into an array of candidate sample ids.
+//
+// One wave = one row and up to 64 of its candidates.  The candidate sample lives in the lane
+// and is read straight from the reference layout (7 x 16 B per chunk, scattered between
+// lanes -- the list has no structure to tile); the row sample is wave-uniform and arrives
+// through the scalar cache.  This kernel is bound by the gather (7 168 B per pair at
+// sketchsize64 = 64), not by the VALU, so the half-rate scalar operand is the right
+// trade: no LDS, no staging, any list shape.
+#include "device_common.hpp"
+
+namespace skl {
+
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr_c;
+
+__global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const CandArgs c, const PairArgs g)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_WG + wave;
+    if (w >= c.n_work) return;
+    const uint32_t row = c.work_row[w];
+    const uint64_t start = c.work_start[w];
+    const uint64_t row_end = c.row_offsets[row + 1];
+    const uint32_t cnt = (uint32_t)((row_end - start) < 64ull ? (row_end - start) : 64ull);
+    const uint32_t j = lane < cnt ? c.cand[start + lane] : row;   // idle lanes redo the diagonal
+
+    const size_t kmer_stride = (size_t)g.ss64 * BBITS;
+    const size_t sample_stride = kmer_stride * g.nk;
+    const uint64_t *pi = g.A + (size_t)row * sample_stride + (size_t)g.k_begin * kmer_stride;
+    const uint4 *pj = reinterpret_cast<const uint4 *>(g.A + (size_t)j * sample_stride + (size_t)g.k_begin * kmer_stride);
+
+    uint32_t mism = 0;
+    uint4 b[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) b[q] = pj[q];
+    for (uint32_t ch = 0; ch < g.ss64; ++ch) {
+        const uint32_t cn = ch + 1 < g.ss64 ? ch + 1 : ch;
+        uint4 bn[7];   // next chunk of the candidate: in flight under this chunk's work
+#pragma unroll
+        for (int q = 0; q < 7; ++q) bn[q] = pj[(size_t)cn * 7 + q];
+        const_u32_ptr_c a = (const_u32_ptr_c)(uintptr_t)(pi + (size_t)ch * BBITS);
+        uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            // reference layout: plane p = (lo, hi) dwords; b[q] = planes 2q, 2q+1
+            mlo = acc_mismatch<true>(mlo, a[4 * q + 0], b[q].x);
+            mhi = acc_mismatch<true>(mhi, a[4 * q + 1], b[q].y);
+            mlo = acc_mismatch<true>(mlo, a[4 * q + 2], b[q].z);
+            mhi = acc_mismatch<true>(mhi, a[4 * q + 3], b[q].w);
+        }
+        mism += __builtin_popcount(mlo) + __builtin_popcount(mhi);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) b[q] = bn[q];
+    }
+    if (lane < cnt) c.keys[start + lane] = jaccard_out_value(g, row, j, mism);
+}
+
+hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream)
+{
+    if (c.n_work == 0) return hipSuccess;
+    const uint64_t blocks = (c.n_work + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pair_cand_kernel, dim3((unsigned)blocks), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
+    return hipGetLastError();
+}
+
+}  // namespace skl

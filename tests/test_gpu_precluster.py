@@ -1,0 +1,97 @@
+"""Candidate-list kNN on the GPU (skl_self_dists_knn_candidates: the device half of the
+reference's self_dists_knn_precluster, src/distances/mod.rs:399-553) against the oracle's
+restatement: reference fixtures, synthetic clustered databases with ragged candidate lists
+(empty rows, rows shorter and much longer than knn, a reordered index), Jaccard and ANI."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_FIXTURES
+from helpers import FIXTURE_NAMES, load_fixture_bins
+from sketchlib.rust_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def candidates(skq):
+    """CSR of `any_shared_bins` (inverted.rs:259-268) per row, self excluded, ascending ids."""
+    n = skq.shape[0]
+    offs, cols = [0], []
+    for i in range(n):
+        shared = (skq == skq[i]).any(axis=1)
+        shared[i] = False
+        j = np.nonzero(shared)[0]
+        cols.append(j)
+        offs.append(offs[-1] + j.size)
+    return np.array(offs, dtype=np.uint64), (np.concatenate(cols) if cols else np.zeros(0)).astype(np.uint32)
+
+
+def as_pairs(idx, d0):
+    return [[(int(a), float(b)) for a, b in zip(r_i, r_d)] for r_i, r_d in zip(idx, d0)]
+
+
+def oracle_pairs(rows):
+    return [[(int(x["idx"]), float(x["d0"])) for x in r] for r in rows]
+
+
+@pytest.mark.parametrize("ani", [False, True])
+@pytest.mark.parametrize("knn", [1, 3])
+def test_reference_fixture(oracle, skl, gpu_ctx, ani, knn):
+    from oracle import sketcher
+    skq = sketcher.inverted_sketch_files([os.path.join(REF_FIXTURES, n) for n in FIXTURE_NAMES], 21, 10)
+    bins, n, kmers, ss64 = load_fixture_bins("sketches3")
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    offs, cols = candidates(skq)
+    idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21, ani), knn, offs, cols)
+    assert "pair_cand_kernel" in gpu_ctx.last_kernel()
+    assert as_pairs(idx, d0) == oracle_pairs(oracle.self_dists_knn_precluster(o, skq, knn, 0, ani))
+
+
+@pytest.mark.parametrize("ani,comp", [(False, False), (True, False), (False, True)])
+def test_synthetic_ragged_lists(oracle, skl, gpu_ctx, ani, comp):
+    kmers, ss64, n = [17, 21, 25], 16, 700
+    bins = synth.set_r(n, kmers, ss64, n_clusters=23)
+    rng = np.random.default_rng(11)
+    # an index sketch of 12 bins: cluster members share most bins, singletons share none
+    cluster = np.arange(n) % 5                                 # ~140 candidates per row
+    parents = rng.integers(0, 60000, size=(5, 12), dtype=np.uint16)
+    skq = parents[cluster].copy()
+    mutate = rng.random(skq.shape) < 0.35
+    skq[mutate] = rng.integers(0, 65535, size=int(mutate.sum()), dtype=np.uint16)
+    skq[5] = 65535 - np.arange(12, dtype=np.uint16)            # no shared bin at all
+    skq[::97, :] = skq[1]                                      # exact copies of one index sketch
+    skq[10:13] = 61000 + np.arange(12, dtype=np.uint16)        # a triple that only sees itself
+    completeness = np.linspace(0.75, 1.0, n) if comp else None
+    o = oracle.Sketches(bins, n, kmers, ss64, completeness=completeness)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64, completeness=completeness)
+    offs, cols = candidates(skq)
+    lens = np.diff(offs.astype(np.int64))
+    assert lens.min() == 0 and lens.max() > 64 and (lens < 5).any()
+    for knn in (1, 5, 40):
+        idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21, ani), knn, offs, cols)
+        exp = oracle.self_dists_knn_precluster(o, skq, knn, 1, ani, threads=8)
+        if comp:
+            assert np.array_equal(idx, exp["idx"].astype(np.uint64))
+            np.testing.assert_allclose(d0, exp["d0"], atol=1e-6, rtol=0)
+        else:
+            assert as_pairs(idx, d0) == oracle_pairs(exp)
+
+
+def test_reordered_index_and_errors(oracle, skl, gpu_ctx):
+    kmers, ss64, n = [21], 8, 130
+    bins = synth.set_r(n, kmers, ss64, n_clusters=7)
+    rng = np.random.default_rng(3)
+    skq = rng.integers(0, 50, size=(n, 6), dtype=np.uint16)     # small alphabet: many shared bins
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    perm = rng.permutation(n)                                   # ski position of skd sample i
+    skq_ski = np.empty_like(skq)
+    skq_ski[perm] = skq
+    offs, cols = candidates(skq)                                # the host driver maps ski ids back to skd ids
+    idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21), 9, offs, cols)
+    exp = oracle.self_dists_knn_precluster(o, skq_ski, 9, 0, ski_of_skd=perm, threads=4)
+    assert as_pairs(idx, d0) == oracle_pairs(exp)
+    with pytest.raises(skl.SklError) as e:                       # the reference's CoreAcc arm is unimplemented!()
+        skl.self_dists_knn_candidates(gpu_ctx, gpu_ctx.sketches(synth.set_r(4, [15, 19], 2), 4, [15, 19], 2),
+                                      skl.params(), 1, np.zeros(5, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+    assert "single k-mer" in str(e.value)
