@@ -5,6 +5,9 @@
 // (panic -> 101, error -> 1, usage -> 2).  `--threads` (default 1, as in the reference) sets
 // the host threads that format the dense text output; the distances themselves run on the
 // GPU.  `--device` is the one addition.
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +21,7 @@
 #include <vector>
 
 #include "distances.hpp"
+#include "inverted.hpp"
 #include "io.hpp"
 #include "multisketch.hpp"
 #include "sketch.hpp"
@@ -426,6 +430,209 @@ int run_sketch(int argc, char **argv, int first, bool verbose, bool quiet)
     return 0;
 }
 
+// ---- `sketchlib inverted build|precluster` (src/cli.rs:329-461, src/lib.rs:485-600,682-789) ----
+int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
+{
+    if (first >= argc) usage_error("'sketchlib inverted' requires a subcommand: build | precluster");
+    const std::string sub = argv[first];
+    auto next_value = [&](int &i, const std::string &flag) -> std::string {
+        if (i + 1 >= argc) usage_error("a value is required for '" + flag + "' but none was supplied");
+        return argv[++i];
+    };
+    if (sub == "build") {
+        g_usage = "sketchlib inverted build [OPTIONS] -o <OUTPUT> <SEQ_FILES|-f <FILE_LIST>>";
+        std::vector<std::string> seq_files;
+        std::optional<std::string> file_list, output, species_names;
+        bool write_skq_flag = false, single_strand = false;
+        uint64_t sketch_size = 1000;   // DEFAULT_SKETCHSIZE, cli.rs:17
+        size_t kmer = 21, threads = 1; // DEFAULT_KMER, cli.rs:13
+        for (int i = first + 1; i < argc; ++i) {
+            const std::string arg = argv[i];
+            if (arg == "-v" || arg == "--verbose") verbose = true;
+            else if (arg == "--quiet") quiet = true;
+            else if (arg == "-f") file_list = next_value(i, "-f <FILE_LIST>");
+            else if (arg == "-o") output = next_value(i, "-o <OUTPUT>");
+            else if (arg == "--write-skq") write_skq_flag = true;
+            else if (arg == "--species-names") species_names = next_value(i, arg);
+            else if (arg == "--metadata") {
+                std::cerr << "error: --metadata is not part of this build\n";
+                return 2;
+            }
+            else if (arg == "-s" || arg == "--sketch-size") sketch_size = parse_usize("--sketch-size <SKETCH_SIZE>", next_value(i, arg));
+            else if (arg == "-k" || arg == "--kmer-length") kmer = parse_usize("--kmer-length <KMER_LENGTH>", next_value(i, arg));
+            else if (arg == "--single-strand") single_strand = true;
+            else if (arg == "--threads") threads = std::max<size_t>(1, parse_usize("--threads <THREADS>", next_value(i, arg)));
+            else if (arg == "--min-count" || arg == "--min-qual") (void)next_value(i, arg);
+            else if (arg.size() > 1 && arg[0] == '-') usage_error("unexpected argument '" + arg + "' found");
+            else seq_files.push_back(arg);
+        }
+        if (!output) usage_error("the following required arguments were not provided:\n  -o <OUTPUT>");
+        if (seq_files.empty() == !file_list.has_value()) {
+            usage_error("exactly one of <SEQ_FILES>... or -f <FILE_LIST> must be given");
+        }
+        const Logger log{verbose && !quiet, !quiet};
+        log.info("Getting input files");
+        const std::vector<InputFastx> inputs = file_list ? read_rfile(*file_list) : read_input_fastas(seq_files);
+        log.info("Parsed " + std::to_string(inputs.size()) + " samples in input list");
+        {
+            std::vector<std::string> names;
+            for (const auto &in : inputs) names.push_back(in.first);
+            std::sort(names.begin(), names.end());
+            if (std::adjacent_find(names.begin(), names.end()) != names.end()) {
+                std::cerr << "error: samples listed more than once (multi-entry samples) are not part of this build\n";
+                return 2;
+            }
+        }
+        std::optional<std::vector<std::string>> labels;
+        std::vector<size_t> order(inputs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        try {
+            if (species_names) {
+                log.info("Reordering samples using labels in " + *species_names);
+                order = reorder_by_labels(inputs, *species_names, &labels);
+            }
+            log.info("Creating sketches");
+            std::vector<std::vector<uint16_t>> sketches(inputs.size());
+            std::vector<std::string> names(inputs.size());
+            {
+                std::atomic<size_t> next{0};
+                std::exception_ptr err;
+                std::mutex mu;
+                auto work = [&] {
+                    try {
+                        for (;;) {
+                            const size_t i = next.fetch_add(1);
+                            if (i >= inputs.size()) break;
+                            sketches[order[i]] = sketch_sample_inverted(inputs[i], kmer, sketch_size, !single_strand);
+                            names[order[i]] = inputs[i].first;
+                        }
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        err = std::current_exception();
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < threads; ++t) pool.emplace_back(work);
+                work();
+                for (auto &t : pool) t.join();
+                if (err) std::rethrow_exception(err);
+            }
+            if (write_skq_flag) {
+                log.info("Writing bins for use with precluster as " + *output + ".skq");
+                write_skq(*output + ".skq", sketches);
+            }
+            log.info("Inverting sketch order");
+            Inverted inv = Inverted::from_sketches(sketches, names, kmer, !single_strand);
+            inv.labels = labels;
+            inv.save(*output);
+        } catch (const std::exception &e) {
+            throw Panic(e.what());
+        }
+        return 0;
+    }
+    if (sub != "precluster") {
+        std::cerr << "error: unrecognized subcommand 'inverted " << sub << "' (this build provides `inverted build` and `inverted precluster`)\n";
+        return 2;
+    }
+    g_usage = "sketchlib inverted precluster [OPTIONS] <SKI> <--skd <SKD>|--count>";
+    std::optional<std::string> ski, skd, output, completeness_file, retain;
+    bool count = false, ani = false;
+    size_t knn = 50, threads = 1;   // DEFAULT_KNN, cli.rs
+    double cutoff = 0.64;
+    int device = 0;
+    for (int i = first + 1; i < argc; ++i) {
+        const std::string arg = argv[i];
+        if (arg == "-v" || arg == "--verbose") verbose = true;
+        else if (arg == "--quiet") quiet = true;
+        else if (arg == "--skd") skd = next_value(i, "--skd <SKD>");
+        else if (arg == "-o") output = next_value(i, "-o <OUTPUT>");
+        else if (arg == "--count") count = true;
+        else if (arg == "--knn") knn = parse_usize("--knn <KNN>", next_value(i, arg));
+        else if (arg == "--ani") ani = true;
+        else if (arg == "--threads") threads = std::max<size_t>(1, parse_usize("--threads <THREADS>", next_value(i, arg)));
+        else if (arg == "--ref-completeness-file") completeness_file = next_value(i, arg);
+        else if (arg == "--completeness-cutoff") cutoff = std::strtod(next_value(i, arg).c_str(), nullptr);
+        else if (arg == "--retain-unmatched") retain = next_value(i, arg);
+        else if (arg == "--device") device = (int)parse_usize("--device <D>", next_value(i, arg));
+        else if (arg.size() > 1 && arg[0] == '-') usage_error("unexpected argument '" + arg + "' found");
+        else if (!ski) ski = arg;
+        else usage_error("unexpected argument '" + arg + "' found");
+    }
+    if (!ski) usage_error("the following required arguments were not provided:\n  <SKI>");
+    if (count && skd) usage_error("the argument '--skd <SKD>' cannot be used with '--count'");
+    using distances::RetainUnmatched;
+    RetainUnmatched retain_mode = RetainUnmatched::None;
+    if (retain) {
+        if (*retain == "singleton") retain_mode = RetainUnmatched::Singleton;
+        else if (*retain == "bruteforce") retain_mode = RetainUnmatched::Bruteforce;
+        else usage_error("invalid value '" + *retain + "' for '--retain-unmatched <RETAIN_UNMATCHED>'\n  [possible values: singleton, bruteforce]");
+    }
+    const Logger log{verbose && !quiet, !quiet};
+    log.info("Using " + std::to_string(threads) + " threads");
+    const std::string input_prefix = strip_sketch_extension(*ski);
+    const Inverted inv = Inverted::load(input_prefix);   // `?` in the reference: Error, exit 1
+    if (count) {
+        const size_t ns = inv.sample_names.size();
+        std::cout << "Identified " << inv.any_shared_bin_pairs(threads) << " prefilter pairs from a max of "
+                  << ns * (ns - 1) / 2 << "\n";
+        return 0;
+    }
+    if (!skd) return 0;   // neither mode: the reference does nothing (lib.rs:713)
+    std::ofstream out_file;
+    std::ostream *os = &std::cout;
+    if (output) {
+        out_file.open(*output, std::ios::binary);
+        if (!out_file) throw Panic("cannot create output file " + *output);
+        os = &out_file;
+    }
+    const std::string skq_filename = input_prefix + ".skq";
+    log.info("Loading queries from " + skq_filename);
+    std::vector<uint16_t> skq_bins;
+    try {
+        skq_bins = read_skq(skq_filename, inv.sample_names.size(), inv.sketch_size());
+    } catch (const std::exception &e) {
+        throw Panic(e.what());
+    }
+    const std::string ref_db_name = strip_sketch_extension(*skd);
+    MultiSketch references;
+    try {
+        references = MultiSketch::load_metadata(ref_db_name);
+    } catch (const std::exception &) {
+        throw Panic("Could not read sketch metadata from " + ref_db_name + ".skm");
+    }
+    log.info("Loading sketch data from " + ref_db_name + ".skd");
+    references.read_sketch_data(ref_db_name);
+    const size_t n = references.number_samples_loaded();
+    if (knn >= n) {   // lib.rs:737-740
+        log.warn("knn=" + std::to_string(knn) + " is higher than number of samples=" + std::to_string(n));
+        knn = n - 1;
+    }
+    if (knn == 0) throw Panic("chunk size must be non-zero");
+    DistType dist_type;
+    try {
+        dist_type = distances::set_k(references, inv.kmer_size, ani);
+    } catch (const std::exception &e) {
+        throw Panic("K-mer size " + std::to_string(inv.kmer_size) + " used for .ski not found in .skd: " + e.what());
+    }
+    std::optional<std::vector<double>> comp;
+    if (completeness_file) {
+        std::vector<std::string> warnings;
+        comp = read_completeness_file(*completeness_file, references, &warnings);
+        for (const auto &w : warnings) log.warn(w);
+    }
+    log.info("Calculating sparse ref vs ref distances with " + std::to_string(knn) + " nearest neighbours");
+    log.info("Preclustering with k=" + std::to_string(inv.kmer_size) + " and s=" + std::to_string(inv.sketch_size()));
+    if (retain) log.info("Retain unmatched mode: " + *retain);
+    Device dev(device);
+    const SparseDistanceMatrix d = distances::self_dists_knn_precluster(
+        dev, references, inv, skq_bins, inv.sketch_size(), n, knn, dist_type, comp ? &*comp : nullptr, cutoff,
+        retain_mode, threads);
+    log.info("Writing out in sparse matrix form");
+    d.write(*os);
+    os->flush();
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -440,7 +647,8 @@ int main(int argc, char **argv)
     if (sub >= argc || strcmp(argv[sub], "-h") == 0 || strcmp(argv[sub], "--help") == 0) {
         std::cout << "Usage: sketchlib [OPTIONS] <COMMAND>\n\nCommands:\n"
                      "  sketch  Create sketches from input data (DNA assemblies, CPU)\n"
-                     "  dist    Calculate pairwise distances using sketches (GPU)\n";
+                     "  dist    Calculate pairwise distances using sketches (GPU)\n"
+                     "  inverted build|precluster  Inverted index of single-k sketches; kNN restricted to its candidates (GPU)\n";
         return sub >= argc ? 2 : 0;
     }
     if (strcmp(argv[sub], "sketch") == 0) {
@@ -459,9 +667,25 @@ int main(int argc, char **argv)
             return 1;
         }
     }
+    if (strcmp(argv[sub], "inverted") == 0) {
+        bool verbose = false, quiet = false;
+        for (int i = 1; i < sub; ++i) {
+            if (strcmp(argv[i], "--quiet") == 0) quiet = true;
+            else verbose = true;
+        }
+        try {
+            return run_inverted(argc, argv, sub + 1, verbose, quiet);
+        } catch (const Panic &p) {
+            std::cerr << "thread 'main' panicked:\n" << p.what() << "\n";
+            return 101;
+        } catch (const std::exception &e) {
+            std::cerr << "Error: " << e.what() << "\n";
+            return 1;
+        }
+    }
     if (strcmp(argv[sub], "dist") != 0) {
         std::cerr << "error: unrecognized subcommand '" << argv[sub]
-                  << "' (this build provides `sketch` (DNA assemblies, CPU) and `dist` (GPU))\n";
+                  << "' (this build provides `sketch` (DNA assemblies, CPU), `dist` (GPU) and `inverted build|precluster`)\n";
         return 2;
     }
     DistArgs args = parse_dist(argc, argv, sub + 1);

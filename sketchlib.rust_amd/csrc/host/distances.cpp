@@ -1,6 +1,10 @@
 #include "distances.hpp"
 
 #include <chrono>
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include <exception>
 #include <ostream>
 #include <string>
@@ -29,6 +33,23 @@ DeviceSet::DeviceSet(const std::vector<int> &devices)
 }
 
 namespace {
+SparseDistanceMatrix assemble_knn(const DistType &dist_type, size_t knn, const std::vector<uint64_t> &idx,
+                                         const std::vector<float> &d0, const std::vector<float> &d1)
+{
+    SparseDistanceMatrix out;
+    out.jaccard = dist_type;
+    out.knn = knn;
+    out.n_distances = idx.size();
+    if (dist_type.kind == DistType::CoreAcc) {
+        out.coreacc_dists.resize(idx.size());
+        for (size_t i = 0; i < idx.size(); ++i) out.coreacc_dists[i] = {(size_t)idx[i], d0[i], d1[i]};
+    } else {
+        out.jaccard_dists.resize(idx.size());
+        for (size_t i = 0; i < idx.size(); ++i) out.jaccard_dists[i] = {(size_t)idx[i], d0[i]};
+    }
+    return out;
+}
+
 // RAII for a device-resident MultiSketch
 struct Slab {
     skl_sketches *h = nullptr;
@@ -168,6 +189,100 @@ SparseDistanceMatrix cross_dists_knn(Device &dev, const MultiSketch &ref_sketche
 }
 
 // ---------------------------------------------------------------------------
+// precluster
+// ---------------------------------------------------------------------------
+
+SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &sketches, const Inverted &inv,
+                                               const std::vector<uint16_t> &skq_bins, size_t skq_stride, size_t n,
+                                               size_t knn, const DistType &dist_type,
+                                               const std::vector<double> *completeness_vec,
+                                               double completeness_cutoff, RetainUnmatched retain, size_t threads)
+{
+    // sample sets of .ski and .skm must agree; i <-> j lookups (mod.rs:412-440)
+    std::unordered_map<std::string, size_t> skq_lookup;
+    for (size_t i = 0; i < inv.sample_names.size(); ++i) skq_lookup.emplace(inv.sample_names[i], i);
+    std::vector<size_t> ski_of_skd;
+    std::string not_found;
+    for (size_t i = 0; i < sketches.number_samples_loaded(); ++i) {
+        const auto it = skq_lookup.find(sketches.sketch_name(i));
+        if (it != skq_lookup.end()) ski_of_skd.push_back(it->second);
+        else not_found += (not_found.empty() ? "\"" : ", \"") + sketches.sketch_name(i) + "\"";
+    }
+    if (!not_found.empty()) {
+        throw Panic("The following samples in the .skd could not be found in the .ski:\n[" + not_found + "]");
+    }
+    std::vector<size_t> skd_of_ski(std::max(n, inv.sample_names.size()), 0);
+    for (size_t i = 0; i < ski_of_skd.size(); ++i) skd_of_ski[ski_of_skd[i]] = i;
+    if (dist_type.kind == DistType::CoreAcc) {
+        throw Panic("not implemented: Prefilter only available for single k-mer distances");   // mod.rs:549-551
+    }
+
+    // candidate lists (inverted.rs:259-268), in .skd ids, ascending, self excluded
+    std::vector<std::vector<uint32_t>> lists(n);
+    {
+        std::atomic<size_t> next{0};
+        std::exception_ptr err;
+        std::mutex mu;
+        auto work = [&] {
+            try {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= n) break;
+                    const size_t ski_i = ski_of_skd[i];
+                    const std::vector<uint32_t> hits = inv.any_shared_bins(skq_bins.data() + ski_i * skq_stride);
+                    auto &l = lists[i];
+                    l.reserve(hits.size());
+                    for (uint32_t j : hits) {
+                        if (j != ski_i) l.push_back((uint32_t)skd_of_ski[j]);   // mod.rs:458-461
+                    }
+                    std::sort(l.begin(), l.end());
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu);
+                err = std::current_exception();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < std::max<size_t>(1, threads); ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (err) std::rethrow_exception(err);
+    }
+    std::vector<uint64_t> offsets(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + lists[i].size();
+    std::vector<uint32_t> cand(offsets[n]);
+    for (size_t i = 0; i < n; ++i) std::copy(lists[i].begin(), lists[i].end(), cand.begin() + offsets[i]);
+
+    Slab s(dev, sketches, completeness_vec);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    std::vector<uint64_t> idx(n * knn);
+    std::vector<float> d0(n * knn), d1;
+    check(skl_self_dists_knn_candidates(dev.ctx(), s.h, &p, knn, offsets.data(), cand.data(), idx.data(), d0.data()));
+
+    // genomes without a prefilter match (mod.rs:487-527)
+    if (retain != RetainUnmatched::None) {
+        std::vector<uint64_t> bi(knn);
+        std::vector<float> b0(knn), b1(knn);
+        for (size_t i = 0; i < n; ++i) {
+            if (!lists[i].empty()) continue;
+            if (retain == RetainUnmatched::Singleton) {
+                for (size_t t = 0; t < knn; ++t) {
+                    idx[i * knn + t] = i;
+                    d0[i * knn + t] = t == 0 ? 0.0f : 1.0f;
+                }
+            } else {
+                check(skl_self_dists_knn_rows(dev.ctx(), s.h, &p, knn, i, i + 1, bi.data(), b0.data(), b1.data(), 0));
+                std::copy(bi.begin(), bi.end(), idx.begin() + i * knn);
+                std::copy(b0.begin(), b0.end(), d0.begin() + i * knn);
+            }
+        }
+    }
+    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
+    out.ref_names = sketch_names(sketches);
+    return out;
+}
+
+// ---------------------------------------------------------------------------
 // several devices: contiguous row bands, one host thread per device
 // ---------------------------------------------------------------------------
 
@@ -271,22 +386,6 @@ DistanceMatrix cross_dists_all(DeviceSet &devs, const MultiSketch &ref_sketches,
     return out;
 }
 
-static SparseDistanceMatrix assemble_knn(const DistType &dist_type, size_t knn, const std::vector<uint64_t> &idx,
-                                         const std::vector<float> &d0, const std::vector<float> &d1)
-{
-    SparseDistanceMatrix out;
-    out.jaccard = dist_type;
-    out.knn = knn;
-    out.n_distances = idx.size();
-    if (dist_type.kind == DistType::CoreAcc) {
-        out.coreacc_dists.resize(idx.size());
-        for (size_t i = 0; i < idx.size(); ++i) out.coreacc_dists[i] = {(size_t)idx[i], d0[i], d1[i]};
-    } else {
-        out.jaccard_dists.resize(idx.size());
-        for (size_t i = 0; i < idx.size(); ++i) out.jaccard_dists[i] = {(size_t)idx[i], d0[i]};
-    }
-    return out;
-}
 
 SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches, size_t n, size_t knn,
                                     const DistType &dist_type, bool quiet,

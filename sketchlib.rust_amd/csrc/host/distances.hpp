@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "distance_matrix.hpp"
+#include "inverted.hpp"
 #include "multisketch.hpp"
 
 struct skl_ctx;
@@ -90,6 +91,18 @@ void cross_dists_all_streamed(Device &dev, const MultiSketch &ref_sketches, cons
                               TextSink &sink, size_t threads, size_t band_bytes, bool npy = false);
 // The .npy v1.0 header of a (rows, cols) little-endian f32 array.
 std::string npy_header(size_t rows, size_t cols);
+
+// self_dists_knn_precluster (mod.rs:399-553): kNN restricted to the candidates an inverted
+// index returns (any shared bin).  The candidate lists are built on the host from the index
+// (`threads` workers), the distances and the per-row top-k run on the device
+// (skl_self_dists_knn_candidates); rows without candidates follow --retain-unmatched.
+enum class RetainUnmatched { None, Singleton, Bruteforce };
+SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &sketches, const Inverted &inverted_index,
+                                               const std::vector<uint16_t> &skq_bins, size_t skq_stride, size_t n,
+                                               size_t knn, const DistType &dist_type,
+                                               const std::vector<double> *completeness_vec,
+                                               double completeness_cutoff, RetainUnmatched retain_unmatched,
+                                               size_t threads);
 
 // mod.rs:25-37.  Throws std::runtime_error("K-mer size {k} not found in file").
 DistType set_k(const MultiSketch &sketches, std::optional<size_t> kmer, bool ani);

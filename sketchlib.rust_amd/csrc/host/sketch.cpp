@@ -1,4 +1,5 @@
 #include "sketch.hpp"
+#include "inverted.hpp"
 
 #include <zlib.h>
 
@@ -271,6 +272,21 @@ SketchResult sketch_sample(const InputFastx &input, const std::vector<size_t> &k
     out.meta.densified = densified;
     for (int b = 0; b < 4; ++b) out.meta.acgt[b] = seq.acgt[b];
     out.meta.non_acgt = seq.non_acgt;
+    return out;
+}
+
+std::vector<uint16_t> sketch_sample_inverted(const InputFastx &input, size_t k, uint64_t sketch_size, bool rc)
+{
+    Sequence seq;
+    for (const auto &file : input.second) add_fasta(file, seq);
+    uint64_t total = 0;
+    for (uint64_t c : seq.acgt) total += c;
+    if (total == 0) throw std::runtime_error(input.first + " has no valid sequence");
+    std::vector<uint64_t> signs((size_t)sketch_size, UINT64_MAX);   // exactly sketch_size bins, inverted.rs:352-357
+    bin_minima(seq, k, rc, signs);
+    densify_bin(signs);
+    std::vector<uint16_t> out(signs.size());
+    for (size_t i = 0; i < signs.size(); ++i) out[i] = (uint16_t)signs[i];   // `*h as u16`, inverted.rs:380
     return out;
 }
 

@@ -230,3 +230,76 @@ def test_multi_context_synthetic(gpu_ctx, tmp_path):
     assert run(prefix, "--gpus", "1") == one
     knn = run(prefix, "--knn", "10")
     assert run(prefix, "--knn", "10", "--devices", "0,0,0") == knn
+
+
+# ---- `sketchlib inverted precluster`, as tests/inverted.rs drives it ----
+
+def run_cli(wd, *args, ok=True):
+    res = subprocess.run([CLI, *args], cwd=wd, capture_output=True, text=True)
+    if ok:
+        assert res.returncode == 0, res.stderr
+    return res
+
+
+@pytest.fixture()
+def precluster_wd(tmp_path):
+    import shutil
+    for f in FIXTURE_NAMES + ["rfile.txt"]:
+        shutil.copy(os.path.join(REF_FIXTURES, f), tmp_path / f)
+    run_cli(tmp_path, "inverted", "build", "-o", "inverted", "-v", "-k", "21", "-s", "10", "-f", "rfile.txt", "--write-skq")
+    run_cli(tmp_path, "sketch", "-o", "standard", "-v", "--k-vals", "21", "-s", "1000", "-f", "rfile.txt")
+    return tmp_path
+
+
+def test_inverted_precluster_like_reference(gpu_ctx, precluster_wd):
+    """tests/inverted.rs:244-349: knn 1, --ani, and knn 50 (clamped, padding not printed)."""
+    wd = precluster_wd
+    golden = sorted(open(os.path.join(REF_FIXTURES, "inverted_precluster.stdout")).read().splitlines())
+    golden_ani = sorted(open(os.path.join(REF_FIXTURES, "inverted_precluster_ani.stdout")).read().splitlines())
+    out = run_cli(wd, "inverted", "precluster", "-v", "--knn", "1", "--skd", "standard", "inverted.ski")
+    assert sorted(out.stdout.splitlines()) == golden
+    out = run_cli(wd, "inverted", "precluster", "-v", "--knn", "1", "--ani", "--skd", "standard", "inverted.ski")
+    assert sorted(out.stdout.splitlines()) == golden_ani
+    out = run_cli(wd, "inverted", "precluster", "-v", "--knn", "50", "--skd", "standard", "inverted.ski")
+    assert sorted(out.stdout.splitlines()) == golden and "knn=50 is higher than number of samples=4" in out.stderr
+    run_cli(wd, "inverted", "precluster", "--knn", "1", "--skd", "standard.skm", "-o", "pre.txt", "inverted.ski")
+    assert sorted((wd / "pre.txt").read_text().splitlines()) == golden
+
+
+def test_inverted_precluster_reordered_index_and_retain(gpu_ctx, precluster_wd):
+    """An index in a different sample order gives the same rows (tests/inverted.rs:352-452); a
+    .skd with a k the index was not built for panics; unmatched genomes follow --retain-unmatched."""
+    wd = precluster_wd
+    golden = sorted(open(os.path.join(REF_FIXTURES, "inverted_precluster.stdout")).read().splitlines())
+    (wd / "species.txt").write_text("TIGR4.fa.gz\ta\n14412_3#82.contigs_velvet.fa.gz\tb\nR6.fa.gz\ta\n")
+    run_cli(wd, "inverted", "build", "-o", "reordered", "-k", "21", "-s", "10", "-f", "rfile.txt", "--write-skq",
+            "--species-names", "species.txt")
+    out = run_cli(wd, "inverted", "precluster", "--knn", "3", "--skd", "standard", "reordered.ski")
+    assert sorted(out.stdout.splitlines()) == golden
+    run_cli(wd, "sketch", "-o", "other_k", "--k-vals", "17", "-s", "1000", "-f", "rfile.txt")
+    res = run_cli(wd, "inverted", "precluster", "--skd", "other_k", "inverted.ski", ok=False)
+    assert res.returncode == 101 and "K-mer size 21 used for .ski not found in .skd" in res.stderr
+    # an index over fewer samples than the .skd
+    run_cli(wd, "inverted", "build", "-o", "two", "-k", "21", "-s", "10", "--write-skq", "R6.fa.gz", "TIGR4.fa.gz")
+    res = run_cli(wd, "inverted", "precluster", "--skd", "standard", "two.ski", ok=False)
+    assert res.returncode == 101 and "could not be found in the .ski" in res.stderr
+    # three genomes: R6 shares bins only with TIGR4 (the golden pairs), so without it R6 is unmatched
+    three = ["14412_3#82.contigs_velvet.fa.gz", "14412_3#84.contigs_velvet.fa.gz", "R6.fa.gz"]
+    run_cli(wd, "inverted", "build", "-o", "sparse", "-k", "21", "-s", "10", "--write-skq", *three)
+    run_cli(wd, "sketch", "-o", "standard3", "--k-vals", "21", "-s", "1000", *three)
+    skq = np.fromfile(wd / "sparse.skq", dtype="<u2").reshape(3, 10)
+    lonely = [i for i in range(3) if not any((skq[i] == skq[j]).any() for j in range(3) if j != i)]
+    assert lonely == [2]
+    plain = run_cli(wd, "inverted", "precluster", "--knn", "2", "--skd", "standard3", "sparse.ski").stdout
+    names_in = {l.split("\t")[0] for l in plain.splitlines()}
+    assert all(three[i] not in names_in for i in lonely)                   # only padding: nothing printed
+    single = run_cli(wd, "inverted", "precluster", "--knn", "2", "--skd", "standard3", "sparse.ski",
+                     "--retain-unmatched", "singleton").stdout
+    for i in lonely:                                                       # tests/inverted.rs:702-748
+        assert f"{three[i]}\t{three[i]}\t0\n" in single
+    brute = run_cli(wd, "inverted", "precluster", "--knn", "2", "--skd", "standard3", "sparse.ski",
+                    "--retain-unmatched", "bruteforce").stdout
+    full = run_cli(wd, "dist", "standard3", "-k", "21", "--knn", "2").stdout
+    for i in lonely:                                                       # tests/inverted.rs:751-802
+        rows = sorted(l for l in brute.splitlines() if l.startswith(three[i] + "\t"))
+        assert rows and rows == sorted(l for l in full.splitlines() if l.startswith(three[i] + "\t"))
