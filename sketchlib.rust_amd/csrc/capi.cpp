@@ -995,7 +995,18 @@ extern "C" int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s
     c.work_start = (const uint64_t *)d_wstart.p;
     c.n_work = work_row.size();
     c.keys = (float *)d_keys.p;
-    HIP_TRY(launch_pair_cand(c, g, ctx->stream));
+    {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
+        if (ctx->events_used == ctx->events.size() && ctx->events.size() < 4096) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            ctx->events.emplace_back(a, b);
+        }
+        const bool timed = ctx->events_used < ctx->events.size();
+        if (timed) HIP_TRY(hipEventRecord(ctx->events[ctx->events_used].first, ctx->stream));
+        HIP_TRY(launch_pair_cand(c, g, ctx->stream));
+        if (timed) HIP_TRY(hipEventRecord(ctx->events[ctx->events_used++].second, ctx->stream));
+    }
     ctx->last_kernel = "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)";
     TopkArgs t;
     memset(&t, 0, sizeof t);
