@@ -225,11 +225,17 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
         std::mutex mu;
         auto work = [&] {
             try {
+                std::vector<uint32_t> stamp(inv.n_samples, 0), hits;   // per-thread scratch
+                uint32_t epoch = 0;
                 for (;;) {
                     const size_t i = next.fetch_add(1);
                     if (i >= n) break;
                     const size_t ski_i = ski_of_skd[i];
-                    const std::vector<uint32_t> hits = inv.any_shared_bins(skq_bins.data() + ski_i * skq_stride);
+                    if (++epoch == 0) {   // wrapped: start over
+                        std::fill(stamp.begin(), stamp.end(), 0u);
+                        epoch = 1;
+                    }
+                    inv.any_shared_bins(skq_bins.data() + ski_i * skq_stride, stamp, epoch, hits);
                     auto &l = lists[i];
                     l.reserve(hits.size());
                     for (uint32_t j : hits) {

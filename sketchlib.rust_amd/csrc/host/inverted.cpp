@@ -229,18 +229,27 @@ Inverted Inverted::load(const std::string &file_prefix)
     return inv;
 }
 
-std::vector<uint32_t> Inverted::any_shared_bins(const uint16_t *query_sigs) const
+void Inverted::any_shared_bins(const uint16_t *query_sigs, std::vector<uint32_t> &stamp, uint32_t epoch,
+                               std::vector<uint32_t> &out) const
 {
-    std::vector<uint8_t> hit(n_samples, 0);
+    out.clear();
     for (size_t b = 0; b < index.size(); ++b) {
         const auto it = index[b].find(query_sigs[b]);
         if (it == index[b].end()) continue;
-        for (uint32_t s : it->second) hit[s] = 1;
+        for (uint32_t s : it->second) {
+            if (stamp[s] != epoch) {
+                stamp[s] = epoch;
+                out.push_back(s);
+            }
+        }
     }
-    std::vector<uint32_t> out;
-    for (size_t s = 0; s < n_samples; ++s) {
-        if (hit[s]) out.push_back((uint32_t)s);
-    }
+    std::sort(out.begin(), out.end());
+}
+
+std::vector<uint32_t> Inverted::any_shared_bins(const uint16_t *query_sigs) const
+{
+    std::vector<uint32_t> stamp(n_samples, 0), out;
+    any_shared_bins(query_sigs, stamp, 1u, out);
     return out;
 }
 

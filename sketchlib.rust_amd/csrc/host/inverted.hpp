@@ -44,6 +44,11 @@ class Inverted {
 
     // Samples sharing at least one bin with the query sketch, ascending (inverted.rs:259-268).
     std::vector<uint32_t> any_shared_bins(const uint16_t *query_sigs) const;
+    // The same with caller-owned scratch, for loops over many queries: `stamp` has n_samples
+    // entries (zero-initialised once), `epoch` must differ between calls (and be non-zero).
+    // Cost is proportional to the lists touched, not to n_samples.
+    void any_shared_bins(const uint16_t *query_sigs, std::vector<uint32_t> &stamp, uint32_t epoch,
+                         std::vector<uint32_t> &out) const;
     // Number of distinct sample pairs sharing at least one bin (inverted.rs:271-300).
     uint64_t any_shared_bin_pairs(size_t threads) const;
 };
