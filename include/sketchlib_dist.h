@@ -141,6 +141,20 @@ int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_param
 int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
                             size_t knn, size_t row_begin, size_t row_end, uint64_t *out_idx,
                             float *out_d0, float *out_d1, int out_on_device);
+/* GPU sketching: bin minima of `canonical ntHash % SIGN_MOD` over every
+ * valid k-mer of DNA samples -- Sketch::get_signs_no_densify (src/sketch/mod.rs:156-176) over
+ * NtHashIterator (src/hashing/nthash_iterator.rs:325-523), all samples and k-mer lengths of a
+ * batch in one launch.  `codes`: 2-bit base codes ((byte >> 1) & 3, hashing/mod.rs:82-85), one
+ * byte per valid base, samples concatenated; sample s owns codes[code_begin[s] .. code_begin[s+1]).
+ * `offsets`: for each sample the ascending positions (in its own code coordinates) of every
+ * invalid base and record end (NtHashIterator::add_dna_seq, nthash_iterator.rs:205-251); a
+ * window [p, p+k) is hashed iff no offset o has p < o < p+k.  out_signs: [n_samples][nk][num_bins]
+ * u64, u64::MAX for an empty bin; densify_bin and the 14-plane transpose are the caller's
+ * (they touch num_bins words, not the genome).  Host pointers. */
+int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64_t *code_begin,
+                     const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
+                     const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs);
+
 /* Candidate-list form of skl_self_dists_knn: the device half of self_dists_knn_precluster
  * (src/distances/mod.rs:399-553).  Row i is compared only with the samples
  * cand[row_offsets[i] .. row_offsets[i+1]) (ascending sample ids, i itself excluded) -- what

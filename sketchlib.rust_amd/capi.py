@@ -77,6 +77,7 @@ _SIG = [
     ("skl_cross_dists_knn_rows", C.c_int, [_P, _P, _P, C.POINTER(DistParams), C.c_size_t,
                                            C.c_size_t, C.c_size_t, _P, _P, _P, C.c_int]),
     ("skl_self_dists_knn_candidates", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, _P, _P, _P, _P]),
+    ("skl_sketch_signs", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.c_int, _P]),
     ("skl_self_binmatch", C.c_int, [_P, _P, _P, C.c_int]),
     ("skl_cross_binmatch", C.c_int, [_P, _P, _P, _P, C.c_int]),
     ("skl_self_dists_all_host", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, C.c_size_t,
@@ -323,6 +324,22 @@ def self_dists_knn_candidates(ctx, s, p, knn, row_offsets, cand):
                                                 cand.ctypes.data if cand.size else None, idx.ctypes.data,
                                                 d0.ctypes.data))
     return idx, d0
+
+
+def sketch_signs(ctx, codes, code_begin, offsets, offset_begin, kmers, num_bins, rc=True):
+    """GPU bin minima of the canonical ntHash (get_signs_no_densify, sketch/mod.rs:156-176):
+    -> [n_samples, nk, num_bins] uint64, u64::MAX for empty bins."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    code_begin = np.ascontiguousarray(code_begin, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    offset_begin = np.ascontiguousarray(offset_begin, dtype=np.uint64)
+    kmers = np.ascontiguousarray(kmers, dtype=np.uintp)
+    n = code_begin.size - 1
+    out = np.zeros((n, kmers.size, num_bins), dtype=np.uint64)
+    _check(load().skl_sketch_signs(ctx._h, codes.ctypes.data if codes.size else None, code_begin.ctypes.data,
+                                   offsets.ctypes.data if offsets.size else None, offset_begin.ctypes.data, n,
+                                   kmers.ctypes.data, kmers.size, num_bins, int(rc), out.ctypes.data))
+    return out
 
 
 # ---- raw counts ----

@@ -936,6 +936,114 @@ extern "C" int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl
     return skl_self_dists_knn_rows(ctx, s, p, knn, 0, s->n, out_idx, out_d0, out_d1, out_on_device);
 }
 
+// ---------------------------------------------------------------------------
+// GPU sketching
+// ---------------------------------------------------------------------------
+
+namespace {
+inline uint64_t h_rotl1(uint64_t v) { return (v << 1) | (v >> 63); }
+inline uint64_t h_swapbits033(uint64_t v)
+{
+    const uint64_t x = (v ^ (v >> 33)) & 1ull;
+    return v ^ (x | (x << 33));
+}
+inline uint64_t h_srol(uint64_t v) { return h_swapbits033(h_rotl1(v)); }
+}  // namespace
+
+extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64_t *code_begin,
+                                const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
+                                const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!code_begin || !offset_begin || !kmers || !out_signs) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (n_samples == 0 || nk == 0) return SKL_OK;
+    if (num_bins == 0) return fail(SKL_ERR_INVALID_ARG, "num_bins is zero");
+    const uint64_t n_codes = code_begin[n_samples], n_offs = offset_begin[n_samples];
+    if ((n_codes && !codes) || (n_offs && !offsets)) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    static const uint64_t seeds_f[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x295549f54be24456ull,
+                                        0x20323ed082572324ull};   // src/hashing/nthash_tables.rs:4-16
+    std::vector<uint32_t> k32(nk);
+    std::vector<uint64_t> top_f(nk * 4), top_r(nk * 4);
+    for (size_t ki = 0; ki < nk; ++ki) {
+        if (kmers[ki] == 0 || kmers[ki] > 0xFFFFu) return fail(SKL_ERR_INVALID_ARG, "k-mer length out of range");
+        k32[ki] = (uint32_t)kmers[ki];
+        for (int b = 0; b < 4; ++b) {
+            uint64_t f = seeds_f[b], r = seeds_f[b ^ 2];
+            for (size_t m = 1; m < kmers[ki]; ++m) {
+                f = h_srol(f);
+                r = h_srol(r);
+            }
+            top_f[ki * 4 + b] = f;
+            top_r[ki * 4 + b] = r;
+        }
+    }
+    const uint64_t span = (uint64_t)sketch_span();
+    std::vector<uint64_t> span_begin(n_samples + 1, 0);
+    for (size_t s = 0; s < n_samples; ++s) {
+        if (code_begin[s + 1] < code_begin[s] || offset_begin[s + 1] < offset_begin[s]) {
+            return fail(SKL_ERR_INVALID_ARG, "sample ranges must not decrease");
+        }
+        span_begin[s + 1] = span_begin[s] + (code_begin[s + 1] - code_begin[s] + span - 1) / span;
+    }
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } d_codes, d_cb, d_offs, d_ob, d_sb, d_k, d_tf, d_tr, d_signs;
+    auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(&b.p, std::max<size_t>(bytes, 16)));
+        if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SKL_OK;
+    };
+    SKL_TRY(upload(d_codes, codes, n_codes));
+    SKL_TRY(upload(d_cb, code_begin, (n_samples + 1) * sizeof(uint64_t)));
+    SKL_TRY(upload(d_offs, offsets, n_offs * sizeof(uint64_t)));
+    SKL_TRY(upload(d_ob, offset_begin, (n_samples + 1) * sizeof(uint64_t)));
+    SKL_TRY(upload(d_sb, span_begin.data(), (n_samples + 1) * sizeof(uint64_t)));
+    SKL_TRY(upload(d_k, k32.data(), nk * sizeof(uint32_t)));
+    SKL_TRY(upload(d_tf, top_f.data(), top_f.size() * sizeof(uint64_t)));
+    SKL_TRY(upload(d_tr, top_r.data(), top_r.size() * sizeof(uint64_t)));
+    const size_t sign_bytes = n_samples * nk * num_bins * sizeof(uint64_t);
+    HIP_TRY(hipMalloc(&d_signs.p, sign_bytes));
+    HIP_TRY(hipMemsetAsync(d_signs.p, 0xFF, sign_bytes, ctx->stream));   // u64::MAX
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // pageable uploads done before the vectors die
+
+    SketchArgs a;
+    memset(&a, 0, sizeof a);
+    a.codes = (const uint8_t *)d_codes.p;
+    a.code_begin = (const uint64_t *)d_cb.p;
+    a.offsets = (const uint64_t *)d_offs.p;
+    a.offset_begin = (const uint64_t *)d_ob.p;
+    a.span_begin = (const uint64_t *)d_sb.p;
+    a.n_spans = span_begin[n_samples];
+    a.n_samples = (uint32_t)n_samples;
+    a.nk = (uint32_t)nk;
+    a.kmers = (const uint32_t *)d_k.p;
+    a.top_f = (const uint64_t *)d_tf.p;
+    a.top_r = (const uint64_t *)d_tr.p;
+    a.num_bins = num_bins;
+    const uint64_t sign_mod = (1ull << 61) - 1;
+    a.bin_size = (sign_mod + num_bins - 1) / num_bins;   // SIGN_MOD.div_ceil(num_bins), sketch/mod.rs:170
+    a.inv_bin_size = 1.0 / (double)a.bin_size;
+    a.rc = rc ? 1 : 0;
+    a.signs = (uint64_t *)d_signs.p;
+    {
+        if (ctx->events_used == ctx->events.size() && ctx->events.size() < 4096) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            ctx->events.emplace_back(e0, e1);
+        }
+        const bool timed = ctx->events_used < ctx->events.size();
+        if (timed) HIP_TRY(hipEventRecord(ctx->events[ctx->events_used].first, ctx->stream));
+        HIP_TRY(launch_sketch_signs(a, ctx->stream));
+        if (timed) HIP_TRY(hipEventRecord(ctx->events[ctx->events_used++].second, ctx->stream));
+    }
+    ctx->last_kernel = "skl::nthash_binmin_kernel (256 window starts per thread, rolling canonical ntHash, atomicMin per bin)";
+    HIP_TRY(hipMemcpyAsync(out_signs, d_signs.p, sign_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
 // Candidate-list kNN: the device half of the reference's self_dists_knn_precluster
 // (src/distances/mod.rs:399-553).  Host pointers in, host pointers out.
 extern "C" int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,

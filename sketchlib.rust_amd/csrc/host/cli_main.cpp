@@ -366,6 +366,7 @@ struct SketchArgs {
     bool single_strand = false;
     size_t threads = 1;
     bool verbose = false, quiet = false;
+    int gpu = -1;   // --gpu [D]: hash and take bin minima on device D (default: CPU)
 };
 
 std::vector<size_t> parse_list(const std::string &flag, const std::string &v)
@@ -403,6 +404,8 @@ int run_sketch(int argc, char **argv, int first, bool verbose, bool quiet)
         else if (arg == "-s" || arg == "--sketch-size") a.sketch_size = parse_usize("--sketch-size <SKETCH_SIZE>", value(arg));
         else if (arg == "--single-strand") a.single_strand = true;
         else if (arg == "--threads") a.threads = std::max<size_t>(1, parse_usize("--threads <THREADS>", value(arg)));
+        else if (arg == "--gpu") a.gpu = 0;
+        else if (arg == "--device") a.gpu = (int)parse_usize("--device <D>", value(arg));
         else if (arg == "--seq-type") {
             const std::string v = value(arg);
             if (v != "dna") { std::cerr << "error: this build sketches DNA assemblies only (--seq-type " << v << ")\n"; return 2; }
@@ -423,7 +426,13 @@ int run_sketch(int argc, char **argv, int first, bool verbose, bool quiet)
     const uint64_t bins = (a.sketch_size + 63) / 64 * 64;
     log.info("Running sketching: sketch_size:" + std::to_string(bins) + " threads:" + std::to_string(a.threads));
     try {
-        sketch_files(*a.output, inputs, kmers, a.sketch_size, !a.single_strand, a.threads);
+        if (a.gpu >= 0) {
+            log.info("Hashing on GPU " + std::to_string(a.gpu));
+            Device dev(a.gpu);
+            sketch_files_gpu(dev, *a.output, inputs, kmers, a.sketch_size, !a.single_strand, a.threads);
+        } else {
+            sketch_files(*a.output, inputs, kmers, a.sketch_size, !a.single_strand, a.threads);
+        }
     } catch (const std::exception &e) {
         throw Panic(e.what());   // the reference panics on unreadable / empty input
     }

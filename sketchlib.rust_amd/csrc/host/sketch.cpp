@@ -4,6 +4,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstring>
 #include <fstream>
@@ -44,23 +45,21 @@ std::string read_maybe_gz(const std::string &path)
 {
     gzFile f = gzopen(path.c_str(), "rb");  // transparently reads plain files too
     if (!f) throw std::runtime_error("Invalid path/file: " + path);
+    gzbuffer(f, 1 << 20);
     std::string data;
-    char buf[1 << 16];
+    {
+        std::ifstream probe(path, std::ios::binary | std::ios::ate);
+        if (probe) data.reserve((size_t)probe.tellg() * (gzdirect(f) ? 1 : 4) + 16);
+    }
+    std::vector<char> buf(1 << 20);
     int n;
-    while ((n = gzread(f, buf, sizeof buf)) > 0) data.append(buf, (size_t)n);
+    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) data.append(buf.data(), (size_t)n);
     gzclose(f);
     if (n < 0) throw std::runtime_error("Invalid FASTA/Q record in " + path);
     return data;
 }
 
-// NtHashIterator::add_dna_seq (nthash_iterator.rs:205-251): valid bases as 2-bit codes, plus
-// the valid-base coordinates of every N and record end.
-struct Sequence {
-    std::vector<uint8_t> codes;
-    std::vector<size_t> offsets;
-    uint64_t acgt[4] = {0, 0, 0, 0};
-    uint64_t non_acgt = 0;
-};
+}  // namespace
 
 void add_fasta(const std::string &path, Sequence &s)
 {
@@ -68,30 +67,59 @@ void add_fasta(const std::string &path, Sequence &s)
     if (!data.empty() && data[0] == '@') {
         throw std::runtime_error(path + ": FASTQ input (reads) is not supported by this build");
     }
-    size_t i = 0;
+    // byte classes: 0-3 = base code, 4 = line break (skipped), 5 = anything else inside a record
+    // (an invalid base: recorded as a break)
+    static const auto table = [] {
+        std::array<uint8_t, 256> t;
+        t.fill(5);
+        t[(uint8_t)'\n'] = 4;
+        t[(uint8_t)'\r'] = 4;
+        for (int c = 0; c < 256; ++c) {
+            if (valid_base((uint8_t)c)) t[c] = encode_base((uint8_t)c);
+        }
+        return t;
+    }();
     const size_t n = data.size();
+    const size_t base0 = s.codes.size();
+    s.codes.resize(base0 + n);          // upper bound; trimmed below (one allocation, no per-base growth)
+    uint8_t *out = s.codes.data() + base0;
+    size_t n_out = 0;
+    uint64_t counts[6] = {0, 0, 0, 0, 0, 0};
+    size_t i = 0;
     bool in_record = false;
     while (i < n) {
         if (data[i] == '>') {
-            if (in_record) s.offsets.push_back(s.codes.size());  // record boundary
+            if (in_record) s.offsets.push_back(base0 + n_out);  // record boundary
             in_record = true;
-            while (i < n && data[i] != '\n') ++i;  // skip header line
+            const void *nl = std::memchr(data.data() + i, '\n', n - i);   // skip header line
+            i = nl ? (size_t)((const char *)nl - data.data()) : n;
             continue;
         }
-        const char c = data[i++];
-        if (c == '\n' || c == '\r') continue;
-        if (!in_record) continue;
-        if (valid_base((uint8_t)c)) {
-            const uint8_t e = encode_base((uint8_t)c);
-            s.acgt[e] += 1;
-            s.codes.push_back(e);
-        } else {
-            s.non_acgt += 1;
-            s.offsets.push_back(s.codes.size());
+        if (!in_record) {
+            ++i;
+            continue;
+        }
+        // sequence bytes up to the next header
+        const void *gt = std::memchr(data.data() + i, '>', n - i);
+        const size_t end = gt ? (size_t)((const char *)gt - data.data()) : n;
+        for (; i < end; ++i) {
+            const uint8_t cls = table[(uint8_t)data[i]];
+            if (cls < 4) {
+                out[n_out++] = cls;
+                ++counts[cls];
+            } else if (cls == 5) {
+                ++counts[5];
+                s.offsets.push_back(base0 + n_out);
+            }
         }
     }
-    if (in_record) s.offsets.push_back(s.codes.size());
+    if (in_record) s.offsets.push_back(base0 + n_out);
+    s.codes.resize(base0 + n_out);
+    for (int b = 0; b < 4; ++b) s.acgt[b] += counts[b];
+    s.non_acgt += counts[5];
 }
+
+namespace {
 
 // Bin minima of hash % SIGN_MOD over every valid k-mer (get_signs, sketch/mod.rs:132-153);
 // canonical hash = min(forward, reverse-complement) when rc (nthash_iterator.rs:62-68).
@@ -156,6 +184,8 @@ inline uint64_t universal_hash(uint64_t s, uint64_t t)
     return (x * 48271ull + 11ull) % ((1ull << 31) - 1);
 }
 
+}  // namespace
+
 // densify_bin, sketch/mod.rs:237-258
 bool densify_bin(std::vector<uint64_t> &signs)
 {
@@ -184,8 +214,6 @@ void fill_usigs(uint64_t *usigs, const std::vector<uint64_t> &signs)
         }
     }
 }
-
-}  // namespace
 
 std::vector<InputFastx> read_input_fastas(const std::vector<std::string> &seq_files)
 {

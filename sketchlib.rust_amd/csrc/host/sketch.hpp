@@ -24,6 +24,18 @@ std::vector<InputFastx> read_input_fastas(const std::vector<std::string> &seq_fi
 std::vector<InputFastx> read_rfile(const std::string &file_list);                      // name<TAB>file[<TAB>file]
 std::vector<size_t> parse_kmers(const std::vector<size_t> &k_vals, const std::vector<size_t> &k_seq);  // io.rs:140-159
 
+// NtHashIterator::add_dna_seq (nthash_iterator.rs:205-251): valid bases as 2-bit codes, plus
+// the valid-base coordinates of every N and record end.
+struct Sequence {
+    std::vector<uint8_t> codes;
+    std::vector<size_t> offsets;
+    uint64_t acgt[4] = {0, 0, 0, 0};
+    uint64_t non_acgt = 0;
+};
+void add_fasta(const std::string &path, Sequence &s);
+bool densify_bin(std::vector<uint64_t> &signs);                     // sketch/mod.rs:237-258
+void fill_usigs(uint64_t *usigs, const std::vector<uint64_t> &signs);  // sketch/mod.rs:215-223
+
 struct SketchResult {
     SketchMeta meta;
     std::vector<uint64_t> usigs;  // [k][chunk][plane]
@@ -37,5 +49,12 @@ SketchResult sketch_sample(const InputFastx &input, const std::vector<size_t> &k
 // keep their input order (what the reference yields with --threads 1).
 MultiSketch sketch_files(const std::string &output_prefix, const std::vector<InputFastx> &inputs,
                          const std::vector<size_t> &kmers, uint64_t sketch_size, bool rc, size_t threads);
+
+class Device;
+// The same with the hashing / bin-minimum loop on the GPU (SURVEY 8f row f4,
+// skl_sketch_signs): FASTA parsing, densification, transpose and the file writers stay on the
+// host.  Output files are byte-identical to sketch_files'.
+MultiSketch sketch_files_gpu(Device &dev, const std::string &output_prefix, const std::vector<InputFastx> &inputs,
+                             const std::vector<size_t> &kmers, uint64_t sketch_size, bool rc, size_t threads);
 
 }  // namespace skl_host

@@ -138,6 +138,25 @@ struct CandArgs {
 };
 hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream);
 
+// GPU sketching (sketch_kernel.hip): bin minima of the canonical ntHash of every valid k-mer.
+struct SketchArgs {
+    const uint8_t *codes;          // 2-bit base codes, one byte each, all samples concatenated
+    const uint64_t *code_begin;    // [n_samples + 1]
+    const uint64_t *offsets;       // breaks (N / record ends) in each sample's own coordinates
+    const uint64_t *offset_begin;  // [n_samples + 1]
+    const uint64_t *span_begin;    // [n_samples + 1] prefix sum of ceil(len / span) per sample
+    uint64_t n_spans;
+    uint32_t n_samples, nk;
+    const uint32_t *kmers;         // [nk]
+    const uint64_t *top_f, *top_r; // [nk][4] srol^(k-1) of the forward / reverse seeds
+    uint64_t num_bins, bin_size;
+    double inv_bin_size;
+    int32_t rc;
+    uint64_t *signs;               // [n_samples][nk][num_bins], pre-set to UINT64_MAX
+};
+hipError_t launch_sketch_signs(const SketchArgs &args, hipStream_t stream);
+int sketch_span();
+
 struct TopkArgs {
     const float *keys;      // [rows][cols] or [rows][cols][2] when stride2
     uint32_t rows, cols;
