@@ -89,6 +89,8 @@ def main():
                     help="U = random-bin sketches (north-star workload), R = related clusters")
     ap.add_argument("--no-gather", action="store_true", help="skip assembling the output on rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: finish each step's gather before the next step's kernel (default: one step of overlap)")
     args = ap.parse_args()
 
     import numpy as np
@@ -147,17 +149,26 @@ def main():
     p = sk.set_k()  # core/accessory
     if rank == 0:
         full = torch.zeros((total_pairs, 2), dtype=torch.float32, device=device)
-        local = full[p0:p0 + my_pairs]
+        bands = [full[p0:p0 + my_pairs]]
     else:
         full = None
-        local = torch.zeros((my_pairs, 2), dtype=torch.float32, device=device)
+        # two band buffers: the gather of step i overlaps the kernel of step i + 1
+        bands = [torch.zeros((my_pairs, 2), dtype=torch.float32, device=device) for _ in range(2)]
 
     host_staged = dist is not None and dist.get_backend() != "nccl"
+    pipe = None
+    if dist is not None and not host_staged and not args.no_gather and not args.no_overlap:
+        pipe = multi_gpu.PipelinedGather(full, slices, rank, world, dist, depth=2)
+    step_no = [0]
 
     def step():
+        local = bands[step_no[0] % len(bands)]
+        step_no[0] += 1
         capi.self_dists_rows(ctx, sk, p, r0, r1, out=local)
         if dist is not None and not args.no_gather:
-            if host_staged:  # gloo debugging path
+            if pipe is not None:
+                pipe.submit(local)
+            elif host_staged:  # gloo debugging path
                 torch.cuda.synchronize(device)
                 if rank == 0:
                     full_h = torch.empty((total_pairs, 2), dtype=torch.float32)
@@ -171,6 +182,8 @@ def main():
                 multi_gpu.gather_to_root(full, local, slices, rank, world, dist)
 
     def fence():
+        if pipe is not None:
+            pipe.drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
@@ -243,7 +256,8 @@ def main():
                 "kmers": KMERS,
                 "dataset": "Set U (uniform random bins)" if args.dataset == "U" else "Set R (related clusters)",
                 "partition": f"{world} row band(s) of equal pair count"
-                             + ("" if world == 1 or args.no_gather else ", grouped send/recv gather to rank 0"),
+                             + ("" if world == 1 or args.no_gather else ", grouped send/recv gather to rank 0"
+                                + (" overlapped with the next step's kernel" if pipe is not None else "")),
                 "output_checksum": checksum,
             },
             "roofline": {

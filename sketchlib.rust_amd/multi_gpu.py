@@ -77,3 +77,45 @@ def gather_to_root(full, local, slices, rank, world, dist, root=0):
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+
+
+class PipelinedGather:
+    """The same gather, one step behind the compute.
+
+    submit(local) starts the send / receives of a step and returns at once; before it returns
+    it waits for the gather of `depth` steps ago, so a sender that rotates `depth` band buffers
+    never overwrites one that is still being sent.  With "nccl" (RCCL) the transfers run on
+    the communicator's stream and `wait()` is a stream dependency, not a host block: the next
+    step's kernel overlaps the previous step's xGMI traffic.  drain() waits for everything.
+    Root receives every step into the same `full` (its own band is computed in place); the
+    receives of consecutive steps are ordered by the communicator.
+    """
+
+    def __init__(self, full, slices, rank, world, dist, root=0, depth=2):
+        import collections
+
+        self.full, self.slices, self.rank, self.world, self.dist, self.root = full, slices, rank, world, dist, root
+        self.depth = max(1, depth)
+        self.pending = collections.deque()
+
+    def submit(self, local):
+        if self.world == 1:
+            return
+        ops = []
+        if self.rank == self.root:
+            for w in range(self.world):
+                if w == self.root or self.slices[w][3] == 0:
+                    continue
+                p0, cnt = self.slices[w][2], self.slices[w][3]
+                ops.append(self.dist.P2POp(self.dist.irecv, self.full[p0:p0 + cnt], w))
+        elif self.slices[self.rank][3] > 0:
+            ops.append(self.dist.P2POp(self.dist.isend, local, self.root))
+        self.pending.append(self.dist.batch_isend_irecv(ops) if ops else [])
+        while len(self.pending) >= self.depth:
+            for req in self.pending.popleft():
+                req.wait()
+
+    def drain(self):
+        while self.pending:
+            for req in self.pending.popleft():
+                req.wait()

@@ -58,6 +58,23 @@ multi_gpu.gather_to_root(full, mine, slices, rank, world, dist)
 if rank == 0:
     assert torch.equal(full, ref), "assembled matrix differs"
     print("GATHER_OK")
+# the pipelined form bench.py uses with RCCL: several steps in flight, two rotating band buffers
+# per sender, a different payload every step (so a buffer overwritten too early would show)
+if rank == 0:
+    full.fill_(-1.0)
+pipe = multi_gpu.PipelinedGather(full, slices, rank, world, dist, depth=2)
+bufs = [torch.empty_like(mine), torch.empty_like(mine)]
+steps = 7
+for it in range(steps):
+    b = bufs[it %% 2]
+    b.copy_(ref[p0:p0 + cnt] + it)               # "compute" of step `it`
+    if rank == 0:
+        full[p0:p0 + cnt] = b
+    pipe.submit(b)
+pipe.drain()
+if rank == 0:
+    assert torch.equal(full, ref + (steps - 1)), "pipelined gather: last step's matrix differs"
+    print("PIPELINE_OK")
 dist.barrier()
 dist.destroy_process_group()
 """ % ROOT
@@ -72,4 +89,4 @@ def test_gloo_world2_gather(oracle, tmp_path):
          "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
         env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    assert "GATHER_OK" in res.stdout
+    assert "GATHER_OK" in res.stdout and "PIPELINE_OK" in res.stdout
