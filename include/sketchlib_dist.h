@@ -141,6 +141,17 @@ int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_param
 int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
                             size_t knn, size_t row_begin, size_t row_end, uint64_t *out_idx,
                             float *out_d0, float *out_d1, int out_on_device);
+/* The same with the candidate lists built on the device as well: skq holds the index sketch
+ * (u16 bins, `.skq` layout [sample][sketch_size]) of every sample of `s`, row i = sample i (the
+ * caller applies the .ski -> .skd order map); candidates of i = samples sharing at least one
+ * bin value at the same position, i excluded (Inverted::any_shared_bins, inverted.rs:259-268).
+ * At most 1 294 336 samples per call (an n-bit bitmap per row lives in LDS).
+ * out_n_candidates (nullable): total number of candidate pairs found. */
+size_t skl_shared_bins_max_samples(void);
+int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                   size_t knn, const uint16_t *skq, size_t sketch_size,
+                                   uint64_t *out_idx, float *out_d0, uint64_t *out_n_candidates);
+
 /* GPU sketching: bin minima of `canonical ntHash % SIGN_MOD` over every
  * valid k-mer of DNA samples -- Sketch::get_signs_no_densify (src/sketch/mod.rs:156-176) over
  * NtHashIterator (src/hashing/nthash_iterator.rs:325-523), all samples and k-mer lengths of a

@@ -77,6 +77,8 @@ _SIG = [
     ("skl_cross_dists_knn_rows", C.c_int, [_P, _P, _P, C.POINTER(DistParams), C.c_size_t,
                                            C.c_size_t, C.c_size_t, _P, _P, _P, C.c_int]),
     ("skl_self_dists_knn_candidates", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, _P, _P, _P, _P]),
+    ("skl_shared_bins_max_samples", C.c_size_t, []),
+    ("skl_self_dists_knn_shared_bins", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, _P, C.c_size_t, _P, _P, _P]),
     ("skl_sketch_signs", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.c_int, _P]),
     ("skl_self_binmatch", C.c_int, [_P, _P, _P, C.c_int]),
     ("skl_cross_binmatch", C.c_int, [_P, _P, _P, _P, C.c_int]),
@@ -324,6 +326,18 @@ def self_dists_knn_candidates(ctx, s, p, knn, row_offsets, cand):
                                                 cand.ctypes.data if cand.size else None, idx.ctypes.data,
                                                 d0.ctypes.data))
     return idx, d0
+
+
+def self_dists_knn_shared_bins(ctx, s, p, knn, skq):
+    """Precluster kNN with the candidate lists built on the device from the index sketches
+    (skq: [n, sketch_size] u16, row i = sample i).  -> (idx, d0, total candidate pairs)."""
+    skq = np.ascontiguousarray(skq, dtype=np.uint16)
+    assert skq.shape[0] == s.n
+    idx, d0, _ = _knn_out(s.n, knn)
+    total = C.c_uint64(0)
+    _check(load().skl_self_dists_knn_shared_bins(ctx._h, s._h, C.byref(p), knn, skq.ctypes.data, skq.shape[1],
+                                                 idx.ctypes.data, d0.ctypes.data, C.byref(total)))
+    return idx, d0, int(total.value)
 
 
 def sketch_signs(ctx, codes, code_begin, offsets, offset_begin, kmers, num_bins, rc=True):

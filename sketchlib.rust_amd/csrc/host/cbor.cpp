@@ -19,6 +19,55 @@ struct Reader {
         for (int k = 0; k < bytes; ++k) v = (v << 8) | byte();
         return v;
     }
+    // skip one value without materialising it; returns the element count of an array / map
+    // header (0 for anything else)
+    uint64_t skip(int depth = 0)
+    {
+        if (depth > 64) throw std::runtime_error("CBOR: nesting too deep");
+        const uint8_t ib = byte();
+        const int mt = ib >> 5, ai = ib & 31;
+        uint64_t v = 0;
+        bool indefinite = false;
+        if (ai < 24) v = ai;
+        else if (ai == 24) v = be(1);
+        else if (ai == 25) v = be(2);
+        else if (ai == 26) v = be(4);
+        else if (ai == 27) v = be(8);
+        else if (ai == 31) indefinite = true;
+        else throw std::runtime_error("CBOR: reserved additional info");
+        switch (mt) {
+            case 0:
+            case 1: return 0;
+            case 2:
+            case 3:
+                if (indefinite) {
+                    while (i < n && p[i] != 0xFF) skip(depth + 1);
+                    byte();
+                } else {
+                    if (i + v > n) throw std::runtime_error("CBOR: string runs past the end");
+                    i += (size_t)v;
+                }
+                return 0;
+            case 4:
+            case 5: {
+                const uint64_t per = mt == 5 ? 2 : 1;
+                uint64_t count = 0;
+                if (indefinite) {
+                    while (i < n && p[i] != 0xFF) {
+                        for (uint64_t k = 0; k < per; ++k) skip(depth + 1);
+                        ++count;
+                    }
+                    byte();
+                } else {
+                    for (uint64_t k = 0; k < v * per; ++k) skip(depth + 1);
+                    count = v;
+                }
+                return count;
+            }
+            case 6: return skip(depth + 1);
+            default: return 0;   // simple values / floats: the argument bytes are already consumed
+        }
+    }
     CborValue value(int depth = 0)
     {
         if (depth > 64) throw std::runtime_error("CBOR: nesting too deep");
@@ -118,6 +167,37 @@ void enc(std::vector<uint8_t> &o, const CborValue &v)
     }
 }
 }  // namespace
+
+CborValue cbor_decode_map_skipping(const std::vector<uint8_t> &bytes, const std::string &skip_key,
+                                   uint64_t *skipped_count)
+{
+    Reader r{bytes.data(), bytes.size()};
+    const uint8_t ib = r.byte();
+    if ((ib >> 5) != 5) throw std::runtime_error("CBOR: top-level value is not a map");
+    const int ai = ib & 31;
+    uint64_t v = 0;
+    bool indefinite = false;
+    if (ai < 24) v = ai;
+    else if (ai == 24) v = r.be(1);
+    else if (ai == 25) v = r.be(2);
+    else if (ai == 26) v = r.be(4);
+    else if (ai == 27) v = r.be(8);
+    else if (ai == 31) indefinite = true;
+    else throw std::runtime_error("CBOR: reserved additional info");
+    CborValue root = CborValue::object();
+    if (skipped_count) *skipped_count = 0;
+    for (uint64_t k = 0; indefinite ? (r.i < r.n && r.p[r.i] != 0xFF) : k < v; ++k) {
+        CborValue key = r.value(1);
+        if (key.kind == CborValue::TEXT && key.s == skip_key) {
+            const uint64_t c = r.skip(1);
+            if (skipped_count) *skipped_count = c;
+        } else {
+            CborValue x = r.value(1);
+            root.map.emplace_back(std::move(key), std::move(x));
+        }
+    }
+    return root;
+}
 
 CborValue cbor_decode(const std::vector<uint8_t> &bytes)
 {

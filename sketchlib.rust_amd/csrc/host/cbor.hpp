@@ -44,6 +44,10 @@ struct CborValue {
 };
 
 CborValue cbor_decode(const std::vector<uint8_t> &bytes);
+// Decode a top-level map but do not materialise the value stored under `skip_key`; its element
+// count (array / map length) is returned through skipped_count.
+CborValue cbor_decode_map_skipping(const std::vector<uint8_t> &bytes, const std::string &skip_key,
+                                   uint64_t *skipped_count);
 std::vector<uint8_t> cbor_encode(const CborValue &v);
 
 }  // namespace skl_host

@@ -22,6 +22,7 @@
 
 #include "distances.hpp"
 #include "inverted.hpp"
+#include "sketchlib_dist.h"
 #include "io.hpp"
 #include "multisketch.hpp"
 #include "sketch.hpp"
@@ -213,21 +214,16 @@ int run_dist(const DistArgs &a)
     const Logger log{a.verbose && !a.quiet, !a.quiet};
     log.info("Using " + std::to_string(a.threads) + " threads");   // cli.rs:75-86 (host threads unused)
 
-    // dense listings go through a TextSink (regular file: blocks written at offsets from all
-    // formatting threads); sparse listings are small and use the plain stream
-    std::ofstream out_file;
+    // listings go through a TextSink (regular file: blocks written at offsets from all
+    // formatting threads; stdout: in order)
     std::ostream *os = &std::cout;
     std::unique_ptr<TextSink> sink;
-    if (a.output && !a.knn) {
+    if (a.output) {
         try {
             sink = std::make_unique<FileSink>(*a.output);
         } catch (const std::exception &e) {
             throw Panic(e.what());
         }
-    } else if (a.output) {
-        out_file.open(*a.output, std::ios::binary);
-        if (!out_file) throw Panic("cannot create output file " + *a.output);
-        os = &out_file;
     }
     if (!sink) sink = std::make_unique<StreamSink>(*os);
 
@@ -318,7 +314,7 @@ int run_dist(const DistArgs &a)
             const SparseDistanceMatrix d = distances::self_dists_knn(dev, references, n, nn, dist_type, a.quiet,
                                                                      rc, a.completeness_cutoff);
             log.info("Writing out in sparse matrix form");
-            d.write(*os);
+            d.write(*sink, a.threads);
         }
     } else {
         const size_t n_query = queries->number_samples_loaded();
@@ -333,7 +329,7 @@ int run_dist(const DistArgs &a)
                                                                       dist_type, a.quiet, rc, qc,
                                                                       a.completeness_cutoff);
             log.info("Writing out in sparse matrix form");
-            d.write(*os);
+            d.write(*sink, a.threads);
         } else {
             log.info("Calculating all ref vs query distances");
             if (a.devices.size() == 1) {
@@ -545,7 +541,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     }
     g_usage = "sketchlib inverted precluster [OPTIONS] <SKI> <--skd <SKD>|--count>";
     std::optional<std::string> ski, skd, output, completeness_file, retain;
-    bool count = false, ani = false;
+    bool count = false, ani = false, host_candidates = false;
     size_t knn = 50, threads = 1;   // DEFAULT_KNN, cli.rs
     double cutoff = 0.64;
     int device = 0;
@@ -563,6 +559,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
         else if (arg == "--completeness-cutoff") cutoff = std::strtod(next_value(i, arg).c_str(), nullptr);
         else if (arg == "--retain-unmatched") retain = next_value(i, arg);
         else if (arg == "--device") device = (int)parse_usize("--device <D>", next_value(i, arg));
+        else if (arg == "--host-candidates") host_candidates = true;   // candidate lists from the .ski on host threads
         else if (arg.size() > 1 && arg[0] == '-') usage_error("unexpected argument '" + arg + "' found");
         else if (!ski) ski = arg;
         else usage_error("unexpected argument '" + arg + "' found");
@@ -578,8 +575,18 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     }
     const Logger log{verbose && !quiet, !quiet};
     log.info("Using " + std::to_string(threads) + " threads");
+    const bool timing = std::getenv("SKL_CLI_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     const std::string input_prefix = strip_sketch_extension(*ski);
-    const Inverted inv = Inverted::load(input_prefix);   // `?` in the reference: Error, exit 1
+    // The bitmaps of the index are only needed for --count and for the host candidate search;
+    // by default the candidates are found on the device from the .skq alone.
+    Inverted inv = Inverted::load(input_prefix, count || host_candidates);   // `?` in the reference: Error, exit 1
+    if (!inv.has_index() && inv.sample_names.size() > skl_shared_bins_max_samples()) {
+        log.info("More samples than the on-device candidate search takes: using the index on the host");
+        inv = Inverted::load(input_prefix, true);
+    }
+    const double t_ski = since_start();
     if (count) {
         const size_t ns = inv.sample_names.size();
         std::cout << "Identified " << inv.any_shared_bin_pairs(threads) << " prefilter pairs from a max of "
@@ -587,12 +594,16 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
         return 0;
     }
     if (!skd) return 0;   // neither mode: the reference does nothing (lib.rs:713)
-    std::ofstream out_file;
     std::ostream *os = &std::cout;
+    std::unique_ptr<TextSink> sink;
     if (output) {
-        out_file.open(*output, std::ios::binary);
-        if (!out_file) throw Panic("cannot create output file " + *output);
-        os = &out_file;
+        try {
+            sink = std::make_unique<FileSink>(*output);
+        } catch (const std::exception &e) {
+            throw Panic(e.what());
+        }
+    } else {
+        sink = std::make_unique<StreamSink>(*os);
     }
     const std::string skq_filename = input_prefix + ".skq";
     log.info("Loading queries from " + skq_filename);
@@ -632,13 +643,20 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     log.info("Calculating sparse ref vs ref distances with " + std::to_string(knn) + " nearest neighbours");
     log.info("Preclustering with k=" + std::to_string(inv.kmer_size) + " and s=" + std::to_string(inv.sketch_size()));
     if (retain) log.info("Retain unmatched mode: " + *retain);
+    const double t_loaded = since_start();
     Device dev(device);
+    const double t_device = since_start();
     const SparseDistanceMatrix d = distances::self_dists_knn_precluster(
         dev, references, inv, skq_bins, inv.sketch_size(), n, knn, dist_type, comp ? &*comp : nullptr, cutoff,
         retain_mode, threads);
+    const double t_dist = since_start();
     log.info("Writing out in sparse matrix form");
-    d.write(*os);
+    d.write(*sink, threads);
     os->flush();
+    if (timing) {
+        std::fprintf(stderr, "TIMING precluster: load_ski=%.3fs load_skq+skd=%.3fs device_init=%.3fs candidates+distances=%.3fs write=%.3fs\n",
+                     t_ski, t_loaded - t_ski, t_device - t_loaded, t_dist - t_device, since_start() - t_dist);
+    }
     return 0;
 }
 

@@ -209,37 +209,15 @@ void FileSink::finish(uint64_t off, const char *p, size_t len)
     }
 }
 
-void DistanceMatrix::write(std::ostream &os, size_t threads) const
+// Blocks 0..n_blocks-1 formatted by `threads` workers (each into a private reusable buffer)
+// and handed to the sink in block order: threads take blocks from a shared counter, format,
+// then pass through an ordered section (stream: write there; file: reserve the byte range there
+// and pwrite outside it).
+template <class Format>
+static void write_blocks_in_order(TextSink &sink, size_t n_blocks, size_t threads, Format format)
 {
-    StreamSink sink(os);
-    write_rows(sink, 0, ref_names.size(), distances.data(), threads);
-}
-
-void DistanceMatrix::write_rows(TextSink &sink, size_t r0, size_t r1, const float *band, size_t threads) const
-{
-    const size_t n_rows = ref_names.size();
-    r1 = std::min(r1, n_rows);
-    if (r1 <= r0) return;
-    const size_t ncols = jaccard.n_dist_cols();
-    const size_t dist_base = (query_names ? r0 * query_names->size()
-                                          : (r0 + 1 < n_rows ? square_to_condensed(r0, r0 + 1, n_rows) : 0)) * ncols;
-    // Blocks of whole rows, ~32K lines each (about a megabyte of text: stays cache-resident
-    // between formatting and the write).  Threads take blocks from a shared counter, format
-    // into a private reusable buffer, then pass through an ordered section in block order
-    // (stream: write there; file: reserve the byte range there and pwrite outside it).
-    constexpr size_t BLOCK_LINES = 1 << 15;
-    std::vector<size_t> bounds = {r0};
-    size_t acc = 0;
-    for (size_t i = r0; i < r1; ++i) {
-        acc += query_names ? query_names->size() : n_rows - 1 - i;
-        if (acc >= BLOCK_LINES || i + 1 == r1) {
-            bounds.push_back(i + 1);
-            acc = 0;
-        }
-    }
-    const size_t n_blocks = bounds.size() - 1;
+    if (n_blocks == 0) return;
     threads = std::max<size_t>(1, std::min(threads, n_blocks));
-
     const double t_begin = now_s();
     std::atomic<size_t> next{0};
     std::mutex mu;
@@ -254,7 +232,8 @@ void DistanceMatrix::write_rows(TextSink &sink, size_t r0, size_t r1, const floa
             for (;;) {
                 const size_t b = next.fetch_add(1);
                 if (b >= n_blocks) break;
-                format_rows(*this, bounds[b], bounds[b + 1], band, dist_base, block);
+                block.len = 0;
+                format(b, block);
                 const double t0 = now_s();
                 uint64_t token;
                 {
@@ -294,26 +273,77 @@ void DistanceMatrix::write_rows(TextSink &sink, size_t r0, size_t r1, const floa
     output_timing().format_s += wall * (1.0 - sink_share);
 }
 
+void DistanceMatrix::write(std::ostream &os, size_t threads) const
+{
+    StreamSink sink(os);
+    write_rows(sink, 0, ref_names.size(), distances.data(), threads);
+}
+
+void DistanceMatrix::write_rows(TextSink &sink, size_t r0, size_t r1, const float *band, size_t threads) const
+{
+    const size_t n_rows = ref_names.size();
+    r1 = std::min(r1, n_rows);
+    if (r1 <= r0) return;
+    const size_t ncols = jaccard.n_dist_cols();
+    const size_t dist_base = (query_names ? r0 * query_names->size()
+                                          : (r0 + 1 < n_rows ? square_to_condensed(r0, r0 + 1, n_rows) : 0)) * ncols;
+    // Blocks of whole rows, ~32K lines each (about a megabyte of text: stays cache-resident
+    // between formatting and the write).  Threads take blocks from a shared counter, format
+    // into a private reusable buffer, then pass through an ordered section in block order
+    // (stream: write there; file: reserve the byte range there and pwrite outside it).
+    constexpr size_t BLOCK_LINES = 1 << 15;
+    std::vector<size_t> bounds = {r0};
+    size_t acc = 0;
+    for (size_t i = r0; i < r1; ++i) {
+        acc += query_names ? query_names->size() : n_rows - 1 - i;
+        if (acc >= BLOCK_LINES || i + 1 == r1) {
+            bounds.push_back(i + 1);
+            acc = 0;
+        }
+    }
+    write_blocks_in_order(sink, bounds.size() - 1, threads, [&](size_t b, TextBlock &block) {
+        format_rows(*this, bounds[b], bounds[b + 1], band, dist_base, block);
+    });
+}
+
 void SparseDistanceMatrix::write(std::ostream &os) const
+{
+    StreamSink sink(os);
+    write(sink, 1);
+}
+
+void SparseDistanceMatrix::write(TextSink &sink, size_t threads) const
 {
     // rows are labelled by query names in cross mode, ref names otherwise
     const std::vector<std::string> &rows = query_names ? *query_names : ref_names;
-    if (jaccard.kind == DistType::Jaccard) {
-        for (size_t x = 0; x < jaccard_dists.size(); ++x) {
+    const bool jac = jaccard.kind == DistType::Jaccard;
+    const size_t n_items = jac ? jaccard_dists.size() : coreacc_dists.size();
+    if (n_items == 0 || knn == 0) return;
+    const size_t n_rows = n_items / knn;
+    const size_t rows_per_block = std::max<size_t>(1, (1 << 15) / knn);   // ~32K lines per block
+    const size_t n_blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+    write_blocks_in_order(sink, n_blocks, threads, [&](size_t b, TextBlock &out) {
+        const size_t x1 = std::min(n_items, (b + 1) * rows_per_block * knn);
+        for (size_t x = b * rows_per_block * knn; x < x1; ++x) {
             const std::string &row_name = rows[x / knn];
-            const std::string &col_name = ref_names[jaccard_dists[x].idx];
+            const std::string &col_name = ref_names[jac ? jaccard_dists[x].idx : coreacc_dists[x].idx];
             // Padding entries (dist == 1.0, col == row) are skipped, distance_matrix.rs:379-381
-            if (jaccard_dists[x].dist < 1.0f || col_name != row_name) {
-                os << row_name << '\t' << col_name << '\t' << format_f32(jaccard_dists[x].dist) << '\n';
+            if (jac && !(jaccard_dists[x].dist < 1.0f || col_name != row_name)) continue;
+            out.need(row_name.size() + col_name.size() + 2 * F32_TEXT_MAX + 4);
+            out.put(row_name);
+            out.put('\t');
+            out.put(col_name);
+            out.put('\t');
+            if (jac) {
+                put_f32(out, jaccard_dists[x].dist);
+            } else {
+                put_f32(out, coreacc_dists[x].core);
+                out.put('\t');
+                put_f32(out, coreacc_dists[x].acc);
             }
+            out.put('\n');
         }
-    } else {
-        for (size_t x = 0; x < coreacc_dists.size(); ++x) {
-            os << rows[x / knn] << '\t' << ref_names[coreacc_dists[x].idx] << '\t'
-               << format_f32(coreacc_dists[x].core) << '\t' << format_f32(coreacc_dists[x].acc)
-               << '\n';
-        }
-    }
+    });
 }
 
 }  // namespace skl_host

@@ -111,6 +111,8 @@ class SparseDistanceMatrix {
     std::optional<std::vector<std::string>> query_names;
 
     void write(std::ostream &os) const;
+    // block-parallel form (same bytes): `threads` formatters, ordered hand-over to the sink
+    void write(TextSink &sink, size_t threads) const;
 };
 
 }  // namespace skl_host

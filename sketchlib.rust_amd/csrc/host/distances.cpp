@@ -1,8 +1,11 @@
 #include "distances.hpp"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <exception>
@@ -217,31 +220,71 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
         throw Panic("not implemented: Prefilter only available for single k-mer distances");   // mod.rs:549-551
     }
 
-    // candidate lists (inverted.rs:259-268), in .skd ids, ascending, self excluded
-    std::vector<std::vector<uint32_t>> lists(n);
+    const bool timing = std::getenv("SKL_CLI_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    Slab s(dev, sketches, completeness_vec);
+    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
+    std::vector<uint64_t> idx(n * knn);
+    std::vector<float> d0(n * knn), d1;
+    std::vector<uint8_t> unmatched(n, 0);
+    if (!inv.has_index()) {
+        // candidate lists on the device: index sketches re-ordered to .skd order
+        std::vector<uint16_t> skq_skd(n * skq_stride);
+        for (size_t i = 0; i < n; ++i) {
+            std::copy(skq_bins.begin() + ski_of_skd[i] * skq_stride, skq_bins.begin() + (ski_of_skd[i] + 1) * skq_stride,
+                      skq_skd.begin() + i * skq_stride);
+        }
+        uint64_t total = 0;
+        check(skl_self_dists_knn_shared_bins(dev.ctx(), s.h, &p, knn, skq_skd.data(), skq_stride, idx.data(), d0.data(),
+                                             &total));
+        // a row whose first entry is padding (itself at distance 1) had no candidate at all
+        for (size_t i = 0; i < n; ++i) unmatched[i] = idx[i * knn] == i;
+        if (timing) {
+            std::fprintf(stderr, "TIMING precluster: %llu candidate pairs; device candidate search + distances + top-k=%.3fs\n",
+                         (unsigned long long)total, since());
+        }
+    } else {
+    // candidate lists (inverted.rs:259-268), in .skd ids, ascending, self excluded.  Every
+    // worker appends its rows' lists to ONE growing buffer of its own (a few large allocations
+    // instead of one per row: 64 threads faulting in millions of small blocks serialise on the
+    // address-space lock) and records where each row went.
+    const size_t n_workers = std::max<size_t>(1, threads);
+    struct RowRef {
+        uint32_t worker = 0;
+        uint32_t len = 0;
+        uint64_t begin = 0;
+    };
+    std::vector<RowRef> rows(n);
+    std::vector<std::vector<uint32_t>> arena(n_workers);
     {
         std::atomic<size_t> next{0};
         std::exception_ptr err;
         std::mutex mu;
-        auto work = [&] {
+        auto work = [&](size_t wid) {
             try {
                 std::vector<uint32_t> stamp(inv.n_samples, 0), hits;   // per-thread scratch
+                std::vector<uint32_t> &buf = arena[wid];
                 uint32_t epoch = 0;
                 for (;;) {
-                    const size_t i = next.fetch_add(1);
-                    if (i >= n) break;
-                    const size_t ski_i = ski_of_skd[i];
-                    if (++epoch == 0) {   // wrapped: start over
-                        std::fill(stamp.begin(), stamp.end(), 0u);
-                        epoch = 1;
+                    const size_t i0 = next.fetch_add(256);
+                    if (i0 >= n) break;
+                    for (size_t i = i0; i < std::min(n, i0 + 256); ++i) {
+                        const size_t ski_i = ski_of_skd[i];
+                        if (++epoch == 0) {   // wrapped: start over
+                            std::fill(stamp.begin(), stamp.end(), 0u);
+                            epoch = 1;
+                        }
+                        inv.any_shared_bins(skq_bins.data() + ski_i * skq_stride, stamp, epoch, hits);
+                        const size_t begin = buf.size();
+                        for (uint32_t j : hits) {
+                            if (j != ski_i) buf.push_back((uint32_t)skd_of_ski[j]);   // mod.rs:458-461
+                        }
+                        std::sort(buf.begin() + begin, buf.end());
+                        rows[i].worker = (uint32_t)wid;
+                        rows[i].begin = begin;
+                        rows[i].len = (uint32_t)(buf.size() - begin);
                     }
-                    inv.any_shared_bins(skq_bins.data() + ski_i * skq_stride, stamp, epoch, hits);
-                    auto &l = lists[i];
-                    l.reserve(hits.size());
-                    for (uint32_t j : hits) {
-                        if (j != ski_i) l.push_back((uint32_t)skd_of_ski[j]);   // mod.rs:458-461
-                    }
-                    std::sort(l.begin(), l.end());
                 }
             } catch (...) {
                 std::lock_guard<std::mutex> lk(mu);
@@ -249,28 +292,52 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
             }
         };
         std::vector<std::thread> pool;
-        for (size_t t = 1; t < std::max<size_t>(1, threads); ++t) pool.emplace_back(work);
-        work();
+        for (size_t t = 1; t < n_workers; ++t) pool.emplace_back(work, t);
+        work(0);
         for (auto &t : pool) t.join();
         if (err) std::rethrow_exception(err);
     }
+    const double t_lists = since();
     std::vector<uint64_t> offsets(n + 1, 0);
-    for (size_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + lists[i].size();
-    std::vector<uint32_t> cand(offsets[n]);
-    for (size_t i = 0; i < n; ++i) std::copy(lists[i].begin(), lists[i].end(), cand.begin() + offsets[i]);
+    for (size_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + rows[i].len;
+    std::unique_ptr<uint32_t[]> cand(new uint32_t[std::max<uint64_t>(offsets[n], 1)]);   // not zero-filled
+    {
+        std::atomic<size_t> next{0};
+        auto copy_work = [&] {
+            for (;;) {
+                const size_t i0 = next.fetch_add(1024);
+                if (i0 >= n) break;
+                for (size_t i = i0; i < std::min(n, i0 + 1024); ++i) {
+                    const uint32_t *src = arena[rows[i].worker].data() + rows[i].begin;
+                    std::copy(src, src + rows[i].len, cand.get() + offsets[i]);
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_workers; ++t) pool.emplace_back(copy_work);
+        copy_work();
+        for (auto &t : pool) t.join();
+    }
+    std::vector<std::vector<uint32_t>>().swap(arena);
+    for (size_t i = 0; i < n; ++i) unmatched[i] = rows[i].len == 0;
+    const double t_csr = since();
 
-    Slab s(dev, sketches, completeness_vec);
-    const skl_dist_params p = to_params(dist_type, completeness_cutoff);
-    std::vector<uint64_t> idx(n * knn);
-    std::vector<float> d0(n * knn), d1;
-    check(skl_self_dists_knn_candidates(dev.ctx(), s.h, &p, knn, offsets.data(), cand.data(), idx.data(), d0.data()));
+    const double t_slab = since();
+    check(skl_self_dists_knn_candidates(dev.ctx(), s.h, &p, knn, offsets.data(), cand.get(), idx.data(), d0.data()));
+    if (timing) {
+        std::fprintf(stderr, "TIMING precluster: %llu candidate pairs; lists=%.3fs csr=%.3fs slab upload=%.3fs "
+                             "candidate upload+distances+top-k=%.3fs\n",
+                     (unsigned long long)offsets[n], t_lists, t_csr - t_lists, t_slab - t_csr, since() - t_slab);
+    }
+
+    }
 
     // genomes without a prefilter match (mod.rs:487-527)
     if (retain != RetainUnmatched::None) {
         std::vector<uint64_t> bi(knn);
         std::vector<float> b0(knn), b1(knn);
         for (size_t i = 0; i < n; ++i) {
-            if (!lists[i].empty()) continue;
+            if (!unmatched[i]) continue;
             if (retain == RetainUnmatched::Singleton) {
                 for (size_t t = 0; t < knn; ++t) {
                     idx[i * knn + t] = i;

@@ -95,7 +95,9 @@ std::string npy_header(size_t rows, size_t cols);
 // self_dists_knn_precluster (mod.rs:399-553): kNN restricted to the candidates an inverted
 // index returns (any shared bin).  The candidate lists are built on the host from the index
 // (`threads` workers), the distances and the per-row top-k run on the device
-// (skl_self_dists_knn_candidates); rows without candidates follow --retain-unmatched.
+// (skl_self_dists_knn_candidates); rows without candidates follow --retain-unmatched.  If the
+// index was loaded without its bitmaps (Inverted::load(prefix, false)) the candidate lists are
+// built on the device too, from the .skq alone (skl_self_dists_knn_shared_bins).
 enum class RetainUnmatched { None, Singleton, Bruteforce };
 SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &sketches, const Inverted &inverted_index,
                                                const std::vector<uint16_t> &skq_bins, size_t skq_stride, size_t n,

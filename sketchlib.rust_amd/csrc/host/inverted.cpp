@@ -182,13 +182,15 @@ void Inverted::save(const std::string &file_prefix) const
     f.write(reinterpret_cast<const char *>(framed.data()), (std::streamsize)framed.size());
 }
 
-Inverted Inverted::load(const std::string &file_prefix)
+Inverted Inverted::load(const std::string &file_prefix, bool with_index)
 {
     const std::string path = file_prefix + ".ski";
     std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("Could not open " + path);
     std::vector<uint8_t> framed((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    const CborValue root = cbor_decode(snappy_frame_decode(framed));
+    uint64_t n_bins = 0;
+    const CborValue root = with_index ? cbor_decode(snappy_frame_decode(framed))
+                                      : cbor_decode_map_skipping(snappy_frame_decode(framed), "index", &n_bins);
     if (root.kind != CborValue::MAP) throw std::runtime_error(path + ": not an inverted index");
     auto need = [&](const char *k) -> const CborValue & {
         const CborValue *v = root.get(k);
@@ -196,6 +198,8 @@ Inverted Inverted::load(const std::string &file_prefix)
         return *v;
     };
     Inverted inv;
+    inv.sketch_size_hint = (size_t)n_bins;
+    if (with_index)
     for (const auto &bin : need("index").arr) {
         inv.index.emplace_back();
         for (const auto &kv : bin.map) {

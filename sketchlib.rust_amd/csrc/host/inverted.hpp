@@ -34,13 +34,17 @@ class Inverted {
     bool rc = true;
     std::string hash_type = "DNA";
 
-    size_t sketch_size() const { return index.size(); }
+    size_t sketch_size() const { return index.empty() ? sketch_size_hint : index.size(); }
+    bool has_index() const { return !index.empty() || sketch_size_hint == 0; }
+    size_t sketch_size_hint = 0;   // set by load(prefix, false): number of bins of the skipped index
 
     // Inverted::new minus the sketching (inverted.rs:99-112,467-499); sketches in index order.
     static Inverted from_sketches(const std::vector<std::vector<uint16_t>> &sketches,
                                   std::vector<std::string> names, size_t k, bool rc);
     void save(const std::string &file_prefix) const;          // <prefix>.ski
-    static Inverted load(const std::string &file_prefix);     // throws std::runtime_error
+    // with_index = false reads everything but the bitmaps (names, k, sketch size): enough when
+    // the candidate search runs on the device from the .skq
+    static Inverted load(const std::string &file_prefix, bool with_index = true);   // throws std::runtime_error
 
     // Samples sharing at least one bin with the query sketch, ascending (inverted.rs:259-268).
     std::vector<uint32_t> any_shared_bins(const uint16_t *query_sigs) const;

@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <vector>
 
 namespace skl {
@@ -156,6 +157,20 @@ struct SketchArgs {
 };
 hipError_t launch_sketch_signs(const SketchArgs &args, hipStream_t stream);
 int sketch_span();
+
+// Candidate lists on the device (cand_gen.hip): any shared bin between index sketches.
+struct CandGenArgs {
+    const uint16_t *skq;      // [n][sketch_size] index sketches, row = sample id
+    uint32_t n, sketch_size;
+    uint32_t *starts, *cursor;  // [sketch_size][65536] group begin / (after the scatter) end
+    uint32_t *members;          // [sketch_size][n] sample ids grouped by value
+    uint32_t *counts;           // [n] candidates per row (pass 1)
+    const uint64_t *row_offsets;  // [n + 1] (pass 2)
+    uint32_t *cand;             // candidate ids, ascending inside a row (pass 2)
+};
+hipError_t launch_cand_groups(const CandGenArgs &g, hipStream_t stream);
+hipError_t launch_cand_rows(const CandGenArgs &g, bool fill, hipStream_t stream);
+constexpr size_t MAX_DEVICE_CANDGEN_SAMPLES = 158ull * 1024 * 8;   // n-bit bitmap in LDS
 
 struct TopkArgs {
     const float *keys;      // [rows][cols] or [rows][cols][2] when stride2

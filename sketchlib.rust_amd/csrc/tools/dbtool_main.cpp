@@ -7,6 +7,9 @@
 //                                       print a raw f32 distance array as the dense long-form text
 //                                       (names s0,s1,.. / q0,q1,..), in row bands of <band_rows> rows,
 //                                       to stdout or (block-parallel) to <out>
+//   skl_dbtool make-ski <prefix> <k> <sketch_size> <name>...   write <prefix>.ski for an existing
+//                                       <prefix>.skq ([sample][sketch_size] u16) whose rows are in
+//                                       the order of the names
 // Used by the test-suite to pin the file-format code without a GPU, and to write
 // synthetic databases in the reference's on-disk layout.
 #include <cstdio>
@@ -19,10 +22,29 @@
 #include <fstream>
 
 #include "../host/distance_matrix.hpp"
+#include "../host/inverted.hpp"
 #include "../host/io.hpp"
 #include "../host/multisketch.hpp"
 
 using namespace skl_host;
+
+// names given as arguments, or `@file` = one name per line (command lines have a length limit)
+static std::vector<std::string> collect_names(int argc, char **argv, int first)
+{
+    std::vector<std::string> names;
+    for (int i = first; i < argc; ++i) {
+        if (argv[i][0] == '@') {
+            std::ifstream f(argv[i] + 1);
+            std::string line;
+            while (std::getline(f, line)) {
+                if (!line.empty()) names.push_back(line);
+            }
+        } else {
+            names.push_back(argv[i]);
+        }
+    }
+    return names;
+}
 
 int main(int argc, char **argv)
 {
@@ -91,6 +113,18 @@ int main(int argc, char **argv)
             std::cout.flush();
             return 0;
         }
+        if (argc >= 6 && std::string(argv[1]) == "make-ski") {
+            const std::string prefix = argv[2];
+            const size_t k = strtoull(argv[3], nullptr, 10), sketch_size = strtoull(argv[4], nullptr, 10);
+            const std::vector<std::string> names = collect_names(argc, argv, 5);
+            const std::vector<uint16_t> flat = read_skq(prefix + ".skq", names.size(), sketch_size);
+            std::vector<std::vector<uint16_t>> sketches(names.size());
+            for (size_t i = 0; i < names.size(); ++i) {
+                sketches[i].assign(flat.begin() + i * sketch_size, flat.begin() + (i + 1) * sketch_size);
+            }
+            Inverted::from_sketches(sketches, names, k, true).save(prefix);
+            return 0;
+        }
         if (argc >= 6 && std::string(argv[1]) == "make") {
             // make <prefix> <sketch_size_bins> <k1,k2,...> <name>...: write <prefix>.skm for an
             // existing <prefix>.skd whose sample blocks are in the order of the names
@@ -107,10 +141,11 @@ int main(int argc, char **argv)
                 pos = comma + 1;
             }
             std::vector<SketchMeta> meta;
-            for (int i = 5; i < argc; ++i) {
+            const std::vector<std::string> names = collect_names(argc, argv, 5);
+            for (size_t i = 0; i < names.size(); ++i) {
                 SketchMeta sm;
-                sm.name = argv[i];
-                sm.index = (uint64_t)(i - 5);
+                sm.name = names[i];
+                sm.index = (uint64_t)i;
                 meta.push_back(sm);
             }
             MultiSketch m(std::move(meta), bins, kmers);

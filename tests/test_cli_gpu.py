@@ -264,6 +264,10 @@ def test_inverted_precluster_like_reference(gpu_ctx, precluster_wd):
     assert sorted(out.stdout.splitlines()) == golden and "knn=50 is higher than number of samples=4" in out.stderr
     run_cli(wd, "inverted", "precluster", "--knn", "1", "--skd", "standard.skm", "-o", "pre.txt", "inverted.ski")
     assert sorted((wd / "pre.txt").read_text().splitlines()) == golden
+    # candidate lists from the .ski bitmaps on host threads instead of on the device
+    out = run_cli(wd, "inverted", "precluster", "--knn", "1", "--skd", "standard", "inverted.ski", "--host-candidates",
+                  "--threads", "3")
+    assert sorted(out.stdout.splitlines()) == golden
 
 
 def test_inverted_precluster_reordered_index_and_retain(gpu_ctx, precluster_wd):
@@ -274,8 +278,9 @@ def test_inverted_precluster_reordered_index_and_retain(gpu_ctx, precluster_wd):
     (wd / "species.txt").write_text("TIGR4.fa.gz\ta\n14412_3#82.contigs_velvet.fa.gz\tb\nR6.fa.gz\ta\n")
     run_cli(wd, "inverted", "build", "-o", "reordered", "-k", "21", "-s", "10", "-f", "rfile.txt", "--write-skq",
             "--species-names", "species.txt")
-    out = run_cli(wd, "inverted", "precluster", "--knn", "3", "--skd", "standard", "reordered.ski")
-    assert sorted(out.stdout.splitlines()) == golden
+    for extra in ((), ("--host-candidates",)):
+        out = run_cli(wd, "inverted", "precluster", "--knn", "3", "--skd", "standard", "reordered.ski", *extra)
+        assert sorted(out.stdout.splitlines()) == golden
     run_cli(wd, "sketch", "-o", "other_k", "--k-vals", "17", "-s", "1000", "-f", "rfile.txt")
     res = run_cli(wd, "inverted", "precluster", "--skd", "other_k", "inverted.ski", ok=False)
     assert res.returncode == 101 and "K-mer size 21 used for .ski not found in .skd" in res.stderr
@@ -297,6 +302,8 @@ def test_inverted_precluster_reordered_index_and_retain(gpu_ctx, precluster_wd):
                      "--retain-unmatched", "singleton").stdout
     for i in lonely:                                                       # tests/inverted.rs:702-748
         assert f"{three[i]}\t{three[i]}\t0\n" in single
+    assert single == run_cli(wd, "inverted", "precluster", "--knn", "2", "--skd", "standard3", "sparse.ski",
+                             "--retain-unmatched", "singleton", "--host-candidates").stdout
     brute = run_cli(wd, "inverted", "precluster", "--knn", "2", "--skd", "standard3", "sparse.ski",
                     "--retain-unmatched", "bruteforce").stdout
     full = run_cli(wd, "dist", "standard3", "-k", "21", "--knn", "2").stdout

@@ -70,6 +70,9 @@ def test_synthetic_ragged_lists(oracle, skl, gpu_ctx, ani, comp):
     assert lens.min() == 0 and lens.max() > 64 and (lens < 5).any()
     for knn in (1, 5, 40):
         idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21, ani), knn, offs, cols)
+        # the same with the candidate lists built on the device from the index sketches
+        idx2, d02, total = skl.self_dists_knn_shared_bins(gpu_ctx, g, g.set_k(21, ani), knn, skq)
+        assert total == cols.size and np.array_equal(idx2, idx) and np.array_equal(d02, d0)
         exp = oracle.self_dists_knn_precluster(o, skq, knn, 1, ani, threads=8)
         if comp:
             assert np.array_equal(idx, exp["idx"].astype(np.uint64))
@@ -95,3 +98,26 @@ def test_reordered_index_and_errors(oracle, skl, gpu_ctx):
         skl.self_dists_knn_candidates(gpu_ctx, gpu_ctx.sketches(synth.set_r(4, [15, 19], 2), 4, [15, 19], 2),
                                       skl.params(), 1, np.zeros(5, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
     assert "single k-mer" in str(e.value)
+
+
+def test_device_candidate_lists_many_bins_and_samples(oracle, skl, gpu_ctx):
+    """cand_gen.hip on its own terms: 5 000 samples (157 bitmap words per row, 20 per thread),
+    300 bins (more bins than waves), values that collide in one bin only, a value shared by
+    everybody in one bin (a 5 000-member group), against the numpy definition."""
+    kmers, ss64, n = [21], 2, 5000
+    bins = synth.set_u(n, 1, ss64)
+    rng = np.random.default_rng(9)
+    skq = rng.integers(0, 65536, size=(n, 300), dtype=np.uint16)
+    skq[:, 7] = rng.integers(0, 400, size=n)            # small alphabet in bin 7: ~12 partners each
+    skq[::50, 250] = 4242                               # a 100-member group in bin 250
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    offs, cols = candidates(skq)
+    idx, d0, total = skl.self_dists_knn_shared_bins(gpu_ctx, g, g.set_k(21), 3, skq)
+    assert total == cols.size
+    idx_ref, d0_ref = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21), 3, offs, cols)
+    assert np.array_equal(idx, idx_ref) and np.array_equal(d0, d0_ref)
+    skq[:, 0] = 1                                       # everybody shares bin 0: all-vs-all
+    idx, d0, total = skl.self_dists_knn_shared_bins(gpu_ctx, g, g.set_k(21), 4, skq)
+    assert total == n * (n - 1)
+    fi, fd, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), 4)
+    assert np.array_equal(idx, fi) and np.array_equal(d0, fd)
