@@ -1,4 +1,10 @@
 #include "multisketch.hpp"
+#include <algorithm>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <thread>
+#include <atomic>
 
 #include <cstring>
 #include <fstream>
@@ -148,10 +154,39 @@ void MultiSketch::write_sketch_data(const std::string &file_prefix, const uint64
 
 void MultiSketch::read_sketch_data(const std::string &file_prefix)
 {
-    // read_all_from_skd streams the whole file (sketch_datafile.rs:159-168)
-    const std::vector<uint8_t> raw = read_file(file_prefix + ".skd");
-    sketch_bins_.resize(raw.size() / sizeof(uint64_t));
-    memcpy(sketch_bins_.data(), raw.data(), sketch_bins_.size() * sizeof(uint64_t));
+    // read_all_from_skd streams the whole file (sketch_datafile.rs:159-168); here straight into
+    // the bins, in slices read concurrently (a GB-sized .skd is otherwise a second of memcpy)
+    const std::string path = file_prefix + ".skd";
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st;
+    if (::fstat(fd, &st) != 0) {
+        ::close(fd);
+        throw std::runtime_error("cannot stat " + path);
+    }
+    const size_t bytes = (size_t)st.st_size / sizeof(uint64_t) * sizeof(uint64_t);
+    sketch_bins_.resize(bytes / sizeof(uint64_t));
+    char *dst = reinterpret_cast<char *>(sketch_bins_.data());
+    const size_t n_slices = bytes >= (64u << 20) ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::atomic<bool> ok{true};
+    auto read_slice = [&](size_t sl) {
+        size_t off = bytes * sl / n_slices;
+        const size_t end = bytes * (sl + 1) / n_slices;
+        while (off < end) {
+            const ssize_t got = ::pread(fd, dst + off, end - off, (off_t)off);
+            if (got <= 0) {
+                ok = false;
+                return;
+            }
+            off += (size_t)got;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t sl = 1; sl < n_slices; ++sl) pool.emplace_back(read_slice, sl);
+    read_slice(0);
+    for (auto &t : pool) t.join();
+    ::close(fd);
+    if (!ok) throw std::runtime_error("error reading " + path);
     block_reindex_.reset();
 }
 
