@@ -220,3 +220,17 @@ def test_usage_and_errors(wd):
     assert res.returncode == 1 and "missing.ski" in res.stderr
     res = run(wd, "inverted", "precluster", "x.ski", "--retain-unmatched", "maybe", ok=False)
     assert res.returncode == 2 and "singleton, bruteforce" in res.stderr
+
+
+def test_gpu_paths_refuse_without_a_device(wd, skl):
+    """No silent CPU fallback: the commands whose compute runs on the device fail loudly on a
+    box without one (the product has no CPU distance / candidate / hashing path behind them)."""
+    if skl.device_count() > 0:
+        pytest.skip("a GPU is present; the refusal path is only reachable without one")
+    res = run(wd, "sketch", "--gpu", "-o", "x", "-k", "21", "R6.fa.gz", ok=False)
+    assert res.returncode != 0 and "no CPU path" in res.stderr
+    run(wd, "inverted", "build", "-o", "idx", "-k", "21", "-s", "10", "--write-skq", "R6.fa.gz", "TIGR4.fa.gz")
+    run(wd, "sketch", "-o", "db", "-k", "21", "R6.fa.gz", "TIGR4.fa.gz")
+    for extra in ((), ("--host-candidates",)):
+        res = run(wd, "inverted", "precluster", "idx.ski", "--skd", "db", *extra, ok=False)
+        assert res.returncode != 0 and "no CPU path" in res.stderr
