@@ -71,6 +71,18 @@ def full_size(which):
         print(json.dumps({"mode": "cfg5 / 10: kNN-50 (Jaccard k=21), 1M refs x 100k query rows, 1 GPU",
                           "sketchsize64": 32, "pairs": nr * nq, "wall_s": wall,
                           "pairs_per_s": nr * nq / wall, "rows_per_s": nq / wall}), flush=True)
+        q.close()
+        r.close()
+        torch.cuda.empty_cache()
+    if "cfg5full" in which:
+        n = 1000000                # the whole of cfg 5: self kNN-50 over 1M x 1M
+        s = ctx.sketches(synth.set_u_device(n, 5, 32, dev), n, K4, 32)
+        t0 = time.perf_counter()
+        idx, d0, d1 = capi.self_dists_knn(ctx, s, s.set_k(21), 50)
+        wall = time.perf_counter() - t0
+        print(json.dumps({"mode": "cfg5 FULL: self kNN-50 (Jaccard k=21), 1M x 1M, 1 GPU", "sketchsize64": 32,
+                          "pair_evaluations": n * (n - 1), "wall_s": wall, "pairs_per_s": n * (n - 1) / wall,
+                          "rows_per_s": n / wall, "idx_checksum": int(idx.sum())}), flush=True)
 
 
 def main():
