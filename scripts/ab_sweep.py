@@ -66,11 +66,12 @@ def main():
     modes = sys.argv[2].split(",")
     variants = sys.argv[3:] or [""]
     K = [15, 19, 23, 27, 31]
+    SS64 = int(os.environ.get("AB_SS64", "64"))     # sketchsize64 of the synthetic database
     dev = torch.device("cuda", 0)
     default_lib = capi.load()
     state = {}   # library build -> (ctx, sketches)
     for n in ns:
-        bins = synth.set_u_device(n, 5, 64, dev)
+        bins = synth.set_u_device(n, 5, SS64, dev)
         for v in variants:
             L = lib_of(v)
             if id(L) not in state:
@@ -79,7 +80,7 @@ def main():
                 state[id(L)] = [ctx, None]
             if state[id(L)][1] is None:
                 capi._lib = L
-                state[id(L)][1] = state[id(L)][0].sketches(bins, n, K, 64)
+                state[id(L)][1] = state[id(L)][0].sketches(bins, n, K, SS64)
         del bins
         pairs = n * (n - 1) // 2
         for mode in modes:

@@ -96,8 +96,10 @@ struct skl_ctx {
     hipStream_t stream = nullptr;
     // grow-only scratch: 0 = dense band, 1 = bin-match counts (unfused core/acc),
     // 2 = kNN result staging
-    void *scratch[3] = {nullptr, nullptr, nullptr};
-    size_t scratch_bytes[3] = {0, 0, 0};
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // 0/3: key bands, 1: counts, 2: kNN staging
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
+    hipEvent_t knn_pair_done[2] = {nullptr, nullptr}, knn_topk_done[2] = {nullptr, nullptr};
     // timing of pair-kernel launches of the last call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -155,6 +157,15 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
         return fail(SKL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    for (int x = 0; x < 2 && e == hipSuccess; ++x) {
+        e = hipEventCreateWithFlags(&ctx->knn_pair_done[x], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->knn_topk_done[x], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(SKL_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e));
+    }
     {
         std::lock_guard<std::mutex> lock(g_registry_mutex);
         g_live_ctx.insert(ctx);
@@ -186,6 +197,11 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     if (ctx->tile_scratch.h_staging) (void)hipHostFree(ctx->tile_scratch.h_staging);
     if (ctx->tile_scratch.staged) (void)hipEventDestroy(ctx->tile_scratch.staged);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (int x = 0; x < 2; ++x) {
+        if (ctx->knn_pair_done[x]) (void)hipEventDestroy(ctx->knn_pair_done[x]);
+        if (ctx->knn_topk_done[x]) (void)hipEventDestroy(ctx->knn_topk_done[x]);
+    }
     delete ctx;
     return SKL_OK;
 }
@@ -864,19 +880,22 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         band_bytes = std::max(band_bytes, std::min<size_t>(free_b / 4, 8ull << 30));
     }
-    size_t band_rows = std::max<size_t>(1, band_bytes / (n_cand * rec));
+    // two key bands: the row-wise top-k of band i (memory / LDS bound, on the auxiliary stream)
+    // runs while the pair kernel of band i + 1 (VALU bound) fills the other one
+    size_t band_rows = std::max<size_t>(1, band_bytes / 2 / (n_cand * rec));
     static const size_t forced_band_rows = [] {
         const char *e = getenv("SKL_KNN_BAND_ROWS");  // test knob: force several bands
         return e ? (size_t)atoll(e) : (size_t)0;
     }();
     if (forced_band_rows) band_rows = forced_band_rows;
     band_rows = std::min(band_rows, r1 - r0);
+    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;
 
     // device staging for host-destined results
     uint64_t *d_idx = out_idx;
     float *d_d0 = out_d0, *d_d1 = out_d1;
     const size_t items = (r1 - r0) * knn;
-    void *band = nullptr;
+    void *band[2] = {nullptr, nullptr};
     if (!out_on_device) {
         void *stage = nullptr;
         SKL_TRY(ctx_scratch(ctx, items * (sizeof(uint64_t) + 2 * sizeof(float)), &stage, 2));
@@ -884,14 +903,25 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         d_d0 = (float *)(d_idx + items);
         d_d1 = d_d0 + items;
     }
-    SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band, 0));
+    SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[0], 0));
+    band[1] = band[0];
+    if (overlap) SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[1], 3));
+    hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
 
-    for (size_t b0 = r0; b0 < r1; b0 += band_rows) {
+    size_t it = 0;
+    for (size_t b0 = r0; b0 < r1; b0 += band_rows, ++it) {
         const size_t b1 = std::min(r1, b0 + band_rows);
-        SKL_TRY(dense_band(ctx, rows, cands, p, mode, jout, 0, b0, b1, band));
+        const int buf = overlap ? (int)(it & 1) : 0;
+        // the top-k that read this buffer two bands ago must be done before it is overwritten
+        if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
+        SKL_TRY(dense_band(ctx, rows, cands, p, mode, jout, 0, b0, b1, band[buf]));
+        if (overlap) {
+            HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
+        }
         TopkArgs t;
         memset(&t, 0, sizeof t);
-        t.keys = (const float *)band;
+        t.keys = (const float *)band[buf];
         t.rows = (uint32_t)(b1 - b0);
         t.cols = (uint32_t)n_cand;
         t.stride2 = coreacc ? 2 : 1;
@@ -902,7 +932,12 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         t.out_idx = d_idx + (b0 - r0) * knn;
         t.out_d0 = d_d0 + (b0 - r0) * knn;
         t.out_d1 = coreacc ? d_d1 + (b0 - r0) * knn : nullptr;
-        HIP_TRY(launch_topk(t, ctx->stream));
+        HIP_TRY(launch_topk(t, topk_stream));
+        if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
+    }
+    if (overlap) {   // results (and the band buffers) belong to the context's stream again
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
+        if (it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[1], 0));
     }
     if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out_idx, d_idx, items * sizeof(uint64_t), hipMemcpyDeviceToHost,
