@@ -490,7 +490,19 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
         for (uint32_t c = tid; c < n_cols; c += TOPK_THREADS) {
             if (c == self_col) continue;
             const uint32_t u = sortable_bits(keys[(size_t)c * g.stride2]);
-            if ((u & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(u >> (pass * 8)) & 0xFFu], 1u);
+            const bool in = (u & hi_mask) == (prefix & hi_mask);
+            const uint32_t bin = (u >> (pass * 8)) & 0xFFu;
+            // wave-aggregated update: distances cluster (unrelated genomes all sit at 1.0), so most
+            // lanes of a wave hit the same counter -- one lane adds the whole group
+            const uint32_t lead_bin = __builtin_amdgcn_readfirstlane(bin);
+            const uint64_t same = __ballot(in && bin == lead_bin);
+            if (in) {
+                if (bin == lead_bin) {
+                    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(same)) atomicAdd(&hist[bin], (uint32_t)__popcll(same));
+                } else {
+                    atomicAdd(&hist[bin], 1u);
+                }
+            }
         }
         __syncthreads();
         if (tid == 0) {
