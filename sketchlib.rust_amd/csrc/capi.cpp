@@ -99,6 +99,8 @@ struct skl_ctx {
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // 0/3: key bands, 1: counts, 2: kNN staging
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
+    // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
+    // "producer finished buffer b" / "consumer finished buffer b"
     hipEvent_t knn_pair_done[2] = {nullptr, nullptr}, knn_topk_done[2] = {nullptr, nullptr};
     // timing of pair-kernel launches of the last call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -754,9 +756,16 @@ static int dense_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches
     if (out_on_device) {
         return dense_band(ctx, rows, cols, p, mode, jout, self_mode, r0, r1, out);
     }
-    // host destination: bands of at most BAND_BYTES
+    // host destination: bands of at most BAND_BYTES through two device buffers -- band i is
+    // copied back on the auxiliary stream while band i + 1 is computed
     const uint64_t first = self_mode ? cond_index(r0, r0 + 1, n_cols) : r0 * n_cols;
+    void *dev[2] = {nullptr, nullptr};
+    const uint64_t all_pairs = self_mode ? self_rows_pairs(r0, r1, n_cols) : (r1 - r0) * n_cols;
+    const size_t band_alloc = (size_t)std::min<uint64_t>(BAND_BYTES, all_pairs * rec);
+    SKL_TRY(ctx_scratch(ctx, band_alloc, &dev[0], 0));
+    SKL_TRY(ctx_scratch(ctx, all_pairs * rec > BAND_BYTES ? band_alloc : 16, &dev[1], 3));
     uint64_t b0 = r0;
+    size_t it = 0;
     while (b0 < r1) {
         uint64_t b1 = b0;
         uint64_t pairs = 0;
@@ -766,15 +775,26 @@ static int dense_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches
             pairs += row_pairs;
             ++b1;
         }
-        void *dev = nullptr;
-        SKL_TRY(ctx_scratch(ctx, pairs * rec, &dev, 0));
-        SKL_TRY(dense_band(ctx, rows, cols, p, mode, jout, self_mode, b0, b1, dev));
+        const int buf = (int)(it & 1);
+        void *band = dev[buf];
+        if (pairs * rec > band_alloc) {   // a single row wider than a band: its own buffer
+            HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+            SKL_TRY(ctx_scratch(ctx, pairs * rec, &dev[buf], buf == 0 ? 0 : 3));
+            band = dev[buf];
+        }
+        // the copy that read this buffer two bands ago must be done before it is overwritten
+        if (it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
+        SKL_TRY(dense_band(ctx, rows, cols, p, mode, jout, self_mode, b0, b1, band));
+        HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->knn_pair_done[buf], 0));
         const uint64_t off = (self_mode ? cond_index(b0, b0 + 1, n_cols) : b0 * n_cols) - first;
-        HIP_TRY(hipMemcpyAsync((char *)out + off * rec, dev, pairs * rec, hipMemcpyDeviceToHost,
-                               ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpyAsync((char *)out + off * rec, band, pairs * rec, hipMemcpyDeviceToHost, ctx->aux_stream));
+        HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], ctx->aux_stream));
         b0 = b1;
+        ++it;
     }
+    HIP_TRY(hipStreamSynchronize(ctx->aux_stream));   // host memory is complete on return
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SKL_OK;
 }
 
