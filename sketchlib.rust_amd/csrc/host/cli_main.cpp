@@ -15,6 +15,7 @@
 #include <fstream>
 #include <algorithm>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <optional>
 #include <string>
@@ -447,7 +448,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     if (sub == "build") {
         g_usage = "sketchlib inverted build [OPTIONS] -o <OUTPUT> <SEQ_FILES|-f <FILE_LIST>>";
         std::vector<std::string> seq_files;
-        std::optional<std::string> file_list, output, species_names;
+        std::optional<std::string> file_list, output, species_names, metadata_file;
         bool write_skq_flag = false, single_strand = false;
         uint64_t sketch_size = 1000;   // DEFAULT_SKETCHSIZE, cli.rs:17
         size_t kmer = 21, threads = 1; // DEFAULT_KMER, cli.rs:13
@@ -459,10 +460,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
             else if (arg == "-o") output = next_value(i, "-o <OUTPUT>");
             else if (arg == "--write-skq") write_skq_flag = true;
             else if (arg == "--species-names") species_names = next_value(i, arg);
-            else if (arg == "--metadata") {
-                std::cerr << "error: --metadata is not part of this build\n";
-                return 2;
-            }
+            else if (arg == "--metadata") metadata_file = next_value(i, arg);
             else if (arg == "-s" || arg == "--sketch-size") sketch_size = parse_usize("--sketch-size <SKETCH_SIZE>", next_value(i, arg));
             else if (arg == "-k" || arg == "--kmer-length") kmer = parse_usize("--kmer-length <KMER_LENGTH>", next_value(i, arg));
             else if (arg == "--single-strand") single_strand = true;
@@ -529,6 +527,28 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
             log.info("Inverting sketch order");
             Inverted inv = Inverted::from_sketches(sketches, names, kmer, !single_strand);
             inv.labels = labels;
+            if (metadata_file) {   // parse_metadata_info, src/io.rs:118-137; lib.rs:557-568
+                std::ifstream mf(*metadata_file);
+                if (!mf) throw std::runtime_error("Unable to open species name file " + *metadata_file);
+                std::map<std::string, std::string> dict;
+                std::string line;
+                while (std::getline(mf, line)) {
+                    const size_t tab = line.find('\t');
+                    const std::string key = line.substr(0, tab);
+                    std::string val = tab == std::string::npos ? "" : line.substr(tab + 1);
+                    const size_t tab2 = val.find('\t');
+                    if (tab2 != std::string::npos) val.resize(tab2);
+                    if (!dict.emplace(key, val).second) throw std::runtime_error("Some entry in metadata is duplicated");
+                }
+                log.info("Got metadata for " + std::to_string(dict.size()) + " labels");
+                std::vector<std::string> md(inputs.size());
+                for (size_t i = 0; i < inputs.size(); ++i) {
+                    const auto it = dict.find(inputs[i].first);
+                    if (it == dict.end()) throw std::runtime_error("no metadata for sample " + inputs[i].first);
+                    md[order[i]] = it->second;
+                }
+                inv.metadata = md;
+            }
             inv.save(*output);
         } catch (const std::exception &e) {
             throw Panic(e.what());

@@ -212,6 +212,25 @@ def test_species_names_reorder_the_index(wd):
         "Identified 2 prefilter pairs from a max of 6\n"
 
 
+def test_metadata_is_stored_in_index_order(wd):
+    """tests/inverted.rs:52-77 (`inverted build --species-names --metadata`)."""
+    (wd / "metadata.txt").write_text("TIGR4.fa.gz\tMetadata of TIGR4\nR6.fa.gz\tMetadata of R6\n"
+                                     "14412_3#82.contigs_velvet.fa.gz\tMetadata of 14412_3 82\n"
+                                     "14412_3#84.contigs_velvet.fa.gz\tMetadata of 14412_3 84\n")
+    (wd / "species.txt").write_text("R6.fa.gz\tpneumo\nTIGR4.fa.gz\tpneumo\n")
+    run(wd, "inverted", "build", "-o", "meta", "-k", "31", "-f", "rfile.txt", "--species-names", "species.txt",
+        "--metadata", "metadata.txt")
+    ski, _ = cbor_decode(_py_unframe((wd / "meta.ski").read_bytes()))
+    assert ski["sample_names"][:2] == ["R6.fa.gz", "TIGR4.fa.gz"]
+    assert ski["metadata"] == ["Metadata of " + {"R6.fa.gz": "R6", "TIGR4.fa.gz": "TIGR4",
+                                                  "14412_3#82.contigs_velvet.fa.gz": "14412_3 82",
+                                                  "14412_3#84.contigs_velvet.fa.gz": "14412_3 84"}[n]
+                               for n in ski["sample_names"]]
+    (wd / "dup.txt").write_text("R6.fa.gz\ta\nR6.fa.gz\tb\n")
+    res = run(wd, "inverted", "build", "-o", "bad", "-k", "31", "-f", "rfile.txt", "--metadata", "dup.txt", ok=False)
+    assert res.returncode == 101 and "duplicated" in res.stderr
+
+
 def test_usage_and_errors(wd):
     assert run(wd, "inverted", ok=False).returncode == 2
     assert run(wd, "inverted", "query", "x.ski", ok=False).returncode == 2
