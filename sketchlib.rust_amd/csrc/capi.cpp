@@ -185,6 +185,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     if (!g_live_ctx.erase(ctx)) return SKL_OK;  // already destroyed
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     // slabs die with their context; their handles become inert
     const std::set<skl_sketches *> owned = ctx->sketches;
     for (skl_sketches *s : owned) free_sketches_locked(s);
@@ -275,19 +276,19 @@ static int forced_kernel()
     return 0;
 }
 
-// Two implementations of the same tile computation: rows through LDS broadcast
-// (pair_lds.hip, default) or through the scalar cache (kernels.hip).  SKL_KERNEL=smem
-// selects the latter (kept for A/B measurements).
+// One tile computation, four implementations (the dispatcher's rule is in DESIGN.md 4.2):
+//   kslice (pair_kslice.hip)  default: 16 x 128 tiles, chunks split over the 4 waves, rows by
+//                             LDS DMA; one workgroup per (tile, k) for small launches and for
+//                             single-k Jaccard, all k + fused regression otherwise
+//   ksplit (pair_ksplit.hip)  fallback for shapes kslice does not take (ss64 > 1023)
+//   lds    (pair_lds.hip)     R x 256/512 tiles, rows broadcast from LDS (A/B only)
+//   smem   (kernels.hip)      rows through the scalar cache (A/B only)
+// SKL_KERNEL = kslice | ksplit | lds | smem forces one.
 static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream,
                                        std::string *name, TileScratch &tiles)
 {
     static const char *mode_names[] = {"COUNTS", "JACCARD", "COREACC"};
     const std::string m = mode_names[mode];
-    // Three implementations of the same tile computation, chosen by launch size:
-    //   ksplit (pair_ksplit.hip)  small launches: chunks split over the 4 waves of a workgroup
-    //   lds    (pair_lds.hip)     large launches: R x 256/512 tiles, rows broadcast from LDS
-    //   smem   (kernels.hip)      rows through the scalar cache; kept for A/B measurements
-    // SKL_KERNEL = ksplit | lds | smem forces one.
     // (tuning knobs are read on every call so an A/B run can interleave variants in one
     // process: scripts/ab_sweep.py)
     const int forced = forced_kernel();
@@ -337,7 +338,11 @@ static int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int n
     if (ctx->events_used == ctx->events.size()) {
         hipEvent_t a, b;
         HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
+        const hipError_t eb = hipEventCreate(&b);
+        if (eb != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return fail(SKL_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(eb));
+        }
         ctx->events.emplace_back(a, b);
     }
     auto &ev = ctx->events[ctx->events_used++];
@@ -394,8 +399,14 @@ static int ensure_ytab(const skl_sketches *cs)
     const size_t m = 64 * s->ss64 + 1;
     std::vector<double> tab(m);
     for (size_t b = 0; b < m; ++b) tab[b] = std::log(host_jaccard((uint32_t)b, s->ss64));
-    HIP_TRY(hipMalloc((void **)&s->d_ytab, m * sizeof(double)));
-    HIP_TRY(hipMemcpy(s->d_ytab, tab.data(), m * sizeof(double), hipMemcpyHostToDevice));
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, m * sizeof(double)));
+    const hipError_t e = hipMemcpy(d, tab.data(), m * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(SKL_ERR_HIP, "ln J table upload: %s", hipGetErrorString(e));
+    }
+    s->d_ytab = d;
     return SKL_OK;
 }
 
@@ -423,7 +434,11 @@ static int ensure_dtab(const skl_sketches *cs, int jout, size_t k_idx, float **o
     }
     float *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, m * sizeof(float)));
-    HIP_TRY(hipMemcpy(d, tab.data(), m * sizeof(float), hipMemcpyHostToDevice));
+    const hipError_t e = hipMemcpy(d, tab.data(), m * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(SKL_ERR_HIP, "distance table upload: %s", hipGetErrorString(e));
+    }
     s->d_dtab[{jout, key_k}] = d;
     *out = d;
     return SKL_OK;
@@ -884,8 +899,9 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     if (coreacc && !out_d1) return fail(SKL_ERR_INVALID_ARG, "out_d1 is required for core/accessory");
     if (r0 > r1 || r1 > rows->n) return fail(SKL_ERR_INVALID_ARG, "row range out of bounds");
     const size_t n_cand = cands->n;
-    if (knn == 0 || knn > n_cand - (self_mode ? 1 : 0)) {
-        return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, n_cand - (self_mode ? 1 : 0));
+    const size_t max_knn = n_cand > (size_t)(self_mode ? 1 : 0) ? n_cand - (self_mode ? 1 : 0) : 0;
+    if (knn == 0 || knn > max_knn) {
+        return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, max_knn);
     }
     if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
     if (r1 == r0) return SKL_OK;
@@ -903,10 +919,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     // two key bands: the row-wise top-k of band i (memory / LDS bound, on the auxiliary stream)
     // runs while the pair kernel of band i + 1 (VALU bound) fills the other one
     size_t band_rows = std::max<size_t>(1, band_bytes / 2 / (n_cand * rec));
-    static const size_t forced_band_rows = [] {
-        const char *e = getenv("SKL_KNN_BAND_ROWS");  // test knob: force several bands
-        return e ? (size_t)atoll(e) : (size_t)0;
-    }();
+    const size_t forced_band_rows = (size_t)std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));  // test knob: force several bands
     if (forced_band_rows) band_rows = forced_band_rows;
     band_rows = std::min(band_rows, r1 - r0);
     const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;

@@ -118,6 +118,12 @@ def test_incompatible_and_empty_databases(skl, gpu_ctx):
     with pytest.raises(skl.SklError) as e:
         skl.cross_dists_knn(gpu_ctx, a, empty, a.set_k(), 1)
     assert e.value.code == skl.ERR_EMPTY_DB and "Query database has no loaded samples" in e.value.message
+    # self kNN over zero or one sample has no neighbour to report: an argument error, not a crash
+    one = gpu_ctx.sketches(synth.set_u(1, 2, 2), 1, [17, 21], 2)
+    for db in (empty, one):
+        with pytest.raises(skl.SklError) as e:
+            skl.self_dists_knn(gpu_ctx, db, db.set_k(), 1)
+        assert e.value.code == skl.ERR_INVALID_ARG
 
 
 def test_one_shot_host_entry_point(oracle, skl, gpu_ctx):

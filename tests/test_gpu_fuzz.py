@@ -76,7 +76,7 @@ def test_random_configuration(oracle, skl, gpu_ctx, seed):
 
 
 def test_knn_multiple_bands_subprocess(oracle):
-    """Force 7-row bands (SKL_KNN_BAND_ROWS is read once per process) and compare with the oracle."""
+    """Force 7-row bands (child process: the knob stays out of the other tests) and compare with the oracle."""
     code = r"""
 import sys; sys.path.insert(0, %r)
 import numpy as np
