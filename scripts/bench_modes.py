@@ -74,20 +74,41 @@ def full_size(which):
         q.close()
         r.close()
         torch.cuda.empty_cache()
-    if "cfg5full" in which:
-        n = 1000000                # the whole of cfg 5: self kNN-50 over 1M x 1M
-        s = ctx.sketches(synth.set_u_device(n, 5, 32, dev), n, K4, 32)
-        t0 = time.perf_counter()
-        idx, d0, d1 = capi.self_dists_knn(ctx, s, s.set_k(21), 50)
-        wall = time.perf_counter() - t0
-        print(json.dumps({"mode": "cfg5 FULL: self kNN-50 (Jaccard k=21), 1M x 1M, 1 GPU", "sketchsize64": 32,
-                          "pair_evaluations": n * (n - 1), "wall_s": wall, "pairs_per_s": n * (n - 1) / wall,
-                          "rows_per_s": n / wall, "idx_checksum": int(idx.sum())}), flush=True)
+    for tag in [w for w in which if w.startswith("cfg5full") or w.startswith("knn")]:
+        # cfg5full[_r][@rows]: the whole of cfg 5, self kNN-50 over 1M x 1M; knn<N>[_r]: the same at n = N.
+        # _r = clustered sketches (200 close neighbours per row) instead of Set U (every key ties at 1.0).
+        # Each data set runs in both forms of the driver: every pair once (symmetric) and row by row.
+        n = 1000000 if tag.startswith("cfg5full") else int(tag[3:].split("_")[0])
+        clustered = tag.endswith("_r")
+        bins = (synth.set_clustered_device(n, 5, 32, dev) if clustered else synth.set_u_device(n, 5, 32, dev))
+        s = ctx.sketches(bins, n, K4, 32)
+        del bins
+        torch.cuda.empty_cache()
+        ref = None
+        for sym in ("1", "0"):
+            os.environ["SKL_KNN_SYMMETRIC"] = sym
+            ctx.timing_reset()
+            t0 = time.perf_counter()
+            idx, d0, d1 = capi.self_dists_knn(ctx, s, s.set_k(21), 50)
+            wall = time.perf_counter() - t0
+            kms, launches = ctx.kernel_ms()
+            same = None if ref is None else bool((ref[0] == idx).all() and (ref[1] == d0).all())
+            ref = (idx, d0)
+            print(json.dumps({"mode": f"self kNN-50 (Jaccard k=21), {n} x {n}, 1 GPU, "
+                                      f"{'clustered' if clustered else 'Set U'}",
+                              "driver": "every pair once" if sym == "1" else "row by row", "sketchsize64": 32,
+                              "pair_distances_defined": n * (n - 1), "wall_s": wall, "pair_kernel_s": kms / 1e3,
+                              "pair_launches": launches, "pairs_per_s": n * (n - 1) / wall, "rows_per_s": n / wall,
+                              "idx_checksum": int(idx.sum()), "mean_nearest": float(d0[:, 0].mean()),
+                              "same_as_previous_driver": same}), flush=True)
+        os.environ.pop("SKL_KNN_SYMMETRIC", None)
+        s.close()
+        torch.cuda.empty_cache()
 
 
 def main():
     which = sys.argv[1:] or ["self50k", "cross", "selfknn", "crossknn"]
-    if any(w.startswith("cfg") for w in which):
+    if any(w.startswith("cfg") or w.startswith("knn") for w in which):
         full_size(which)
         return
     if "self50k" in which:

@@ -94,10 +94,9 @@ struct skl_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    // grow-only scratch: 0 = dense band, 1 = bin-match counts (unfused core/acc),
-    // 2 = kNN result staging
-    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // 0/3: key bands, 1: counts, 2: kNN staging
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    // grow-only scratch
+    void *scratch[6] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN)
+    size_t scratch_bytes[6] = {};
     hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
     // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
     // "producer finished buffer b" / "consumer finished buffer b"
@@ -889,53 +888,122 @@ extern "C" int skl_cross_binmatch(skl_ctx *ctx, const skl_sketches *ref,
 // sparse kNN: dense row bands into scratch, then a row-wise top-k kernel
 // ---------------------------------------------------------------------------
 
-static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
-                    const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
-                    uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device)
+// Symmetric self kNN (whole matrix in one call, single-k keys): band [b0, b1) is compared with the
+// columns from b0 on only.  The pair kernel stores every key twice -- row-major for the rows of
+// the band, and turned (pair_kslice.hip, out_t) as candidates of the rows below the band -- and
+// both copies are merged into a running per-row top-k (topk_merge_kernel), so each (i, j) is
+// evaluated once instead of twice (the reference evaluates both, mod.rs:148-171; distances are
+// symmetric).  Same neighbours, same order as the row-by-row form.
+static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
 {
-    SKL_TRY(ctx_bind(ctx));
-    if (!out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "output pointers are null");
-    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
-    if (coreacc && !out_d1) return fail(SKL_ERR_INVALID_ARG, "out_d1 is required for core/accessory");
-    if (r0 > r1 || r1 > rows->n) return fail(SKL_ERR_INVALID_ARG, "row range out of bounds");
-    const size_t n_cand = cands->n;
-    const size_t max_knn = n_cand > (size_t)(self_mode ? 1 : 0) ? n_cand - (self_mode ? 1 : 0) : 0;
-    if (knn == 0 || knn > max_knn) {
-        return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, max_knn);
-    }
-    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
-    if (r1 == r0) return SKL_OK;
+    if (p->dist_type != SKL_DIST_JACCARD || s->ss64 > 1023) return false;
+    const int forced = forced_kernel();
+    if (forced != 0 && forced != 4) return false;          // the turned store lives in pair_kslice.hip
+    const long long shape = env_int("SKL_KSLICE_SHAPE", 0);
+    if (shape != 0 && shape != 81 && shape != 82 && shape != 161 && shape != 162) return false;
+    return env_int("SKL_KNN_SYMMETRIC", 1) != 0;
+}
 
+static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                              size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0)
+{
+    const size_t n = s->n;
+    const size_t t_stride = (band_rows + 15) / 16 * 16;
+    const int jout = p->ani ? JOUT_ANI_KEY : JOUT_DIST;
+    void *kband[2] = {nullptr, nullptr}, *tband[2] = {nullptr, nullptr};
+    SKL_TRY(ctx_scratch(ctx, band_rows * n * sizeof(float), &kband[0], 0));
+    SKL_TRY(ctx_scratch(ctx, n * t_stride * sizeof(float), &tband[0], 4));
+    kband[1] = kband[0];
+    tband[1] = tband[0];
+    if (overlap) {
+        SKL_TRY(ctx_scratch(ctx, band_rows * n * sizeof(float), &kband[1], 3));
+        SKL_TRY(ctx_scratch(ctx, n * t_stride * sizeof(float), &tband[1], 5));
+    }
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } run_key, run_idx;
+    HIP_TRY(hipMalloc(&run_key.p, n * knn * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&run_idx.p, n * knn * sizeof(uint32_t)));
+    hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
+    HIP_TRY(hipMemsetAsync(run_key.p, 0xFF, n * knn * sizeof(uint32_t), ctx->stream));   // empty states
+    HIP_TRY(hipMemsetAsync(run_idx.p, 0xFF, n * knn * sizeof(uint32_t), ctx->stream));
+
+    const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
+    size_t it = 0;
+    for (size_t b0 = 0; b0 < n; b0 += band_rows, ++it) {
+        const size_t b1 = std::min(n, b0 + band_rows);
+        const int buf = overlap ? (int)(it & 1) : 0;
+        if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
+        // the band against the column view that starts at the 64-column block holding b0
+        const size_t col0 = b0 / 64 * 64;
+        PairArgs g;
+        SKL_TRY(fill_args(s, s, p, MODE_JACCARD, jout, &g));
+        g.B += (b0 / 64) * jb_words;
+        g.nB = (uint32_t)(n - col0);
+        if (g.compB) g.compB += col0;
+        g.row_begin = (uint32_t)b0;
+        g.row_end = (uint32_t)b1;
+        g.self_mode = 0;
+        g.out_base = (uint64_t)b0 * g.nB;
+        g.out = kband[buf];
+        g.out_t = b1 < n ? (float *)tband[buf] : nullptr;
+        g.t_col_begin = (uint32_t)(b1 - col0);
+        g.t_stride = (uint32_t)t_stride;
+        SKL_TRY(timed_pair_launch(ctx, g, MODE_JACCARD, choose_na(b1 - b0, g.nB, 0, MODE_JACCARD)));
+        if (overlap) {
+            HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
+        }
+        TopkMergeArgs m;
+        memset(&m, 0, sizeof m);
+        m.knn = (uint32_t)knn;
+        m.run_key = (uint32_t *)run_key.p;
+        m.run_idx = (uint32_t *)run_idx.p;
+        // rows of the band: columns [b0, n) minus themselves (the view's first b0 - col0 columns
+        // reached them turned, from earlier bands)
+        m.keys = (const float *)kband[buf];
+        m.key_stride = g.nB;
+        m.rows = (uint32_t)(b1 - b0);
+        m.cols = g.nB;
+        m.id_base = (uint32_t)col0;
+        m.skip_below = (uint32_t)b0;
+        m.row_id_base = (uint32_t)b0;
+        HIP_TRY(launch_topk_merge(m, topk_stream));
+        // rows below the band: the band's samples as their candidates
+        m.keys = (const float *)tband[buf];
+        m.key_stride = t_stride;
+        m.rows = (uint32_t)(n - b1);
+        m.cols = (uint32_t)(b1 - b0);
+        m.id_base = (uint32_t)b0;
+        m.skip_below = 0;
+        m.row_id_base = (uint32_t)b1;
+        HIP_TRY(launch_topk_merge(m, topk_stream));
+        if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
+    }
+    HIP_TRY(launch_topk_finalize((const uint32_t *)run_key.p, (const uint32_t *)run_idx.p, n * knn, p->ani ? 1 : 0,
+                                 d_idx, d_d0, topk_stream));
+    if (overlap) {   // results (and the band buffers) belong to the context's stream again
+        HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
+    return SKL_OK;
+}
+
+// Row-by-row kNN: dense bands of keys into scratch, then the row-wise top-k kernel.  With two
+// key bands the top-k of band i (memory / LDS bound, on the auxiliary stream) runs while the pair
+// kernel of band i + 1 (VALU bound) fills the other one.
+static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
+                           const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
+                           size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
+{
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
     const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
     const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
     const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
-    // the key band lives only on the device: take up to a quarter of the free HBM (<= 8 GiB)
-    // so that the row-wise top-k kernel has thousands of rows (= workgroups) per launch
-    size_t free_b = 0, total_b = 0;
-    size_t band_bytes = BAND_BYTES;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        band_bytes = std::max(band_bytes, std::min<size_t>(free_b / 4, 8ull << 30));
-    }
-    // two key bands: the row-wise top-k of band i (memory / LDS bound, on the auxiliary stream)
-    // runs while the pair kernel of band i + 1 (VALU bound) fills the other one
-    size_t band_rows = std::max<size_t>(1, band_bytes / 2 / (n_cand * rec));
-    const size_t forced_band_rows = (size_t)std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));  // test knob: force several bands
-    if (forced_band_rows) band_rows = forced_band_rows;
-    band_rows = std::min(band_rows, r1 - r0);
-    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;
-
-    // device staging for host-destined results
-    uint64_t *d_idx = out_idx;
-    float *d_d0 = out_d0, *d_d1 = out_d1;
-    const size_t items = (r1 - r0) * knn;
+    const size_t n_cand = cands->n;
     void *band[2] = {nullptr, nullptr};
-    if (!out_on_device) {
-        void *stage = nullptr;
-        SKL_TRY(ctx_scratch(ctx, items * (sizeof(uint64_t) + 2 * sizeof(float)), &stage, 2));
-        d_idx = (uint64_t *)stage;
-        d_d0 = (float *)(d_idx + items);
-        d_d1 = d_d0 + items;
-    }
     SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[0], 0));
     band[1] = band[0];
     if (overlap) SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[1], 3));
@@ -971,6 +1039,66 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     if (overlap) {   // results (and the band buffers) belong to the context's stream again
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
         if (it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[1], 0));
+    }
+    return SKL_OK;
+}
+
+static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
+                    const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
+                    uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "output pointers are null");
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    if (coreacc && !out_d1) return fail(SKL_ERR_INVALID_ARG, "out_d1 is required for core/accessory");
+    if (r0 > r1 || r1 > rows->n) return fail(SKL_ERR_INVALID_ARG, "row range out of bounds");
+    const size_t n_cand = cands->n;
+    const size_t max_knn = n_cand > (size_t)(self_mode ? 1 : 0) ? n_cand - (self_mode ? 1 : 0) : 0;
+    if (knn == 0 || knn > max_knn) {
+        return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, max_knn);
+    }
+    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
+    if (r1 == r0) return SKL_OK;
+
+    const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
+    // the key band lives only on the device: take up to a quarter of the free HBM (<= 8 GiB)
+    // so that the row-wise top-k kernel has thousands of rows (= workgroups) per launch
+    size_t free_b = 0, total_b = 0;
+    size_t band_bytes = BAND_BYTES;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        band_bytes = std::max(band_bytes, std::min<size_t>(free_b / 4, 8ull << 30));
+    }
+    size_t band_rows = std::max<size_t>(1, band_bytes / 2 / (n_cand * rec));   // two key bands
+    const size_t forced_band_rows = (size_t)std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));  // test knob: force several bands
+    if (forced_band_rows) band_rows = forced_band_rows;
+    band_rows = std::min(band_rows, r1 - r0);
+    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;
+    // the whole self matrix in more than one band: evaluate each pair once
+    const bool symmetric = self_mode && r0 == 0 && r1 == n_cand && band_rows < n_cand && knn_symmetric_ok(rows, p);
+    if (symmetric && !forced_band_rows) {
+        // four band buffers instead of two, and none of them needs to stay small: up to half of
+        // the free HBM (<= 32 GiB) -- fewer, larger merges
+        size_t budget = band_bytes;
+        if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, 32ull << 30));
+        band_rows = std::max<size_t>(16, budget / 4 / (n_cand * rec) / 16 * 16);
+        band_rows = std::min(band_rows, n_cand);
+    }
+
+    // device staging for host-destined results
+    uint64_t *d_idx = out_idx;
+    float *d_d0 = out_d0, *d_d1 = out_d1;
+    const size_t items = (r1 - r0) * knn;
+    if (!out_on_device) {
+        void *stage = nullptr;
+        SKL_TRY(ctx_scratch(ctx, items * (sizeof(uint64_t) + 2 * sizeof(float)), &stage, 2));
+        d_idx = (uint64_t *)stage;
+        d_d0 = (float *)(d_idx + items);
+        d_d1 = d_d0 + items;
+    }
+    if (symmetric) {
+        SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0));
+    } else {
+        SKL_TRY(knn_rows_banded(ctx, rows, cands, p, knn, self_mode, r0, r1, band_rows, overlap, d_idx, d_d0, d_d1));
     }
     if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out_idx, d_idx, items * sizeof(uint64_t), hipMemcpyDeviceToHost,

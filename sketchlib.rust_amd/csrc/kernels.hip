@@ -452,11 +452,145 @@ __device__ __forceinline__ uint32_t sortable_bits(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+__device__ __forceinline__ float from_sortable_bits(uint32_t s)
+{
+    return __uint_as_float((s & 0x80000000u) ? (s & 0x7FFFFFFFu) : ~s);
+}
+
+struct TopkShared {
+    uint32_t hist[256];
+    uint32_t prefix, remaining, count, taken;
+    uint32_t wave_cnt[TOPK_THREADS / 64];
+    uint64_t items[TOPK_MAX];  // (sortable key << 32) | position
+};
+
+// Bitonic sort of sh.items[0, m) (m a power of two), ascending.
+__device__ __forceinline__ void sort_items(TopkShared &sh, uint32_t m)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t size = 2; size <= m; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t x = tid; x < m / 2; x += TOPK_THREADS) {
+                const uint32_t lo = 2 * x - (x & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = sh.items[lo], b = sh.items[hi];
+                if ((a > b) == up) {
+                    sh.items[lo] = b;
+                    sh.items[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// The knn_eff smallest (key, position) of positions [0, n_items) for which item(c, u) is true
+// (u = sortable key bits), left sorted in sh.items[0, knn_eff).  At least knn_eff positions
+// must be valid.  Called by the whole workgroup.
+template <class Item>
+__device__ __forceinline__ void select_smallest(const Item &item, uint32_t n_items, uint32_t knn_eff, TopkShared &sh)
+{
+    const uint32_t tid = threadIdx.x;
+    // ---- radix select: key value of the knn-th smallest ----
+    if (tid == 0) {
+        sh.prefix = 0;
+        sh.remaining = knn_eff;
+    }
+    __syncthreads();
+    for (int pass = 3; pass >= 0; --pass) {
+        sh.hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh.prefix;
+        const uint32_t hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << ((pass + 1) * 8));
+        for (uint32_t c = tid; c < n_items; c += TOPK_THREADS) {
+            uint32_t u;
+            if (!item(c, u)) continue;
+            const bool in = (u & hi_mask) == (prefix & hi_mask);
+            const uint32_t bin = (u >> (pass * 8)) & 0xFFu;
+            // wave-aggregated update: distances cluster (unrelated genomes all sit at 1.0), so most
+            // lanes of a wave hit the same counter -- one lane adds the whole group
+            const uint32_t lead_bin = __builtin_amdgcn_readfirstlane(bin);
+            const uint64_t same = __ballot(in && bin == lead_bin);
+            if (in) {
+                if (bin == lead_bin) {
+                    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(same)) atomicAdd(&sh.hist[bin], (uint32_t)__popcll(same));
+                } else {
+                    atomicAdd(&sh.hist[bin], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t rem = sh.remaining, b = 0;
+            for (; b < 256; ++b) {
+                if (sh.hist[b] >= rem) break;
+                rem -= sh.hist[b];
+            }
+            if (b > 255) b = 255;
+            sh.prefix = prefix | (b << (pass * 8));
+            sh.remaining = rem;
+        }
+        __syncthreads();
+    }
+    const uint32_t thresh = sh.prefix;      // exact key bits of the knn-th smallest
+    const uint32_t take_eq = sh.remaining;  // how many == thresh to take, lowest position first
+
+    // ---- collect: everything below the threshold (any order) ----
+    if (tid == 0) {
+        sh.count = 0;
+        sh.taken = 0;
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < n_items; c += TOPK_THREADS) {
+        uint32_t u;
+        if (!item(c, u)) continue;
+        if (u < thresh) {
+            const uint32_t pos = atomicAdd(&sh.count, 1u);
+            sh.items[pos] = ((uint64_t)u << 32) | c;
+        }
+    }
+    __syncthreads();
+    // ---- ties at the threshold: ordered compaction, lowest position first ----
+    const uint32_t n_less = sh.count;
+    for (uint32_t base = 0; base < n_items && sh.taken < take_eq; base += TOPK_THREADS) {
+        const uint32_t c = base + tid;
+        bool eq = false;
+        if (c < n_items) {
+            uint32_t u;
+            eq = item(c, u) && u == thresh;
+        }
+        // block-wide exclusive prefix of `eq` via per-wave ballots
+        const uint64_t ballot = __ballot(eq);
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(ballot);
+        __syncthreads();
+        uint32_t before = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) before += sh.wave_cnt[w];
+        const uint32_t taken = sh.taken;
+        if (eq && taken + before < take_eq) {
+            sh.items[n_less + taken + before] = ((uint64_t)thresh << 32) | c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < TOPK_THREADS / 64; ++w) tot += sh.wave_cnt[w];
+            sh.taken = taken + tot;
+        }
+        __syncthreads();
+    }
+
+    // ---- bitonic sort of the knn items by (key, position) ----
+    uint32_t m = 1;
+    while (m < knn_eff) m <<= 1;
+    for (uint32_t x = knn_eff + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
+    __syncthreads();
+    sort_items(sh, m);
+}
+
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
 {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh_prefix, sh_remaining, sh_count, sh_taken;
-    __shared__ uint64_t items[TOPK_MAX];  // (sortable key << 32) | col
+    __shared__ TopkShared sh;
 
     const uint32_t row = blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -475,117 +609,16 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
         }
         if (knn_eff == 0) return;
     }
-
-    // ---- radix select: key value of the knn-th smallest ----
-    if (tid == 0) {
-        sh_prefix = 0;
-        sh_remaining = knn_eff;
-    }
-    __syncthreads();
-    for (int pass = 3; pass >= 0; --pass) {
-        hist[tid] = 0;
-        __syncthreads();
-        const uint32_t prefix = sh_prefix;
-        const uint32_t hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << ((pass + 1) * 8));
-        for (uint32_t c = tid; c < n_cols; c += TOPK_THREADS) {
-            if (c == self_col) continue;
-            const uint32_t u = sortable_bits(keys[(size_t)c * g.stride2]);
-            const bool in = (u & hi_mask) == (prefix & hi_mask);
-            const uint32_t bin = (u >> (pass * 8)) & 0xFFu;
-            // wave-aggregated update: distances cluster (unrelated genomes all sit at 1.0), so most
-            // lanes of a wave hit the same counter -- one lane adds the whole group
-            const uint32_t lead_bin = __builtin_amdgcn_readfirstlane(bin);
-            const uint64_t same = __ballot(in && bin == lead_bin);
-            if (in) {
-                if (bin == lead_bin) {
-                    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(same)) atomicAdd(&hist[bin], (uint32_t)__popcll(same));
-                } else {
-                    atomicAdd(&hist[bin], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t rem = sh_remaining, b = 0;
-            for (; b < 256; ++b) {
-                if (hist[b] >= rem) break;
-                rem -= hist[b];
-            }
-            if (b > 255) b = 255;
-            sh_prefix = prefix | (b << (pass * 8));
-            sh_remaining = rem;
-        }
-        __syncthreads();
-    }
-    const uint32_t thresh = sh_prefix;   // exact key bits of the knn-th smallest
-    const uint32_t take_eq = sh_remaining;  // how many == thresh to take, lowest index first
-
-    // ---- collect: everything below the threshold (any order) ----
-    if (tid == 0) {
-        sh_count = 0;
-        sh_taken = 0;
-    }
-    __syncthreads();
-    for (uint32_t c = tid; c < n_cols; c += TOPK_THREADS) {
-        if (c == self_col) continue;
-        const uint32_t u = sortable_bits(keys[(size_t)c * g.stride2]);
-        if (u < thresh) {
-            const uint32_t pos = atomicAdd(&sh_count, 1u);
-            items[pos] = ((uint64_t)u << 32) | c;
-        }
-    }
-    __syncthreads();
-    // ---- ties at the threshold: ordered compaction, lowest column first ----
-    const uint32_t n_less = sh_count;
-    for (uint32_t base = 0; base < n_cols && sh_taken < take_eq; base += TOPK_THREADS) {
-        const uint32_t c = base + tid;
-        bool eq = false;
-        if (c < n_cols && c != self_col) {
-            eq = sortable_bits(keys[(size_t)c * g.stride2]) == thresh;
-        }
-        // block-wide exclusive prefix of `eq` via per-wave ballots
-        const uint64_t ballot = __ballot(eq);
-        const uint32_t wave = tid >> 6, lane = tid & 63u;
-        __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(ballot);
-        __syncthreads();
-        uint32_t before = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; ++w) before += wave_cnt[w];
-        const uint32_t taken = sh_taken;
-        if (eq && taken + before < take_eq) {
-            items[n_less + taken + before] = ((uint64_t)thresh << 32) | c;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t tot = 0;
-            for (uint32_t w = 0; w < TOPK_THREADS / 64; ++w) tot += wave_cnt[w];
-            sh_taken = taken + tot;
-        }
-        __syncthreads();
-    }
-
-    // ---- bitonic sort of the knn items by (key, col) ----
-    uint32_t m = 1;
-    while (m < knn_eff) m <<= 1;
-    for (uint32_t x = knn_eff + tid; x < m; x += TOPK_THREADS) items[x] = ~0ull;
-    __syncthreads();
-    for (uint32_t size = 2; size <= m; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t x = tid; x < m / 2; x += TOPK_THREADS) {
-                const uint32_t lo = 2 * x - (x & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint64_t a = items[lo], b = items[hi];
-                if ((a > b) == up) {
-                    items[lo] = b;
-                    items[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
+    const uint32_t stride2 = g.stride2;
+    select_smallest(
+        [&](uint32_t c, uint32_t &u) {
+            if (c == self_col) return false;
+            u = sortable_bits(keys[(size_t)c * stride2]);
+            return true;
+        },
+        n_cols, knn_eff, sh);
     for (uint32_t x = tid; x < knn_eff; x += TOPK_THREADS) {
-        const uint32_t col = (uint32_t)(items[x] & 0xFFFFFFFFu);
+        const uint32_t col = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
         const size_t o = (size_t)row * g.knn + x;
         const float key = keys[(size_t)col * g.stride2];
         g.out_idx[o] = g.col_ids ? g.col_ids[row_base + col] : col;
@@ -599,6 +632,114 @@ hipError_t launch_topk(const TopkArgs &args, hipStream_t stream)
     if (args.rows == 0) return hipSuccess;
     if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+// Running top-k of one row (TopkMergeArgs).  Most calls end after the first pass: once a row's
+// state is warm, a band rarely holds a key below its knn-th best.
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMergeArgs g)
+{
+    __shared__ TopkShared sh;
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    const uint32_t grow = g.row_id_base + row;
+    const uint32_t knn = g.knn;
+    uint32_t *sk = g.run_key + (size_t)grow * knn;
+    uint32_t *si = g.run_idx + (size_t)grow * knn;
+    const float *keys = g.keys + (size_t)row * g.key_stride;
+    const uint32_t worst = sk[knn - 1];   // 0xFFFFFFFF while the state is not full
+
+    auto fresh = [&](uint32_t q, uint32_t &u) {   // new key at position q of this launch
+        const uint32_t id = g.id_base + q;
+        if (id < g.skip_below || id == grow) return false;
+        u = sortable_bits(keys[q]);
+        return true;
+    };
+
+    // ---- pass 1: how many new keys beat the current knn-th best?  (a tie loses: its id is larger) ----
+    if (tid == 0) sh.count = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t q = tid; q < g.cols; q += TOPK_THREADS) {
+        uint32_t u;
+        if (fresh(q, u) && u < worst) ++mine;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((tid & 63u) == 0 && mine) atomicAdd(&sh.count, mine);
+    __syncthreads();
+    const uint32_t n_better = sh.count;
+    if (n_better == 0) return;
+    __syncthreads();
+
+    if (n_better + knn <= (uint32_t)TOPK_MAX) {
+        // ---- few: sort state + qualifiers in LDS ----
+        for (uint32_t x = tid; x < knn; x += TOPK_THREADS) sh.items[x] = ((uint64_t)sk[x] << 32) | x;
+        if (tid == 0) sh.count = knn;
+        __syncthreads();
+        for (uint32_t q = tid; q < g.cols; q += TOPK_THREADS) {
+            uint32_t u;
+            if (fresh(q, u) && u < worst) {
+                const uint32_t pos = atomicAdd(&sh.count, 1u);
+                sh.items[pos] = ((uint64_t)u << 32) | (knn + q);
+            }
+        }
+        __syncthreads();
+        const uint32_t total = knn + n_better;
+        uint32_t m = 1;
+        while (m < total) m <<= 1;
+        for (uint32_t x = total + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
+        __syncthreads();
+        sort_items(sh, m);
+    } else {
+        // ---- many (a cold state): select over state ++ new keys ----
+        select_smallest(
+            [&](uint32_t c, uint32_t &u) {
+                if (c < knn) {
+                    u = sk[c];
+                    return true;
+                }
+                return fresh(c - knn, u);
+            },
+            knn + g.cols, knn, sh);
+    }
+    // ---- items[0, knn) = the new state as (key, position): resolve ids, then write in place ----
+    for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+        const uint32_t pos = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+        const uint32_t id = pos < knn ? si[pos] : g.id_base + (pos - knn);
+        sh.items[x] = (sh.items[x] & 0xFFFFFFFF00000000ull) | id;
+    }
+    __syncthreads();
+    for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+        sk[x] = (uint32_t)(sh.items[x] >> 32);
+        si[x] = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+    }
+}
+
+hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0 || args.cols == 0) return hipSuccess;
+    if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+__global__ void topk_finalize_kernel(const uint32_t *run_key, const uint32_t *run_idx, uint64_t items, int ani_undo,
+                                     uint64_t *out_idx, float *out_d0)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < items; x += stride) {
+        const float key = from_sortable_bits(run_key[x]);
+        out_idx[x] = run_idx[x];
+        out_d0[x] = ani_undo ? 1.0f - key : key;
+    }
+}
+
+hipError_t launch_topk_finalize(const uint32_t *run_key, const uint32_t *run_idx, uint64_t items, int ani_undo,
+                                uint64_t *out_idx, float *out_d0, hipStream_t stream)
+{
+    if (items == 0) return hipSuccess;
+    const uint64_t blocks = std::min<uint64_t>((items + 255) / 256, 65536);
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, run_key, run_idx, items,
+                       ani_undo, out_idx, out_d0);
     return hipGetLastError();
 }
 

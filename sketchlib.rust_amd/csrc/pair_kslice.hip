@@ -303,6 +303,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
         }
         __syncthreads();
         // wave w finishes packed slots x = w (mod 4); fields stay below 2^16 (ss64 <= 1023)
+        float tval[(MODE == MODE_JACCARD && KSL) ? SLOTS * 2 : 1];   // this wave's keys, for out_t
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const uint32_t x = (uint32_t)i * W + wave;
@@ -319,8 +320,47 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
                     const uint32_t mism = h ? (total >> 16) : (total & 0xFFFFu);
                     if constexpr (MODE == MODE_COUNTS) {
                         store_count(g, a0 + r, (jb0 + j) * 64u + lane, kk, mism);
+                    } else if constexpr (KSL) {
+                        const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
+                        float v = __builtin_inff();
+                        if (pair_valid(g, i_, jc_)) {
+                            v = jaccard_out_value(g, i_, jc_, mism);
+                            ((float *)g.out)[pair_out_index(g, i_, jc_)] = v;
+                        }
+                        tval[i * 2 + h] = v;
                     } else {
                         store_jaccard(g, a0 + r, (jb0 + j) * 64u + lane, mism);
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == MODE_JACCARD && KSL) {
+            // Symmetric self kNN: the keys of columns >= t_col_begin are also candidates of the
+            // ROW with that sample id.  The tile is turned through LDS so that a column's R keys
+            // leave as R/4 16-byte stores (one 64-byte run per column at R = 16).
+            if (g.out_t != nullptr && min((jb0 + (uint32_t)JL) * 64u, g.nB) > g.t_col_begin) {   // workgroup-uniform
+                constexpr uint32_t TP = R + 4;   // padded column pitch (floats), keeps 16-byte alignment
+                static_assert(JL * 64 * TP * 4 <= W * 2 * PPL * LANES * 16, "the turned tile fits the row buffers");
+                float *tt = reinterpret_cast<float *>(&lds_rows[0][0][0]);
+                __syncthreads();   // every wave is done with the reduction words
+#pragma unroll
+                for (int i = 0; i < SLOTS; ++i) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t pair = 2u * ((uint32_t)i * W + wave) + h;
+                        const uint32_t r = pair / JL, j = pair % JL;
+                        tt[(j * 64u + lane) * TP + r] = tval[i * 2 + h];
+                    }
+                }
+                __syncthreads();
+                constexpr uint32_t QUADS = R / 4;
+                for (uint32_t item = tid; item < (uint32_t)JL * 64u * QUADS; item += LANES * W) {
+                    const uint32_t c = item / QUADS, q = item % QUADS;
+                    const uint32_t jc = jb0 * 64u + c;
+                    if (jc >= g.t_col_begin && jc < g.nB) {
+                        const float4 v = *reinterpret_cast<const float4 *>(&tt[c * TP + 4u * q]);
+                        *reinterpret_cast<float4 *>(&g.out_t[(size_t)(jc - g.t_col_begin) * g.t_stride +
+                                                             (a0 - g.row_begin) + 4u * q]) = v;
                     }
                 }
             }

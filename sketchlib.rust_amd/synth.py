@@ -132,3 +132,32 @@ def set_u_device(n, nk, ss64, device, first_sample=0, seed=SEED_U, chunk=4096):
         base = _mix_t(ids + seed, torch)
         out[s0:s1] = _mix_t(base[:, None] + w[None, :], torch)
     return out
+
+
+def set_clustered_device(n, nk, ss64, device, cluster_size=200, keep=0.9, seed=SEED_R, chunk=2048):
+    """Clustered sketches generated on `device` for large kNN benchmarks: sample s belongs to
+    cluster s % (n / cluster_size) and keeps each of its cluster's bin values with probability
+    `keep` (an independent 14-bit value otherwise), so a row has ~cluster_size close neighbours
+    scattered over the whole id range and every other distance sits at ~1.  Returns an int64
+    tensor [n, words] whose bit pattern is the uint64 slab (fill_usigs layout,
+    src/sketch/mod.rs:215-223)."""
+    import torch
+
+    nb = ss64 * 64
+    words = nk * ss64 * BBITS
+    n_clusters = max(1, n // cluster_size)
+    out = torch.empty((n, words), dtype=torch.int64, device=device)
+    gold = _GOLD - (1 << 64)
+    w = torch.arange(1, nk * nb + 1, dtype=torch.int64, device=device) * gold
+    bit = torch.arange(64, dtype=torch.int64, device=device)
+    thresh = int(keep * 65536)
+    for s0 in range(0, n, chunk):
+        s1 = min(n, s0 + chunk)
+        ids = torch.arange(s0, s1, dtype=torch.int64, device=device)
+        own = _mix_t(_mix_t(ids + seed, torch)[:, None] + w[None, :], torch)
+        par = _mix_t(_mix_t((ids % n_clusters) + (seed ^ 0xA5A5), torch)[:, None] + w[None, :], torch)
+        coin = (own >> 14) & 0xFFFF
+        vals = torch.where(coin < thresh, par & 0x3FFF, own & 0x3FFF).view(s1 - s0, nk, ss64, 64)
+        planes = [(((vals >> p) & 1) << bit).sum(dim=-1) for p in range(BBITS)]   # disjoint bits: sum == or
+        out[s0:s1] = torch.stack(planes, dim=-1).view(s1 - s0, words)
+    return out

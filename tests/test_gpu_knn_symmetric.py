@@ -1,0 +1,87 @@
+"""Symmetric self kNN (every pair evaluated once, running per-row top-k) against the oracle and
+against the row-by-row form of the same library: same neighbours in the same order.
+
+The reference evaluates both (i, j) and (j, i) (src/distances/mod.rs:148-171); the results it
+defines are what is compared here.
+"""
+import numpy as np
+import pytest
+
+from sketchlib.rust_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+def _knn(skl, ctx, g, p, knn, monkeypatch, band_rows, symmetric):
+    monkeypatch.setenv("SKL_KNN_BAND_ROWS", str(band_rows))
+    monkeypatch.setenv("SKL_KNN_SYMMETRIC", "1" if symmetric else "0")
+    idx, d0, _ = skl.self_dists_knn(ctx, g, p, knn)
+    return idx, d0
+
+
+@pytest.mark.parametrize("band_rows", [7, 16, 40, 64, 100, 332])
+@pytest.mark.parametrize("ani", [False, True], ids=["dist", "ani"])
+def test_bands_of_every_shape_match_the_oracle(oracle, skl, gpu_ctx, monkeypatch, band_rows, ani):
+    kmers, ss64, n, knn = [17, 21, 25], 8, 333, 11
+    bins = synth.set_r(n, kmers, ss64, n_clusters=9)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21, ani)
+    idx, d0 = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True)
+    assert "k-sliced" in gpu_ctx.last_kernel()
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, ani, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"])
+    np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
+
+
+def test_all_keys_tie(oracle, skl, gpu_ctx, monkeypatch):
+    """n copies of one sketch: every distance is 0, so the neighbours are decided by the tie rule
+    alone (smallest sample id first), whichever band or copy of a key reaches a row first."""
+    kmers, ss64, n, knn = [21], 4, 200, 5
+    bins = np.tile(synth.set_u(1, len(kmers), ss64), (n, 1))
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    for band_rows in (48, 7):
+        idx, d0 = _knn(skl, gpu_ctx, g, g.set_k(21), knn, monkeypatch, band_rows, True)
+        assert np.all(d0 == 0.0)
+        for row in range(n):
+            assert idx[row].tolist() == [j for j in range(n) if j != row][:knn]
+
+
+def test_completeness_correction(oracle, skl, gpu_ctx, monkeypatch):
+    kmers, ss64, n, knn = [17, 21], 8, 150, 6
+    bins = synth.set_r(n, kmers, ss64, n_clusters=5)
+    comp = np.random.default_rng(5).uniform(0.7, 1.0, n)
+    o, g = oracle.Sketches(bins, n, kmers, ss64, comp), gpu_ctx.sketches(bins, n, kmers, ss64, comp)
+    idx, d0 = _knn(skl, gpu_ctx, g, g.set_k(21), knn, monkeypatch, 32, True)
+    ref_idx, ref_d0 = _knn(skl, gpu_ctx, g, g.set_k(21), knn, monkeypatch, 32, False)
+    assert np.array_equal(idx, ref_idx) and np.array_equal(d0, ref_d0)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, False, ties=oracle.TIES_CANONICAL, threads=8)
+    np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("n,band_rows,knn", [(3000, 256, 10), (5000, 2100, 20), (4099, 1000, 64)])
+def test_same_as_row_by_row(oracle, skl, gpu_ctx, monkeypatch, n, band_rows, knn):
+    """Cold states with more than 2048 candidates take the radix-select branch of the merge; warm
+    ones the in-LDS sort; both forms of the driver must agree bit for bit."""
+    kmers, ss64 = [21], 3
+    bins = synth.set_r(n, kmers, ss64, n_clusters=40)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21)
+    idx, d0 = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True)
+    ref_idx, ref_d0 = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, False)
+    assert np.array_equal(idx, ref_idx) and np.array_equal(d0, ref_d0)
+    o = oracle.Sketches(bins, n, kmers, ss64)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"])
+
+
+def test_device_output_and_default_band_size(skl, gpu_ctx, monkeypatch):
+    """No knobs: the driver sizes the bands itself; one band means the row-by-row form runs."""
+    monkeypatch.delenv("SKL_KNN_BAND_ROWS", raising=False)
+    monkeypatch.delenv("SKL_KNN_SYMMETRIC", raising=False)
+    kmers, ss64, n, knn = [21], 2, 500, 4
+    bins = synth.set_r(n, kmers, ss64, n_clusters=7)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), knn)
+    assert idx.shape == (n, knn) and np.all(np.diff(d0, axis=1) >= 0)
