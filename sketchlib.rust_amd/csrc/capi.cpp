@@ -888,15 +888,41 @@ extern "C" int skl_cross_binmatch(skl_ctx *ctx, const skl_sketches *ref,
 // sparse kNN: dense row bands into scratch, then a row-wise top-k kernel
 // ---------------------------------------------------------------------------
 
-// Symmetric self kNN (whole matrix in one call, single-k keys): band [b0, b1) is compared with the
-// columns from b0 on only.  The pair kernel stores every key twice -- row-major for the rows of
-// the band, and turned (pair_kslice.hip, out_t) as candidates of the rows below the band -- and
+// Running top-k states of a kNN call: (sortable key, sample id[, second value]) x knn per row.
+namespace {
+struct KnnState {
+    uint32_t *key = nullptr, *idx = nullptr;
+    float *d1 = nullptr;
+    ~KnnState()
+    {
+        if (key) (void)hipFree(key);
+        if (idx) (void)hipFree(idx);
+        if (d1) (void)hipFree(d1);
+    }
+};
+}  // namespace
+
+static int knn_state_init(KnnState &st, size_t rows, size_t knn, bool coreacc, hipStream_t stream)
+{
+    const size_t items = rows * knn;
+    HIP_TRY(hipMalloc((void **)&st.key, items * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&st.idx, items * sizeof(uint32_t)));
+    if (coreacc) HIP_TRY(hipMalloc((void **)&st.d1, items * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(st.key, 0xFF, items * sizeof(uint32_t), stream));   // empty
+    HIP_TRY(hipMemsetAsync(st.idx, 0xFF, items * sizeof(uint32_t), stream));
+    return SKL_OK;
+}
+
+// Symmetric self kNN (whole matrix in one call): band [b0, b1) is compared with the columns
+// from b0 on only.  The pair kernel stores every record twice -- row-major for the rows of the
+// band, and turned (pair_kslice.hip, out_t) as candidates of the rows below the band -- and
 // both copies are merged into a running per-row top-k (topk_merge_kernel), so each (i, j) is
 // evaluated once instead of twice (the reference evaluates both, mod.rs:148-171; distances are
 // symmetric).  Same neighbours, same order as the row-by-row form.
 static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
 {
-    if (p->dist_type != SKL_DIST_JACCARD || s->ss64 > 1023) return false;
+    if (s->ss64 > 1023) return false;
+    if (p->dist_type == SKL_DIST_COREACC && !fused_coreacc_ok(s)) return false;
     const int forced = forced_kernel();
     if (forced != 0 && forced != 4) return false;          // the turned store lives in pair_kslice.hip
     const long long shape = env_int("SKL_KSLICE_SHAPE", 0);
@@ -905,29 +931,26 @@ static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
 }
 
 static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
-                              size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0)
+                              size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
 {
     const size_t n = s->n;
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
+    const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
+    const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
     const size_t t_stride = (band_rows + 15) / 16 * 16;
-    const int jout = p->ani ? JOUT_ANI_KEY : JOUT_DIST;
     void *kband[2] = {nullptr, nullptr}, *tband[2] = {nullptr, nullptr};
-    SKL_TRY(ctx_scratch(ctx, band_rows * n * sizeof(float), &kband[0], 0));
-    SKL_TRY(ctx_scratch(ctx, n * t_stride * sizeof(float), &tband[0], 4));
+    SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[0], 0));
+    SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[0], 4));
     kband[1] = kband[0];
     tband[1] = tband[0];
     if (overlap) {
-        SKL_TRY(ctx_scratch(ctx, band_rows * n * sizeof(float), &kband[1], 3));
-        SKL_TRY(ctx_scratch(ctx, n * t_stride * sizeof(float), &tband[1], 5));
+        SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[1], 3));
+        SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[1], 5));
     }
-    struct DevBuf {
-        void *p = nullptr;
-        ~DevBuf() { if (p) (void)hipFree(p); }
-    } run_key, run_idx;
-    HIP_TRY(hipMalloc(&run_key.p, n * knn * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&run_idx.p, n * knn * sizeof(uint32_t)));
+    KnnState st;
+    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
-    HIP_TRY(hipMemsetAsync(run_key.p, 0xFF, n * knn * sizeof(uint32_t), ctx->stream));   // empty states
-    HIP_TRY(hipMemsetAsync(run_idx.p, 0xFF, n * knn * sizeof(uint32_t), ctx->stream));
 
     const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
     size_t it = 0;
@@ -938,7 +961,7 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
         // the band against the column view that starts at the 64-column block holding b0
         const size_t col0 = b0 / 64 * 64;
         PairArgs g;
-        SKL_TRY(fill_args(s, s, p, MODE_JACCARD, jout, &g));
+        SKL_TRY(fill_args(s, s, p, mode, jout, &g));
         g.B += (b0 / 64) * jb_words;
         g.nB = (uint32_t)(n - col0);
         if (g.compB) g.compB += col0;
@@ -950,7 +973,7 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
         g.out_t = b1 < n ? (float *)tband[buf] : nullptr;
         g.t_col_begin = (uint32_t)(b1 - col0);
         g.t_stride = (uint32_t)t_stride;
-        SKL_TRY(timed_pair_launch(ctx, g, MODE_JACCARD, choose_na(b1 - b0, g.nB, 0, MODE_JACCARD)));
+        SKL_TRY(timed_pair_launch(ctx, g, mode, choose_na(b1 - b0, g.nB, 0, mode)));
         if (overlap) {
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
             HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
@@ -958,31 +981,33 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
         TopkMergeArgs m;
         memset(&m, 0, sizeof m);
         m.knn = (uint32_t)knn;
-        m.run_key = (uint32_t *)run_key.p;
-        m.run_idx = (uint32_t *)run_idx.p;
+        m.stride2 = coreacc ? 2 : 1;
+        m.run_key = st.key;
+        m.run_idx = st.idx;
+        m.run_d1 = st.d1;
         // rows of the band: columns [b0, n) minus themselves (the view's first b0 - col0 columns
         // reached them turned, from earlier bands)
         m.keys = (const float *)kband[buf];
-        m.key_stride = g.nB;
+        m.key_stride = (uint64_t)g.nB * m.stride2;
         m.rows = (uint32_t)(b1 - b0);
         m.cols = g.nB;
         m.id_base = (uint32_t)col0;
         m.skip_below = (uint32_t)b0;
-        m.row_id_base = (uint32_t)b0;
+        m.self_id_base = m.state_row_base = (uint32_t)b0;
         HIP_TRY(launch_topk_merge(m, topk_stream));
         // rows below the band: the band's samples as their candidates
         m.keys = (const float *)tband[buf];
-        m.key_stride = t_stride;
+        m.key_stride = (uint64_t)t_stride * m.stride2;
         m.rows = (uint32_t)(n - b1);
         m.cols = (uint32_t)(b1 - b0);
         m.id_base = (uint32_t)b0;
         m.skip_below = 0;
-        m.row_id_base = (uint32_t)b1;
+        m.self_id_base = m.state_row_base = (uint32_t)b1;
         HIP_TRY(launch_topk_merge(m, topk_stream));
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
     }
-    HIP_TRY(launch_topk_finalize((const uint32_t *)run_key.p, (const uint32_t *)run_idx.p, n * knn, p->ani ? 1 : 0,
-                                 d_idx, d_d0, topk_stream));
+    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, n * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0, d_d1,
+                                 topk_stream));
     if (overlap) {   // results (and the band buffers) belong to the context's stream again
         HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
@@ -991,9 +1016,11 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
     return SKL_OK;
 }
 
-// Row-by-row kNN: dense bands of keys into scratch, then the row-wise top-k kernel.  With two
-// key bands the top-k of band i (memory / LDS bound, on the auxiliary stream) runs while the pair
-// kernel of band i + 1 (VALU bound) fills the other one.
+// Row-by-row kNN: dense bands of records into scratch, then a per-row top-k.  With two bands
+// the top-k of band i (memory / LDS bound, on the auxiliary stream) runs while the pair kernel
+// of band i + 1 (VALU bound) fills the other one.  The top-k is the running one of the
+// symmetric driver (topk_merge_kernel) fed a whole row at once: an empty state goes straight to
+// the radix select.
 static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
                            const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
                            size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
@@ -1008,6 +1035,16 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
     band[1] = band[0];
     if (overlap) SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[1], 3));
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
+    KnnState st;
+    SKL_TRY(knn_state_init(st, r1 - r0, knn, coreacc, ctx->stream));
+    if (overlap) {   // the states are cleared on the context's stream, the merges run on the other one
+        HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[0], 0));
+    }
+    // SKL_KNN_WARM_COLS = c feeds a row in two steps, c columns first (A/B knob, off by default: a
+    // row's close neighbours are too few to be met in a prefix, so the state stays at the tie
+    // value of unrelated pairs and the second step selects again -- measured 7 % slower)
+    const size_t warm_cols = std::min<size_t>(n_cand, (size_t)std::max(0ll, env_int("SKL_KNN_WARM_COLS", 0)));
 
     size_t it = 0;
     for (size_t b0 = r0; b0 < r1; b0 += band_rows, ++it) {
@@ -1020,26 +1057,37 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
             HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
         }
-        TopkArgs t;
-        memset(&t, 0, sizeof t);
-        t.keys = (const float *)band[buf];
-        t.rows = (uint32_t)(b1 - b0);
-        t.cols = (uint32_t)n_cand;
-        t.stride2 = coreacc ? 2 : 1;
-        t.knn = (uint32_t)knn;
-        t.self_mode = self_mode;
-        t.row_begin = (uint32_t)b0;
-        t.ani_undo = (!coreacc && p->ani) ? 1 : 0;
-        t.out_idx = d_idx + (b0 - r0) * knn;
-        t.out_d0 = d_d0 + (b0 - r0) * knn;
-        t.out_d1 = coreacc ? d_d1 + (b0 - r0) * knn : nullptr;
-        HIP_TRY(launch_topk(t, topk_stream));
+        TopkMergeArgs m;
+        memset(&m, 0, sizeof m);
+        m.knn = (uint32_t)knn;
+        m.stride2 = coreacc ? 2 : 1;
+        m.run_key = st.key;
+        m.run_idx = st.idx;
+        m.run_d1 = st.d1;
+        m.key_stride = (uint64_t)n_cand * m.stride2;
+        m.rows = (uint32_t)(b1 - b0);
+        m.self_id_base = self_mode ? (uint32_t)b0 : 0xFFFFFFFFu;
+        m.state_row_base = (uint32_t)(b0 - r0);
+        const size_t first = warm_cols ? warm_cols : n_cand;
+        m.keys = (const float *)band[buf];
+        m.cols = (uint32_t)first;
+        m.id_base = 0;
+        HIP_TRY(launch_topk_merge(m, topk_stream));
+        if (first < n_cand) {
+            m.keys = (const float *)band[buf] + first * m.stride2;
+            m.cols = (uint32_t)(n_cand - first);
+            m.id_base = (uint32_t)first;
+            HIP_TRY(launch_topk_merge(m, topk_stream));
+        }
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
     }
+    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, (r1 - r0) * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0,
+                                 d_d1, topk_stream));
     if (overlap) {   // results (and the band buffers) belong to the context's stream again
+        HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
-        if (it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[1], 0));
     }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
     return SKL_OK;
 }
 
@@ -1072,17 +1120,22 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     const size_t forced_band_rows = (size_t)std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));  // test knob: force several bands
     if (forced_band_rows) band_rows = forced_band_rows;
     band_rows = std::min(band_rows, r1 - r0);
-    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;
-    // the whole self matrix in more than one band: evaluate each pair once
-    const bool symmetric = self_mode && r0 == 0 && r1 == n_cand && band_rows < n_cand && knn_symmetric_ok(rows, p);
-    if (symmetric && !forced_band_rows) {
-        // four band buffers instead of two, and none of them needs to stay small: up to half of
-        // the free HBM (<= 32 GiB) -- fewer, larger merges
+    // The whole self matrix: evaluate each pair once (knn_self_symmetric) when that leaves bands
+    // worth launching -- about 8 of them (7/16 of the pair evaluations saved), each at least 32 M
+    // pairs, within four band buffers of up to half the free HBM (<= 32 GiB) together.
+    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p);
+    if (symmetric) {
+        auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
         size_t budget = band_bytes;
         if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, 32ull << 30));
-        band_rows = std::max<size_t>(16, budget / 4 / (n_cand * rec) / 16 * 16);
-        band_rows = std::min(band_rows, n_cand);
+        const size_t budget_rows = std::max<size_t>(16, budget / 4 / (n_cand * rec) / 16 * 16);
+        const size_t want = forced_band_rows
+                                ? forced_band_rows
+                                : std::min(budget_rows, std::max(up16((n_cand + 7) / 8), up16((32ull << 20) / n_cand + 1)));
+        if (want >= n_cand) symmetric = false;
+        else band_rows = want;
     }
+    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;
 
     // device staging for host-destined results
     uint64_t *d_idx = out_idx;
@@ -1096,7 +1149,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         d_d1 = d_d0 + items;
     }
     if (symmetric) {
-        SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0));
+        SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0, d_d1));
     } else {
         SKL_TRY(knn_rows_banded(ctx, rows, cands, p, knn, self_mode, r0, r1, band_rows, overlap, d_idx, d_d0, d_d1));
     }

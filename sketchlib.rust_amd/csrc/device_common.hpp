@@ -170,10 +170,9 @@ __device__ __forceinline__ void store_jaccard(const PairArgs &g, uint32_t i, uin
 
 // MODE_COREACC: core_acc_dist + simple_linear_regression (jaccard.rs:61-142) from the
 // packed per-k mismatch counts (u16 fields, newest k lowest, s2:s1:s0).
-__device__ __forceinline__ void store_coreacc(const PairArgs &g, uint32_t i, uint32_t jcol,
-                                              uint32_t s0, uint32_t s1, uint32_t s2)
+__device__ __forceinline__ float2 coreacc_value(const PairArgs &g, uint32_t i, uint32_t jcol,
+                                                uint32_t s0, uint32_t s1, uint32_t s2)
 {
-    if (!pair_valid(g, i, jcol)) return;
     const uint32_t maxnbits = g.ss64 * 64u;
     double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
     double c1 = 0.0, c2 = 0.0;
@@ -206,8 +205,14 @@ __device__ __forceinline__ void store_coreacc(const PairArgs &g, uint32_t i, uin
             }
         }
     }
-    ((float2 *)g.out)[pair_out_index(g, i, jcol)] =
-        simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
+    return simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
+}
+
+__device__ __forceinline__ void store_coreacc(const PairArgs &g, uint32_t i, uint32_t jcol,
+                                              uint32_t s0, uint32_t s1, uint32_t s2)
+{
+    if (!pair_valid(g, i, jcol)) return;
+    ((float2 *)g.out)[pair_out_index(g, i, jcol)] = coreacc_value(g, i, jcol, s0, s1, s2);
 }
 
 }  // namespace skl

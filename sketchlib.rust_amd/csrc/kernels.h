@@ -56,10 +56,11 @@ struct PairArgs {
     // ([pair][k] for the public bin-match calls, k-major for the internal counts scratch)
     uint64_t cnt_pair_stride, cnt_k_stride;
     uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
-    // Symmetric self kNN (k-sliced MODE_JACCARD of pair_kslice.hip only): besides out, the key of
-    // (row i, column j >= t_col_begin) also goes to out_t[(j - t_col_begin) * t_stride + (i - row_begin)],
-    // i.e. as a candidate of row j.  t_stride is a multiple of 4 and >= the rows of the launch
-    // rounded up to the tile height.  Null = off.
+    // Symmetric self kNN (pair_kslice.hip: k-sliced MODE_JACCARD and all-k MODE_COREACC): besides
+    // out, the record of (row i, column j >= t_col_begin) also goes to record
+    // (j - t_col_begin) * t_stride + (i - row_begin) of out_t, i.e. as a candidate of row j.
+    // t_stride (records) is a multiple of 4 and >= the rows of the launch rounded up to the
+    // tile height.  Null = off.
     float *out_t;
     uint32_t t_col_begin, t_stride;
     // epilogue
@@ -196,24 +197,27 @@ struct TopkArgs {
 };
 hipError_t launch_topk(const TopkArgs &args, hipStream_t stream);
 
-// Running per-row top-k (symmetric self kNN): merges a row's new keys into its sorted state of
-// knn (sortable key, sample id) entries.  New ids must all be larger than the ids already in
-// the state (the driver walks the bands in ascending order), which makes "smallest (key, id)"
-// the same as "smallest (key, position)" with the state placed first.
+// Running per-row top-k: merges a row's new keys into its sorted state of knn (sortable key,
+// sample id[, second value]) entries.  New ids must all be larger than the ids already in the
+// state (drivers feed columns / bands in ascending order), which makes "smallest (key, id)" the
+// same as "smallest (key, position)" with the state placed first.
 struct TopkMergeArgs {
-    const float *keys;        // row r's new keys at keys + r * key_stride
+    const float *keys;        // row r's new records at keys + r * key_stride (floats)
     uint64_t key_stride;
-    uint32_t rows, cols;      // rows of this launch, new keys per row
-    uint32_t id_base;         // sample id of key position 0
+    uint32_t stride2;         // 1: plain keys; 2: (core, acc) records, key = core
+    uint32_t rows, cols;      // rows of this launch, new records per row
+    uint32_t id_base;         // sample id of record position 0
     uint32_t skip_below;      // positions with id < skip_below are not candidates
-    uint32_t row_id_base;     // sample id of row 0: selects the state row, and is skipped as a candidate
+    uint32_t self_id_base;    // row r is sample self_id_base + r and not its own candidate; 0xFFFFFFFF = off
+    uint32_t state_row_base;  // row r's state is row state_row_base + r of run_*
     uint32_t knn;
-    uint32_t *run_key;        // [n][knn] sortable key bits, ascending; 0xFFFFFFFF = empty
-    uint32_t *run_idx;        // [n][knn]
+    uint32_t *run_key;        // [.][knn] sortable key bits, ascending; 0xFFFFFFFF = empty
+    uint32_t *run_idx;        // [.][knn]
+    float *run_d1;            // [.][knn] second values (stride2 == 2) or null
 };
 hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream);
 // state -> (out_idx, out_d0) in the public form
-hipError_t launch_topk_finalize(const uint32_t *run_key, const uint32_t *run_idx, uint64_t items, int ani_undo,
-                                uint64_t *out_idx, float *out_d0, hipStream_t stream);
+hipError_t launch_topk_finalize(const uint32_t *run_key, const uint32_t *run_idx, const float *run_d1, uint64_t items,
+                                int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1, hipStream_t stream);
 
 }  // namespace skl

@@ -640,35 +640,42 @@ hipError_t launch_topk(const TopkArgs &args, hipStream_t stream)
 __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMergeArgs g)
 {
     __shared__ TopkShared sh;
+    __shared__ float second[TOPK_MAX];   // second values of the new state (stride2 == 2)
     const uint32_t row = blockIdx.x, tid = threadIdx.x;
-    const uint32_t grow = g.row_id_base + row;
+    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
     const uint32_t knn = g.knn;
-    uint32_t *sk = g.run_key + (size_t)grow * knn;
-    uint32_t *si = g.run_idx + (size_t)grow * knn;
+    const size_t srow = (size_t)(g.state_row_base + row) * knn;
+    uint32_t *sk = g.run_key + srow;
+    uint32_t *si = g.run_idx + srow;
+    const uint32_t stride2 = g.stride2;
     const float *keys = g.keys + (size_t)row * g.key_stride;
     const uint32_t worst = sk[knn - 1];   // 0xFFFFFFFF while the state is not full
 
     auto fresh = [&](uint32_t q, uint32_t &u) {   // new key at position q of this launch
         const uint32_t id = g.id_base + q;
-        if (id < g.skip_below || id == grow) return false;
-        u = sortable_bits(keys[q]);
+        if (id < g.skip_below || id == self_id) return false;
+        u = sortable_bits(keys[(size_t)q * stride2]);
         return true;
     };
 
     // ---- pass 1: how many new keys beat the current knn-th best?  (a tie loses: its id is larger) ----
-    if (tid == 0) sh.count = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t q = tid; q < g.cols; q += TOPK_THREADS) {
-        uint32_t u;
-        if (fresh(q, u) && u < worst) ++mine;
+    // (an empty state facing more keys than the LDS sort holds goes straight to the select)
+    uint32_t n_better = 0xFFFFFFFFu - knn;
+    if (worst != 0xFFFFFFFFu || g.cols + knn <= (uint32_t)TOPK_MAX) {
+        if (tid == 0) sh.count = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t q = tid; q < g.cols; q += TOPK_THREADS) {
+            uint32_t u;
+            if (fresh(q, u) && u < worst) ++mine;
+        }
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+        if ((tid & 63u) == 0 && mine) atomicAdd(&sh.count, mine);
+        __syncthreads();
+        n_better = sh.count;
+        if (n_better == 0) return;
+        __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    if ((tid & 63u) == 0 && mine) atomicAdd(&sh.count, mine);
-    __syncthreads();
-    const uint32_t n_better = sh.count;
-    if (n_better == 0) return;
-    __syncthreads();
 
     if (n_better + knn <= (uint32_t)TOPK_MAX) {
         // ---- few: sort state + qualifiers in LDS ----
@@ -705,12 +712,14 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
     for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
         const uint32_t pos = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
         const uint32_t id = pos < knn ? si[pos] : g.id_base + (pos - knn);
+        if (stride2 == 2) second[x] = pos < knn ? g.run_d1[srow + pos] : keys[(size_t)(pos - knn) * 2 + 1];
         sh.items[x] = (sh.items[x] & 0xFFFFFFFF00000000ull) | id;
     }
     __syncthreads();
     for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
         sk[x] = (uint32_t)(sh.items[x] >> 32);
         si[x] = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+        if (stride2 == 2) g.run_d1[srow + x] = second[x];
     }
 }
 
@@ -718,28 +727,31 @@ hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream)
 {
     if (args.rows == 0 || args.cols == 0) return hipSuccess;
     if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
+    if (args.stride2 != 1 && !(args.stride2 == 2 && args.run_d1)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
     return hipGetLastError();
 }
 
-__global__ void topk_finalize_kernel(const uint32_t *run_key, const uint32_t *run_idx, uint64_t items, int ani_undo,
-                                     uint64_t *out_idx, float *out_d0)
+__global__ void topk_finalize_kernel(const uint32_t *run_key, const uint32_t *run_idx, const float *run_d1,
+                                     uint64_t items, int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < items; x += stride) {
         const float key = from_sortable_bits(run_key[x]);
         out_idx[x] = run_idx[x];
         out_d0[x] = ani_undo ? 1.0f - key : key;
+        if (run_d1) out_d1[x] = run_d1[x];
     }
 }
 
-hipError_t launch_topk_finalize(const uint32_t *run_key, const uint32_t *run_idx, uint64_t items, int ani_undo,
-                                uint64_t *out_idx, float *out_d0, hipStream_t stream)
+hipError_t launch_topk_finalize(const uint32_t *run_key, const uint32_t *run_idx, const float *run_d1, uint64_t items,
+                                int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1, hipStream_t stream)
 {
     if (items == 0) return hipSuccess;
+    if (run_d1 && !out_d1) return hipErrorInvalidValue;
     const uint64_t blocks = std::min<uint64_t>((items + 255) / 256, 65536);
-    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, run_key, run_idx, items,
-                       ani_undo, out_idx, out_d0);
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, run_key, run_idx, run_d1,
+                       items, ani_undo, out_idx, out_d0, out_d1);
     return hipGetLastError();
 }
 

@@ -371,6 +371,12 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
 #undef SKL_STAGE_DMA
 
     if constexpr (MODE == MODE_COREACC) {
+        // symmetric self kNN: (core, acc) of columns >= t_col_begin also leave turned, see MODE_JACCARD
+        constexpr uint32_t TP = R + 4;
+        static_assert(JL * 64 * TP * 8 <= W * 2 * PPL * LANES * 16, "the turned tile fits the row buffers");
+        const bool turned = g.out_t != nullptr && min((jb0 + (uint32_t)JL) * 64u, g.nB) > g.t_col_begin;   // workgroup-uniform
+        float2 *tt = reinterpret_cast<float2 *>(&lds_rows[0][0][0]);
+        if (turned) __syncthreads();   // every wave is done with the reduction words
         // store_coreacc() takes u16 fields, newest k lowest, as s2:s1:s0
 #pragma clang loop unroll(disable)
         for (int i = 0; i < SLOTS; ++i) {
@@ -388,7 +394,26 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
                 const uint32_t s0 = ((word[0] >> sh) & 0xFFFFu) | (((word[1] >> sh) & 0xFFFFu) << 16);
                 const uint32_t s1 = ((word[2] >> sh) & 0xFFFFu) | (((word[3] >> sh) & 0xFFFFu) << 16);
                 const uint32_t s2 = ((word[4] >> sh) & 0xFFFFu) | (((word[5] >> sh) & 0xFFFFu) << 16);
-                store_coreacc(g, a0 + r, (jb0 + j) * 64u + lane, s0, s1, s2);
+                const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
+                float2 v = make_float2(__builtin_inff(), __builtin_inff());
+                if (pair_valid(g, i_, jc_)) {
+                    v = coreacc_value(g, i_, jc_, s0, s1, s2);
+                    ((float2 *)g.out)[pair_out_index(g, i_, jc_)] = v;
+                }
+                if (turned) tt[(j * 64u + lane) * TP + r] = v;
+            }
+        }
+        if (turned) {
+            __syncthreads();
+            constexpr uint32_t DUOS = R / 2;   // two records = one 16-byte store
+            for (uint32_t item = tid; item < (uint32_t)JL * 64u * DUOS; item += LANES * W) {
+                const uint32_t c = item / DUOS, q = item % DUOS;
+                const uint32_t jc = jb0 * 64u + c;
+                if (jc >= g.t_col_begin && jc < g.nB) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&tt[c * TP + 2u * q]);
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(g.out_t) +
+                                                (size_t)(jc - g.t_col_begin) * g.t_stride + (a0 - g.row_begin) + 2u * q) = v;
+                }
             }
         }
     }

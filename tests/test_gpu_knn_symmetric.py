@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6
 
 
-def _knn(skl, ctx, g, p, knn, monkeypatch, band_rows, symmetric):
+def _knn(skl, ctx, g, p, knn, monkeypatch, band_rows, symmetric, with_d1=False):
     monkeypatch.setenv("SKL_KNN_BAND_ROWS", str(band_rows))
     monkeypatch.setenv("SKL_KNN_SYMMETRIC", "1" if symmetric else "0")
-    idx, d0, _ = skl.self_dists_knn(ctx, g, p, knn)
-    return idx, d0
+    idx, d0, d1 = skl.self_dists_knn(ctx, g, p, knn)
+    return (idx, d0, d1) if with_d1 else (idx, d0)
 
 
 @pytest.mark.parametrize("band_rows", [7, 16, 40, 64, 100, 332])
@@ -33,6 +33,23 @@ def test_bands_of_every_shape_match_the_oracle(oracle, skl, gpu_ctx, monkeypatch
     exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, ani, ties=oracle.TIES_CANONICAL, threads=8)
     assert np.array_equal(idx, exp["idx"])
     np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("band_rows", [7, 16, 50, 128])
+def test_core_accessory_keys(oracle, skl, gpu_ctx, monkeypatch, band_rows):
+    """(core, acc) records: the key is the core distance, the accessory distance rides along
+    (distance_matrix.rs:245-248), through both copies of a record and the running top-k."""
+    kmers, ss64, n, knn = [15, 19, 23, 27, 31], 8, 211, 9
+    bins = synth.set_r(n, kmers, ss64, n_clusters=6)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    idx, d0, d1 = _knn(skl, gpu_ctx, g, g.set_k(), knn, monkeypatch, band_rows, True, with_d1=True)
+    assert "COREACC, all k" in gpu_ctx.last_kernel()
+    ref = _knn(skl, gpu_ctx, g, g.set_k(), knn, monkeypatch, band_rows, False, with_d1=True)
+    assert np.array_equal(idx, ref[0]) and np.array_equal(d0, ref[1]) and np.array_equal(d1, ref[2])
+    exp = oracle.self_dists_knn(o, knn, oracle.COREACC, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"])
+    np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(d1, exp["d1"], atol=TOL, rtol=0)
 
 
 def test_all_keys_tie(oracle, skl, gpu_ctx, monkeypatch):
@@ -58,6 +75,28 @@ def test_completeness_correction(oracle, skl, gpu_ctx, monkeypatch):
     assert np.array_equal(idx, ref_idx) and np.array_equal(d0, ref_d0)
     exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, False, ties=oracle.TIES_CANONICAL, threads=8)
     np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
+
+
+def test_row_by_row_with_and_without_the_warm_up_step(oracle, skl, gpu_ctx, monkeypatch):
+    """The row-by-row driver can feed a row in two steps (SKL_KNN_WARM_COLS columns, then the rest:
+    the second step meets a warm state); the lists must not depend on it, for single-k and for
+    core/accessory keys, self and cross."""
+    kmers, ss64, n, knn = [17, 21, 25], 2, 6000, 12
+    bins = synth.set_r(n, kmers, ss64, n_clusters=50)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    q = gpu_ctx.sketches(bins[:300].copy(), 300, kmers, ss64)
+    monkeypatch.setenv("SKL_KNN_SYMMETRIC", "0")
+    for p in (g.set_k(21), g.set_k()):
+        got = {}
+        for warm in ("0", "1000", "4096"):
+            monkeypatch.setenv("SKL_KNN_WARM_COLS", warm)
+            got[warm] = skl.self_dists_knn(gpu_ctx, g, p, knn) + skl.cross_dists_knn(gpu_ctx, g, q, p, knn)
+        for warm in ("1000", "4096"):
+            for a, b in zip(got["0"], got[warm]):
+                assert np.array_equal(a, b)
+    o = oracle.Sketches(bins, n, kmers, ss64)
+    exp = oracle.self_dists_knn(o, knn, oracle.COREACC, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(got["0"][0], exp["idx"])
 
 
 @pytest.mark.parametrize("n,band_rows,knn", [(3000, 256, 10), (5000, 2100, 20), (4099, 1000, 64)])
