@@ -141,6 +141,27 @@ int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_param
 int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
                             size_t knn, size_t row_begin, size_t row_end, uint64_t *out_idx,
                             float *out_d0, float *out_d1, int out_on_device);
+/* self_dists_knn split over several devices with every pair evaluated ONCE (the reference
+ * evaluates (i, j) and (j, i), mod.rs:148-171; distances are symmetric).  The rows are cut into
+ * bands of band_rows samples (skl_knn_band_rows gives a size every participant agrees on); a
+ * participant takes a subset of the bands (ascending band indices; deal them so that costs
+ * balance: band b costs ~ n - b*band_rows) and gets back, for ALL n rows, the knn best
+ * candidates seen in its share: state_key = order-preserving u32 image of the f32 key (empty
+ * entries 0xFFFFFFFF), state_idx = neighbour, state_d1 = accessory distance (CoreAcc only, may
+ * be NULL otherwise), each [n][knn], sorted ascending per row.  The participants then exchange
+ * row shards of these states (an all-to-all: the one data-path collective of this library) and
+ * skl_knn_merge_states turns the n_states partial states of a row shard -- stacked
+ * [n_states][rows][knn] -- into the rows of skl_self_dists_knn's output.
+ * Returns SKL_ERR_INVALID_ARG when the configuration has no one-evaluation form (more than 6
+ * k-mer lengths for CoreAcc, sketchsize64 > 1023): shard rows with skl_self_dists_knn_rows then. */
+size_t skl_knn_band_rows(const skl_sketches *s, const skl_dist_params *p, size_t n_participants);
+int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                               size_t band_rows, const uint32_t *bands, size_t n_bands,
+                               uint32_t *state_key, uint32_t *state_idx, float *state_d1, int out_on_device);
+int skl_knn_merge_states(skl_ctx *ctx, size_t n_states, size_t rows, size_t knn, const uint32_t *state_key,
+                         const uint32_t *state_idx, const float *state_d1, int states_on_device, int ani,
+                         uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device);
+
 /* The same with the candidate lists built on the device as well: skq holds the index sketch
  * (u16 bins, `.skq` layout [sample][sketch_size]) of every sample of `s`, row i = sample i (the
  * caller applies the .ski -> .skd order map); candidates of i = samples sharing at least one

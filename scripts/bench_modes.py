@@ -81,7 +81,7 @@ def full_size(which):
         q.close()
         r.close()
         torch.cuda.empty_cache()
-    for tag in [w for w in which if w.startswith("cfg5full") or w.startswith("knn")]:
+    for tag in [w for w in which if (w.startswith("cfg5full") or w.startswith("knn")) and not w.startswith("@")]:
         # cfg5full[_r][@rows]: the whole of cfg 5, self kNN-50 over 1M x 1M; knn<N>[_r]: the same at n = N.
         # _r = clustered sketches (200 close neighbours per row) instead of Set U (every key ties at 1.0).
         # Each data set runs in both forms of the driver: every pair once (symmetric) and row by row.
@@ -109,6 +109,33 @@ def full_size(which):
                               "idx_checksum": int(idx.sum()), "mean_nearest": float(d0[:, 0].mean()),
                               "same_as_previous_driver": same}), flush=True)
         os.environ.pop("SKL_KNN_SYMMETRIC", None)
+        if "@ranks" in " ".join(which):
+            # the 8-GPU form of the same job on this one GPU: time rank 0's and rank 7's share of
+            # the bands (partial states for all rows) and the merge of one row shard
+            from sketchlib.rust_amd import multi_gpu
+            world = 8
+            p = s.set_k(21)
+            band_rows = capi.knn_band_rows(s, p, world)
+            deal = multi_gpu.knn_band_deal((n + band_rows - 1) // band_rows, world)
+            st = (torch.empty((n, 50), dtype=torch.int32, device=dev), torch.empty((n, 50), dtype=torch.int32, device=dev), None)
+            for r in (0, world - 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                capi.self_dists_knn_partial(ctx, s, p, 50, band_rows, deal[r], out=st)
+                torch.cuda.synchronize()
+                print(json.dumps({"mode": f"rank {r} of {world}: its bands of the one-evaluation self kNN-50, n = {n}",
+                                  "band_rows": band_rows, "bands": len(deal[r]), "wall_s": time.perf_counter() - t0}), flush=True)
+            rows = n // world
+            stack_k = st[0][:rows].unsqueeze(0).repeat(world, 1, 1).contiguous()
+            stack_i = st[1][:rows].unsqueeze(0).repeat(world, 1, 1).contiguous()
+            out = (torch.empty((rows, 50), dtype=torch.int64, device=dev), torch.empty((rows, 50), dtype=torch.float32, device=dev), None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            capi.knn_merge_states(ctx, stack_k, stack_i, None, out=out)
+            torch.cuda.synchronize()
+            print(json.dumps({"mode": f"merge of {world} partial states for one row shard ({rows} rows)",
+                              "wall_s": time.perf_counter() - t0,
+                              "exchange_bytes_per_rank": (world - 1) * rows * 50 * 8}), flush=True)
         s.close()
         torch.cuda.empty_cache()
 

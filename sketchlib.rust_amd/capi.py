@@ -79,6 +79,11 @@ _SIG = [
     ("skl_self_dists_knn_candidates", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, _P, _P, _P, _P]),
     ("skl_shared_bins_max_samples", C.c_size_t, []),
     ("skl_self_dists_knn_shared_bins", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, _P, C.c_size_t, _P, _P, _P]),
+    ("skl_knn_band_rows", C.c_size_t, [_P, C.POINTER(DistParams), C.c_size_t]),
+    ("skl_self_dists_knn_partial", C.c_int, [_P, _P, C.POINTER(DistParams), C.c_size_t, C.c_size_t, _P, C.c_size_t,
+                                             _P, _P, _P, C.c_int]),
+    ("skl_knn_merge_states", C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, C.c_int, C.c_int,
+                                       _P, _P, _P, C.c_int]),
     ("skl_sketch_signs", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.c_int, _P]),
     ("skl_self_binmatch", C.c_int, [_P, _P, _P, C.c_int]),
     ("skl_cross_binmatch", C.c_int, [_P, _P, _P, _P, C.c_int]),
@@ -313,6 +318,39 @@ def cross_dists_knn(ctx, r, q, p, knn, q0=0, q1=None):
     _check(load().skl_cross_dists_knn_rows(ctx._h, r._h, q._h, C.byref(p), knn, q0, q1,
                                            idx.ctypes.data, d0.ctypes.data, d1.ctypes.data, 0))
     return idx, d0, d1
+
+
+def knn_band_rows(s, p, participants=1):
+    """Band height of the one-evaluation self kNN that every participant agrees on."""
+    return int(load().skl_knn_band_rows(s._h, C.byref(p), participants))
+
+
+def self_dists_knn_partial(ctx, s, p, knn, band_rows, bands, out=None):
+    """This participant's share (ascending band indices) of the one-evaluation self kNN:
+    -> (state_key u32, state_idx u32, state_d1 f32 | None), each [n, knn], for ALL n rows.
+    `out` = a tuple of preallocated numpy arrays or device tensors (int32 bit patterns) instead."""
+    bands = np.ascontiguousarray(bands, dtype=np.uint32)
+    coreacc = p.dist_type == COREACC
+    if out is None:
+        out = (np.empty((s.n, knn), dtype=np.uint32), np.empty((s.n, knn), dtype=np.uint32),
+               np.empty((s.n, knn), dtype=np.float32) if coreacc else None)
+    (ka, dev), (ia, _), (da, _) = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
+    _check(load().skl_self_dists_knn_partial(ctx._h, s._h, C.byref(p), knn, band_rows,
+                                             bands.ctypes.data if bands.size else None, bands.size, ka, ia, da, dev))
+    return out
+
+
+def knn_merge_states(ctx, state_key, state_idx, state_d1, ani=False, out=None):
+    """Partial states of the same rows, stacked [n_states, rows, knn] (numpy or device tensors)
+    -> (idx u64, d0 f32, d1 f32 | None) [rows, knn] as self_dists_knn returns them."""
+    n_states, rows, knn = state_key.shape
+    (ka, dev), (ia, _), (da, _) = _ptr(state_key), _ptr(state_idx), _ptr(state_d1)
+    if out is None:
+        out = _knn_out(rows, knn)
+    (oi, odev), (o0, _), (o1, _) = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
+    _check(load().skl_knn_merge_states(ctx._h, n_states, rows, knn, ka, ia, da, dev, int(ani), oi, o0,
+                                       o1 if state_d1 is not None else None, odev))
+    return out
 
 
 def self_dists_knn_candidates(ctx, s, p, knn, row_offsets, cand):

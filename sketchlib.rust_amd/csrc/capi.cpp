@@ -902,6 +902,16 @@ struct KnnState {
 };
 }  // namespace
 
+// Rows per band of the symmetric drivers: about 8 bands per participant (7/16 of the pair
+// evaluations saved), each band at least 32 M pairs, four band buffers within `budget` bytes.
+static size_t symmetric_band_rows(size_t n, size_t rec, size_t budget, size_t participants)
+{
+    auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    const size_t budget_rows = std::max<size_t>(16, budget / 4 / (n * rec) / 16 * 16);
+    const size_t parts = std::max<size_t>(1, participants);
+    return std::min(budget_rows, std::max(up16((n + 8 * parts - 1) / (8 * parts)), up16((32ull << 20) / n + 1)));
+}
+
 static int knn_state_init(KnnState &st, size_t rows, size_t knn, bool coreacc, hipStream_t stream)
 {
     const size_t items = rows * knn;
@@ -926,12 +936,13 @@ static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
     const int forced = forced_kernel();
     if (forced != 0 && forced != 4) return false;          // the turned store lives in pair_kslice.hip
     const long long shape = env_int("SKL_KSLICE_SHAPE", 0);
-    if (shape != 0 && shape != 81 && shape != 82 && shape != 161 && shape != 162) return false;
-    return env_int("SKL_KNN_SYMMETRIC", 1) != 0;
+    return shape == 0 || shape == 81 || shape == 82 || shape == 161 || shape == 162;
 }
 
-static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
-                              size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
+// The bands `bands` (ascending indices; band b = rows [b*band_rows, (b+1)*band_rows)) merged into
+// the running states `st` of all n rows.
+static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                               size_t band_rows, const std::vector<uint32_t> &bands, bool overlap, KnnState &st)
 {
     const size_t n = s->n;
     const bool coreacc = p->dist_type == SKL_DIST_COREACC;
@@ -948,13 +959,16 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
         SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[1], 3));
         SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[1], 5));
     }
-    KnnState st;
-    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
+    if (overlap) {   // the states were cleared on the context's stream, the merges run on the other one
+        HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[0], 0));
+    }
 
     const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
     size_t it = 0;
-    for (size_t b0 = 0; b0 < n; b0 += band_rows, ++it) {
+    for (const uint32_t band : bands) {
+        const size_t b0 = (size_t)band * band_rows;
         const size_t b1 = std::min(n, b0 + band_rows);
         const int buf = overlap ? (int)(it & 1) : 0;
         if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
@@ -1005,13 +1019,27 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
         m.self_id_base = m.state_row_base = (uint32_t)b1;
         HIP_TRY(launch_topk_merge(m, topk_stream));
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
+        ++it;
     }
-    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, n * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0, d_d1,
-                                 topk_stream));
-    if (overlap) {   // results (and the band buffers) belong to the context's stream again
+    if (overlap && it) {   // the states (and the band buffers) belong to the context's stream again
         HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
     }
+    return SKL_OK;
+}
+
+static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                              size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
+{
+    const size_t n = s->n;
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    KnnState st;
+    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
+    std::vector<uint32_t> bands((n + band_rows - 1) / band_rows);
+    for (size_t b = 0; b < bands.size(); ++b) bands[b] = (uint32_t)b;
+    SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, bands, overlap, st));
+    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, n * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0, d_d1,
+                                 ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
     return SKL_OK;
 }
@@ -1123,15 +1151,12 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     // The whole self matrix: evaluate each pair once (knn_self_symmetric) when that leaves bands
     // worth launching -- about 8 of them (7/16 of the pair evaluations saved), each at least 32 M
     // pairs, within four band buffers of up to half the free HBM (<= 32 GiB) together.
-    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p);
+    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p) &&
+                     env_int("SKL_KNN_SYMMETRIC", 1) != 0;   // (0: A/B against the row-by-row form)
     if (symmetric) {
-        auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
         size_t budget = band_bytes;
         if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, 32ull << 30));
-        const size_t budget_rows = std::max<size_t>(16, budget / 4 / (n_cand * rec) / 16 * 16);
-        const size_t want = forced_band_rows
-                                ? forced_band_rows
-                                : std::min(budget_rows, std::max(up16((n_cand + 7) / 8), up16((32ull << 20) / n_cand + 1)));
+        const size_t want = forced_band_rows ? forced_band_rows : symmetric_band_rows(n_cand, rec, budget, 1);
         if (want >= n_cand) symmetric = false;
         else band_rows = want;
     }
@@ -1469,6 +1494,145 @@ extern "C" int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *
     (void)hipFree(d_cursor.p); d_cursor.p = nullptr;
     return knn_from_device_csr(ctx, s, p, knn, offsets.data(), (const uint64_t *)d_off.p, (const uint32_t *)d_cand.p,
                                out_idx, out_d0);
+}
+
+extern "C" size_t skl_knn_band_rows(const skl_sketches *s, const skl_dist_params *p, size_t n_participants)
+{
+    if (!s || !p || s->n == 0) return 0;
+    const size_t rec = p->dist_type == SKL_DIST_COREACC ? 2 * sizeof(float) : sizeof(float);
+    const long long forced = env_int("SKL_KNN_BAND_ROWS", 0);   // test knob (the same for every participant)
+    if (forced > 0) return std::min<size_t>(s->n, (size_t)forced);
+    // a fixed budget (no free-memory query): every participant must arrive at the same number
+    return std::min(s->n, symmetric_band_rows(s->n, rec, 32ull << 30, n_participants));
+}
+
+extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                                          size_t band_rows, const uint32_t *bands, size_t n_bands,
+                                          uint32_t *state_key, uint32_t *state_idx, float *state_d1,
+                                          int out_on_device)
+{
+    SKL_TRY(check_params(s, s, p));
+    SKL_TRY(ctx_bind(ctx));
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    if (!state_key || !state_idx || (coreacc && !state_d1)) return fail(SKL_ERR_INVALID_ARG, "state pointers are null");
+    const size_t n = s->n;
+    if (n < 2 || knn == 0 || knn > n - 1) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, n ? n - 1 : 0);
+    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
+    if (band_rows == 0) return fail(SKL_ERR_INVALID_ARG, "band_rows is zero");
+    if (n_bands && !bands) return fail(SKL_ERR_INVALID_ARG, "bands is null");
+    if (!knn_symmetric_ok(s, p)) {
+        return fail(SKL_ERR_INVALID_ARG, "no one-evaluation kNN for this configuration; shard rows with skl_self_dists_knn_rows");
+    }
+    const size_t total_bands = (n + band_rows - 1) / band_rows;
+    std::vector<uint32_t> list(bands, bands + n_bands);
+    for (size_t x = 0; x < list.size(); ++x) {
+        if (list[x] >= total_bands || (x && list[x] <= list[x - 1])) {
+            return fail(SKL_ERR_INVALID_ARG, "bands must be ascending and below %zu", total_bands);
+        }
+    }
+    KnnState st;
+    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
+    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && list.size() > 1;
+    SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
+    const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const size_t items = n * knn;
+    HIP_TRY(hipMemcpyAsync(state_key, st.key, items * sizeof(uint32_t), kind, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(state_idx, st.idx, items * sizeof(uint32_t), kind, ctx->stream));
+    if (coreacc) HIP_TRY(hipMemcpyAsync(state_d1, st.d1, items * sizeof(float), kind, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
+    return SKL_OK;
+}
+
+extern "C" int skl_knn_merge_states(skl_ctx *ctx, size_t n_states, size_t rows, size_t knn,
+                                    const uint32_t *state_key, const uint32_t *state_idx, const float *state_d1,
+                                    int states_on_device, int ani, uint64_t *out_idx, float *out_d0, float *out_d1,
+                                    int out_on_device)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!state_key || !state_idx || !out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (state_d1 && !out_d1) return fail(SKL_ERR_INVALID_ARG, "out_d1 is required with second values");
+    if (n_states == 0 || knn == 0 || knn > 2048) return fail(SKL_ERR_INVALID_ARG, "n_states and knn (<= 2048) must be positive");
+    if (rows == 0) return SKL_OK;
+    const size_t items = rows * knn;
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } in_key, in_idx, in_d1, tmp_key[2], tmp_idx[2], tmp_d1[2], o_idx, o_d0, o_d1;
+    const uint32_t *d_key = state_key, *d_idx = state_idx;
+    const float *d_d1 = state_d1;
+    if (!states_on_device) {
+        HIP_TRY(hipMalloc(&in_key.p, n_states * items * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&in_idx.p, n_states * items * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(in_key.p, state_key, n_states * items * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(in_idx.p, state_idx, n_states * items * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        d_key = (const uint32_t *)in_key.p;
+        d_idx = (const uint32_t *)in_idx.p;
+        if (state_d1) {
+            HIP_TRY(hipMalloc(&in_d1.p, n_states * items * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(in_d1.p, state_d1, n_states * items * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            d_d1 = (const float *)in_d1.p;
+        }
+    }
+    // fold the states, as many per launch as fit the LDS sort
+    std::vector<const uint32_t *> keys, idxs;
+    std::vector<const float *> d1s;
+    for (size_t x = 0; x < n_states; ++x) {
+        keys.push_back(d_key + x * items);
+        idxs.push_back(d_idx + x * items);
+        d1s.push_back(d_d1 ? d_d1 + x * items : nullptr);
+    }
+    const size_t group = std::max<size_t>(2, std::min<size_t>(MERGE_STATES_MAX, MERGE_STATES_ITEMS / knn));
+    int flip = 0;
+    for (;;) {   // (one state: a pass through the kernel is a copy)
+        const size_t take = std::min(group, keys.size());
+        if (!tmp_key[flip].p) {
+            HIP_TRY(hipMalloc(&tmp_key[flip].p, items * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&tmp_idx[flip].p, items * sizeof(uint32_t)));
+            if (d_d1) HIP_TRY(hipMalloc(&tmp_d1[flip].p, items * sizeof(float)));
+        }
+        MergeStatesArgs m;
+        memset(&m, 0, sizeof m);
+        for (size_t x = 0; x < take; ++x) {
+            m.key[x] = keys[x];
+            m.idx[x] = idxs[x];
+            m.d1[x] = d1s[x];
+        }
+        m.n_in = (uint32_t)take;
+        m.rows = (uint32_t)rows;
+        m.knn = (uint32_t)knn;
+        m.out_key = (uint32_t *)tmp_key[flip].p;
+        m.out_idx = (uint32_t *)tmp_idx[flip].p;
+        m.out_d1 = d_d1 ? (float *)tmp_d1[flip].p : nullptr;
+        HIP_TRY(launch_merge_states(m, ctx->stream));
+        keys.erase(keys.begin(), keys.begin() + take);
+        idxs.erase(idxs.begin(), idxs.begin() + take);
+        d1s.erase(d1s.begin(), d1s.begin() + take);
+        keys.insert(keys.begin(), m.out_key);
+        idxs.insert(idxs.begin(), m.out_idx);
+        d1s.insert(d1s.begin(), m.out_d1);
+        flip ^= 1;
+        if (keys.size() == 1) break;
+    }
+    uint64_t *r_idx = out_idx;
+    float *r_d0 = out_d0, *r_d1 = out_d1;
+    if (!out_on_device) {
+        HIP_TRY(hipMalloc(&o_idx.p, items * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&o_d0.p, items * sizeof(float)));
+        r_idx = (uint64_t *)o_idx.p;
+        r_d0 = (float *)o_d0.p;
+        if (d_d1) {
+            HIP_TRY(hipMalloc(&o_d1.p, items * sizeof(float)));
+            r_d1 = (float *)o_d1.p;
+        }
+    }
+    HIP_TRY(launch_topk_finalize(keys[0], idxs[0], d1s[0], items, (!d_d1 && ani) ? 1 : 0, r_idx, r_d0, r_d1, ctx->stream));
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out_idx, r_idx, items * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out_d0, r_d0, items * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (d_d1) HIP_TRY(hipMemcpyAsync(out_d1, r_d1, items * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // temporaries are freed on return
+    return SKL_OK;
 }
 
 extern "C" int skl_cross_dists_knn_rows(skl_ctx *ctx, const skl_sketches *ref,

@@ -470,6 +470,63 @@ SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches
     std::vector<float> d0(n * knn), d1(n * knn);
     const skl_dist_params p = to_params(dist_type, completeness_cutoff);
     const std::vector<size_t> b = even_bounds(n, devs.size());
+    // Every pair once across the devices (the reference evaluates (i, j) and (j, i), mod.rs:148-171):
+    // the row bands are dealt back and forth over the devices (band b costs ~ n - b*band_rows), each
+    // device returns its partial top-k states for ALL rows, and every device then merges one row
+    // shard of the stacked states.  Configurations without that form fall through to row shards.
+    {
+        const size_t W = devs.size();
+        const bool coreacc = p.dist_type == SKL_DIST_COREACC;
+        std::vector<std::vector<uint32_t>> key(W), sid(W);
+        std::vector<std::vector<float>> sd1(W);
+        std::vector<int> rc(W, SKL_OK);
+        std::vector<std::string> msg(W);
+        for_each_device(devs, [&](size_t d) {
+            Slab s(devs[d], sketches, completeness_vec);
+            const size_t band_rows = skl_knn_band_rows(s.h, &p, W);
+            if (band_rows == 0) {
+                rc[d] = SKL_ERR_INVALID_ARG;
+                return;
+            }
+            const size_t n_bands = (n + band_rows - 1) / band_rows;
+            std::vector<uint32_t> mine;
+            for (size_t band = 0; band < n_bands; ++band) {
+                const size_t lap = band / W, pos = band % W;
+                if ((lap % 2 == 0 ? pos : W - 1 - pos) == d) mine.push_back((uint32_t)band);
+            }
+            key[d].resize(n * knn);
+            sid[d].resize(n * knn);
+            if (coreacc) sd1[d].resize(n * knn);
+            rc[d] = skl_self_dists_knn_partial(devs[d].ctx(), s.h, &p, knn, band_rows, mine.data(), mine.size(),
+                                               key[d].data(), sid[d].data(), coreacc ? sd1[d].data() : nullptr, 0);
+            if (rc[d] != SKL_OK) msg[d] = skl_last_error();
+        });
+        bool once = true;
+        for (size_t d = 0; d < W; ++d) {
+            if (rc[d] == SKL_ERR_INVALID_ARG) once = false;
+            else if (rc[d] == SKL_ERR_KMER_COUNT || rc[d] == SKL_ERR_EMPTY_DB) throw Panic(msg[d]);
+            else if (rc[d] != SKL_OK) throw std::runtime_error(msg[d]);
+        }
+        if (once) {
+            for_each_device(devs, [&](size_t d) {
+                const size_t rows = b[d + 1] - b[d];
+                if (rows == 0) return;
+                std::vector<uint32_t> k_all(W * rows * knn), i_all(W * rows * knn);
+                std::vector<float> d_all(coreacc ? W * rows * knn : 0);
+                for (size_t w = 0; w < W; ++w) {
+                    std::copy_n(key[w].data() + b[d] * knn, rows * knn, k_all.data() + w * rows * knn);
+                    std::copy_n(sid[w].data() + b[d] * knn, rows * knn, i_all.data() + w * rows * knn);
+                    if (coreacc) std::copy_n(sd1[w].data() + b[d] * knn, rows * knn, d_all.data() + w * rows * knn);
+                }
+                check(skl_knn_merge_states(devs[d].ctx(), W, rows, knn, k_all.data(), i_all.data(),
+                                           coreacc ? d_all.data() : nullptr, 0, p.ani, idx.data() + b[d] * knn,
+                                           d0.data() + b[d] * knn, d1.data() + b[d] * knn, 0));
+            });
+            SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
+            out.ref_names = sketch_names(sketches);
+            return out;
+        }
+    }
     for_each_device(devs, [&](size_t d) {
         if (b[d + 1] <= b[d]) return;
         Slab s(devs[d], sketches, completeness_vec);

@@ -216,6 +216,19 @@ struct TopkMergeArgs {
     float *run_d1;            // [.][knn] second values (stride2 == 2) or null
 };
 hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream);
+// Union of up to MERGE_STATES_MAX partial states of the same rows (disjoint candidate sets) ->
+// one state: the knn smallest (key, id) per row.  n_in * knn <= MERGE_STATES_ITEMS.
+constexpr int MERGE_STATES_MAX = 16;
+constexpr int MERGE_STATES_ITEMS = 4096;
+struct MergeStatesArgs {
+    const uint32_t *key[MERGE_STATES_MAX];
+    const uint32_t *idx[MERGE_STATES_MAX];
+    const float *d1[MERGE_STATES_MAX];   // all null or all set
+    uint32_t n_in, rows, knn;
+    uint32_t *out_key, *out_idx;
+    float *out_d1;
+};
+hipError_t launch_merge_states(const MergeStatesArgs &args, hipStream_t stream);
 // state -> (out_idx, out_d0) in the public form
 hipError_t launch_topk_finalize(const uint32_t *run_key, const uint32_t *run_idx, const float *run_d1, uint64_t items,
                                 int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1, hipStream_t stream);

@@ -732,6 +732,65 @@ hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream)
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(TOPK_THREADS) void merge_states_kernel(const MergeStatesArgs g)
+{
+    __shared__ uint64_t items[MERGE_STATES_ITEMS];   // (sortable key << 32) | sample id
+    __shared__ uint16_t slot[MERGE_STATES_ITEMS];    // where the item came from: state * knn + position
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, knn = g.knn;
+    const uint32_t total = g.n_in * knn;
+    uint32_t m = 1;
+    while (m < total) m <<= 1;
+    for (uint32_t x = tid; x < m; x += TOPK_THREADS) {
+        if (x < total) {
+            const uint32_t st = x / knn, pos = x - st * knn;
+            const size_t o = (size_t)row * knn + pos;
+            items[x] = ((uint64_t)g.key[st][o] << 32) | g.idx[st][o];
+        } else {
+            items[x] = ~0ull;
+        }
+        slot[x] = (uint16_t)x;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= m; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t x = tid; x < m / 2; x += TOPK_THREADS) {
+                const uint32_t lo = 2 * x - (x & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = items[lo], b = items[hi];
+                if ((a > b) == up) {
+                    items[lo] = b;
+                    items[hi] = a;
+                    const uint16_t sa = slot[lo];
+                    slot[lo] = slot[hi];
+                    slot[hi] = sa;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+        const size_t o = (size_t)row * knn + x;
+        g.out_key[o] = (uint32_t)(items[x] >> 32);
+        g.out_idx[o] = (uint32_t)(items[x] & 0xFFFFFFFFu);
+        if (g.out_d1) {
+            const uint32_t st = slot[x] / knn, pos = slot[x] - st * knn;
+            g.out_d1[o] = st < g.n_in ? g.d1[st][(size_t)row * knn + pos] : 0.0f;
+        }
+    }
+}
+
+hipError_t launch_merge_states(const MergeStatesArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0) return hipSuccess;
+    if (args.n_in == 0 || args.n_in > (uint32_t)MERGE_STATES_MAX || args.knn == 0 ||
+        (uint64_t)args.n_in * args.knn > (uint64_t)MERGE_STATES_ITEMS) {
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(merge_states_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
 __global__ void topk_finalize_kernel(const uint32_t *run_key, const uint32_t *run_idx, const float *run_d1,
                                      uint64_t items, int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1)
 {

@@ -7,9 +7,14 @@ The path shards by independent row bands:
     (distance_matrix.rs:11-14);
   * dense cross: contiguous bands of reference rows (output index i_ref*n_query + j);
   * kNN: contiguous bands of query rows.
-There is no reduction anywhere; the only exchange is assembling the output on rank 0,
+There is no reduction there; the only exchange is assembling the output on rank 0,
 done as grouped point-to-point send/recv straight into the final offsets (what
 ncclGather does internally, but with per-rank counts and no staging copy).
+
+The one-evaluation self kNN (every pair {i, j} computed once instead of twice) is the
+exception: a pair's key is a candidate of BOTH rows, which belong to different ranks, so every
+rank keeps partial top-k states for all rows and the ranks exchange row shards of them with
+one all-to-all before the final merge (knn_band_deal / exchange_knn_states / self_knn_once).
 """
 import numpy as np
 
@@ -119,3 +124,67 @@ class PipelinedGather:
         while self.pending:
             for req in self.pending.popleft():
                 req.wait()
+
+
+# ---------------------------------------------------------------------------
+# self kNN, every pair once
+# ---------------------------------------------------------------------------
+
+def knn_band_deal(n_bands, world):
+    """Band indices per rank, ascending.  Band b costs ~ (n_bands - b): deal them back and forth
+    (0..W-1, W-1..0, ...) so that every rank gets the same cost to first order."""
+    out = [[] for _ in range(world)]
+    for b in range(n_bands):
+        lap, pos = divmod(b, world)
+        out[pos if lap % 2 == 0 else world - 1 - pos].append(b)
+    return out
+
+
+def exchange_knn_states(states, bounds, rank, world, dist):
+    """All-to-all of row shards: `states` = this rank's [n, knn] tensors (some may be None);
+    returns, for each, the [world, rows_of_this_rank, knn] stack of every rank's view of the rows
+    bounds[rank]..bounds[rank+1]."""
+    import torch
+
+    rows = [bounds[w + 1] - bounds[w] for w in range(world)]
+    out = []
+    for t in states:
+        if t is None:
+            out.append(None)
+            continue
+        knn = t.shape[1]
+        recv = torch.empty((world * rows[rank], knn), dtype=t.dtype, device=t.device)
+        if world == 1:
+            recv.copy_(t[bounds[0]:bounds[1]])
+        else:
+            dist.all_to_all_single(recv, t.contiguous(), output_split_sizes=[rows[rank]] * world,
+                                   input_split_sizes=rows)
+        out.append(recv.view(world, rows[rank], knn))
+    return out
+
+
+def self_knn_once(ctx, sk, p, knn, rank, world, dist, device):
+    """One-evaluation self kNN over `world` ranks: -> (row0, row1, idx, d0, d1) for this rank's
+    row shard, as device tensors.  Every rank must call it."""
+    import torch
+
+    from . import capi
+
+    n = sk.n
+    band_rows = capi.knn_band_rows(sk, p, world)
+    n_bands = (n + band_rows - 1) // band_rows
+    mine = knn_band_deal(n_bands, world)[rank]
+    coreacc = p.dist_type == capi.COREACC
+    key = torch.empty((n, knn), dtype=torch.int32, device=device)
+    idx = torch.empty((n, knn), dtype=torch.int32, device=device)
+    d1 = torch.empty((n, knn), dtype=torch.float32, device=device) if coreacc else None
+    capi.self_dists_knn_partial(ctx, sk, p, knn, band_rows, mine, out=(key, idx, d1))
+    bounds = even_row_bounds(n, world)
+    k_all, i_all, d_all = exchange_knn_states([key, idx, d1], bounds, rank, world, dist)
+    rows = bounds[rank + 1] - bounds[rank]
+    out = (torch.empty((rows, knn), dtype=torch.int64, device=device),
+           torch.empty((rows, knn), dtype=torch.float32, device=device),
+           torch.empty((rows, knn), dtype=torch.float32, device=device) if coreacc else None)
+    if rows:
+        capi.knn_merge_states(ctx, k_all, i_all, d_all, ani=bool(p.ani), out=out)
+    return bounds[rank], bounds[rank + 1], out[0], out[1], out[2]

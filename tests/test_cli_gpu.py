@@ -230,6 +230,12 @@ def test_multi_context_synthetic(gpu_ctx, tmp_path):
     assert run(prefix, "--gpus", "1") == one
     knn = run(prefix, "--knn", "10")
     assert run(prefix, "--knn", "10", "--devices", "0,0,0") == knn
+    # several bands per device: every pair is evaluated once across the devices, the partial
+    # top-k states are merged shard by shard (single-k and core/accessory keys)
+    for flags in (("--knn", "10"), ("--knn", "7", "-k", "23"), ("--knn", "7", "-k", "23", "--ani")):
+        want = run(prefix, *flags)
+        for devices in ("0,0", "0,0,0,0,0"):
+            assert run(prefix, *flags, "--devices", devices, env={"SKL_KNN_BAND_ROWS": "16"}) == want
 
 
 # ---- `sketchlib inverted precluster`, as tests/inverted.rs drives it ----

@@ -124,3 +124,58 @@ def test_device_output_and_default_band_size(skl, gpu_ctx, monkeypatch):
     g = gpu_ctx.sketches(bins, n, kmers, ss64)
     idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), knn)
     assert idx.shape == (n, knn) and np.all(np.diff(d0, axis=1) >= 0)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("dist", ["jaccard", "ani", "coreacc"])
+def test_partial_states_of_every_rank_merge_to_the_whole(skl, gpu_ctx, monkeypatch, world, dist):
+    """The multi-GPU form on one device: each 'rank' computes its dealt bands (every pair once
+    across the ranks), the row shards of the partial states are stacked as the all-to-all would
+    deliver them, and skl_knn_merge_states must give the rows of the single-call result."""
+    from sketchlib.rust_amd import multi_gpu
+    kmers, ss64, n, knn, band_rows = [15, 19, 23, 27], 4, 203, 7, 16
+    bins = synth.set_r(n, kmers, ss64, n_clusters=5)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k() if dist == "coreacc" else g.set_k(23, dist == "ani")
+    monkeypatch.setenv("SKL_KNN_SYMMETRIC", "0")
+    whole = skl.self_dists_knn(gpu_ctx, g, p, knn)
+    n_bands = (n + band_rows - 1) // band_rows
+    deal = multi_gpu.knn_band_deal(n_bands, world)
+    states = [skl.self_dists_knn_partial(gpu_ctx, g, p, knn, band_rows, deal[r]) for r in range(world)]
+    bounds = multi_gpu.even_row_bounds(n, world)
+    for r in range(world):
+        r0, r1 = bounds[r], bounds[r + 1]
+        if r1 == r0:
+            continue
+        stack = [np.ascontiguousarray(np.stack([st[x][r0:r1] for st in states])) if states[0][x] is not None else None
+                 for x in range(3)]
+        idx, d0, d1 = skl.knn_merge_states(gpu_ctx, stack[0], stack[1], stack[2], ani=dist == "ani")
+        assert np.array_equal(idx, whole[0][r0:r1]) and np.array_equal(d0, whole[1][r0:r1])
+        if dist == "coreacc":
+            assert np.array_equal(d1, whole[2][r0:r1])
+
+
+def test_merge_states_folds_more_than_one_launch(skl, gpu_ctx):
+    """knn = 1500: two states fill the 4096-item sort, so 5 states are folded in several launches."""
+    rng = np.random.default_rng(11)
+    n_states, rows, knn = 5, 9, 1500
+    keys = rng.integers(0x80000000, 0xBF800000, size=(n_states, rows, knn), dtype=np.uint32)
+    keys.sort(axis=2)
+    ids = rng.permutation(n_states * rows * knn).astype(np.uint32).reshape(n_states, rows, knn)
+    idx, d0, _ = skl.knn_merge_states(gpu_ctx, keys, ids, None)
+    for r in range(rows):
+        union = sorted(zip(keys[:, r].ravel().tolist(), ids[:, r].ravel().tolist()))[:knn]
+        assert idx[r].tolist() == [j for _, j in union]
+        exp = (np.array([k for k, _ in union], dtype=np.uint32) & np.uint32(0x7FFFFFFF)).view(np.float32)
+        assert np.array_equal(d0[r], exp)
+
+
+def test_partial_rejects_bad_band_lists(skl, gpu_ctx):
+    kmers, ss64, n = [21], 2, 100
+    g = gpu_ctx.sketches(synth.set_u(n, 1, ss64), n, kmers, ss64)
+    p = g.set_k(21)
+    for bands in ([3, 2], [0, 0], [7]):
+        with pytest.raises(skl.SklError) as e:
+            skl.self_dists_knn_partial(gpu_ctx, g, p, 5, 16, bands)
+        assert e.value.code == skl.ERR_INVALID_ARG
+    assert skl.knn_band_rows(g, p, 8) == skl.knn_band_rows(g, p, 8) > 0

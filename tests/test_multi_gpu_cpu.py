@@ -90,3 +90,75 @@ def test_gloo_world2_gather(oracle, tmp_path):
         env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "GATHER_OK" in res.stdout and "PIPELINE_OK" in res.stdout
+
+
+@pytest.mark.parametrize("n_bands,world", [(1, 1), (5, 2), (16, 8), (489, 8), (7, 3)])
+def test_knn_band_deal(n_bands, world):
+    deal = multi_gpu.knn_band_deal(n_bands, world)
+    assert sorted(b for r in deal for b in r) == list(range(n_bands))
+    assert all(r == sorted(r) for r in deal)
+    if n_bands >= 16 * world:   # band b costs ~ (n_bands - b): the back-and-forth deal evens it out
+        cost = [sum(n_bands - b for b in r) for r in deal]
+        assert max(cost) - min(cost) <= 2 * n_bands
+
+
+KNN_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from sketchlib.rust_amd import multi_gpu, synth
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, kmers, ss64, knn, band_rows = 97, [17, 21, 25], 4, 6, 10
+s = O.Sketches(synth.set_r(n, kmers, ss64, n_clusters=4), n, kmers, ss64)
+dense = O.self_dists_all(s, O.JACCARD, 1, False)[:, 0]     # condensed (i < j), f32
+sortable = lambda f: (f.view(np.uint32) | np.uint32(0x80000000)).astype(np.uint32)   # keys are >= 0
+n_bands = (n + band_rows - 1) // band_rows
+mine = multi_gpu.knn_band_deal(n_bands, world)[rank]
+# stand-in for skl_self_dists_knn_partial (the GPU half): the pairs {i < j} whose band of i is
+# ours, each a candidate of both rows; per row the knn smallest (key, id)
+cand = [[] for _ in range(n)]
+pos = 0
+for i in range(n):
+    for j in range(i + 1, n):
+        if i // band_rows in mine:
+            k = int(sortable(dense[pos:pos + 1])[0])
+            cand[i].append((k, j)); cand[j].append((k, i))
+        pos += 1
+key = np.full((n, knn), 0xFFFFFFFF, dtype=np.uint32); idx = np.full((n, knn), 0xFFFFFFFF, dtype=np.uint32)
+for r in range(n):
+    best = sorted(cand[r])[:knn]
+    for x, (k, j) in enumerate(best):
+        key[r, x], idx[r, x] = k, j
+bounds = multi_gpu.even_row_bounds(n, world)
+tk = torch.from_numpy(key.view(np.int32)); ti = torch.from_numpy(idx.view(np.int32))
+k_all, i_all, none = multi_gpu.exchange_knn_states([tk, ti, None], bounds, rank, world, dist)
+assert none is None and tuple(k_all.shape) == (world, bounds[rank + 1] - bounds[rank], knn)
+# stand-in for skl_knn_merge_states: knn smallest (key, id) of the union
+ka = k_all.numpy().view(np.uint32); ia = i_all.numpy().view(np.uint32)
+exp = O.self_dists_knn(s, knn, O.JACCARD, 1, False, ties=O.TIES_CANONICAL)
+for r in range(bounds[rank], bounds[rank + 1]):
+    union = sorted((int(ka[w, r - bounds[rank], x]), int(ia[w, r - bounds[rank], x]))
+                   for w in range(world) for x in range(knn))[:knn]
+    assert [j for _, j in union] == exp["idx"][r].tolist(), (rank, r)
+    assert [k for k, _ in union] == sortable(exp["d0"][r]).tolist()
+print("KNN_ONCE_OK", rank)
+dist.barrier()
+dist.destroy_process_group()
+""" % ROOT
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_knn_every_pair_once_exchange(oracle, tmp_path, world):
+    """The all-to-all of partial kNN states: deal of the bands, routing of the row shards, and
+    that the union of the ranks' partial lists holds every row's true neighbours."""
+    script = tmp_path / "knn_worker.py"
+    script.write_text(KNN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+         "--master-addr", "127.0.0.1", "--master-port", str(29540 + world), str(script)],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("KNN_ONCE_OK") == world
