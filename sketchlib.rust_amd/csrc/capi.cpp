@@ -999,6 +999,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         m.run_key = st.key;
         m.run_idx = st.idx;
         m.run_d1 = st.d1;
+        m.streaming = env_int("SKL_TOPK_STREAM", 1) != 0;
         // rows of the band: columns [b0, n) minus themselves (the view's first b0 - col0 columns
         // reached them turned, from earlier bands)
         m.keys = (const float *)kband[buf];
@@ -1046,9 +1047,8 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
 
 // Row-by-row kNN: dense bands of records into scratch, then a per-row top-k.  With two bands
 // the top-k of band i (memory / LDS bound, on the auxiliary stream) runs while the pair kernel
-// of band i + 1 (VALU bound) fills the other one.  The top-k is the running one of the
-// symmetric driver (topk_merge_kernel) fed a whole row at once: an empty state goes straight to
-// the radix select.
+// of band i + 1 (VALU bound) fills the other one.  The top-k is the streaming one of the
+// symmetric driver (topk_merge_kernel), fed a whole row at once.
 static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
                            const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
                            size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
@@ -1069,10 +1069,6 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
         HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
         HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[0], 0));
     }
-    // SKL_KNN_WARM_COLS = c feeds a row in two steps, c columns first (A/B knob, off by default: a
-    // row's close neighbours are too few to be met in a prefix, so the state stays at the tie
-    // value of unrelated pairs and the second step selects again -- measured 7 % slower)
-    const size_t warm_cols = std::min<size_t>(n_cand, (size_t)std::max(0ll, env_int("SKL_KNN_WARM_COLS", 0)));
 
     size_t it = 0;
     for (size_t b0 = r0; b0 < r1; b0 += band_rows, ++it) {
@@ -1092,21 +1088,15 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
         m.run_key = st.key;
         m.run_idx = st.idx;
         m.run_d1 = st.d1;
+        m.streaming = env_int("SKL_TOPK_STREAM", 1) != 0;
         m.key_stride = (uint64_t)n_cand * m.stride2;
         m.rows = (uint32_t)(b1 - b0);
         m.self_id_base = self_mode ? (uint32_t)b0 : 0xFFFFFFFFu;
         m.state_row_base = (uint32_t)(b0 - r0);
-        const size_t first = warm_cols ? warm_cols : n_cand;
         m.keys = (const float *)band[buf];
-        m.cols = (uint32_t)first;
+        m.cols = (uint32_t)n_cand;
         m.id_base = 0;
         HIP_TRY(launch_topk_merge(m, topk_stream));
-        if (first < n_cand) {
-            m.keys = (const float *)band[buf] + first * m.stride2;
-            m.cols = (uint32_t)(n_cand - first);
-            m.id_base = (uint32_t)first;
-            HIP_TRY(launch_topk_merge(m, topk_stream));
-        }
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
     }
     HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, (r1 - r0) * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0,

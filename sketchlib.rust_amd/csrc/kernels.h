@@ -214,6 +214,7 @@ struct TopkMergeArgs {
     uint32_t *run_key;        // [.][knn] sortable key bits, ascending; 0xFFFFFFFF = empty
     uint32_t *run_idx;        // [.][knn]
     float *run_d1;            // [.][knn] second values (stride2 == 2) or null
+    uint32_t streaming;       // 1: one-pass streaming merge (default); 0: radix select only (A/B)
 };
 hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream);
 // Union of up to MERGE_STATES_MAX partial states of the same rows (disjoint candidate sets) ->

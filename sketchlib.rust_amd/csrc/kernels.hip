@@ -635,13 +635,20 @@ hipError_t launch_topk(const TopkArgs &args, hipStream_t stream)
     return hipGetLastError();
 }
 
-// Running top-k of one row (TopkMergeArgs).  Most calls end after the first pass: once a row's
-// state is warm, a band rarely holds a key below its knn-th best.
+// Running top-k of one row (TopkMergeArgs): a streaming merge.  The state sits in LDS as sorted
+// (sortable key << 32 | sample id) items -- that composite IS the canonical order, smallest
+// (key, id) first.  The row's new records are scanned ONCE, in segments: an item below the
+// state's current knn-th one is appended behind the state (up to TOPK_MAX items together), the
+// lot is sorted, the first knn are the new state.  A cold state starts with a segment that fits
+// the buffer outright; segments grow while few items qualify and shrink (the segment is
+// scanned again) when the buffer overflows.  Data that keeps overflowing -- keys arriving in
+// descending order -- falls back to the radix select over state ++ remaining records, which
+// needs the drivers' guarantee that new ids are larger than the ids already in the state.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMergeArgs g)
 {
     __shared__ TopkShared sh;
     __shared__ float second[TOPK_MAX];   // second values of the new state (stride2 == 2)
-    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
     const uint32_t knn = g.knn;
     const size_t srow = (size_t)(g.state_row_base + row) * knn;
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
     uint32_t *si = g.run_idx + srow;
     const uint32_t stride2 = g.stride2;
     const float *keys = g.keys + (size_t)row * g.key_stride;
-    const uint32_t worst = sk[knn - 1];   // 0xFFFFFFFF while the state is not full
+    const uint32_t cols = g.cols;
 
     auto fresh = [&](uint32_t q, uint32_t &u) {   // new key at position q of this launch
         const uint32_t id = g.id_base + q;
@@ -657,62 +664,106 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
         u = sortable_bits(keys[(size_t)q * stride2]);
         return true;
     };
-
-    // ---- pass 1: how many new keys beat the current knn-th best?  (a tie loses: its id is larger) ----
-    // (an empty state facing more keys than the LDS sort holds goes straight to the select)
-    uint32_t n_better = 0xFFFFFFFFu - knn;
-    if (worst != 0xFFFFFFFFu || g.cols + knn <= (uint32_t)TOPK_MAX) {
-        if (tid == 0) sh.count = 0;
-        __syncthreads();
-        uint32_t mine = 0;
-        for (uint32_t q = tid; q < g.cols; q += TOPK_THREADS) {
-            uint32_t u;
-            if (fresh(q, u) && u < worst) ++mine;
+    // second value of a state item: from this launch's records, or from the old state (still
+    // untouched in global memory, sorted by the same composite: binary search)
+    auto second_of = [&](uint64_t item) {
+        const uint32_t id = (uint32_t)(item & 0xFFFFFFFFu);
+        const uint32_t q = id - g.id_base;
+        if (id >= g.id_base && q < cols && id >= g.skip_below && id != self_id) return keys[(size_t)q * 2 + 1];
+        uint32_t lo = 0, hi = knn;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t old = ((uint64_t)sk[mid] << 32) | si[mid];
+            if (old < item) lo = mid + 1; else hi = mid;
         }
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-        if ((tid & 63u) == 0 && mine) atomicAdd(&sh.count, mine);
-        __syncthreads();
-        n_better = sh.count;
-        if (n_better == 0) return;
-        __syncthreads();
-    }
-
-    if (n_better + knn <= (uint32_t)TOPK_MAX) {
-        // ---- few: sort state + qualifiers in LDS ----
-        for (uint32_t x = tid; x < knn; x += TOPK_THREADS) sh.items[x] = ((uint64_t)sk[x] << 32) | x;
-        if (tid == 0) sh.count = knn;
-        __syncthreads();
-        for (uint32_t q = tid; q < g.cols; q += TOPK_THREADS) {
-            uint32_t u;
-            if (fresh(q, u) && u < worst) {
-                const uint32_t pos = atomicAdd(&sh.count, 1u);
-                sh.items[pos] = ((uint64_t)u << 32) | (knn + q);
-            }
+        return g.run_d1[srow + (lo < knn ? lo : knn - 1)];
+    };
+    auto write_state = [&]() {   // items[0, knn) (composite) -> global state; whole workgroup
+        if (stride2 == 2) {
+            for (uint32_t x = tid; x < knn; x += TOPK_THREADS) second[x] = second_of(sh.items[x]);
         }
         __syncthreads();
-        const uint32_t total = knn + n_better;
-        uint32_t m = 1;
-        while (m < total) m <<= 1;
-        for (uint32_t x = total + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
+        for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+            sk[x] = (uint32_t)(sh.items[x] >> 32);
+            si[x] = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+            if (stride2 == 2) g.run_d1[srow + x] = second[x];
+        }
         __syncthreads();
-        sort_items(sh, m);
-    } else {
-        // ---- many (a cold state): select over state ++ new keys ----
-        select_smallest(
-            [&](uint32_t c, uint32_t &u) {
-                if (c < knn) {
-                    u = sk[c];
-                    return true;
+    };
+
+    const uint32_t cap = (uint32_t)TOPK_MAX - knn;   // room behind the state
+    uint32_t begin = 0;
+    bool changed = false;
+    if (cap >= 256u && g.streaming) {
+        for (uint32_t x = tid; x < knn; x += TOPK_THREADS) sh.items[x] = ((uint64_t)sk[x] << 32) | si[x];
+        __syncthreads();
+        uint64_t worst = sh.items[knn - 1];           // ~0 while the state is not full
+        uint32_t seg = worst == ~0ull ? cap : 4u * cap;
+        uint32_t overflows = 0;
+        while (begin < cols) {
+            const uint32_t len = min(seg, cols - begin);
+            if (tid == 0) sh.count = 0;
+            __syncthreads();
+            for (uint32_t q0 = begin; q0 < begin + len; q0 += TOPK_THREADS) {
+                const uint32_t q = q0 + tid;
+                uint32_t u = 0;
+                uint64_t item = ~0ull;
+                if (q < begin + len && fresh(q, u)) item = ((uint64_t)u << 32) | (g.id_base + q);
+                const bool take = item < worst;
+                const uint64_t votes = __ballot(take);
+                if (votes) {   // one LDS atomic per wave
+                    const uint32_t leader = (uint32_t)__builtin_ctzll(votes);
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&sh.count, (uint32_t)__popcll(votes));
+                    base = __shfl(base, leader);
+                    const uint32_t pos = base + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+                    if (take && pos < cap) sh.items[knn + pos] = item;
                 }
-                return fresh(c - knn, u);
-            },
-            knn + g.cols, knn, sh);
+            }
+            __syncthreads();
+            const uint32_t cnt = sh.count;
+            __syncthreads();   // (everyone has read the count before the next segment clears it)
+            if (cnt > cap) {   // too many for the buffer: scan a shorter segment again
+                if (++overflows > 6u) break;
+                seg = max(cap, len / 4u);
+                continue;
+            }
+            if (cnt) {
+                const uint32_t total = knn + cnt;
+                uint32_t m = 1;
+                while (m < total) m <<= 1;
+                for (uint32_t x = total + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
+                __syncthreads();
+                sort_items(sh, m);
+                worst = sh.items[knn - 1];
+                changed = true;
+            }
+            begin += len;
+            if (cnt * 8u <= cap) seg = min(seg * 2u, 1u << 20);
+            else if (cnt * 2u > cap) seg = max(cap, seg / 2u);
+        }
+        if (begin >= cols) {
+            if (changed) write_state();
+            return;
+        }
+        if (changed) write_state();   // the select below reads the state from global memory
     }
-    // ---- items[0, knn) = the new state as (key, position): resolve ids, then write in place ----
+
+    // ---- radix select over state ++ records [begin, cols) (position order = id order) ----
+    const uint32_t rest = cols - begin;
+    select_smallest(
+        [&](uint32_t c, uint32_t &u) {
+            if (c < knn) {
+                u = sk[c];
+                return true;
+            }
+            return fresh(begin + (c - knn), u);
+        },
+        knn + rest, knn, sh);
     for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
         const uint32_t pos = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
-        const uint32_t id = pos < knn ? si[pos] : g.id_base + (pos - knn);
-        if (stride2 == 2) second[x] = pos < knn ? g.run_d1[srow + pos] : keys[(size_t)(pos - knn) * 2 + 1];
+        const uint32_t id = pos < knn ? si[pos] : g.id_base + begin + (pos - knn);
+        if (stride2 == 2) second[x] = pos < knn ? g.run_d1[srow + pos] : keys[(size_t)(begin + pos - knn) * 2 + 1];
         sh.items[x] = (sh.items[x] & 0xFFFFFFFF00000000ull) | id;
     }
     __syncthreads();

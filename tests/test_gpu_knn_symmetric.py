@@ -77,28 +77,6 @@ def test_completeness_correction(oracle, skl, gpu_ctx, monkeypatch):
     np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
 
 
-def test_row_by_row_with_and_without_the_warm_up_step(oracle, skl, gpu_ctx, monkeypatch):
-    """The row-by-row driver can feed a row in two steps (SKL_KNN_WARM_COLS columns, then the rest:
-    the second step meets a warm state); the lists must not depend on it, for single-k and for
-    core/accessory keys, self and cross."""
-    kmers, ss64, n, knn = [17, 21, 25], 2, 6000, 12
-    bins = synth.set_r(n, kmers, ss64, n_clusters=50)
-    g = gpu_ctx.sketches(bins, n, kmers, ss64)
-    q = gpu_ctx.sketches(bins[:300].copy(), 300, kmers, ss64)
-    monkeypatch.setenv("SKL_KNN_SYMMETRIC", "0")
-    for p in (g.set_k(21), g.set_k()):
-        got = {}
-        for warm in ("0", "1000", "4096"):
-            monkeypatch.setenv("SKL_KNN_WARM_COLS", warm)
-            got[warm] = skl.self_dists_knn(gpu_ctx, g, p, knn) + skl.cross_dists_knn(gpu_ctx, g, q, p, knn)
-        for warm in ("1000", "4096"):
-            for a, b in zip(got["0"], got[warm]):
-                assert np.array_equal(a, b)
-    o = oracle.Sketches(bins, n, kmers, ss64)
-    exp = oracle.self_dists_knn(o, knn, oracle.COREACC, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
-    assert np.array_equal(got["0"][0], exp["idx"])
-
-
 @pytest.mark.parametrize("n,band_rows,knn", [(3000, 256, 10), (5000, 2100, 20), (4099, 1000, 64)])
 def test_same_as_row_by_row(oracle, skl, gpu_ctx, monkeypatch, n, band_rows, knn):
     """Cold states with more than 2048 candidates take the radix-select branch of the merge; warm
@@ -179,3 +157,33 @@ def test_partial_rejects_bad_band_lists(skl, gpu_ctx):
             skl.self_dists_knn_partial(gpu_ctx, g, p, 5, 16, bands)
         assert e.value.code == skl.ERR_INVALID_ARG
     assert skl.knn_band_rows(g, p, 8) == skl.knn_band_rows(g, p, 8) > 0
+
+
+def test_streaming_merge_against_the_radix_select(oracle, skl, gpu_ctx, monkeypatch):
+    """The one-pass streaming top-k and the radix-select-only form (SKL_TOPK_STREAM=0) on data
+    that exercises growth, overflow + rescan and the give-up branch: keys in random order, in
+    ascending order (nothing qualifies after the first segment) and in descending order (every
+    key qualifies: the segments shrink and the kernel falls back to the select)."""
+    kmers, ss64, knn = [21], 8, 25
+    rng = np.random.default_rng(17)
+    base = synth.set_u(1, 1, ss64)[0]
+    n = 9000
+    # sample s differs from sample 0 in m(s) bins: distance to sample 0 is a known, strictly
+    # monotone function of m
+    order = {"random": rng.permutation(n - 1) % 500, "ascending": np.arange(n - 1) * 500 // (n - 1),
+             "descending": 499 - np.arange(n - 1) * 500 // (n - 1)}
+    for name, m_of in order.items():
+        vals = np.zeros((n, ss64 * 64), dtype=np.uint16)
+        for s_ in range(1, n):
+            vals[s_, :int(m_of[s_ - 1]) + 1] = 1 + (s_ % 3)      # that many bins differ from sample 0 (all zero)
+        bins = synth.bitslice(vals).reshape(n, -1)
+        g = gpu_ctx.sketches(bins, n, kmers, ss64)
+        q = gpu_ctx.sketches(bins[:1].copy(), 1, kmers, ss64)
+        got = {}
+        for stream in ("1", "0"):
+            monkeypatch.setenv("SKL_TOPK_STREAM", stream)
+            got[stream] = skl.cross_dists_knn(gpu_ctx, g, q, g.set_k(21), knn)
+        assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1]), name
+        o_r, o_q = oracle.Sketches(bins, n, kmers, ss64), oracle.Sketches(bins[:1].copy(), 1, kmers, ss64)
+        exp = oracle.cross_dists_knn(o_r, o_q, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL)
+        assert np.array_equal(got["1"][0], exp["idx"]), name
