@@ -187,3 +187,17 @@ def test_streaming_merge_against_the_radix_select(oracle, skl, gpu_ctx, monkeypa
         o_r, o_q = oracle.Sketches(bins, n, kmers, ss64), oracle.Sketches(bins[:1].copy(), 1, kmers, ss64)
         exp = oracle.cross_dists_knn(o_r, o_q, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL)
         assert np.array_equal(got["1"][0], exp["idx"]), name
+
+
+@pytest.mark.parametrize("knn", [1000, 1900, 2048])
+def test_large_knn(oracle, skl, gpu_ctx, monkeypatch, knn):
+    """knn close to the 2048 the LDS buffer holds: little or no room behind the state, so the
+    streaming merge hands over to the radix select; both drivers against the oracle."""
+    kmers, ss64, n = [21], 2, 2300
+    bins = synth.set_r(n, kmers, ss64, n_clusters=3)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    for symmetric in (True, False):
+        idx, d0 = _knn(skl, gpu_ctx, g, g.set_k(21), knn, monkeypatch, 512, symmetric)
+        assert np.array_equal(idx, exp["idx"]), symmetric
+        assert np.array_equal(d0, exp["d0"])
