@@ -58,9 +58,11 @@ def cpu_baseline(n, kmers, ss64, dataset):
     bins = synth.set_u(n, len(kmers), ss64) if dataset == "U" else synth.set_r(n, kmers, ss64)
     s = O.Sketches(bins, n, kmers, ss64)
     pairs = n * (n - 1) // 2
+    m = min(n, 1000)                                    # single-thread calibration on <= 1000 samples
+    sub = s if m == n else O.Sketches(bins[:m].copy(), m, kmers, ss64)
     t0 = time.perf_counter()
-    O.self_dists_all(s, O.COREACC, threads=1)           # single-thread calibration pass
-    single = time.perf_counter() - t0
+    O.self_dists_all(sub, O.COREACC, threads=1)
+    single = (time.perf_counter() - t0) * pairs / (m * (m - 1) // 2)   # one pass of the workload, one thread
     repeat = max(1, int(round(15.0 / single)))
     best = float("inf")
     for _ in range(3):
