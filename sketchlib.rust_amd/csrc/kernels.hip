@@ -661,7 +661,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
     auto fresh = [&](uint32_t q, uint32_t &u) {   // new key at position q of this launch
         const uint32_t id = g.id_base + q;
         if (id < g.skip_below || id == self_id) return false;
-        u = sortable_bits(keys[(size_t)q * stride2]);
+        u = sortable_bits(__builtin_nontemporal_load(&keys[(size_t)q * stride2]));   // read once
         return true;
     };
     // second value of a state item: from this launch's records, or from the old state (still
@@ -704,20 +704,36 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
             const uint32_t len = min(seg, cols - begin);
             if (tid == 0) sh.count = 0;
             __syncthreads();
-            for (uint32_t q0 = begin; q0 < begin + len; q0 += TOPK_THREADS) {
-                const uint32_t q = q0 + tid;
-                uint32_t u = 0;
-                uint64_t item = ~0ull;
-                if (q < begin + len && fresh(q, u)) item = ((uint64_t)u << 32) | (g.id_base + q);
-                const bool take = item < worst;
-                const uint64_t votes = __ballot(take);
-                if (votes) {   // one LDS atomic per wave
-                    const uint32_t leader = (uint32_t)__builtin_ctzll(votes);
-                    uint32_t base = 0;
-                    if (lane == leader) base = atomicAdd(&sh.count, (uint32_t)__popcll(votes));
-                    base = __shfl(base, leader);
-                    const uint32_t pos = base + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
-                    if (take && pos < cap) sh.items[knn + pos] = item;
+            // (UNROLL independent loads per thread before any of them is looked at: one workgroup
+            // walks a whole row, so its memory-level parallelism is what the scan runs at)
+            constexpr uint32_t UNROLL = 4;
+            for (uint32_t q0 = begin; q0 < begin + len; q0 += TOPK_THREADS * UNROLL) {
+                uint64_t item[UNROLL];
+                float raw[UNROLL];
+#pragma unroll
+                for (uint32_t j = 0; j < UNROLL; ++j) {   // unconditional (clamped) loads, all in flight together
+                    const uint32_t q = min(q0 + j * TOPK_THREADS + tid, cols - 1u);
+                    raw[j] = __builtin_nontemporal_load(&keys[(size_t)q * stride2]);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < UNROLL; ++j) {
+                    const uint32_t q = q0 + j * TOPK_THREADS + tid;
+                    const uint32_t id = g.id_base + q;
+                    const bool valid = q < begin + len && id >= g.skip_below && id != self_id;
+                    item[j] = valid ? ((uint64_t)sortable_bits(raw[j]) << 32) | id : ~0ull;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < UNROLL; ++j) {
+                    const bool take = item[j] < worst;
+                    const uint64_t votes = __ballot(take);
+                    if (votes) {   // one LDS atomic per wave
+                        const uint32_t leader = (uint32_t)__builtin_ctzll(votes);
+                        uint32_t base = 0;
+                        if (lane == leader) base = atomicAdd(&sh.count, (uint32_t)__popcll(votes));
+                        base = __shfl(base, leader);
+                        const uint32_t pos = base + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+                        if (take && pos < cap) sh.items[knn + pos] = item[j];
+                    }
                 }
             }
             __syncthreads();
