@@ -20,7 +20,7 @@ def _stale(target, sources):
 
 
 def build_library(force=False, verbose=False):
-    """make -C csrc: kernels.hip + capi.cpp -> libsketchlib_dist_hip.so (and the CLI)."""
+    """make -C csrc: *.hip + capi*.cpp -> libsketchlib_dist_hip.so (and the CLI)."""
     srcs = []
     for root, _dirs, files in os.walk(CSRC):
         if "_build" in root:

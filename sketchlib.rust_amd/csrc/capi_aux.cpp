@@ -1,0 +1,273 @@
+// capi_aux.cpp -- the entry points of include/sketchlib_dist.h either side of the distance
+// path: GPU sketching and the candidate-list kNN of the precluster mode
+// (row f2).  Kernels: sketch_kernel.hip, cand_gen.hip, pair_cand.hip, kernels.hip (topk_kernel).
+#include "capi_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+using namespace skl;
+
+// ---------------------------------------------------------------------------
+// GPU sketching
+// ---------------------------------------------------------------------------
+
+namespace {
+inline uint64_t h_rotl1(uint64_t v) { return (v << 1) | (v >> 63); }
+inline uint64_t h_swapbits033(uint64_t v)
+{
+    const uint64_t x = (v ^ (v >> 33)) & 1ull;
+    return v ^ (x | (x << 33));
+}
+inline uint64_t h_srol(uint64_t v) { return h_swapbits033(h_rotl1(v)); }
+}  // namespace
+
+extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64_t *code_begin,
+                                const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
+                                const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!code_begin || !offset_begin || !kmers || !out_signs) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (n_samples == 0 || nk == 0) return SKL_OK;
+    if (num_bins == 0) return fail(SKL_ERR_INVALID_ARG, "num_bins is zero");
+    const uint64_t n_codes = code_begin[n_samples], n_offs = offset_begin[n_samples];
+    if ((n_codes && !codes) || (n_offs && !offsets)) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    static const uint64_t seeds_f[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x295549f54be24456ull,
+                                        0x20323ed082572324ull};   // src/hashing/nthash_tables.rs:4-16
+    std::vector<uint32_t> k32(nk);
+    std::vector<uint64_t> top_f(nk * 4), top_r(nk * 4);
+    for (size_t ki = 0; ki < nk; ++ki) {
+        if (kmers[ki] == 0 || kmers[ki] > 0xFFFFu) return fail(SKL_ERR_INVALID_ARG, "k-mer length out of range");
+        k32[ki] = (uint32_t)kmers[ki];
+        for (int b = 0; b < 4; ++b) {
+            uint64_t f = seeds_f[b], r = seeds_f[b ^ 2];
+            for (size_t m = 1; m < kmers[ki]; ++m) {
+                f = h_srol(f);
+                r = h_srol(r);
+            }
+            top_f[ki * 4 + b] = f;
+            top_r[ki * 4 + b] = r;
+        }
+    }
+    const uint64_t span = (uint64_t)sketch_span();
+    std::vector<uint64_t> span_begin(n_samples + 1, 0);
+    for (size_t s = 0; s < n_samples; ++s) {
+        if (code_begin[s + 1] < code_begin[s] || offset_begin[s + 1] < offset_begin[s]) {
+            return fail(SKL_ERR_INVALID_ARG, "sample ranges must not decrease");
+        }
+        span_begin[s + 1] = span_begin[s] + (code_begin[s + 1] - code_begin[s] + span - 1) / span;
+    }
+    DevBuf d_codes, d_cb, d_offs, d_ob, d_sb, d_k, d_tf, d_tr, d_signs;
+    auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(&b.p, std::max<size_t>(bytes, 16)));
+        if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SKL_OK;
+    };
+    SKL_TRY(upload(d_codes, codes, n_codes));
+    SKL_TRY(upload(d_cb, code_begin, (n_samples + 1) * sizeof(uint64_t)));
+    SKL_TRY(upload(d_offs, offsets, n_offs * sizeof(uint64_t)));
+    SKL_TRY(upload(d_ob, offset_begin, (n_samples + 1) * sizeof(uint64_t)));
+    SKL_TRY(upload(d_sb, span_begin.data(), (n_samples + 1) * sizeof(uint64_t)));
+    SKL_TRY(upload(d_k, k32.data(), nk * sizeof(uint32_t)));
+    SKL_TRY(upload(d_tf, top_f.data(), top_f.size() * sizeof(uint64_t)));
+    SKL_TRY(upload(d_tr, top_r.data(), top_r.size() * sizeof(uint64_t)));
+    const size_t sign_bytes = n_samples * nk * num_bins * sizeof(uint64_t);
+    HIP_TRY(hipMalloc(&d_signs.p, sign_bytes));
+    HIP_TRY(hipMemsetAsync(d_signs.p, 0xFF, sign_bytes, ctx->stream));   // u64::MAX
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // pageable uploads done before the vectors die
+
+    SketchArgs a;
+    memset(&a, 0, sizeof a);
+    a.codes = (const uint8_t *)d_codes.p;
+    a.code_begin = (const uint64_t *)d_cb.p;
+    a.offsets = (const uint64_t *)d_offs.p;
+    a.offset_begin = (const uint64_t *)d_ob.p;
+    a.span_begin = (const uint64_t *)d_sb.p;
+    a.n_spans = span_begin[n_samples];
+    a.n_samples = (uint32_t)n_samples;
+    a.nk = (uint32_t)nk;
+    a.kmers = (const uint32_t *)d_k.p;
+    a.top_f = (const uint64_t *)d_tf.p;
+    a.top_r = (const uint64_t *)d_tr.p;
+    a.num_bins = num_bins;
+    const uint64_t sign_mod = (1ull << 61) - 1;
+    a.bin_size = (sign_mod + num_bins - 1) / num_bins;   // SIGN_MOD.div_ceil(num_bins), sketch/mod.rs:170
+    a.inv_bin_size = 1.0 / (double)a.bin_size;
+    a.rc = rc ? 1 : 0;
+    a.signs = (uint64_t *)d_signs.p;
+    {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
+        std::pair<hipEvent_t, hipEvent_t> *ev = timing_slot(ctx);
+        if (ev) HIP_TRY(hipEventRecord(ev->first, ctx->stream));
+        HIP_TRY(launch_sketch_signs(a, ctx->stream));
+        if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
+    }
+    ctx->last_kernel = "skl::nthash_binmin_kernel (256 window starts per thread, rolling canonical ntHash, atomicMin per bin)";
+    HIP_TRY(hipMemcpyAsync(out_signs, d_signs.p, sign_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
+// Candidate-list kNN: the device half of the reference's self_dists_knn_precluster
+// (src/distances/mod.rs:399-553).  Host pointers in, host pointers out.
+// Distances + ragged top-k for candidate lists that are already on the device.  host_offsets is
+// the host copy of the CSR offsets (the 64-candidate work items are cut on the host).
+static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                               const uint64_t *host_offsets, const uint64_t *d_off, const uint32_t *d_cand,
+                               uint64_t *out_idx, float *out_d0)
+{
+    const size_t n = s->n;
+    const uint64_t total = host_offsets[n];
+    std::vector<uint32_t> work_row;
+    std::vector<uint64_t> work_start;
+    for (size_t i = 0; i < n; ++i) {
+        for (uint64_t c0 = host_offsets[i]; c0 < host_offsets[i + 1]; c0 += 64) {
+            work_row.push_back((uint32_t)i);
+            work_start.push_back(c0);
+        }
+    }
+    DevBuf d_wrow, d_wstart, d_keys, d_idx, d_d0;
+    HIP_TRY(hipMalloc(&d_wrow.p, std::max<size_t>(work_row.size() * sizeof(uint32_t), 16)));
+    HIP_TRY(hipMalloc(&d_wstart.p, std::max<size_t>(work_start.size() * sizeof(uint64_t), 16)));
+    if (!work_row.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_wrow.p, work_row.data(), work_row.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_wstart.p, work_start.data(), work_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(hipMalloc(&d_keys.p, std::max<size_t>(total * sizeof(float), 16)));
+    HIP_TRY(hipMalloc(&d_idx.p, n * knn * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&d_d0.p, n * knn * sizeof(float)));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // pageable uploads done before the vectors die
+
+    PairArgs g;
+    SKL_TRY(fill_args(s, s, p, MODE_JACCARD, p->ani ? JOUT_ANI_KEY : JOUT_DIST, &g));
+    CandArgs c;
+    memset(&c, 0, sizeof c);
+    c.row_offsets = d_off;
+    c.cand = d_cand;
+    c.work_row = (const uint32_t *)d_wrow.p;
+    c.work_start = (const uint64_t *)d_wstart.p;
+    c.n_work = work_row.size();
+    c.keys = (float *)d_keys.p;
+    {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
+        std::pair<hipEvent_t, hipEvent_t> *ev = timing_slot(ctx);
+        if (ev) HIP_TRY(hipEventRecord(ev->first, ctx->stream));
+        HIP_TRY(launch_pair_cand(c, g, ctx->stream));
+        if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
+    }
+    ctx->last_kernel = "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)";
+    TopkArgs t;
+    memset(&t, 0, sizeof t);
+    t.keys = (const float *)d_keys.p;
+    t.rows = (uint32_t)n;
+    t.cols = 0;
+    t.stride2 = 1;
+    t.knn = (uint32_t)knn;
+    t.self_mode = 0;
+    t.row_begin = 0;
+    t.ani_undo = p->ani ? 1 : 0;
+    t.out_idx = (uint64_t *)d_idx.p;
+    t.out_d0 = (float *)d_d0.p;
+    t.out_d1 = nullptr;
+    t.row_offsets = d_off;
+    t.col_ids = d_cand;
+    HIP_TRY(launch_topk(t, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_idx, d_idx.p, n * knn * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_d0, d_d0.p, n * knn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
+static int check_candidate_call(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn)
+{
+    SKL_TRY(check_params(s, s, p));
+    SKL_TRY(ctx_bind(ctx));
+    if (p->dist_type != SKL_DIST_JACCARD) {
+        return fail(SKL_ERR_INVALID_ARG, "Prefilter only available for single k-mer distances");  // mod.rs:549-551
+    }
+    if (knn == 0 || knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, 2048]", knn);
+    return SKL_OK;
+}
+
+extern "C" int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                             size_t knn, const uint64_t *row_offsets, const uint32_t *cand,
+                                             uint64_t *out_idx, float *out_d0)
+{
+    SKL_TRY(check_candidate_call(ctx, s, p, knn));
+    if (!row_offsets || !out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    const size_t n = s->n;
+    if (n == 0) return SKL_OK;
+    const uint64_t total = row_offsets[n];
+    if (total && !cand) return fail(SKL_ERR_INVALID_ARG, "cand is null");
+    for (size_t i = 0; i < n; ++i) {
+        if (row_offsets[i + 1] < row_offsets[i]) return fail(SKL_ERR_INVALID_ARG, "row_offsets must not decrease");
+    }
+    for (uint64_t x = 0; x < total; ++x) {
+        if (cand[x] >= n) return fail(SKL_ERR_INVALID_ARG, "candidate id %u out of range", cand[x]);
+    }
+    DevBuf d_off, d_cand;
+    HIP_TRY(hipMalloc(&d_off.p, (n + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&d_cand.p, std::max<size_t>(total * sizeof(uint32_t), 16)));
+    HIP_TRY(hipMemcpyAsync(d_off.p, row_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(d_cand.p, cand, total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    return knn_from_device_csr(ctx, s, p, knn, row_offsets, (const uint64_t *)d_off.p, (const uint32_t *)d_cand.p,
+                               out_idx, out_d0);
+}
+
+extern "C" size_t skl_shared_bins_max_samples(void) { return MAX_DEVICE_CANDGEN_SAMPLES; }
+
+// The whole precluster kNN on the device: candidate lists from the index sketches (cand_gen.hip),
+// then distances and ragged top-k.
+extern "C" int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                              size_t knn, const uint16_t *skq, size_t sketch_size,
+                                              uint64_t *out_idx, float *out_d0, uint64_t *out_n_candidates)
+{
+    SKL_TRY(check_candidate_call(ctx, s, p, knn));
+    if (!skq || !out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    const size_t n = s->n;
+    if (out_n_candidates) *out_n_candidates = 0;
+    if (n == 0) return SKL_OK;
+    if (sketch_size == 0) return fail(SKL_ERR_INVALID_ARG, "sketch_size is zero");
+    if (n > MAX_DEVICE_CANDGEN_SAMPLES) {
+        return fail(SKL_ERR_INVALID_ARG, "%zu samples exceed the %zu the on-device candidate search handles per call",
+                    n, (size_t)MAX_DEVICE_CANDGEN_SAMPLES);
+    }
+    DevBuf d_skq, d_starts, d_cursor, d_members, d_counts, d_off, d_cand;
+    const size_t table = sketch_size * 65536 * sizeof(uint32_t);
+    HIP_TRY(hipMalloc(&d_skq.p, n * sketch_size * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc(&d_starts.p, table));
+    HIP_TRY(hipMalloc(&d_cursor.p, table));
+    HIP_TRY(hipMalloc(&d_members.p, n * sketch_size * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_counts.p, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_off.p, (n + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(d_skq.p, skq, n * sketch_size * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_starts.p, 0, table, ctx->stream));
+    CandGenArgs cg;
+    memset(&cg, 0, sizeof cg);
+    cg.skq = (const uint16_t *)d_skq.p;
+    cg.n = (uint32_t)n;
+    cg.sketch_size = (uint32_t)sketch_size;
+    cg.starts = (uint32_t *)d_starts.p;
+    cg.cursor = (uint32_t *)d_cursor.p;
+    cg.members = (uint32_t *)d_members.p;
+    cg.counts = (uint32_t *)d_counts.p;
+    HIP_TRY(launch_cand_groups(cg, ctx->stream));
+    HIP_TRY(launch_cand_rows(cg, false, ctx->stream));
+    std::vector<uint32_t> counts(n);
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> offsets(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + counts[i];
+    const uint64_t total = offsets[n];
+    if (out_n_candidates) *out_n_candidates = total;
+    HIP_TRY(hipMalloc(&d_cand.p, std::max<size_t>(total * sizeof(uint32_t), 16)));
+    HIP_TRY(hipMemcpyAsync(d_off.p, offsets.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    cg.row_offsets = (const uint64_t *)d_off.p;
+    cg.cand = (uint32_t *)d_cand.p;
+    HIP_TRY(launch_cand_rows(cg, true, ctx->stream));
+    // the group tables are no longer needed: release them before the distance buffers are allocated
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_members.p); d_members.p = nullptr;
+    (void)hipFree(d_starts.p); d_starts.p = nullptr;
+    (void)hipFree(d_cursor.p); d_cursor.p = nullptr;
+    return knn_from_device_csr(ctx, s, p, knn, offsets.data(), (const uint64_t *)d_off.p, (const uint32_t *)d_cand.p,
+                               out_idx, out_d0);
+}

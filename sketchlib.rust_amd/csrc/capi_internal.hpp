@@ -1,0 +1,102 @@
+// capi_internal.hpp -- shared between the translation units that implement
+// include/sketchlib_dist.h (capi.cpp: contexts, slabs, dense calls; capi_knn.cpp: the kNN
+// drivers; capi_aux.cpp: candidate lists and sketching).  Not part of the public boundary.
+#pragma once
+
+#include "../../include/sketchlib_dist.h"
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kernels.h"
+
+#define SKL_INTERNAL __attribute__((visibility("hidden")))
+
+// ---- error plumbing: status code + message for skl_last_error() ----
+SKL_INTERNAL int fail(int code, const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? SKL_ERR_OOM : SKL_ERR_HIP, "%s: %s",   \
+                        #expr, hipGetErrorString(e_));                                     \
+        }                                                                                  \
+    } while (0)
+
+#define SKL_TRY(expr)             \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != SKL_OK) return rc_; \
+    } while (0)
+
+struct skl_sketches;
+
+struct skl_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // grow-only scratch
+    void *scratch[6] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN)
+    size_t scratch_bytes[6] = {};
+    hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
+    // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
+    // "producer finished buffer b" / "consumer finished buffer b"
+    hipEvent_t knn_pair_done[2] = {nullptr, nullptr}, knn_topk_done[2] = {nullptr, nullptr};
+    // timing of pair-kernel launches of the last call
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    std::string last_kernel;
+    skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration
+    std::set<skl_sketches *> sketches;  // slabs created on this context
+};
+
+struct skl_sketches {
+    skl_ctx *ctx = nullptr;
+    size_t n = 0, nk = 0, ss64 = 0;
+    std::vector<size_t> kmers;
+    uint64_t *d_rows = nullptr;  // reference layout + A_PAD_ROWS zero rows (scalar operand)
+    uint4 *d_lanes = nullptr;    // lane-interleaved layout (vector operand), built on demand
+    double *d_comp = nullptr;    // completeness or null
+    double *d_ytab = nullptr;    // ln J table [64*ss64+1]
+    double *d_kf = nullptr;      // k-mer lengths as f64 [nk]
+    std::map<std::pair<int, size_t>, float *> d_dtab;  // (jout, k_idx) -> f32 table
+    size_t sample_words() const { return nk * ss64 * skl::BBITS; }
+};
+
+// device allocation freed at scope exit
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+constexpr size_t BAND_BYTES = 512ull << 20;  // scratch bound for host-destined / banded output
+
+SKL_INTERNAL int ctx_bind(skl_ctx *ctx);
+// grow-only scratch slot `which` of the context, at least `bytes` large
+SKL_INTERNAL int ctx_scratch(skl_ctx *ctx, size_t bytes, void **out, int which = 0);
+// tuning knobs are read on every call so an A/B run can interleave variants in one process
+SKL_INTERNAL long long env_int(const char *name, long long dflt);
+SKL_INTERNAL int forced_kernel();   // SKL_KERNEL: 0 none, 1 smem, 2 lds, 3 ksplit, 4 kslice
+// the pair kernel bracketed by HIP events on the context's stream (skl_ctx_kernel_ms)
+SKL_INTERNAL int timed_pair_launch(skl_ctx *ctx, const skl::PairArgs &args, int mode, int na);
+// records [first, second) events around a launch of another kernel the same way; returns the
+// slot to record into or null when the event budget is used up
+SKL_INTERNAL std::pair<hipEvent_t, hipEvent_t> *timing_slot(skl_ctx *ctx);
+SKL_INTERNAL int check_params(const skl_sketches *a, const skl_sketches *b, const skl_dist_params *p);
+SKL_INTERNAL bool fused_coreacc_ok(const skl_sketches *s);
+// operand / epilogue fields common to every launch: `rows` is the scalar operand (A), `cols` the lane operand (B)
+SKL_INTERNAL int fill_args(const skl_sketches *rows, const skl_sketches *cols, const skl_dist_params *p, int mode,
+                           int jout, skl::PairArgs *g);
+// rows [r0, r1) of the pair space into `dst_dev` (device memory)
+SKL_INTERNAL int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
+                            const skl_dist_params *p, int mode, int jout, int self_mode, uint64_t r0, uint64_t r1,
+                            void *dst_dev);

@@ -1,0 +1,488 @@
+// capi_knn.cpp -- the sparse (k nearest neighbours) entry points of include/sketchlib_dist.h:
+// row-by-row bands, the one-evaluation self kNN, its multi-GPU split and the merge of partial
+// states.  Kernels: pair_kslice.hip (pair distances, turned second store), kernels.hip
+// (topk_merge_kernel, merge_states_kernel).
+#include "capi_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+using namespace skl;
+
+// ---------------------------------------------------------------------------
+// sparse kNN: dense row bands into scratch, then a row-wise top-k kernel
+// ---------------------------------------------------------------------------
+
+// Running top-k states of a kNN call: (sortable key, sample id[, second value]) x knn per row.
+namespace {
+struct KnnState {
+    uint32_t *key = nullptr, *idx = nullptr;
+    float *d1 = nullptr;
+    ~KnnState()
+    {
+        if (key) (void)hipFree(key);
+        if (idx) (void)hipFree(idx);
+        if (d1) (void)hipFree(d1);
+    }
+};
+}  // namespace
+
+// Rows per band of the symmetric drivers: about 8 bands per participant (7/16 of the pair
+// evaluations saved), each band at least 32 M pairs, four band buffers within `budget` bytes.
+static size_t symmetric_band_rows(size_t n, size_t rec, size_t budget, size_t participants)
+{
+    auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    const size_t budget_rows = std::max<size_t>(16, budget / 4 / (n * rec) / 16 * 16);
+    const size_t parts = std::max<size_t>(1, participants);
+    return std::min(budget_rows, std::max(up16((n + 8 * parts - 1) / (8 * parts)), up16((32ull << 20) / n + 1)));
+}
+
+static int knn_state_init(KnnState &st, size_t rows, size_t knn, bool coreacc, hipStream_t stream)
+{
+    const size_t items = rows * knn;
+    HIP_TRY(hipMalloc((void **)&st.key, items * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&st.idx, items * sizeof(uint32_t)));
+    if (coreacc) HIP_TRY(hipMalloc((void **)&st.d1, items * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(st.key, 0xFF, items * sizeof(uint32_t), stream));   // empty
+    HIP_TRY(hipMemsetAsync(st.idx, 0xFF, items * sizeof(uint32_t), stream));
+    return SKL_OK;
+}
+
+// Symmetric self kNN (whole matrix in one call): band [b0, b1) is compared with the columns
+// from b0 on only.  The pair kernel stores every record twice -- row-major for the rows of the
+// band, and turned (pair_kslice.hip, out_t) as candidates of the rows below the band -- and
+// both copies are merged into a running per-row top-k (topk_merge_kernel), so each (i, j) is
+// evaluated once instead of twice (the reference evaluates both, mod.rs:148-171; distances are
+// symmetric).  Same neighbours, same order as the row-by-row form.
+static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
+{
+    if (s->ss64 > 1023) return false;
+    if (p->dist_type == SKL_DIST_COREACC && !fused_coreacc_ok(s)) return false;
+    const int forced = forced_kernel();
+    if (forced != 0 && forced != 4) return false;          // the turned store lives in pair_kslice.hip
+    const long long shape = env_int("SKL_KSLICE_SHAPE", 0);
+    return shape == 0 || shape == 81 || shape == 82 || shape == 161 || shape == 162;
+}
+
+// The bands `bands` (ascending indices; band b = rows [b*band_rows, (b+1)*band_rows)) merged into
+// the running states `st` of all n rows.
+static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                               size_t band_rows, const std::vector<uint32_t> &bands, bool overlap, KnnState &st)
+{
+    const size_t n = s->n;
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
+    const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
+    const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
+    const size_t t_stride = (band_rows + 15) / 16 * 16;
+    void *kband[2] = {nullptr, nullptr}, *tband[2] = {nullptr, nullptr};
+    SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[0], 0));
+    SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[0], 4));
+    kband[1] = kband[0];
+    tband[1] = tband[0];
+    if (overlap) {
+        SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[1], 3));
+        SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[1], 5));
+    }
+    hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
+    if (overlap) {   // the states were cleared on the context's stream, the merges run on the other one
+        HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[0], 0));
+    }
+
+    const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
+    size_t it = 0;
+    for (const uint32_t band : bands) {
+        const size_t b0 = (size_t)band * band_rows;
+        const size_t b1 = std::min(n, b0 + band_rows);
+        const int buf = overlap ? (int)(it & 1) : 0;
+        if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
+        // the band against the column view that starts at the 64-column block holding b0
+        const size_t col0 = b0 / 64 * 64;
+        PairArgs g;
+        SKL_TRY(fill_args(s, s, p, mode, jout, &g));
+        g.B += (b0 / 64) * jb_words;
+        g.nB = (uint32_t)(n - col0);
+        if (g.compB) g.compB += col0;
+        g.row_begin = (uint32_t)b0;
+        g.row_end = (uint32_t)b1;
+        g.self_mode = 0;
+        g.out_base = (uint64_t)b0 * g.nB;
+        g.out = kband[buf];
+        g.out_t = b1 < n ? (float *)tband[buf] : nullptr;
+        g.t_col_begin = (uint32_t)(b1 - col0);
+        g.t_stride = (uint32_t)t_stride;
+        SKL_TRY(timed_pair_launch(ctx, g, mode, choose_na(b1 - b0, g.nB, 0, mode)));
+        if (overlap) {
+            HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
+        }
+        TopkMergeArgs m;
+        memset(&m, 0, sizeof m);
+        m.knn = (uint32_t)knn;
+        m.stride2 = coreacc ? 2 : 1;
+        m.run_key = st.key;
+        m.run_idx = st.idx;
+        m.run_d1 = st.d1;
+        m.streaming = env_int("SKL_TOPK_STREAM", 1) != 0;
+        // rows of the band: columns [b0, n) minus themselves (the view's first b0 - col0 columns
+        // reached them turned, from earlier bands)
+        m.keys = (const float *)kband[buf];
+        m.key_stride = (uint64_t)g.nB * m.stride2;
+        m.rows = (uint32_t)(b1 - b0);
+        m.cols = g.nB;
+        m.id_base = (uint32_t)col0;
+        m.skip_below = (uint32_t)b0;
+        m.self_id_base = m.state_row_base = (uint32_t)b0;
+        HIP_TRY(launch_topk_merge(m, topk_stream));
+        // rows below the band: the band's samples as their candidates
+        m.keys = (const float *)tband[buf];
+        m.key_stride = (uint64_t)t_stride * m.stride2;
+        m.rows = (uint32_t)(n - b1);
+        m.cols = (uint32_t)(b1 - b0);
+        m.id_base = (uint32_t)b0;
+        m.skip_below = 0;
+        m.self_id_base = m.state_row_base = (uint32_t)b1;
+        HIP_TRY(launch_topk_merge(m, topk_stream));
+        if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
+        ++it;
+    }
+    if (overlap && it) {   // the states (and the band buffers) belong to the context's stream again
+        HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
+    }
+    return SKL_OK;
+}
+
+static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                              size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
+{
+    const size_t n = s->n;
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    KnnState st;
+    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
+    std::vector<uint32_t> bands((n + band_rows - 1) / band_rows);
+    for (size_t b = 0; b < bands.size(); ++b) bands[b] = (uint32_t)b;
+    SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, bands, overlap, st));
+    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, n * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0, d_d1,
+                                 ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
+    return SKL_OK;
+}
+
+// Row-by-row kNN: dense bands of records into scratch, then a per-row top-k.  With two bands
+// the top-k of band i (memory / LDS bound, on the auxiliary stream) runs while the pair kernel
+// of band i + 1 (VALU bound) fills the other one.  The top-k is the streaming one of the
+// symmetric driver (topk_merge_kernel), fed a whole row at once.
+static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
+                           const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
+                           size_t band_rows, bool overlap, uint64_t *d_idx, float *d_d0, float *d_d1)
+{
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
+    const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
+    const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
+    const size_t n_cand = cands->n;
+    void *band[2] = {nullptr, nullptr};
+    SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[0], 0));
+    band[1] = band[0];
+    if (overlap) SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[1], 3));
+    hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
+    KnnState st;
+    SKL_TRY(knn_state_init(st, r1 - r0, knn, coreacc, ctx->stream));
+    if (overlap) {   // the states are cleared on the context's stream, the merges run on the other one
+        HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[0], 0));
+    }
+
+    size_t it = 0;
+    for (size_t b0 = r0; b0 < r1; b0 += band_rows, ++it) {
+        const size_t b1 = std::min(r1, b0 + band_rows);
+        const int buf = overlap ? (int)(it & 1) : 0;
+        // the top-k that read this buffer two bands ago must be done before it is overwritten
+        if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
+        SKL_TRY(dense_band(ctx, rows, cands, p, mode, jout, 0, b0, b1, band[buf]));
+        if (overlap) {
+            HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
+        }
+        TopkMergeArgs m;
+        memset(&m, 0, sizeof m);
+        m.knn = (uint32_t)knn;
+        m.stride2 = coreacc ? 2 : 1;
+        m.run_key = st.key;
+        m.run_idx = st.idx;
+        m.run_d1 = st.d1;
+        m.streaming = env_int("SKL_TOPK_STREAM", 1) != 0;
+        m.key_stride = (uint64_t)n_cand * m.stride2;
+        m.rows = (uint32_t)(b1 - b0);
+        m.self_id_base = self_mode ? (uint32_t)b0 : 0xFFFFFFFFu;
+        m.state_row_base = (uint32_t)(b0 - r0);
+        m.keys = (const float *)band[buf];
+        m.cols = (uint32_t)n_cand;
+        m.id_base = 0;
+        HIP_TRY(launch_topk_merge(m, topk_stream));
+        if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
+    }
+    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, (r1 - r0) * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0,
+                                 d_d1, topk_stream));
+    if (overlap) {   // results (and the band buffers) belong to the context's stream again
+        HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
+    return SKL_OK;
+}
+
+static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cands,
+                    const skl_dist_params *p, size_t knn, int self_mode, size_t r0, size_t r1,
+                    uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "output pointers are null");
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    if (coreacc && !out_d1) return fail(SKL_ERR_INVALID_ARG, "out_d1 is required for core/accessory");
+    if (r0 > r1 || r1 > rows->n) return fail(SKL_ERR_INVALID_ARG, "row range out of bounds");
+    const size_t n_cand = cands->n;
+    const size_t max_knn = n_cand > (size_t)(self_mode ? 1 : 0) ? n_cand - (self_mode ? 1 : 0) : 0;
+    if (knn == 0 || knn > max_knn) {
+        return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, max_knn);
+    }
+    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
+    if (r1 == r0) return SKL_OK;
+
+    const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
+    // the key band lives only on the device: take up to a quarter of the free HBM (<= 8 GiB)
+    // so that the row-wise top-k kernel has thousands of rows (= workgroups) per launch
+    size_t free_b = 0, total_b = 0;
+    size_t band_bytes = BAND_BYTES;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        band_bytes = std::max(band_bytes, std::min<size_t>(free_b / 4, 8ull << 30));
+    }
+    size_t band_rows = std::max<size_t>(1, band_bytes / 2 / (n_cand * rec));   // two key bands
+    const size_t forced_band_rows = (size_t)std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));  // test knob: force several bands
+    if (forced_band_rows) band_rows = forced_band_rows;
+    band_rows = std::min(band_rows, r1 - r0);
+    // The whole self matrix: evaluate each pair once (knn_self_symmetric) when that leaves bands
+    // worth launching -- about 8 of them (7/16 of the pair evaluations saved), each at least 32 M
+    // pairs, within four band buffers of up to half the free HBM (<= 32 GiB) together.
+    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p) &&
+                     env_int("SKL_KNN_SYMMETRIC", 1) != 0;   // (0: A/B against the row-by-row form)
+    if (symmetric) {
+        size_t budget = band_bytes;
+        if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, 32ull << 30));
+        const size_t want = forced_band_rows ? forced_band_rows : symmetric_band_rows(n_cand, rec, budget, 1);
+        if (want >= n_cand) symmetric = false;
+        else band_rows = want;
+    }
+    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;
+
+    // device staging for host-destined results
+    uint64_t *d_idx = out_idx;
+    float *d_d0 = out_d0, *d_d1 = out_d1;
+    const size_t items = (r1 - r0) * knn;
+    if (!out_on_device) {
+        void *stage = nullptr;
+        SKL_TRY(ctx_scratch(ctx, items * (sizeof(uint64_t) + 2 * sizeof(float)), &stage, 2));
+        d_idx = (uint64_t *)stage;
+        d_d0 = (float *)(d_idx + items);
+        d_d1 = d_d0 + items;
+    }
+    if (symmetric) {
+        SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0, d_d1));
+    } else {
+        SKL_TRY(knn_rows_banded(ctx, rows, cands, p, knn, self_mode, r0, r1, band_rows, overlap, d_idx, d_d0, d_d1));
+    }
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out_idx, d_idx, items * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out_d0, d_d0, items * sizeof(float), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        if (coreacc) {
+            HIP_TRY(hipMemcpyAsync(out_d1, d_d1, items * sizeof(float), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return SKL_OK;
+}
+
+extern "C" int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s,
+                                       const skl_dist_params *p, size_t knn, size_t row_begin,
+                                       size_t row_end, uint64_t *out_idx, float *out_d0,
+                                       float *out_d1, int out_on_device)
+{
+    SKL_TRY(check_params(s, s, p));
+    return knn_rows(ctx, s, s, p, knn, 1, row_begin, row_end, out_idx, out_d0, out_d1,
+                    out_on_device);
+}
+
+extern "C" int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p,
+                                  size_t knn, uint64_t *out_idx, float *out_d0, float *out_d1,
+                                  int out_on_device)
+{
+    if (!s) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    return skl_self_dists_knn_rows(ctx, s, p, knn, 0, s->n, out_idx, out_d0, out_d1, out_on_device);
+}
+
+extern "C" size_t skl_knn_band_rows(const skl_sketches *s, const skl_dist_params *p, size_t n_participants)
+{
+    if (!s || !p || s->n == 0) return 0;
+    const size_t rec = p->dist_type == SKL_DIST_COREACC ? 2 * sizeof(float) : sizeof(float);
+    const long long forced = env_int("SKL_KNN_BAND_ROWS", 0);   // test knob (the same for every participant)
+    if (forced > 0) return std::min<size_t>(s->n, (size_t)forced);
+    // a fixed budget (no free-memory query): every participant must arrive at the same number
+    return std::min(s->n, symmetric_band_rows(s->n, rec, 32ull << 30, n_participants));
+}
+
+extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                                          size_t band_rows, const uint32_t *bands, size_t n_bands,
+                                          uint32_t *state_key, uint32_t *state_idx, float *state_d1,
+                                          int out_on_device)
+{
+    SKL_TRY(check_params(s, s, p));
+    SKL_TRY(ctx_bind(ctx));
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    if (!state_key || !state_idx || (coreacc && !state_d1)) return fail(SKL_ERR_INVALID_ARG, "state pointers are null");
+    const size_t n = s->n;
+    if (n < 2 || knn == 0 || knn > n - 1) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, n ? n - 1 : 0);
+    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
+    if (band_rows == 0) return fail(SKL_ERR_INVALID_ARG, "band_rows is zero");
+    if (n_bands && !bands) return fail(SKL_ERR_INVALID_ARG, "bands is null");
+    if (!knn_symmetric_ok(s, p)) {
+        return fail(SKL_ERR_INVALID_ARG, "no one-evaluation kNN for this configuration; shard rows with skl_self_dists_knn_rows");
+    }
+    const size_t total_bands = (n + band_rows - 1) / band_rows;
+    std::vector<uint32_t> list(bands, bands + n_bands);
+    for (size_t x = 0; x < list.size(); ++x) {
+        if (list[x] >= total_bands || (x && list[x] <= list[x - 1])) {
+            return fail(SKL_ERR_INVALID_ARG, "bands must be ascending and below %zu", total_bands);
+        }
+    }
+    KnnState st;
+    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
+    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && list.size() > 1;
+    SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
+    const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const size_t items = n * knn;
+    HIP_TRY(hipMemcpyAsync(state_key, st.key, items * sizeof(uint32_t), kind, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(state_idx, st.idx, items * sizeof(uint32_t), kind, ctx->stream));
+    if (coreacc) HIP_TRY(hipMemcpyAsync(state_d1, st.d1, items * sizeof(float), kind, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
+    return SKL_OK;
+}
+
+extern "C" int skl_knn_merge_states(skl_ctx *ctx, size_t n_states, size_t rows, size_t knn,
+                                    const uint32_t *state_key, const uint32_t *state_idx, const float *state_d1,
+                                    int states_on_device, int ani, uint64_t *out_idx, float *out_d0, float *out_d1,
+                                    int out_on_device)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!state_key || !state_idx || !out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (state_d1 && !out_d1) return fail(SKL_ERR_INVALID_ARG, "out_d1 is required with second values");
+    if (n_states == 0 || knn == 0 || knn > 2048) return fail(SKL_ERR_INVALID_ARG, "n_states and knn (<= 2048) must be positive");
+    if (rows == 0) return SKL_OK;
+    const size_t items = rows * knn;
+    DevBuf in_key, in_idx, in_d1, tmp_key[2], tmp_idx[2], tmp_d1[2], o_idx, o_d0, o_d1;
+    const uint32_t *d_key = state_key, *d_idx = state_idx;
+    const float *d_d1 = state_d1;
+    if (!states_on_device) {
+        HIP_TRY(hipMalloc(&in_key.p, n_states * items * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&in_idx.p, n_states * items * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(in_key.p, state_key, n_states * items * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(in_idx.p, state_idx, n_states * items * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        d_key = (const uint32_t *)in_key.p;
+        d_idx = (const uint32_t *)in_idx.p;
+        if (state_d1) {
+            HIP_TRY(hipMalloc(&in_d1.p, n_states * items * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(in_d1.p, state_d1, n_states * items * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            d_d1 = (const float *)in_d1.p;
+        }
+    }
+    // fold the states, as many per launch as fit the LDS sort
+    std::vector<const uint32_t *> keys, idxs;
+    std::vector<const float *> d1s;
+    for (size_t x = 0; x < n_states; ++x) {
+        keys.push_back(d_key + x * items);
+        idxs.push_back(d_idx + x * items);
+        d1s.push_back(d_d1 ? d_d1 + x * items : nullptr);
+    }
+    const size_t group = std::max<size_t>(2, std::min<size_t>(MERGE_STATES_MAX, MERGE_STATES_ITEMS / knn));
+    int flip = 0;
+    for (;;) {   // (one state: a pass through the kernel is a copy)
+        const size_t take = std::min(group, keys.size());
+        if (!tmp_key[flip].p) {
+            HIP_TRY(hipMalloc(&tmp_key[flip].p, items * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&tmp_idx[flip].p, items * sizeof(uint32_t)));
+            if (d_d1) HIP_TRY(hipMalloc(&tmp_d1[flip].p, items * sizeof(float)));
+        }
+        MergeStatesArgs m;
+        memset(&m, 0, sizeof m);
+        for (size_t x = 0; x < take; ++x) {
+            m.key[x] = keys[x];
+            m.idx[x] = idxs[x];
+            m.d1[x] = d1s[x];
+        }
+        m.n_in = (uint32_t)take;
+        m.rows = (uint32_t)rows;
+        m.knn = (uint32_t)knn;
+        m.out_key = (uint32_t *)tmp_key[flip].p;
+        m.out_idx = (uint32_t *)tmp_idx[flip].p;
+        m.out_d1 = d_d1 ? (float *)tmp_d1[flip].p : nullptr;
+        HIP_TRY(launch_merge_states(m, ctx->stream));
+        keys.erase(keys.begin(), keys.begin() + take);
+        idxs.erase(idxs.begin(), idxs.begin() + take);
+        d1s.erase(d1s.begin(), d1s.begin() + take);
+        keys.insert(keys.begin(), m.out_key);
+        idxs.insert(idxs.begin(), m.out_idx);
+        d1s.insert(d1s.begin(), m.out_d1);
+        flip ^= 1;
+        if (keys.size() == 1) break;
+    }
+    uint64_t *r_idx = out_idx;
+    float *r_d0 = out_d0, *r_d1 = out_d1;
+    if (!out_on_device) {
+        HIP_TRY(hipMalloc(&o_idx.p, items * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&o_d0.p, items * sizeof(float)));
+        r_idx = (uint64_t *)o_idx.p;
+        r_d0 = (float *)o_d0.p;
+        if (d_d1) {
+            HIP_TRY(hipMalloc(&o_d1.p, items * sizeof(float)));
+            r_d1 = (float *)o_d1.p;
+        }
+    }
+    HIP_TRY(launch_topk_finalize(keys[0], idxs[0], d1s[0], items, (!d_d1 && ani) ? 1 : 0, r_idx, r_d0, r_d1, ctx->stream));
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out_idx, r_idx, items * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out_d0, r_d0, items * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (d_d1) HIP_TRY(hipMemcpyAsync(out_d1, r_d1, items * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // temporaries are freed on return
+    return SKL_OK;
+}
+
+extern "C" int skl_cross_dists_knn_rows(skl_ctx *ctx, const skl_sketches *ref,
+                                        const skl_sketches *query, const skl_dist_params *p,
+                                        size_t knn, size_t query_begin, size_t query_end,
+                                        uint64_t *out_idx, float *out_d0, float *out_d1,
+                                        int out_on_device)
+{
+    SKL_TRY(check_params(ref, query, p));
+    if (ref->n == 0) return fail(SKL_ERR_EMPTY_DB, "Reference database has no loaded samples");
+    if (query->n == 0) return fail(SKL_ERR_EMPTY_DB, "Query database has no loaded samples");
+    // rows = queries (scalar operand), candidates = refs (lane operand); samebits and the
+    // completeness factor are symmetric in the pair, so core_acc_dist(ref, query, ri, qi)
+    // (mod.rs:377-385) is computed with the roles swapped.
+    return knn_rows(ctx, query, ref, p, knn, 0, query_begin, query_end, out_idx, out_d0, out_d1,
+                    out_on_device);
+}
+
+extern "C" int skl_cross_dists_knn(skl_ctx *ctx, const skl_sketches *ref,
+                                   const skl_sketches *query, const skl_dist_params *p, size_t knn,
+                                   uint64_t *out_idx, float *out_d0, float *out_d1,
+                                   int out_on_device)
+{
+    if (!ref || !query) return fail(SKL_ERR_INVALID_ARG, "null sketches");
+    return skl_cross_dists_knn_rows(ctx, ref, query, p, knn, 0, query->n, out_idx, out_d0, out_d1,
+                                    out_on_device);
+}

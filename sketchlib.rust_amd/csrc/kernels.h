@@ -1,5 +1,5 @@
-// kernels.h -- internal interface between the C ABI (capi.cpp) and the gfx950
-// device code (kernels.hip).  Not part of the public boundary.
+// kernels.h -- internal interface between the C ABI (capi*.cpp) and the gfx950
+// device code (*.hip).  Not part of the public boundary.
 #pragma once
 
 #include <hip/hip_runtime.h>

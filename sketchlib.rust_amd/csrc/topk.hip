@@ -1,0 +1,457 @@
+// topk.hip -- k nearest neighbours per row on the device: the radix select (select_smallest,
+// topk_kernel for ragged candidate rows), the streaming running top-k of the dense kNN drivers
+// (topk_merge_kernel), the merge of partial states of a multi-GPU run (merge_states_kernel)
+// and the conversion of a state to the public output form.  mod.rs:41-48 semantics with the
+// canonical tie rule: smallest (key, index) first.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace skl {
+
+// ---------------------------------------------------------------------------
+// row-wise k nearest neighbours over a dense band (mod.rs:41-48 semantics with the
+// canonical tie rule: smallest (key, index) first)
+// ---------------------------------------------------------------------------
+
+constexpr int TOPK_THREADS = 256;
+constexpr int TOPK_MAX = 2048;  // knn upper bound handled on device
+
+__device__ __forceinline__ uint32_t sortable_bits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float from_sortable_bits(uint32_t s)
+{
+    return __uint_as_float((s & 0x80000000u) ? (s & 0x7FFFFFFFu) : ~s);
+}
+
+struct TopkShared {
+    uint32_t hist[256];
+    uint32_t prefix, remaining, count, taken;
+    uint32_t wave_cnt[TOPK_THREADS / 64];
+    uint64_t items[TOPK_MAX];  // (sortable key << 32) | position
+};
+
+// Bitonic sort of sh.items[0, m) (m a power of two), ascending.
+__device__ __forceinline__ void sort_items(TopkShared &sh, uint32_t m)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t size = 2; size <= m; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t x = tid; x < m / 2; x += TOPK_THREADS) {
+                const uint32_t lo = 2 * x - (x & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = sh.items[lo], b = sh.items[hi];
+                if ((a > b) == up) {
+                    sh.items[lo] = b;
+                    sh.items[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// The knn_eff smallest (key, position) of positions [0, n_items) for which item(c, u) is true
+// (u = sortable key bits), left sorted in sh.items[0, knn_eff).  At least knn_eff positions
+// must be valid.  Called by the whole workgroup.
+template <class Item>
+__device__ __forceinline__ void select_smallest(const Item &item, uint32_t n_items, uint32_t knn_eff, TopkShared &sh)
+{
+    const uint32_t tid = threadIdx.x;
+    // ---- radix select: key value of the knn-th smallest ----
+    if (tid == 0) {
+        sh.prefix = 0;
+        sh.remaining = knn_eff;
+    }
+    __syncthreads();
+    for (int pass = 3; pass >= 0; --pass) {
+        sh.hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh.prefix;
+        const uint32_t hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << ((pass + 1) * 8));
+        for (uint32_t c = tid; c < n_items; c += TOPK_THREADS) {
+            uint32_t u;
+            if (!item(c, u)) continue;
+            const bool in = (u & hi_mask) == (prefix & hi_mask);
+            const uint32_t bin = (u >> (pass * 8)) & 0xFFu;
+            // wave-aggregated update: distances cluster (unrelated genomes all sit at 1.0), so most
+            // lanes of a wave hit the same counter -- one lane adds the whole group
+            const uint32_t lead_bin = __builtin_amdgcn_readfirstlane(bin);
+            const uint64_t same = __ballot(in && bin == lead_bin);
+            if (in) {
+                if (bin == lead_bin) {
+                    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(same)) atomicAdd(&sh.hist[bin], (uint32_t)__popcll(same));
+                } else {
+                    atomicAdd(&sh.hist[bin], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t rem = sh.remaining, b = 0;
+            for (; b < 256; ++b) {
+                if (sh.hist[b] >= rem) break;
+                rem -= sh.hist[b];
+            }
+            if (b > 255) b = 255;
+            sh.prefix = prefix | (b << (pass * 8));
+            sh.remaining = rem;
+        }
+        __syncthreads();
+    }
+    const uint32_t thresh = sh.prefix;      // exact key bits of the knn-th smallest
+    const uint32_t take_eq = sh.remaining;  // how many == thresh to take, lowest position first
+
+    // ---- collect: everything below the threshold (any order) ----
+    if (tid == 0) {
+        sh.count = 0;
+        sh.taken = 0;
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < n_items; c += TOPK_THREADS) {
+        uint32_t u;
+        if (!item(c, u)) continue;
+        if (u < thresh) {
+            const uint32_t pos = atomicAdd(&sh.count, 1u);
+            sh.items[pos] = ((uint64_t)u << 32) | c;
+        }
+    }
+    __syncthreads();
+    // ---- ties at the threshold: ordered compaction, lowest position first ----
+    const uint32_t n_less = sh.count;
+    for (uint32_t base = 0; base < n_items && sh.taken < take_eq; base += TOPK_THREADS) {
+        const uint32_t c = base + tid;
+        bool eq = false;
+        if (c < n_items) {
+            uint32_t u;
+            eq = item(c, u) && u == thresh;
+        }
+        // block-wide exclusive prefix of `eq` via per-wave ballots
+        const uint64_t ballot = __ballot(eq);
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(ballot);
+        __syncthreads();
+        uint32_t before = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) before += sh.wave_cnt[w];
+        const uint32_t taken = sh.taken;
+        if (eq && taken + before < take_eq) {
+            sh.items[n_less + taken + before] = ((uint64_t)thresh << 32) | c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < TOPK_THREADS / 64; ++w) tot += sh.wave_cnt[w];
+            sh.taken = taken + tot;
+        }
+        __syncthreads();
+    }
+
+    // ---- bitonic sort of the knn items by (key, position) ----
+    uint32_t m = 1;
+    while (m < knn_eff) m <<= 1;
+    for (uint32_t x = knn_eff + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
+    __syncthreads();
+    sort_items(sh, m);
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
+{
+    __shared__ TopkShared sh;
+
+    const uint32_t row = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const bool ragged = g.row_offsets != nullptr;
+    const uint64_t row_base = ragged ? g.row_offsets[row] : (uint64_t)row * g.cols;
+    const uint32_t n_cols = ragged ? (uint32_t)(g.row_offsets[row + 1] - row_base) : g.cols;
+    const uint32_t knn_eff = ragged ? (n_cols < g.knn ? n_cols : g.knn) : g.knn;
+    const float *keys = g.keys + row_base * g.stride2;
+    const uint32_t self_col = g.self_mode ? g.row_begin + row : 0xFFFFFFFFu;
+    if (ragged) {
+        // padding entries (fewer candidates than knn): (this row, 1.0)
+        for (uint32_t x = knn_eff + tid; x < g.knn; x += TOPK_THREADS) {
+            const size_t o = (size_t)row * g.knn + x;
+            g.out_idx[o] = g.row_begin + row;
+            g.out_d0[o] = 1.0f;
+        }
+        if (knn_eff == 0) return;
+    }
+    const uint32_t stride2 = g.stride2;
+    select_smallest(
+        [&](uint32_t c, uint32_t &u) {
+            if (c == self_col) return false;
+            u = sortable_bits(keys[(size_t)c * stride2]);
+            return true;
+        },
+        n_cols, knn_eff, sh);
+    for (uint32_t x = tid; x < knn_eff; x += TOPK_THREADS) {
+        const uint32_t col = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+        const size_t o = (size_t)row * g.knn + x;
+        const float key = keys[(size_t)col * g.stride2];
+        g.out_idx[o] = g.col_ids ? g.col_ids[row_base + col] : col;
+        g.out_d0[o] = g.ani_undo ? 1.0f - key : key;
+        if (g.stride2 == 2 && g.out_d1) g.out_d1[o] = keys[(size_t)col * 2 + 1];
+    }
+}
+
+hipError_t launch_topk(const TopkArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0) return hipSuccess;
+    if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+// Running top-k of one row (TopkMergeArgs): a streaming merge.  The state sits in LDS as sorted
+// (sortable key << 32 | sample id) items -- that composite IS the canonical order, smallest
+// (key, id) first.  The row's new records are scanned ONCE, in segments: an item below the
+// state's current knn-th one is appended behind the state (up to TOPK_MAX items together), the
+// lot is sorted, the first knn are the new state.  A cold state starts with a segment that fits
+// the buffer outright; segments grow while few items qualify and shrink (the segment is
+// scanned again) when the buffer overflows.  Data that keeps overflowing -- keys arriving in
+// descending order -- falls back to the radix select over state ++ remaining records, which
+// needs the drivers' guarantee that new ids are larger than the ids already in the state.
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMergeArgs g)
+{
+    __shared__ TopkShared sh;
+    __shared__ float second[TOPK_MAX];   // second values of the new state (stride2 == 2)
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
+    const uint32_t knn = g.knn;
+    const size_t srow = (size_t)(g.state_row_base + row) * knn;
+    uint32_t *sk = g.run_key + srow;
+    uint32_t *si = g.run_idx + srow;
+    const uint32_t stride2 = g.stride2;
+    const float *keys = g.keys + (size_t)row * g.key_stride;
+    const uint32_t cols = g.cols;
+
+    auto fresh = [&](uint32_t q, uint32_t &u) {   // new key at position q of this launch
+        const uint32_t id = g.id_base + q;
+        if (id < g.skip_below || id == self_id) return false;
+        u = sortable_bits(__builtin_nontemporal_load(&keys[(size_t)q * stride2]));   // read once
+        return true;
+    };
+    // second value of a state item: from this launch's records, or from the old state (still
+    // untouched in global memory, sorted by the same composite: binary search)
+    auto second_of = [&](uint64_t item) {
+        const uint32_t id = (uint32_t)(item & 0xFFFFFFFFu);
+        const uint32_t q = id - g.id_base;
+        if (id >= g.id_base && q < cols && id >= g.skip_below && id != self_id) return keys[(size_t)q * 2 + 1];
+        uint32_t lo = 0, hi = knn;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t old = ((uint64_t)sk[mid] << 32) | si[mid];
+            if (old < item) lo = mid + 1; else hi = mid;
+        }
+        return g.run_d1[srow + (lo < knn ? lo : knn - 1)];
+    };
+    auto write_state = [&]() {   // items[0, knn) (composite) -> global state; whole workgroup
+        if (stride2 == 2) {
+            for (uint32_t x = tid; x < knn; x += TOPK_THREADS) second[x] = second_of(sh.items[x]);
+        }
+        __syncthreads();
+        for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+            sk[x] = (uint32_t)(sh.items[x] >> 32);
+            si[x] = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+            if (stride2 == 2) g.run_d1[srow + x] = second[x];
+        }
+        __syncthreads();
+    };
+
+    const uint32_t cap = (uint32_t)TOPK_MAX - knn;   // room behind the state
+    uint32_t begin = 0;
+    bool changed = false;
+    if (cap >= 256u && g.streaming) {
+        for (uint32_t x = tid; x < knn; x += TOPK_THREADS) sh.items[x] = ((uint64_t)sk[x] << 32) | si[x];
+        __syncthreads();
+        uint64_t worst = sh.items[knn - 1];           // ~0 while the state is not full
+        uint32_t seg = worst == ~0ull ? cap : 4u * cap;
+        uint32_t overflows = 0;
+        while (begin < cols) {
+            const uint32_t len = min(seg, cols - begin);
+            if (tid == 0) sh.count = 0;
+            __syncthreads();
+            // (UNROLL independent loads per thread before any of them is looked at: one workgroup
+            // walks a whole row, so its memory-level parallelism is what the scan runs at)
+            constexpr uint32_t UNROLL = 4;
+            for (uint32_t q0 = begin; q0 < begin + len; q0 += TOPK_THREADS * UNROLL) {
+                uint64_t item[UNROLL];
+                float raw[UNROLL];
+#pragma unroll
+                for (uint32_t j = 0; j < UNROLL; ++j) {   // unconditional (clamped) loads, all in flight together
+                    const uint32_t q = min(q0 + j * TOPK_THREADS + tid, cols - 1u);
+                    raw[j] = __builtin_nontemporal_load(&keys[(size_t)q * stride2]);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < UNROLL; ++j) {
+                    const uint32_t q = q0 + j * TOPK_THREADS + tid;
+                    const uint32_t id = g.id_base + q;
+                    const bool valid = q < begin + len && id >= g.skip_below && id != self_id;
+                    item[j] = valid ? ((uint64_t)sortable_bits(raw[j]) << 32) | id : ~0ull;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < UNROLL; ++j) {
+                    const bool take = item[j] < worst;
+                    const uint64_t votes = __ballot(take);
+                    if (votes) {   // one LDS atomic per wave
+                        const uint32_t leader = (uint32_t)__builtin_ctzll(votes);
+                        uint32_t base = 0;
+                        if (lane == leader) base = atomicAdd(&sh.count, (uint32_t)__popcll(votes));
+                        base = __shfl(base, leader);
+                        const uint32_t pos = base + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+                        if (take && pos < cap) sh.items[knn + pos] = item[j];
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t cnt = sh.count;
+            __syncthreads();   // (everyone has read the count before the next segment clears it)
+            if (cnt > cap) {   // too many for the buffer: scan a shorter segment again
+                if (++overflows > 6u) break;
+                seg = max(cap, len / 4u);
+                continue;
+            }
+            if (cnt) {
+                const uint32_t total = knn + cnt;
+                uint32_t m = 1;
+                while (m < total) m <<= 1;
+                for (uint32_t x = total + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
+                __syncthreads();
+                sort_items(sh, m);
+                worst = sh.items[knn - 1];
+                changed = true;
+            }
+            begin += len;
+            if (cnt * 8u <= cap) seg = min(seg * 2u, 1u << 20);
+            else if (cnt * 2u > cap) seg = max(cap, seg / 2u);
+        }
+        if (begin >= cols) {
+            if (changed) write_state();
+            return;
+        }
+        if (changed) write_state();   // the select below reads the state from global memory
+    }
+
+    // ---- radix select over state ++ records [begin, cols) (position order = id order) ----
+    const uint32_t rest = cols - begin;
+    select_smallest(
+        [&](uint32_t c, uint32_t &u) {
+            if (c < knn) {
+                u = sk[c];
+                return true;
+            }
+            return fresh(begin + (c - knn), u);
+        },
+        knn + rest, knn, sh);
+    for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+        const uint32_t pos = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+        const uint32_t id = pos < knn ? si[pos] : g.id_base + begin + (pos - knn);
+        if (stride2 == 2) second[x] = pos < knn ? g.run_d1[srow + pos] : keys[(size_t)(begin + pos - knn) * 2 + 1];
+        sh.items[x] = (sh.items[x] & 0xFFFFFFFF00000000ull) | id;
+    }
+    __syncthreads();
+    for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+        sk[x] = (uint32_t)(sh.items[x] >> 32);
+        si[x] = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+        if (stride2 == 2) g.run_d1[srow + x] = second[x];
+    }
+}
+
+hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0 || args.cols == 0) return hipSuccess;
+    if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
+    if (args.stride2 != 1 && !(args.stride2 == 2 && args.run_d1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void merge_states_kernel(const MergeStatesArgs g)
+{
+    __shared__ uint64_t items[MERGE_STATES_ITEMS];   // (sortable key << 32) | sample id
+    __shared__ uint16_t slot[MERGE_STATES_ITEMS];    // where the item came from: state * knn + position
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, knn = g.knn;
+    const uint32_t total = g.n_in * knn;
+    uint32_t m = 1;
+    while (m < total) m <<= 1;
+    for (uint32_t x = tid; x < m; x += TOPK_THREADS) {
+        if (x < total) {
+            const uint32_t st = x / knn, pos = x - st * knn;
+            const size_t o = (size_t)row * knn + pos;
+            items[x] = ((uint64_t)g.key[st][o] << 32) | g.idx[st][o];
+        } else {
+            items[x] = ~0ull;
+        }
+        slot[x] = (uint16_t)x;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= m; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t x = tid; x < m / 2; x += TOPK_THREADS) {
+                const uint32_t lo = 2 * x - (x & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = items[lo], b = items[hi];
+                if ((a > b) == up) {
+                    items[lo] = b;
+                    items[hi] = a;
+                    const uint16_t sa = slot[lo];
+                    slot[lo] = slot[hi];
+                    slot[hi] = sa;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
+        const size_t o = (size_t)row * knn + x;
+        g.out_key[o] = (uint32_t)(items[x] >> 32);
+        g.out_idx[o] = (uint32_t)(items[x] & 0xFFFFFFFFu);
+        if (g.out_d1) {
+            const uint32_t st = slot[x] / knn, pos = slot[x] - st * knn;
+            g.out_d1[o] = st < g.n_in ? g.d1[st][(size_t)row * knn + pos] : 0.0f;
+        }
+    }
+}
+
+hipError_t launch_merge_states(const MergeStatesArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0) return hipSuccess;
+    if (args.n_in == 0 || args.n_in > (uint32_t)MERGE_STATES_MAX || args.knn == 0 ||
+        (uint64_t)args.n_in * args.knn > (uint64_t)MERGE_STATES_ITEMS) {
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(merge_states_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+__global__ void topk_finalize_kernel(const uint32_t *run_key, const uint32_t *run_idx, const float *run_d1,
+                                     uint64_t items, int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < items; x += stride) {
+        const float key = from_sortable_bits(run_key[x]);
+        out_idx[x] = run_idx[x];
+        out_d0[x] = ani_undo ? 1.0f - key : key;
+        if (run_d1) out_d1[x] = run_d1[x];
+    }
+}
+
+hipError_t launch_topk_finalize(const uint32_t *run_key, const uint32_t *run_idx, const float *run_d1, uint64_t items,
+                                int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1, hipStream_t stream)
+{
+    if (items == 0) return hipSuccess;
+    if (run_d1 && !out_d1) return hipErrorInvalidValue;
+    const uint64_t blocks = std::min<uint64_t>((items + 255) / 256, 65536);
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, run_key, run_idx, run_d1,
+                       items, ani_undo, out_idx, out_d0, out_d1);
+    return hipGetLastError();
+}
+
+}  // namespace skl
