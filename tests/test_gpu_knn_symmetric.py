@@ -201,3 +201,44 @@ def test_large_knn(oracle, skl, gpu_ctx, monkeypatch, knn):
         idx, d0 = _knn(skl, gpu_ctx, g, g.set_k(21), knn, monkeypatch, 512, symmetric)
         assert np.array_equal(idx, exp["idx"]), symmetric
         assert np.array_equal(d0, exp["d0"])
+
+
+FUZZ_SEEDS = int(__import__("os").environ.get("SKL_FUZZ_SEEDS", "16"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
+def test_random_knn_configuration(oracle, skl, gpu_ctx, monkeypatch, seed):
+    """Random sample count, sketch size, k-mer list, knn, band height, key type and completeness:
+    the one-evaluation driver, the row-by-row driver and a 3-way split into partial states
+    against the oracle."""
+    from sketchlib.rust_amd import multi_gpu
+    rng = np.random.default_rng(9000 + seed)
+    nk = int(rng.integers(2, 7))
+    kmers = sorted(rng.choice(np.arange(9, 60), size=nk, replace=False).tolist())
+    ss64 = int(rng.choice([1, 2, 5, 16, 33]))
+    n = int(rng.integers(40, 700))
+    knn = int(rng.integers(1, min(n - 1, 70) + 1))
+    band_rows = int(rng.integers(3, n))
+    coreacc = rng.random() < 0.4
+    ani = (not coreacc) and rng.random() < 0.4
+    comp = rng.uniform(0.6, 1.0, n) if rng.random() < 0.3 else None
+    bins = synth.set_r(n, kmers, ss64, n_clusters=int(rng.integers(1, 12)), seed=77 + seed)
+    o, g = oracle.Sketches(bins, n, kmers, ss64, comp), gpu_ctx.sketches(bins, n, kmers, ss64, comp)
+    k_idx = int(rng.integers(0, nk))
+    p = g.set_k() if coreacc else g.set_k(kmers[k_idx], ani)
+    exp = oracle.self_dists_knn(o, knn, oracle.COREACC if coreacc else oracle.JACCARD, 0 if coreacc else k_idx, ani,
+                                ties=oracle.TIES_CANONICAL, threads=8)
+    runs = {"once": _knn(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True, with_d1=True),
+            "rows": _knn(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, False, with_d1=True)}
+    deal = multi_gpu.knn_band_deal((n + band_rows - 1) // band_rows, 3)
+    states = [skl.self_dists_knn_partial(gpu_ctx, g, p, knn, band_rows, deal[r]) for r in range(3)]
+    stack = [np.ascontiguousarray(np.stack([st[x] for st in states])) if states[0][x] is not None else None
+             for x in range(3)]
+    runs["split"] = skl.knn_merge_states(gpu_ctx, stack[0], stack[1], stack[2], ani=ani)
+    for name, (idx, d0, d1) in runs.items():
+        np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0, err_msg=name)
+        if comp is None:
+            assert np.array_equal(idx, exp["idx"]), name
+            if coreacc:
+                np.testing.assert_allclose(d1, exp["d1"], atol=TOL, rtol=0, err_msg=name)
+    assert np.array_equal(runs["once"][0], runs["rows"][0]) and np.array_equal(runs["once"][0], runs["split"][0])
