@@ -168,6 +168,65 @@ void enc(std::vector<uint8_t> &o, const CborValue &v)
 }
 }  // namespace
 
+CborCursor::Head CborCursor::head()
+{
+    for (;;) {
+        Reader r{p_, n_, i_};
+        const uint8_t ib = r.byte();
+        Head h;
+        h.major = ib >> 5;
+        h.info = ib & 31;
+        if (h.info < 24) h.value = (uint64_t)h.info;
+        else if (h.info == 24) h.value = r.be(1);
+        else if (h.info == 25) h.value = r.be(2);
+        else if (h.info == 26) h.value = r.be(4);
+        else if (h.info == 27) h.value = r.be(8);
+        else if (h.info == 31) h.indefinite = true;
+        else throw std::runtime_error("CBOR: reserved additional info");
+        i_ = r.i;
+        if (h.major != 6) return h;   // a tag: ignore it, the tagged value follows
+    }
+}
+
+void CborCursor::take_break()
+{
+    if (!at_break()) throw std::runtime_error("CBOR: expected the end of an indefinite-length item");
+    ++i_;
+}
+
+std::string CborCursor::text(const Head &h)
+{
+    if (h.major != 2 && h.major != 3) throw std::runtime_error("CBOR: expected a string");
+    std::string out;
+    if (h.indefinite) {
+        while (!at_break()) {
+            const Head part = head();
+            out += text(part);
+        }
+        take_break();
+    } else {
+        if (h.value > n_ - i_) throw std::runtime_error("CBOR: string runs past the end");
+        out.assign((const char *)p_ + i_, (size_t)h.value);
+        i_ += (size_t)h.value;
+    }
+    return out;
+}
+
+CborValue CborCursor::value()
+{
+    Reader r{p_, n_, i_};
+    CborValue v = r.value();
+    i_ = r.i;
+    return v;
+}
+
+void CborCursor::skip()
+{
+    Reader r{p_, n_, i_};
+    r.skip();
+    i_ = r.i;
+}
+
 CborValue cbor_decode_map_skipping(const std::vector<uint8_t> &bytes, const std::string &skip_key,
                                    uint64_t *skipped_count)
 {

@@ -43,6 +43,34 @@ struct CborValue {
     void put(const std::string &k, CborValue v) { map.emplace_back(text(k), std::move(v)); }
 };
 
+// Pull parser over the same subset, for documents too large to be worth a CborValue tree (the
+// .skm of a 400 000-sample database holds ~8 million values).  Usage: h = head(); then, by
+// h.major: 0/1 -> h.value is the number; 2/3 -> text(h); 4/5 -> iterate h.value items (pairs),
+// or until at_break() when h.indefinite, then take_break(); 7 -> h.info 20/21 = false/true,
+// 22/23 = null.  Tags are skipped transparently by head().
+class CborCursor {
+public:
+    struct Head {
+        int major = 0, info = 0;
+        uint64_t value = 0;
+        bool indefinite = false;
+    };
+    CborCursor(const uint8_t *p, size_t n) : p_(p), n_(n) {}
+    Head head();
+    bool at_break() const { return i_ < n_ && p_[i_] == 0xFF; }
+    void take_break();
+    std::string text(const Head &h);   // body of a text / byte string whose head was just read
+    CborValue value();                 // one whole value, generically
+    void skip();                       // one whole value, unread
+    // true while a container opened by `h` has another item; k counts the items taken so far
+    bool more(const Head &h, uint64_t k) const { return h.indefinite ? !at_break() : k < h.value; }
+    void close(const Head &h) { if (h.indefinite) take_break(); }
+
+private:
+    const uint8_t *p_;
+    size_t n_, i_ = 0;
+};
+
 CborValue cbor_decode(const std::vector<uint8_t> &bytes);
 // Decode a top-level map but do not materialise the value stored under `skip_key`; its element
 // count (array / map length) is returned through skipped_count.

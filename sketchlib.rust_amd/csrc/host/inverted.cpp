@@ -182,12 +182,24 @@ void Inverted::save(const std::string &file_prefix) const
     f.write(reinterpret_cast<const char *>(framed.data()), (std::streamsize)framed.size());
 }
 
+// whole file in one read (an istreambuf_iterator copy is a byte at a time: 0.3 s for a 250 MB index)
+static std::vector<uint8_t> slurp(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("Could not open " + path);
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    f.seekg(0);
+    std::vector<uint8_t> buf((size_t)std::max<std::streamoff>(n, 0));
+    if (n > 0) f.read((char *)buf.data(), n);
+    if (!f) throw std::runtime_error("Could not read " + path);
+    return buf;
+}
+
 Inverted Inverted::load(const std::string &file_prefix, bool with_index)
 {
     const std::string path = file_prefix + ".ski";
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("Could not open " + path);
-    std::vector<uint8_t> framed((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const std::vector<uint8_t> framed = slurp(path);
     uint64_t n_bins = 0;
     const CborValue root = with_index ? cbor_decode(snappy_frame_decode(framed))
                                       : cbor_decode_map_skipping(snappy_frame_decode(framed), "index", &n_bins);
@@ -316,9 +328,7 @@ void write_skq(const std::string &path, const std::vector<std::vector<uint16_t>>
 
 std::vector<uint16_t> read_skq(const std::string &path, size_t n_samples, size_t sketch_size)
 {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("Could not open " + path);
-    std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const std::vector<uint8_t> raw = slurp(path);
     if (raw.size() != n_samples * sketch_size * 2) {
         throw std::runtime_error(path + " does not hold " + std::to_string(n_samples) + " x " +
                                  std::to_string(sketch_size) + " bins");

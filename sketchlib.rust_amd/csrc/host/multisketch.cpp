@@ -3,6 +3,7 @@
 #include <unistd.h>
 #include <sys/stat.h>
 #include <fcntl.h>
+#include <set>
 #include <thread>
 #include <atomic>
 
@@ -50,47 +51,118 @@ MultiSketch::MultiSketch(std::vector<SketchMeta> meta, uint64_t sketch_size_bins
 
 MultiSketch MultiSketch::load_metadata(const std::string &file_prefix)
 {
+    // (a pull parse straight into the struct: the generic CborValue tree of a 400 000-sample .skm
+    // is ~8 million nodes and took longer to build than the .skd took to read)
     const std::string filename = file_prefix + ".skm";
-    const CborValue root = cbor_decode(snappy_frame_decode(read_file(filename)));
-    if (root.kind != CborValue::MAP) throw std::runtime_error(filename + ": not a CBOR map");
-    auto need = [&](const char *key) -> const CborValue & {
-        const CborValue *v = root.get(key);
-        if (!v) throw std::runtime_error(filename + ": missing field " + key);
-        return *v;
+    const std::vector<uint8_t> doc = snappy_frame_decode(read_file(filename));
+    CborCursor c(doc.data(), doc.size());
+    using Head = CborCursor::Head;
+    auto want_uint = [&](const char *what) -> uint64_t {
+        const Head h = c.head();
+        if (h.major != 0) throw std::runtime_error(std::string("CBOR: expected unsigned int for ") + what);
+        return h.value;
     };
+    auto want_bool = [&](const char *what) -> bool {
+        const Head h = c.head();
+        if (h.major != 7 || (h.info != 20 && h.info != 21)) throw std::runtime_error(std::string("CBOR: expected a bool for ") + what);
+        return h.info == 21;
+    };
+    auto want_text = [&](const char *what) -> std::string {
+        const Head h = c.head();
+        if (h.major != 3) throw std::runtime_error(std::string("CBOR: expected text for ") + what);
+        return c.text(h);
+    };
+    const Head root = c.head();
+    if (root.major != 5) throw std::runtime_error(filename + ": not a CBOR map");
     MultiSketch m;
-    m.sketch_size = need("sketch_size").as_u64("sketch_size");
-    if (const CborValue *v = root.get("sketchsize64")) m.sketchsize64 = v->as_u64("sketchsize64");  // #[serde(default)]
-    for (const auto &k : need("kmer_lengths").arr) m.kmer_lengths_.push_back((size_t)k.as_u64("kmer_lengths"));
-    for (const auto &s : need("sketch_metadata").arr) {
-        SketchMeta sm;
-        if (const CborValue *v = s.get("name")) sm.name = v->s;
-        if (const CborValue *v = s.get("index")) {
-            if (v->kind == CborValue::UINT) sm.index = v->u;
+    std::set<std::string> seen;
+    for (uint64_t f = 0; c.more(root, f); ++f) {
+        const std::string key = want_text("a field name");
+        seen.insert(key);
+        if (key == "sketch_size") {
+            m.sketch_size = want_uint("sketch_size");
+        } else if (key == "sketchsize64") {   // #[serde(default)]
+            m.sketchsize64 = want_uint("sketchsize64");
+        } else if (key == "kmer_lengths") {
+            const Head a = c.head();
+            if (a.major != 4) throw std::runtime_error("CBOR: expected an array for kmer_lengths");
+            for (uint64_t k = 0; c.more(a, k); ++k) m.kmer_lengths_.push_back((size_t)want_uint("kmer_lengths"));
+            c.close(a);
+        } else if (key == "sketch_metadata") {
+            const Head a = c.head();
+            if (a.major != 4) throw std::runtime_error("CBOR: expected an array for sketch_metadata");
+            if (!a.indefinite) m.sketch_metadata_.reserve((size_t)a.value);
+            for (uint64_t k = 0; c.more(a, k); ++k) {
+                const Head o = c.head();
+                if (o.major != 5) throw std::runtime_error("CBOR: expected a map for a sketch_metadata entry");
+                SketchMeta sm;
+                for (uint64_t q = 0; c.more(o, q); ++q) {
+                    const std::string field = want_text("a sketch field name");
+                    if (field == "name") {
+                        sm.name = want_text("name");
+                    } else if (field == "index") {
+                        const Head h = c.head();   // uint | null
+                        if (h.major == 0) sm.index = h.value;
+                    } else if (field == "rc") {
+                        sm.rc = want_bool("rc");
+                    } else if (field == "reads") {
+                        sm.reads = want_bool("reads");
+                    } else if (field == "seq_length") {
+                        sm.seq_length = want_uint("seq_length");
+                    } else if (field == "densified") {
+                        sm.densified = want_bool("densified");
+                    } else if (field == "acgt") {
+                        const Head v = c.head();
+                        if (v.major != 4) throw std::runtime_error("CBOR: expected an array for acgt");
+                        for (uint64_t x = 0; c.more(v, x); ++x) {
+                            const uint64_t count = want_uint("acgt");
+                            if (x < 4) sm.acgt[x] = count;
+                        }
+                        c.close(v);
+                    } else if (field == "non_acgt") {
+                        sm.non_acgt = want_uint("non_acgt");
+                    } else {
+                        c.skip();
+                    }
+                }
+                c.close(o);
+                m.sketch_metadata_.push_back(std::move(sm));
+            }
+            c.close(a);
+        } else if (key == "name_map") {
+            const Head o = c.head();
+            if (o.major != 5) throw std::runtime_error("CBOR: expected a map for name_map");
+            if (!o.indefinite) m.name_map_order_.reserve((size_t)o.value);
+            for (uint64_t k = 0; c.more(o, k); ++k) {
+                std::string name = want_text("name_map");
+                const size_t idx = (size_t)want_uint("name_map");
+                m.name_map_[name] = idx;
+                m.name_map_order_.emplace_back(std::move(name), idx);
+            }
+            c.close(o);
+        } else if (key == "bin_stride") {
+            m.bin_stride_ = (size_t)want_uint("bin_stride");
+        } else if (key == "kmer_stride") {
+            m.kmer_stride_ = (size_t)want_uint("kmer_stride");
+        } else if (key == "sample_stride") {
+            m.sample_stride_ = (size_t)want_uint("sample_stride");
+        } else if (key == "sketch_version") {
+            m.sketch_version_ = want_text("sketch_version");
+        } else if (key == "hash_type") {
+            const CborValue ht = c.value();
+            if (ht.kind == CborValue::TEXT) {
+                m.hash_type_ = ht.s;
+            } else if (ht.kind == CborValue::MAP && !ht.map.empty()) {
+                m.hash_type_ = ht.map[0].first.s + ":" + ht.map[0].second.s;  // {"AA": "Level1"}
+            }
+        } else {
+            c.skip();
         }
-        if (const CborValue *v = s.get("rc")) sm.rc = v->b;
-        if (const CborValue *v = s.get("reads")) sm.reads = v->b;
-        if (const CborValue *v = s.get("seq_length")) sm.seq_length = v->as_u64("seq_length");
-        if (const CborValue *v = s.get("densified")) sm.densified = v->b;
-        if (const CborValue *v = s.get("acgt")) {
-            for (size_t i = 0; i < 4 && i < v->arr.size(); ++i) sm.acgt[i] = v->arr[i].as_u64("acgt");
-        }
-        if (const CborValue *v = s.get("non_acgt")) sm.non_acgt = v->as_u64("non_acgt");
-        m.sketch_metadata_.push_back(std::move(sm));
     }
-    for (const auto &kv : need("name_map").map) {
-        m.name_map_[kv.first.s] = (size_t)kv.second.as_u64("name_map");
-        m.name_map_order_.emplace_back(kv.first.s, (size_t)kv.second.u);
-    }
-    m.bin_stride_ = (size_t)need("bin_stride").as_u64("bin_stride");
-    m.kmer_stride_ = (size_t)need("kmer_stride").as_u64("kmer_stride");
-    m.sample_stride_ = (size_t)need("sample_stride").as_u64("sample_stride");
-    m.sketch_version_ = need("sketch_version").s;
-    const CborValue &ht = need("hash_type");
-    if (ht.kind == CborValue::TEXT) {
-        m.hash_type_ = ht.s;
-    } else if (ht.kind == CborValue::MAP && !ht.map.empty()) {
-        m.hash_type_ = ht.map[0].first.s + ":" + ht.map[0].second.s;  // {"AA": "Level1"}
+    c.close(root);
+    for (const char *need : {"sketch_size", "kmer_lengths", "sketch_metadata", "name_map", "bin_stride", "kmer_stride",
+                             "sample_stride", "sketch_version", "hash_type"}) {
+        if (!seen.count(need)) throw std::runtime_error(filename + ": missing field " + need);
     }
     // For backwards compatibility (field added in v0.2.0), multisketch.rs:96-100
     if (m.sketchsize64 == 0) {
@@ -167,7 +239,7 @@ void MultiSketch::read_sketch_data(const std::string &file_prefix)
     const size_t bytes = (size_t)st.st_size / sizeof(uint64_t) * sizeof(uint64_t);
     sketch_bins_.resize(bytes / sizeof(uint64_t));
     char *dst = reinterpret_cast<char *>(sketch_bins_.data());
-    const size_t n_slices = bytes >= (64u << 20) ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    const size_t n_slices = bytes >= (64u << 20) ? std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency())) : 1;
     std::atomic<bool> ok{true};
     auto read_slice = [&](size_t sl) {
         size_t off = bytes * sl / n_slices;

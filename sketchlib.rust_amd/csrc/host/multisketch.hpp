@@ -7,7 +7,11 @@
 #include <cstdint>
 #include <map>
 #include <optional>
+#include <memory>
+#include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace skl_host {
@@ -25,6 +29,28 @@ struct SketchMeta {
     uint64_t acgt[4] = {0, 0, 0, 0};
     uint64_t non_acgt = 0;
 };
+
+// std::vector whose resize() leaves new elements uninitialised: a GB-sized .skd is read straight
+// into it, and value-initialising it first is a second, single-threaded pass over the memory.
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
+    {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+using BinVec = std::vector<uint64_t, DefaultInitAllocator<uint64_t>>;
 
 class MultiSketch {
   public:
@@ -51,8 +77,8 @@ class MultiSketch {
     std::optional<size_t> get_sample_index(const std::string &name) const;  // :148-164
     const uint64_t *get_sketch_slice(size_t sketch_idx, size_t k_idx) const;  // :213-219
     bool is_compatible_with(const MultiSketch &other) const;      // :222-226
-    const std::vector<uint64_t> &bins() const { return sketch_bins_; }
-    void set_bins(std::vector<uint64_t> bins) { sketch_bins_ = std::move(bins); }
+    const BinVec &bins() const { return sketch_bins_; }
+    void set_bins(const std::vector<uint64_t> &bins) { sketch_bins_.assign(bins.begin(), bins.end()); }
     size_t sample_stride() const { return sample_stride_; }
     size_t kmer_stride() const { return kmer_stride_; }
     const std::string &hash_type() const { return hash_type_; }
@@ -65,7 +91,7 @@ class MultiSketch {
     std::vector<std::pair<std::string, size_t>> name_map_order_;  // serialisation order
     std::map<std::string, size_t> name_map_;
     std::optional<std::vector<size_t>> block_reindex_;
-    std::vector<uint64_t> sketch_bins_;
+    BinVec sketch_bins_;
     size_t bin_stride_ = 1, kmer_stride_ = 0, sample_stride_ = 0;
     std::string sketch_version_;
     std::string hash_type_ = "DNA";  // "DNA" | "PDB" | "AA:<level>"
