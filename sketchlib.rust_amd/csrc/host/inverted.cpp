@@ -318,12 +318,16 @@ void write_skq(const std::string &path, const std::vector<std::vector<uint16_t>>
 {
     std::ofstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("Couldn't write to " + path);
-    for (const auto &s : sketches) {
-        for (uint16_t v : s) {
-            const char le[2] = {(char)(v & 0xFF), (char)(v >> 8)};
-            f.write(le, 2);
+    std::vector<char> row;
+    for (const auto &s : sketches) {   // one write per sample (little-endian u16, inverted.rs:94-99)
+        row.resize(s.size() * 2);
+        for (size_t i = 0; i < s.size(); ++i) {
+            row[2 * i] = (char)(s[i] & 0xFF);
+            row[2 * i + 1] = (char)(s[i] >> 8);
         }
+        f.write(row.data(), (std::streamsize)row.size());
     }
+    if (!f) throw std::runtime_error("Couldn't write to " + path);
 }
 
 std::vector<uint16_t> read_skq(const std::string &path, size_t n_samples, size_t sketch_size)
