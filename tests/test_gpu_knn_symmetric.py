@@ -242,3 +242,22 @@ def test_random_knn_configuration(oracle, skl, gpu_ctx, monkeypatch, seed):
             if coreacc:
                 np.testing.assert_allclose(d1, exp["d1"], atol=TOL, rtol=0, err_msg=name)
     assert np.array_equal(runs["once"][0], runs["rows"][0]) and np.array_equal(runs["once"][0], runs["split"][0])
+
+
+@pytest.mark.parametrize("shape", ["81", "82", "161"])
+def test_other_tile_shapes_turn_their_tiles_too(oracle, skl, gpu_ctx, monkeypatch, shape):
+    """The turned second store for the tile shapes that are not the default (8 rows, one column
+    block per lane), single-k and core/accessory records."""
+    kmers, ss64, n, knn = [15, 19, 23], 4, 301, 8
+    bins = synth.set_r(n, kmers, ss64, n_clusters=6)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    o = oracle.Sketches(bins, n, kmers, ss64)
+    monkeypatch.setenv("SKL_KSLICE_SHAPE", shape)
+    for p, oargs in ((g.set_k(19), (oracle.JACCARD, 1, False)), (g.set_k(), (oracle.COREACC, 0, False))):
+        idx, d0, d1 = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, 40, True, with_d1=True)
+        assert f"R={shape[:-1]}, JL={shape[-1]}" in gpu_ctx.last_kernel()
+        exp = oracle.self_dists_knn(o, knn, *oargs, ties=oracle.TIES_CANONICAL, threads=8)
+        assert np.array_equal(idx, exp["idx"])
+        np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
+        if oargs[0] == oracle.COREACC:
+            np.testing.assert_allclose(d1, exp["d1"], atol=TOL, rtol=0)
