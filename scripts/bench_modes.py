@@ -87,7 +87,8 @@ def full_size(which):
         # _r = clustered sketches (200 close neighbours per row) instead of Set U (every key ties at 1.0).
         # Each data set runs in both forms of the driver: every pair once (symmetric) and row by row.
         n = 1000000 if tag.startswith("cfg5full") else int(tag[3:].split("_")[0])
-        clustered = tag.endswith("_r")
+        clustered = "_r" in tag
+        coreacc = tag.endswith("_ca")    # core/accessory keys instead of single-k Jaccard
         bins = (synth.set_clustered_device(n, 5, 32, dev) if clustered else synth.set_u_device(n, 5, 32, dev))
         s = ctx.sketches(bins, n, K4, 32)
         del bins
@@ -97,12 +98,12 @@ def full_size(which):
             os.environ["SKL_KNN_SYMMETRIC"] = sym
             ctx.timing_reset()
             t0 = time.perf_counter()
-            idx, d0, d1 = capi.self_dists_knn(ctx, s, s.set_k(21), 50)
+            idx, d0, d1 = capi.self_dists_knn(ctx, s, s.set_k() if coreacc else s.set_k(21), 50)
             wall = time.perf_counter() - t0
             kms, launches = ctx.kernel_ms()
             same = None if ref is None else bool((ref[0] == idx).all() and (ref[1] == d0).all())
             ref = (idx, d0)
-            print(json.dumps({"mode": f"self kNN-50 (Jaccard k=21), {n} x {n}, 1 GPU, "
+            print(json.dumps({"mode": f"self kNN-50 ({'core/acc' if coreacc else 'Jaccard k=21'}), {n} x {n}, 1 GPU, "
                                       f"{'clustered' if clustered else 'Set U'}",
                               "driver": "every pair once" if sym == "1" else "row by row", "sketchsize64": 32,
                               "pair_distances_defined": n * (n - 1), "wall_s": wall, "pair_kernel_s": kms / 1e3,
