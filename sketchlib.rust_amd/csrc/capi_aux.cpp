@@ -113,7 +113,7 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
 // the host copy of the CSR offsets (the 64-candidate work items are cut on the host).
 static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
                                const uint64_t *host_offsets, const uint64_t *d_off, const uint32_t *d_cand,
-                               uint64_t *out_idx, float *out_d0)
+                               bool symmetric_lists, uint64_t *out_idx, float *out_d0)
 {
     const size_t n = s->n;
     const uint64_t total = host_offsets[n];
@@ -147,6 +147,7 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     c.work_start = (const uint64_t *)d_wstart.p;
     c.n_work = work_row.size();
     c.keys = (float *)d_keys.p;
+    c.symmetric = symmetric_lists && env_int("SKL_CAND_SYMMETRIC", 1) != 0 ? 1u : 0u;
     {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
         std::pair<hipEvent_t, hipEvent_t> *ev = timing_slot(ctx);
         if (ev) HIP_TRY(hipEventRecord(ev->first, ctx->stream));
@@ -208,8 +209,9 @@ extern "C" int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s
     HIP_TRY(hipMalloc(&d_cand.p, std::max<size_t>(total * sizeof(uint32_t), 16)));
     HIP_TRY(hipMemcpyAsync(d_off.p, row_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     if (total) HIP_TRY(hipMemcpyAsync(d_cand.p, cand, total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    // caller-supplied lists: no symmetry assumed, every listed pair is evaluated
     return knn_from_device_csr(ctx, s, p, knn, row_offsets, (const uint64_t *)d_off.p, (const uint32_t *)d_cand.p,
-                               out_idx, out_d0);
+                               false, out_idx, out_d0);
 }
 
 extern "C" size_t skl_shared_bins_max_samples(void) { return MAX_DEVICE_CANDGEN_SAMPLES; }
@@ -268,6 +270,7 @@ extern "C" int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *
     (void)hipFree(d_members.p); d_members.p = nullptr;
     (void)hipFree(d_starts.p); d_starts.p = nullptr;
     (void)hipFree(d_cursor.p); d_cursor.p = nullptr;
+    // "any shared bin" is a symmetric relation: each candidate pair is evaluated once
     return knn_from_device_csr(ctx, s, p, knn, offsets.data(), (const uint64_t *)d_off.p, (const uint32_t *)d_cand.p,
-                               out_idx, out_d0);
+                               true, out_idx, out_d0);
 }

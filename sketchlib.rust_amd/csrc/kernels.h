@@ -143,6 +143,7 @@ struct CandArgs {
     const uint64_t *work_start;   // [n_work] first candidate position of the work item
     uint64_t n_work;
     float *keys;                  // [n_candidates] MODE_JACCARD output per candidate
+    uint32_t symmetric;           // 1: the lists are symmetric -- evaluate j > i only, store both copies
 };
 hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream);
 

@@ -27,7 +27,17 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const Ca
     const uint64_t start = c.work_start[w];
     const uint64_t row_end = c.row_offsets[row + 1];
     const uint32_t cnt = (uint32_t)((row_end - start) < 64ull ? (row_end - start) : 64ull);
-    const uint32_t j = lane < cnt ? c.cand[start + lane] : row;   // idle lanes redo the diagonal
+    uint32_t j = lane < cnt ? c.cand[start + lane] : row;   // idle lanes redo the diagonal
+    // Symmetric lists (j in cand(i) <=> i in cand(j), what "any shared bin" yields): only the
+    // j > i half is evaluated, and the key is stored for both rows.  The kernel is gather-bound,
+    // so the lanes that sit out (their j becomes the row itself: a broadcast load) save their
+    // 3.5-7 KB of scattered traffic per pair.
+    bool active = lane < cnt;
+    if (c.symmetric) {
+        active = active && j > row;
+        if (__ballot(active) == 0) return;
+        if (!active) j = row;
+    }
 
     const size_t kmer_stride = (size_t)g.ss64 * BBITS;
     const size_t sample_stride = kmer_stride * g.nk;
@@ -57,7 +67,18 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const Ca
 #pragma unroll
         for (int q = 0; q < 7; ++q) b[q] = bn[q];
     }
-    if (lane < cnt) c.keys[start + lane] = jaccard_out_value(g, row, j, mism);
+    if (active) {
+        const float key = jaccard_out_value(g, row, j, mism);
+        c.keys[start + lane] = key;
+        if (c.symmetric) {   // row j's copy: position of `row` in its (ascending) list
+            uint64_t lo = c.row_offsets[j], hi = c.row_offsets[j + 1];
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (c.cand[mid] < row) lo = mid + 1; else hi = mid;
+            }
+            if (lo < c.row_offsets[j + 1] && c.cand[lo] == row) c.keys[lo] = key;
+        }
+    }
 }
 
 hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream)
