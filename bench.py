@@ -95,6 +95,12 @@ def main():
                     help="N > 1: finish each step's gather before the next step's kernel (default: one step of overlap)")
     args = ap.parse_args()
 
+    # The library brackets pair-kernel launches with HIP events for skl_ctx_kernel_ms(); an event
+    # record is a barrier packet on the queue and two per launch cost a 0.16 ms step ~5 us.  The
+    # roofline needs the AVERAGE launch duration, so every 8th launch of the timed region is
+    # bracketed (25 of the default 200 steps) and the other seven run as a caller's would.
+    os.environ.setdefault("SKL_TIMING_EVERY", "8")
+
     import numpy as np
     import torch
 
@@ -271,6 +277,9 @@ def main():
                 "traffic": traffic,
                 "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
+                "kernel_launches_timed": launches,
+                "kernel_timing": "HIP events on the launch stream around every "
+                                 f"{os.environ.get('SKL_TIMING_EVERY', '1')}th pair-kernel launch of the timed region",
                 "algorithmic_bytes_per_pair": b_pair,
                 "pairs_per_launch": my_pairs,
                 "note": "no-reuse streaming model (SURVEY 8d): frac > 1 measures on-chip operand reuse; "

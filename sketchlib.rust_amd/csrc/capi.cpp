@@ -202,6 +202,7 @@ extern "C" int skl_ctx_timing_reset(skl_ctx *ctx)
     SKL_TRY(ctx_bind(ctx));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->events_used = 0;
+    ctx->launches_seen = 0;   // SKL_TIMING_EVERY counts from here: the first launch after a reset is bracketed
     return SKL_OK;
 }
 
@@ -294,7 +295,11 @@ static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, h
 int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int na)
 {
     constexpr size_t MAX_EVENTS = 4096;
-    if (ctx->events_used >= MAX_EVENTS) {
+    // SKL_TIMING_EVERY = N brackets every N-th launch only (default 1 = all): an event record is
+    // a barrier packet on the queue, and two per launch cost a sub-millisecond launch ~5 us
+    const long long every = std::max(1ll, env_int("SKL_TIMING_EVERY", 1));
+    const bool sampled = (ctx->launches_seen++ % (size_t)every) == 0;
+    if (!sampled || ctx->events_used >= MAX_EVENTS) {
         HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel, ctx->tile_scratch));
         return SKL_OK;
     }

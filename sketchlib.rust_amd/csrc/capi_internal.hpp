@@ -51,6 +51,7 @@ struct skl_ctx {
     // timing of pair-kernel launches of the last call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    size_t launches_seen = 0;           // pair-kernel launches since the last skl_ctx_timing_reset
     std::string last_kernel;
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration
     std::set<skl_sketches *> sketches;  // slabs created on this context
