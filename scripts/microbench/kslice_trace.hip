@@ -100,6 +100,20 @@ int main(int argc, char **argv)
         per_cu[((uint64_t)xcc << 16) | (se << 8) | (sh << 4) | cu]++;
     }
     if (start.empty()) { printf("no trace records\n"); return 1; }
+    {   // resident waves over time, 10 us buckets
+        printf("  resident waves at t =");
+        for (double t = 5.0; t < (t_max - t_min) / 100.0; t += 10.0) {
+            size_t live = 0;
+            for (size_t w = 0; w < n_waves; ++w) {
+                const uint64_t *r = &tr[w * 5];
+                if (r[3] == 0 || r[0] == 0) continue;
+                const double a = (r[0] - t_min) / 100.0, b = (r[3] - t_min) / 100.0;
+                if (a <= t && t < b) ++live;
+            }
+            printf(" %.0f:%zu", t, live);
+        }
+        printf("\n");
+    }
     auto stats = [](std::vector<double> v, const char *name) {
         std::sort(v.begin(), v.end());
         double sum = 0; for (double x : v) sum += x;
