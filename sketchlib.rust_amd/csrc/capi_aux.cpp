@@ -49,13 +49,20 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
             top_r[ki * 4 + b] = r;
         }
     }
-    const uint64_t span = (uint64_t)sketch_span();
+    // the LDS-staged kernel takes every k-mer length up to its span + 1 (SKL_SKETCH_KERNEL=global: A/B)
+    size_t kmax = 0;
+    for (size_t ki = 0; ki < nk; ++ki) kmax = std::max(kmax, kmers[ki]);
+    const char *forced = getenv("SKL_SKETCH_KERNEL");
+    const bool lds_form = kmax <= (size_t)sketch_span_lds() + 1 && !(forced && strcmp(forced, "global") == 0);
+    const uint64_t span = (uint64_t)(lds_form ? sketch_span_lds() : sketch_span());
     std::vector<uint64_t> span_begin(n_samples + 1, 0);
     for (size_t s = 0; s < n_samples; ++s) {
         if (code_begin[s + 1] < code_begin[s] || offset_begin[s + 1] < offset_begin[s]) {
             return fail(SKL_ERR_INVALID_ARG, "sample ranges must not decrease");
         }
-        span_begin[s + 1] = span_begin[s] + (code_begin[s + 1] - code_begin[s] + span - 1) / span;
+        uint64_t spans = (code_begin[s + 1] - code_begin[s] + span - 1) / span;
+        if (lds_form) spans = (spans + 255) / 256 * 256;   // whole workgroups per sample
+        span_begin[s + 1] = span_begin[s] + spans;
     }
     DevBuf d_codes, d_cb, d_offs, d_ob, d_sb, d_k, d_tf, d_tr, d_signs;
     auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
@@ -95,13 +102,16 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
     a.inv_bin_size = 1.0 / (double)a.bin_size;
     a.rc = rc ? 1 : 0;
     a.signs = (uint64_t *)d_signs.p;
+    a.lds_form = lds_form ? 1u : 0u;
     {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
         std::pair<hipEvent_t, hipEvent_t> *ev = timing_slot(ctx);
         if (ev) HIP_TRY(hipEventRecord(ev->first, ctx->stream));
         HIP_TRY(launch_sketch_signs(a, ctx->stream));
         if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
     }
-    ctx->last_kernel = "skl::nthash_binmin_kernel (256 window starts per thread, rolling canonical ntHash, atomicMin per bin)";
+    ctx->last_kernel = lds_form ? "skl::nthash_binmin_lds_kernel (bases staged in LDS, 128 window starts per thread, rolling canonical "
+                                  "ntHash, bin minima in LDS)"
+                                : "skl::nthash_binmin_kernel (256 window starts per thread, rolling canonical ntHash, atomicMin per bin)";
     HIP_TRY(hipMemcpyAsync(out_signs, d_signs.p, sign_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SKL_OK;

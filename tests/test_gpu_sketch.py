@@ -39,7 +39,7 @@ def test_signs_of_reference_genomes(skl, gpu_ctx, rc):
     samples = [sketcher.read_fasta_bases(os.path.join(REF_FIXTURES, n)) for n in FIXTURE_NAMES[:2]]
     kmers, num_bins = [17, 21, 31], 1024
     got = skl.sketch_signs(gpu_ctx, *pack(samples), kmers, num_bins, rc)
-    assert "nthash_binmin_kernel" in gpu_ctx.last_kernel()
+    assert "nthash_binmin_lds_kernel" in gpu_ctx.last_kernel()
     for s, (codes, offsets) in enumerate(samples):
         for ki, k in enumerate(kmers):
             assert np.array_equal(got[s, ki], oracle_signs(codes, offsets, k, num_bins, rc)), (s, k)
@@ -105,3 +105,30 @@ def test_cli_gpu_sketch_4k_database_and_errors(gpu_ctx, tmp_path):
     cpu = subprocess.run([CLI, "sketch", "-o", str(tmp_path / "y"), "-k", "60", "short_sequence.fa"],
                          cwd=REF_FIXTURES, capture_output=True, text=True)
     assert res.returncode == cpu.returncode == 101 and "K-mer larger than smallest valid sequence" in res.stderr
+
+
+@pytest.mark.parametrize("num_bins", [1000, 5000])
+def test_both_kernel_forms_and_bin_counts(skl, gpu_ctx, monkeypatch, num_bins):
+    """The LDS-staged kernel with bin minima in LDS (<= 4096 bins) and in global memory (more),
+    the global-memory kernel (SKL_SKETCH_KERNEL=global, also what k > 129 takes), many short
+    samples (workgroups padded per sample) and k at the staged kernel's limit."""
+    rng = np.random.default_rng(11)
+    samples = []
+    for ln in (40, 129, 130, 5000, 128 * 256 + 77, 3 * 128 * 256 + 5):
+        codes = rng.integers(0, 4, size=ln, dtype=np.uint8)
+        cuts = np.sort(rng.choice(np.arange(1, ln), size=min(6, ln // 20), replace=False)).astype(np.int64)
+        samples.append((codes, cuts))
+    kmers = [11, 31, 129]
+    got = skl.sketch_signs(gpu_ctx, *pack(samples), kmers, num_bins, True)
+    assert "lds_kernel" in gpu_ctx.last_kernel()
+    monkeypatch.setenv("SKL_SKETCH_KERNEL", "global")
+    ref = skl.sketch_signs(gpu_ctx, *pack(samples), kmers, num_bins, True)
+    assert "lds_kernel" not in gpu_ctx.last_kernel()
+    assert np.array_equal(got, ref)
+    monkeypatch.delenv("SKL_SKETCH_KERNEL")
+    big_k = skl.sketch_signs(gpu_ctx, *pack(samples), [130], num_bins, True)      # past the staged limit
+    assert "lds_kernel" not in gpu_ctx.last_kernel()
+    for s_, (codes, offsets) in enumerate(samples):
+        assert np.array_equal(got[s_, 1], oracle_signs(codes, offsets, 31, num_bins, True)), s_
+        assert np.array_equal(got[s_, 2], oracle_signs(codes, offsets, 129, num_bins, True)), s_
+        assert np.array_equal(big_k[s_, 0], oracle_signs(codes, offsets, 130, num_bins, True)), s_
