@@ -55,7 +55,8 @@ def main():
                              ("cpu --threads 1", ["--threads", "1"])):
             t0 = time.perf_counter()
             subprocess.check_call([CLI, "sketch", "-o", os.path.join(tmp, "db_" + label.split()[0] + extra[-1]),
-                                   "--k-vals", ",".join(map(str, kmers)), "-s", "4096", *extra, *files])
+                                   "--k-vals", ",".join(map(str, kmers)), "-s", "4096", *extra, *files],
+                                  env={**os.environ, "SKL_CLI_TIMING": "1"})
             wall = time.perf_counter() - t0
             print(json.dumps({"mode": f"sketchlib sketch end to end, {label}", "samples": n, "bases": n * length,
                               "wall_s": wall, "Mbases_per_s": n * length / wall / 1e6}), flush=True)
