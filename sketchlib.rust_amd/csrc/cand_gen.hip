@@ -133,6 +133,27 @@ hipError_t launch_cand_groups(const CandGenArgs &g, hipStream_t stream)
     return hipGetLastError();
 }
 
+// first position of a candidate id greater than the row's own id in each (ascending) list
+__global__ void first_greater_kernel(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint64_t *first)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t lo = row_offsets[i], hi = row_offsets[i + 1];
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (cand[mid] <= i) lo = mid + 1; else hi = mid;
+    }
+    first[i] = lo;
+}
+
+hipError_t launch_first_greater(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint64_t *first,
+                                hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(first_greater_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, row_offsets, cand, n, first);
+    return hipGetLastError();
+}
+
 hipError_t launch_cand_rows(const CandGenArgs &g, bool fill, hipStream_t stream)
 {
     if (g.n == 0) return hipSuccess;

@@ -127,10 +127,22 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
 {
     const size_t n = s->n;
     const uint64_t total = host_offsets[n];
+    const bool symmetric = symmetric_lists && env_int("SKL_CAND_SYMMETRIC", 1) != 0;
+    // symmetric lists: only the candidates with a larger id than the row are evaluated (the
+    // kernel stores each key for both rows), so a row's work items start at its first such candidate
+    std::vector<uint64_t> first;
+    if (symmetric && n) {
+        DevBuf d_first;
+        HIP_TRY(hipMalloc(&d_first.p, n * sizeof(uint64_t)));
+        HIP_TRY(launch_first_greater(d_off, d_cand, (uint32_t)n, (uint64_t *)d_first.p, ctx->stream));
+        first.resize(n);
+        HIP_TRY(hipMemcpyAsync(first.data(), d_first.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     std::vector<uint32_t> work_row;
     std::vector<uint64_t> work_start;
     for (size_t i = 0; i < n; ++i) {
-        for (uint64_t c0 = host_offsets[i]; c0 < host_offsets[i + 1]; c0 += 64) {
+        for (uint64_t c0 = symmetric ? first[i] : host_offsets[i]; c0 < host_offsets[i + 1]; c0 += 64) {
             work_row.push_back((uint32_t)i);
             work_start.push_back(c0);
         }
@@ -157,7 +169,7 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     c.work_start = (const uint64_t *)d_wstart.p;
     c.n_work = work_row.size();
     c.keys = (float *)d_keys.p;
-    c.symmetric = symmetric_lists && env_int("SKL_CAND_SYMMETRIC", 1) != 0 ? 1u : 0u;
+    c.symmetric = symmetric ? 1u : 0u;
     {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
         std::pair<hipEvent_t, hipEvent_t> *ev = timing_slot(ctx);
         if (ev) HIP_TRY(hipEventRecord(ev->first, ctx->stream));

@@ -183,6 +183,9 @@ struct CandGenArgs {
 };
 hipError_t launch_cand_groups(const CandGenArgs &g, hipStream_t stream);
 hipError_t launch_cand_rows(const CandGenArgs &g, bool fill, hipStream_t stream);
+// first[i] = position of the first candidate of row i with an id greater than i
+hipError_t launch_first_greater(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint64_t *first,
+                                hipStream_t stream);
 constexpr size_t MAX_DEVICE_CANDGEN_SAMPLES = 158ull * 1024 * 8;   // n-bit bitmap in LDS
 
 struct TopkArgs {
