@@ -138,3 +138,28 @@ def test_cli_rejects_percent_completeness(tmp_path):
     res = subprocess.run([CLI, "dist", os.path.join(REF_FIXTURES, "sketches3"), "-k", "21",
                           "--ref-completeness-file", str(comp)], capture_output=True, text=True)
     assert res.returncode == 1 and "[0.0, 1.0]" in res.stderr and "R6.fa.gz: 95" in res.stderr
+
+
+def test_large_skm_parallel_frame_decode_and_corruption(tmp_path):
+    """A .skm above the 8 MB threshold where the snappy frames are decoded (and CRC-checked) on
+    several threads and the CBOR is pull-parsed: round trip, then one flipped payload byte must be
+    caught by the checksum of its frame."""
+    n, ss64 = 120_000, 1
+    prefix = str(tmp_path / "big")
+    np.zeros(n * ss64 * 14, dtype="<u8").tofile(prefix + ".skd")
+    names = tmp_path / "names.txt"
+    names.write_text("\n".join(f"sample_with_a_longer_name_{i:07d}.fa.gz" for i in range(n)))
+    subprocess.run([DBTOOL, "make", prefix, str(ss64 * 64), "17,21", "@" + str(names)], check=True)
+    assert os.path.getsize(prefix + ".skm") > (8 << 20)
+    # the .skd written above holds 1 k-mer length per sample; make one that matches two
+    np.zeros(n * ss64 * 14 * 2, dtype="<u8").tofile(prefix + ".skd")
+    out = str(tmp_path / "copy")
+    subprocess.run([DBTOOL, "roundtrip", prefix, out], check=True)
+    assert open(prefix + ".skm", "rb").read() == open(out + ".skm", "rb").read()
+    info = subprocess.run([DBTOOL, "info", out], check=True, capture_output=True, text=True).stdout
+    assert f"n_samples\t{n}" in info or str(n) in info
+    raw = bytearray(open(prefix + ".skm", "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    open(prefix + ".skm", "wb").write(raw)
+    res = subprocess.run([DBTOOL, "info", prefix], capture_output=True, text=True)
+    assert res.returncode != 0 and "checksum" in (res.stderr + res.stdout)
