@@ -1,6 +1,7 @@
 // skl_dbtool -- small database utility around the C++ MultiSketch mirror (CPU only):
 //   skl_dbtool info <prefix>            dump the .skm fields (one `key<TAB>value` per line)
 //   skl_dbtool roundtrip <in> <out>     load <in>.skm/.skd and write them back as <out>.*
+//   skl_dbtool unframe <in> <out>       decode a snappy-framed file (.skm / .ski) to its payload
 //   skl_dbtool slice <prefix> <i> <k>   print the u64 words of get_sketch_slice(i, k_idx)
 //   skl_dbtool make <prefix> <bins> <k1,k2,..> <name>...  write <prefix>.skm for an existing .skd
 //   skl_dbtool format <self|cross> <coreacc|jaccard> <n> <nq> <threads> <band_rows> <dists.f32> [out]
@@ -25,6 +26,7 @@
 #include "../host/inverted.hpp"
 #include "../host/io.hpp"
 #include "../host/multisketch.hpp"
+#include "../host/snappy_frame.hpp"
 
 using namespace skl_host;
 
@@ -66,6 +68,18 @@ int main(int argc, char **argv)
                           << s.acgt[0] << "," << s.acgt[1] << "," << s.acgt[2] << "," << s.acgt[3] << "\t"
                           << s.non_acgt << "\n";
             }
+            return 0;
+        }
+        if (argc >= 4 && std::string(argv[1]) == "unframe") {   // snappy-framed file -> its payload
+            std::ifstream f(argv[2], std::ios::binary);
+            if (!f) throw std::runtime_error(std::string("cannot open ") + argv[2]);
+            f.seekg(0, std::ios::end);
+            std::vector<uint8_t> framed((size_t)f.tellg());
+            f.seekg(0);
+            f.read((char *)framed.data(), (std::streamsize)framed.size());
+            const std::vector<uint8_t> raw = snappy_frame_decode(framed);
+            std::ofstream o(argv[3], std::ios::binary);
+            o.write((const char *)raw.data(), (std::streamsize)raw.size());
             return 0;
         }
         if (argc >= 4 && std::string(argv[1]) == "roundtrip") {

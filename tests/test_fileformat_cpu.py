@@ -163,3 +163,48 @@ def test_large_skm_parallel_frame_decode_and_corruption(tmp_path):
     open(prefix + ".skm", "wb").write(raw)
     res = subprocess.run([DBTOOL, "info", prefix], capture_output=True, text=True)
     assert res.returncode != 0 and "checksum" in (res.stderr + res.stdout)
+
+
+def _crc32c_masked(b):
+    table = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        table.append(c)
+    c = 0xFFFFFFFF
+    for x in b:
+        c = table[(c ^ x) & 0xFF] ^ (c >> 8)
+    c ^= 0xFFFFFFFF
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_snappy_compressed_chunks_by_hand(tmp_path):
+    """Raw snappy blocks written by hand (the writer here only emits uncompressed chunks): long
+    literals, 1-, 2- and 4-byte-offset copies, an overlapping run (offset < length), a skippable
+    chunk between them; then malformed blocks must be refused, not read out of bounds."""
+    def chunk(kind, payload, raw):
+        body = _crc32c_masked(raw).to_bytes(4, "little") + payload
+        return bytes([kind]) + len(body).to_bytes(3, "little") + body
+
+    want1 = b"ab" + b"ab" * 5                       # literal "ab", copy offset 2 length 10 (overlapping)
+    blk1 = bytes([12, 0x04]) + b"ab" + bytes([((10 - 4) << 2) | 1, 2])
+    lit = bytes(range(256)) * 2                     # 512-byte literal: 2-byte length form (tag 61)
+    want2 = lit + lit[100:164] + lit[:40]
+    blk2 = (bytes([0x80 | (len(want2) & 0x7F), len(want2) >> 7]) if len(want2) >= 128 else bytes([len(want2)]))
+    blk2 += bytes([61 << 2]) + (len(lit) - 1).to_bytes(2, "little") + lit
+    blk2 += bytes([((64 - 1) << 2) | 2]) + (512 - 100).to_bytes(2, "little")          # copy 64 from offset 412 back
+    blk2 += bytes([((40 - 1) << 2) | 3]) + (512 + 64).to_bytes(4, "little")           # copy 40 from the very start
+    stream = b"\xff\x06\x00\x00sNaPpY" + chunk(0x00, blk1, want1) + b"\x80\x03\x00\x00xyz" + chunk(0x00, blk2, want2) \
+        + chunk(0x01, b"tail", b"tail")
+    (tmp_path / "s.bin").write_bytes(stream)
+    subprocess.run([DBTOOL, "unframe", str(tmp_path / "s.bin"), str(tmp_path / "s.out")], check=True)
+    assert (tmp_path / "s.out").read_bytes() == want1 + want2 + b"tail"
+    bad_blocks = [bytes([12, 0x04]) + b"ab" + bytes([((10 - 4) << 2) | 1, 3]),      # copy reaches before the block
+                  bytes([12, 0x04]) + b"ab" + bytes([((11 - 4) << 2) | 1, 2]),      # one byte too many
+                  bytes([12, 0x04]) + b"ab",                                        # too short
+                  bytes([12, 61 << 2, 0xFF])]                                       # truncated literal length
+    for bad in bad_blocks:
+        (tmp_path / "b.bin").write_bytes(b"\xff\x06\x00\x00sNaPpY" + chunk(0x00, bad, want1))
+        res = subprocess.run([DBTOOL, "unframe", str(tmp_path / "b.bin"), str(tmp_path / "b.out")], capture_output=True, text=True)
+        assert res.returncode != 0 and "snappy" in res.stderr
