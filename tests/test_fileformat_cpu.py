@@ -208,3 +208,55 @@ def test_snappy_compressed_chunks_by_hand(tmp_path):
         (tmp_path / "b.bin").write_bytes(b"\xff\x06\x00\x00sNaPpY" + chunk(0x00, bad, want1))
         res = subprocess.run([DBTOOL, "unframe", str(tmp_path / "b.bin"), str(tmp_path / "b.out")], capture_output=True, text=True)
         assert res.returncode != 0 and "snappy" in res.stderr
+
+
+def _frame(raw):
+    out = b"\xff\x06\x00\x00sNaPpY"
+    for i in range(0, max(len(raw), 1), 65536):
+        part = raw[i:i + 65536]
+        body = _crc32c_masked(part).to_bytes(4, "little") + part
+        out += b"\x01" + len(body).to_bytes(3, "little") + body
+    return out
+
+
+def test_skm_pull_parser_accepts_what_cbor_allows_and_refuses_the_rest(tmp_path):
+    """Hand-written .skm documents: fields in another order, unknown fields of every shape,
+    indefinite-length maps / arrays / strings, a tag in front of a value; then a missing field, a
+    wrong type and a truncated document must be errors, not crashes."""
+    def head(major, v):
+        if v < 24:
+            return bytes([major << 5 | v])
+        if v < 256:
+            return bytes([major << 5 | 24, v])
+        if v < 65536:
+            return bytes([major << 5 | 25]) + v.to_bytes(2, "big")
+        return bytes([major << 5 | 26]) + v.to_bytes(4, "big")
+
+    def u(v): return head(0, v)
+    def t(s): return head(3, len(s)) + s.encode()
+    BREAK = b"\xff"
+    sample = lambda name, idx: (b"\xbf" + t("reads") + b"\xf4" + t("name") + b"\x7f" + t(name[:3]) + t(name[3:]) + BREAK +
+                                t("index") + (u(idx) if idx is not None else b"\xf6") + t("extra") + head(4, 2) + u(1) + head(5, 1) + t("x") + b"\xf5" +
+                                t("rc") + b"\xf5" + t("seq_length") + u(1234) + t("densified") + b"\xf4" +
+                                t("acgt") + b"\x9f" + u(1) + u(2) + u(3) + u(4) + BREAK + t("non_acgt") + u(7) + BREAK)
+    fields = {
+        "hash_type": t("DNA"), "sketch_version": t("0.3.0"), "sample_stride": u(28), "kmer_stride": u(14), "bin_stride": u(1),
+        "name_map": b"\xbf" + t("genomeA") + u(0) + t("genomeB") + u(1) + BREAK,
+        "sketch_metadata": b"\x9f" + sample("genomeA", 0) + sample("genomeB", None) + BREAK,
+        "kmer_lengths": head(4, 2) + b"\xc1" + u(17) + u(21),       # a tag in front of the first length
+        "unknown_blob": head(2, 5) + b"hello", "sketchsize64": u(1), "sketch_size": u(64),
+    }
+    def doc(keys): return b"\xbf" + b"".join(t(k) + fields[k] for k in keys) + BREAK
+    order = list(fields)
+    prefix = str(tmp_path / "hand")
+    np.zeros(2 * 28, dtype="<u8").tofile(prefix + ".skd")
+    (tmp_path / "hand.skm").write_bytes(_frame(doc(order)))
+    info = subprocess.run([DBTOOL, "info", prefix], check=True, capture_output=True, text=True).stdout
+    assert "kmer_lengths\t17,21" in info and "n_samples\t2" in info and "hash_type\tDNA" in info
+    assert "sample\t0\tgenomeA\t0\t1234\t100\t1,2,3,4\t7" in info and "sample\t1\tgenomeB\t-1\t1234" in info
+    for label, raw in (("missing field", doc([k for k in order if k != "kmer_stride"])),
+                       ("wrong type", doc(order).replace(t("sample_stride") + u(28), t("sample_stride") + t("28"))),
+                       ("truncated", doc(order)[:-40])):
+        (tmp_path / "hand.skm").write_bytes(_frame(raw))
+        res = subprocess.run([DBTOOL, "info", prefix], capture_output=True, text=True)
+        assert res.returncode != 0 and res.returncode > 0, label      # an error exit, not a signal
