@@ -44,7 +44,7 @@ struct Reader {
                     while (i < n && p[i] != 0xFF) skip(depth + 1);
                     byte();
                 } else {
-                    if (i + v > n) throw std::runtime_error("CBOR: string runs past the end");
+                    if (v > n - i) throw std::runtime_error("CBOR: string runs past the end");
                     i += (size_t)v;
                 }
                 return 0;
@@ -90,13 +90,13 @@ struct Reader {
             case 3: {
                 c.kind = mt == 2 ? CborValue::BYTES : CborValue::TEXT;
                 if (indefinite) {
-                    while (p[i] != 0xFF) {
+                    while (i < n && p[i] != 0xFF) {
                         CborValue part = value(depth + 1);
                         c.s += part.s;
                     }
-                    ++i;
+                    byte();   // the break (throws at the end of input)
                 } else {
-                    if (i + v > n) throw std::runtime_error("CBOR: string runs past the end");
+                    if (v > n - i) throw std::runtime_error("CBOR: string runs past the end");
                     c.s.assign((const char *)p + i, (size_t)v);
                     i += (size_t)v;
                 }

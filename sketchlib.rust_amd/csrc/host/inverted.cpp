@@ -92,6 +92,7 @@ std::vector<uint32_t> roaring_deserialize(const std::string &bytes)
     } else {
         throw std::runtime_error("roaring: unknown cookie");
     }
+    if (size > 65536) throw std::runtime_error("roaring: more containers than 16-bit keys");
     std::vector<std::pair<uint16_t, uint32_t>> desc(size);   // key, cardinality
     for (auto &d : desc) {
         d.first = r.u16();
@@ -109,6 +110,7 @@ std::vector<uint32_t> roaring_deserialize(const std::string &bytes)
             const uint16_t n_runs = r.u16();
             for (uint16_t k = 0; k < n_runs; ++k) {
                 const uint32_t start = r.u16(), len = r.u16();
+                if (start + len > 0xFFFFu) throw std::runtime_error("roaring: run leaves its container");
                 for (uint32_t x = start; x <= start + len; ++x) out.push_back(hi | x);
             }
         } else if (desc[c].second > 4096) {
@@ -242,6 +244,21 @@ Inverted Inverted::load(const std::string &file_prefix, bool with_index)
     inv.rc = need("rc").b;
     const CborValue &ht = need("hash_type");
     inv.hash_type = ht.kind == CborValue::TEXT ? ht.s : "other";
+    // a file is untrusted input: everything later indexes per-sample arrays with these ids
+    if (inv.n_samples != inv.sample_names.size()) throw std::runtime_error(path + ": n_samples does not match sample_names");
+    if (inv.metadata && inv.metadata->size() != inv.n_samples) throw std::runtime_error(path + ": metadata does not match n_samples");
+    if (inv.labels && inv.labels->size() != inv.n_samples) throw std::runtime_error(path + ": labels do not match n_samples");
+    for (const auto &bin : inv.index) {
+        for (const auto &kv : bin) {
+            uint64_t prev = 0;
+            bool first = true;
+            for (uint32_t id : kv.second) {
+                if (id >= inv.n_samples || (!first && id <= prev)) throw std::runtime_error(path + ": bitmap holds an invalid sample id");
+                prev = id;
+                first = false;
+            }
+        }
+    }
     return inv;
 }
 

@@ -260,3 +260,42 @@ def test_skm_pull_parser_accepts_what_cbor_allows_and_refuses_the_rest(tmp_path)
         (tmp_path / "hand.skm").write_bytes(_frame(raw))
         res = subprocess.run([DBTOOL, "info", prefix], capture_output=True, text=True)
         assert res.returncode != 0 and res.returncode > 0, label      # an error exit, not a signal
+
+
+def test_untrusted_files_are_refused_cleanly(tmp_path):
+    """Findings of a mutation fuzz of the loaders under AddressSanitizer, pinned: an
+    indefinite-length string that never ends, a string longer than the file, an index whose
+    n_samples disagrees with its names or whose bitmaps name samples that do not exist."""
+    prefix = str(tmp_path / "x")
+    np.zeros(28, dtype="<u8").tofile(prefix + ".skd")
+    for raw in (b"\xbf\x7f\x61a",                                   # {_ (_ "a" ...  and the input ends
+                b"\xa1\x7b\xff\xff\xff\xff\xff\xff\xff\xf0abc",     # text of 2^64 - 16 bytes
+                b"\xa1\x69n_samples\x9f\x9f\x9f"):                  # nested arrays cut short
+        (tmp_path / "x.skm").write_bytes(_frame(raw))
+        res = subprocess.run([DBTOOL, "info", prefix], capture_output=True, text=True)
+        assert res.returncode > 0, raw
+    # a real index, then its n_samples / a bitmap entry patched in the (re-framed) payload
+    wd = tmp_path / "idx"
+    wd.mkdir()
+    import shutil
+    for f in FIXTURE_NAMES:
+        shutil.copy(os.path.join(REF_FIXTURES, f), wd / f)
+    subprocess.run([CLI, "inverted", "build", "-o", "i", "-k", "21", "-s", "20", *FIXTURE_NAMES], cwd=wd, check=True)
+    subprocess.run([DBTOOL, "unframe", str(wd / "i.ski"), str(wd / "i.raw")], check=True)
+    raw = (wd / "i.raw").read_bytes()
+    key = b"\x69n_samples\x04"
+    assert raw.count(key) == 1
+    ok = subprocess.run([CLI, "inverted", "precluster", "i.ski", "--count"], cwd=wd, capture_output=True, text=True)
+    assert ok.returncode == 0 and "prefilter pairs" in ok.stdout
+    (wd / "bad.ski").write_bytes(_frame(raw.replace(key, b"\x69n_samples\x05")))
+    res = subprocess.run([CLI, "inverted", "precluster", "bad.ski", "--count"], cwd=wd, capture_output=True, text=True)
+    assert res.returncode > 0 and "n_samples" in res.stderr
+    # roaring array container of one value [cookie 12346, 1 container, key 0, card-1 = 0, offset, value]:
+    one = (12346).to_bytes(4, "little") + (1).to_bytes(4, "little") + b"\x00\x00\x00\x00" + (16).to_bytes(4, "little")
+    hits = [i for i in range(len(raw)) if raw.startswith(one, i)]
+    assert hits
+    at = hits[0] + len(one)
+    patched = raw[:at] + (9).to_bytes(2, "little") + raw[at + 2:]   # sample id 9 of 4
+    (wd / "bad.ski").write_bytes(_frame(patched))
+    res = subprocess.run([CLI, "inverted", "precluster", "bad.ski", "--count"], cwd=wd, capture_output=True, text=True)
+    assert res.returncode > 0 and "invalid sample id" in res.stderr
