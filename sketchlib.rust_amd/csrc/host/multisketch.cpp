@@ -169,6 +169,14 @@ MultiSketch MultiSketch::load_metadata(const std::string &file_prefix)
         m.sketchsize64 = m.sketch_size;
         m.sketch_size *= 64;
     }
+    // the strides are what multisketch.rs:61-73 computes; a file that says otherwise cannot be indexed
+    if (m.bin_stride_ != 1 || m.kmer_stride_ != (size_t)m.sketchsize64 * BBITS ||
+        m.sample_stride_ != m.kmer_stride_ * m.kmer_lengths_.size() || m.kmer_lengths_.empty() || m.sketchsize64 == 0) {
+        throw std::runtime_error(filename + ": strides do not match sketch size and k-mer lengths");
+    }
+    for (const auto &sm : m.sketch_metadata_) {
+        if (sm.index && *sm.index >= m.sketch_metadata_.size()) throw std::runtime_error(filename + ": sample index out of range");
+    }
     return m;
 }
 
@@ -237,6 +245,10 @@ void MultiSketch::read_sketch_data(const std::string &file_prefix)
         throw std::runtime_error("cannot stat " + path);
     }
     const size_t bytes = (size_t)st.st_size / sizeof(uint64_t) * sizeof(uint64_t);
+    if (bytes / sizeof(uint64_t) < sketch_metadata_.size() * sample_stride_) {   // every later index trusts this
+        ::close(fd);
+        throw std::runtime_error(path + " is shorter than its metadata says");
+    }
     sketch_bins_.resize(bytes / sizeof(uint64_t));
     char *dst = reinterpret_cast<char *>(sketch_bins_.data());
     const size_t n_slices = bytes >= (64u << 20) ? std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency())) : 1;

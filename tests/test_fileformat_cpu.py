@@ -299,3 +299,22 @@ def test_untrusted_files_are_refused_cleanly(tmp_path):
     (wd / "bad.ski").write_bytes(_frame(patched))
     res = subprocess.run([CLI, "inverted", "precluster", "bad.ski", "--count"], cwd=wd, capture_output=True, text=True)
     assert res.returncode > 0 and "invalid sample id" in res.stderr
+
+
+def test_short_skd_and_wrong_strides_are_refused(tmp_path):
+    import shutil
+    for ext in (".skm", ".skd"):
+        shutil.copy(os.path.join(REF_FIXTURES, "sketches1" + ext), tmp_path / ("s" + ext))
+    data = (tmp_path / "s.skd").read_bytes()
+    (tmp_path / "s.skd").write_bytes(data[:len(data) - 8 * 14])
+    res = subprocess.run([DBTOOL, "roundtrip", str(tmp_path / "s"), str(tmp_path / "t")], capture_output=True, text=True)
+    assert res.returncode > 0 and "shorter than its metadata" in res.stderr
+    res = subprocess.run([CLI, "dist", str(tmp_path / "s")], capture_output=True, text=True)
+    assert res.returncode > 0 and "shorter than its metadata" in res.stderr      # before any device is touched
+    subprocess.run([DBTOOL, "unframe", str(tmp_path / "s.skm"), str(tmp_path / "s.raw")], check=True)
+    raw = (tmp_path / "s.raw").read_bytes()
+    key = b"\x6bkmer_stride\x18\xe0"          # 16 * 14 = 224
+    assert raw.count(key) == 1
+    (tmp_path / "s.skm").write_bytes(_frame(raw.replace(key, b"\x6bkmer_stride\x18\xe1")))
+    res = subprocess.run([DBTOOL, "info", str(tmp_path / "s")], capture_output=True, text=True)
+    assert res.returncode > 0 and "strides" in res.stderr
