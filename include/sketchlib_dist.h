@@ -91,6 +91,17 @@ int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches);
  * "pair_kernel_ksplit<R=4>" -- for benchmark reports.  Valid until the next call. */
 const char *skl_ctx_last_kernel(skl_ctx *ctx);
 
+/* The reference takes ln J with Rust's f64::ln = the platform libm's log() (jaccard.rs:51,88), and
+ * the core/accessory regression amplifies its last bit without bound on flat fits, so the
+ * device evaluates a restatement of glibc's log() (csrc/glibc_log.hpp) whenever the argument is
+ * not a function of the bin-match count alone (completeness correction).  skl_log_variant(): the
+ * form that reproduces THIS host's log() bit for bit on a probe set: 0 = glibc 2.35 x86-64 FMA
+ * form, 1 = its SSE2 form, -1 = neither (form 0 is used; flat-fit pairs may then differ from a
+ * CPU run on this host).  skl_device_log(): y[i] = that logarithm of x[i], evaluated on the
+ * device (host pointers) -- for tests. */
+int skl_log_variant(void);
+int skl_device_log(skl_ctx *ctx, const double *x_host, size_t n, double *out_host);
+
 /* ---- sketch slabs: MultiSketch::read_sketch_data / get_sketch_slice
  *      (src/sketch/multisketch.rs:167-219) ---- */
 /* bins: n_samples*nk*sketchsize64*14 u64 in the reference layout.  `on_device`

@@ -26,10 +26,13 @@ int main(int argc, char **argv)
     const uint32_t n = argc > 1 ? atoi(argv[1]) : 1000;
     const int shape = argc > 2 ? atoi(argv[2]) : 162;
     const uint32_t nk = 5, ss64 = 64;
+    constexpr size_t TW = 8;   // words per trace record (SKL_TRACE_WORDS)
     const size_t sample_words = (size_t)nk * ss64 * BBITS;
     std::vector<uint64_t> h((size_t)(n + A_PAD_ROWS) * sample_words, 0);
     std::mt19937_64 rng(1);
-    for (size_t i = 0; i < (size_t)n * sample_words; ++i) h[i] = rng();
+    // argv[3]: "zero" = all-zero sketches (same instruction stream, no bit toggling in the datapath)
+    const bool zero_data = argc > 3 && !strcmp(argv[3], "zero");
+    if (!zero_data) for (size_t i = 0; i < (size_t)n * sample_words; ++i) h[i] = rng();
     uint64_t *dA;
     uint4 *dB;
     CK(hipMalloc(&dA, h.size() * 8));
@@ -49,12 +52,15 @@ int main(int argc, char **argv)
     g.k_begin = 0; g.k_count = nk; g.row_begin = 0; g.row_end = n - 1; g.self_mode = 1;
     g.out_base = 0; g.out = dOut; g.cnt_pair_stride = 1; g.cnt_k_stride = pairs;
     uint64_t *dTrace;
-    CK(hipMalloc(&dTrace, (5u << 16) * 8));
-    CK(hipMemset(dTrace, 0, (5u << 16) * 8));
+    const size_t trace_words = (size_t)TW << 20;   // up to 1 M waves
+    CK(hipMalloc(&dTrace, trace_words * 8));
+    CK(hipMemset(dTrace, 0, trace_words * 8));
     g.dtab = (const float *)dTrace;
     TileScratch ts;
     fprintf(stderr, "launch\n");
-    for (int i = 0; i < 3; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ts, 0));
+    // argv[4]: untimed launches before the traced one (the clock settles under sustained load)
+    const int warm = argc > 4 ? atoi(argv[4]) : 3;
+    for (int i = 0; i < warm; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ts, 0));
     CK(hipDeviceSynchronize());
     fprintf(stderr, "warm done\n");
     hipEvent_t e0, e1;
@@ -71,13 +77,14 @@ int main(int argc, char **argv)
     const int wpw = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
     const size_t n_waves = n_wg * wpw;
     fprintf(stderr, "n_wg %llu\n", (unsigned long long)n_wg);
-    std::vector<uint64_t> tr(n_waves * 5);
+    if (n_waves * TW > trace_words) { printf("too many waves for the trace buffer\n"); return 1; }
+    std::vector<uint64_t> tr(n_waves * TW);
     CK(hipMemcpy(tr.data(), dTrace, tr.size() * 8, hipMemcpyDeviceToHost));
     // 100 MHz ticks -> us
     uint64_t t_min = ~0ull, t_max = 0;
     size_t active = 0;
     for (size_t w = 0; w < n_waves; ++w) {
-        const uint64_t *r = &tr[w * 5];
+        const uint64_t *r = &tr[w * TW];
         if (r[3] == 0 || r[0] == 0) continue;   // wave exited early (no tile)
         ++active;
         t_min = std::min(t_min, r[0]);
@@ -85,10 +92,26 @@ int main(int argc, char **argv)
     }
     printf("n=%u shape=%d workgroups=%llu waves=%zu (with work: %zu) event time %.1f us, trace span %.1f us\n", n, shape,
            (unsigned long long)n_wg, n_waves, active, ms * 1e3, (t_max - t_min) / 100.0);
+    {   // the clock the chip held during the streaming phase, and what the SIMDs issued in it
+        std::vector<double> clk, cyc;
+        for (size_t w = 0; w < n_waves; ++w) {
+            const uint64_t *r = &tr[w * TW];
+            if (r[3] == 0 || r[0] == 0 || r[2] <= r[1]) continue;
+            clk.push_back((double)(r[6] - r[5]) / (double)(r[2] - r[1]) * 0.1);
+            cyc.push_back((double)(r[6] - r[5]));
+        }
+        std::sort(clk.begin(), clk.end());
+        std::sort(cyc.begin(), cyc.end());
+        // one wave of a k-sliced workgroup: ss64 / 4 chunks x R rows x JL columns x (28 + 2 half-rate) = 32 issue slots each
+        const double slots = (double)(ss64 / 4) * R * JL * 32.0;
+        printf("  in-kernel clock while streaming: p10 %.3f median %.3f p90 %.3f GHz; streaming phase of a wave: median %.0f cycles = %.2f cycles per issue slot per wave (%.0f slots)\n",
+               clk[clk.size() / 10], clk[clk.size() / 2], clk[clk.size() * 9 / 10], cyc[cyc.size() / 2],
+               cyc[cyc.size() / 2] / slots, slots);
+    }
     std::vector<double> start, wait0, stream, tail, total;
     std::map<uint64_t, int> per_cu;   // (xcc, se, cu) -> waves
     for (size_t w = 0; w < n_waves; ++w) {
-        const uint64_t *r = &tr[w * 5];
+        const uint64_t *r = &tr[w * TW];
         if (r[3] == 0 || r[0] == 0) continue;
         start.push_back((r[0] - t_min) / 100.0);
         wait0.push_back((r[1] - r[0]) / 100.0);
@@ -105,7 +128,7 @@ int main(int argc, char **argv)
         for (double t = 5.0; t < (t_max - t_min) / 100.0; t += 10.0) {
             size_t live = 0;
             for (size_t w = 0; w < n_waves; ++w) {
-                const uint64_t *r = &tr[w * 5];
+                const uint64_t *r = &tr[w * TW];
                 if (r[3] == 0 || r[0] == 0) continue;
                 const double a = (r[0] - t_min) / 100.0, b = (r[3] - t_min) / 100.0;
                 if (a <= t && t < b) ++live;
@@ -130,7 +153,7 @@ int main(int argc, char **argv)
         std::map<int, std::pair<double, int>> by_xcc, by_k, by_wave, by_se;
         const int wpw_ = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
         for (size_t w = 0; w < n_waves; ++w) {
-            const uint64_t *r = &tr[w * 5];
+            const uint64_t *r = &tr[w * TW];
             if (r[3] == 0 || r[0] == 0) continue;
             if ((r[0] - t_min) / 100.0 > 10.0) continue;   // first round only
             const double st = (r[2] - r[1]) / 100.0;
@@ -153,7 +176,7 @@ int main(int argc, char **argv)
             std::map<size_t, std::pair<double, double>> wgmm;
             std::vector<double> first;
             for (size_t w = 0; w < n_waves; ++w) {
-                const uint64_t *r = &tr[w * 5];
+                const uint64_t *r = &tr[w * TW];
                 if (r[3] == 0 || r[0] == 0) continue;
                 if ((r[0] - t_min) / 100.0 > 10.0) continue;
                 const double st = (r[2] - r[1]) / 100.0;

@@ -56,6 +56,8 @@ _SIG = [
     ("skl_ctx_timing_reset", C.c_int, [_P]),
     ("skl_ctx_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     ("skl_ctx_last_kernel", C.c_char_p, [_P]),
+    ("skl_log_variant", C.c_int, []),
+    ("skl_device_log", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("skl_sketches_create", C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_size_t, _P, C.c_size_t,
                                       C.POINTER(_P)]),
     ("skl_sketches_set_completeness", C.c_int, [_P, _P]),
@@ -137,6 +139,19 @@ def _ptr(buf):
     if hasattr(buf, "data_ptr"):
         return buf.data_ptr(), 1 if buf.is_cuda else 0
     raise TypeError(f"unsupported buffer type {type(buf)}")
+
+
+def log_variant():
+    """Which restated form of glibc's log() reproduces this host's libm: 0 FMA, 1 SSE2, -1 neither."""
+    return int(load().skl_log_variant())
+
+
+def device_log(ctx, x):
+    """ln(x) as the kernels evaluate it on the completeness path (csrc/glibc_log.hpp), on the device."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    _check(load().skl_device_log(ctx._h, x.ctypes.data, x.size, out.ctypes.data))
+    return out
 
 
 def device_count():

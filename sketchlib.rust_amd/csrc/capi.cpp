@@ -8,6 +8,7 @@
 //
 // There is deliberately no CPU compute path here: if HIP cannot run, calls fail.
 #include "capi_internal.hpp"
+#include "glibc_log.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -335,6 +336,63 @@ std::pair<hipEvent_t, hipEvent_t> *timing_slot(skl_ctx *ctx)
 }
 
 // ---------------------------------------------------------------------------
+// the host libm's logarithm on the device (completeness path; glibc_log.hpp)
+// ---------------------------------------------------------------------------
+
+static double probe_uniform(uint64_t &state)
+{
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(state >> 11) * 0x1p-53;
+}
+
+int host_log_variant()
+{
+    static const int variant = [] {
+        // arguments of the kind the path takes logarithms of: Jaccard values in (0, 1], the
+        // |x - 1| < 1/16 branch, and the values every k-mer length of a sketch size can give
+        uint64_t st = 0x5EED0001ull;
+        size_t bad[2] = {0, 0};
+        auto check = [&](double x) {
+            volatile double xv = x;   // a run-time call into libm, never folded
+            const double ref = std::log(xv);
+            for (int v = 0; v < 2; ++v) {
+                if (skl_as_u64(glibc_log(x, v)) != skl_as_u64(ref)) ++bad[v];
+            }
+        };
+        for (int i = 0; i < 150000; ++i) check(probe_uniform(st));
+        for (int i = 0; i < 150000; ++i) check(0.9375 + 0.13 * probe_uniform(st));
+        for (uint32_t b = 1; b <= 4096; ++b) check((double)b / 4096.0);
+        if (bad[SKL_LOG_FMA] == 0) return (int)SKL_LOG_FMA;
+        if (bad[SKL_LOG_SSE2] == 0) return (int)SKL_LOG_SSE2;
+        fprintf(stderr,
+                "sketchlib_dist: this host's libm log() is neither form of glibc 2.35's x86-64 log that "
+                "glibc_log.hpp restates (%zu / %zu of 304096 probe values differ); completeness-corrected "
+                "core distances of flat fits may differ from a CPU run on this host in the last bit of ln J\n",
+                bad[0], bad[1]);
+        return -1;
+    }();
+    return variant;
+}
+
+extern "C" int skl_log_variant(void) { return host_log_variant(); }
+
+extern "C" int skl_device_log(skl_ctx *ctx, const double *x_host, size_t n, double *out_host)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (n == 0) return SKL_OK;
+    if (!x_host || !out_host) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    DevBuf dx, dy;
+    HIP_TRY(hipMalloc(&dx.p, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&dy.p, n * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(dx.p, x_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int v = host_log_variant();
+    HIP_TRY(launch_device_log((const double *)dx.p, (double *)dy.p, n, v < 0 ? (int)SKL_LOG_FMA : v, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, dy.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
+// ---------------------------------------------------------------------------
 // sketch slabs
 // ---------------------------------------------------------------------------
 
@@ -588,6 +646,10 @@ int fill_args(const skl_sketches *rows, const skl_sketches *cols, const skl_dist
     g->nk = (uint32_t)rows->nk;
     g->ss64 = (uint32_t)rows->ss64;
     g->has_comp = (rows->d_comp && cols->d_comp) ? 1 : 0;  // both Some, jaccard.rs:36
+    if (g->has_comp) {
+        const int v = host_log_variant();
+        g->log_variant = v < 0 ? (int)SKL_LOG_FMA : v;
+    }
     g->compA = rows->d_comp;
     g->compB = cols->d_comp;
     g->cutoff = p ? p->completeness_cutoff : 0.0;
@@ -693,6 +755,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.n_total = (uint32_t)cols->n;
         e.out_base = base;
         e.has_comp = g.has_comp;
+        e.log_variant = g.log_variant;
         e.ytab = rows->d_ytab;
         e.compA = rows->d_comp;
         e.compB = cols->d_comp;

@@ -82,6 +82,10 @@ struct DevBuf {
 constexpr size_t BAND_BYTES = 512ull << 20;  // scratch bound for host-destined / banded output
 
 SKL_INTERNAL int ctx_bind(skl_ctx *ctx);
+// which glibc_log.hpp form reproduces this host's libm log(): probed once per process against
+// std::log; SKL_LOG_FMA / SKL_LOG_SSE2, or -1 when neither does (the FMA form is then used and a
+// warning printed once)
+SKL_INTERNAL int host_log_variant();
 // grow-only scratch slot `which` of the context, at least `bytes` large
 SKL_INTERNAL int ctx_scratch(skl_ctx *ctx, size_t bytes, void **out, int which = 0);
 // tuning knobs are read on every call so an A/B run can interleave variants in one process

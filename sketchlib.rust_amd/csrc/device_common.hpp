@@ -3,6 +3,7 @@
 // each a restatement of the reference function it cites.
 #pragma once
 
+#include "glibc_log.hpp"
 #include "kernels.h"
 
 namespace skl {
@@ -53,10 +54,10 @@ __device__ __forceinline__ double jaccard_from_samebits_dev(uint32_t samebits, u
     return j;
 }
 
-// jaccard.rs:49-51
-__device__ __forceinline__ double ani_pois_dev(double j, double k)
+// jaccard.rs:49-51; ln = the host libm's, restated (glibc_log.hpp)
+__device__ __forceinline__ double ani_pois_dev(double j, double k, int log_variant)
 {
-    return fmax(0.0, 1.0 + 1.0 / k * log((2.0 * j) / (1.0 + j)));
+    return fmax(0.0, 1.0 + 1.0 / k * glibc_log((2.0 * j) / (1.0 + j), log_variant));
 }
 
 // jaccard.rs:105-142, operation for operation.
@@ -157,8 +158,8 @@ __device__ __forceinline__ float jaccard_out_value(const PairArgs &g, uint32_t i
     const double jac =
         jaccard_from_samebits_dev(same, g.ss64, true, g.compA[i], g.compB[jcol], g.cutoff);
     if (g.jout == JOUT_DIST) return (float)(1.0 - jac);
-    if (g.jout == JOUT_ANI) return (float)ani_pois_dev(jac, g.kf[0]);
-    return (float)(1.0 - ani_pois_dev(jac, g.kf[0]));
+    if (g.jout == JOUT_ANI) return (float)ani_pois_dev(jac, g.kf[0], g.log_variant);
+    return (float)(1.0 - ani_pois_dev(jac, g.kf[0], g.log_variant));
 }
 
 __device__ __forceinline__ void store_jaccard(const PairArgs &g, uint32_t i, uint32_t jcol,
@@ -189,7 +190,7 @@ __device__ __forceinline__ float2 coreacc_value(const PairArgs &g, uint32_t i, u
         if (!g.has_comp) {
             y = g.ytab[same];
         } else {
-            y = log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff));
+            y = glibc_log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff), g.log_variant);
         }
         if (alive) {
             if (y < g.tolerance) {

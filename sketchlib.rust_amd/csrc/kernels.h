@@ -66,6 +66,7 @@ struct PairArgs {
     // epilogue
     int32_t jout;                 // JaccardOut
     int32_t has_comp;
+    int32_t log_variant;          // glibc_log.hpp form the host libm uses (completeness path only)
     const double *ytab;           // [64*ss64 + 1] ln(J(samebits)), host libm
     const float *dtab;            // [64*ss64 + 1] f32 Jaccard-mode output, host libm
     const double *compA, *compB;  // completeness per sample (device) or null
@@ -126,6 +127,7 @@ struct EpilogueArgs {
     uint32_t n_total;           // n (self mode condensed indexing)
     uint64_t out_base;
     int32_t has_comp;
+    int32_t log_variant;        // glibc_log.hpp form (completeness path only)
     const double *ytab;
     const double *compA, *compB;
     double cutoff, tolerance;
@@ -133,6 +135,8 @@ struct EpilogueArgs {
     float *out;
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
+// y[i] = glibc_log(x[i], variant) on the device (glibc_log.hpp)
+hipError_t launch_device_log(const double *x, double *y, uint64_t n, int variant, hipStream_t stream);
 
 // Row-wise top-k over a dense [rows][cols] band of keys (and optional second value).
 // Candidate-list pair kernel (pair_cand.hip): row i against cand[row_offsets[i] .. row_offsets[i+1]).

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
         if (!g.has_comp) {
             y = g.ytab[same <= maxnbits ? same : maxnbits];
         } else {
-            y = log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff));
+            y = glibc_log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff), g.log_variant);
         }
         if (y < g.tolerance) break;
         const double k_fl = g.kf[t];
@@ -426,6 +426,22 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
     }
     ((float2 *)g.out)[p] =
         simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
+}
+
+// skl_device_log: the restated libm logarithm as the kernels evaluate it (diagnostic / tests)
+__global__ void device_log_kernel(const double *x, double *y, uint64_t n, int variant)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = glibc_log(x[i], variant);
+}
+
+hipError_t launch_device_log(const double *x, double *y, uint64_t n, int variant, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(device_log_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, n, variant);
+    return hipGetLastError();
 }
 
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream)

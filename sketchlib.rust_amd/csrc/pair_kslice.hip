@@ -65,12 +65,20 @@ __device__ __forceinline__ uint32_t skl_lds_addr(const void *p)
 }
 
 #ifdef SKL_TRACE
-// scripts/microbench/kslice_trace.hip: per-wave timeline (100 MHz wall clock) + hardware id;
-// the trace buffer rides in the dtab field (unused by MODE_COUNTS)
+// scripts/microbench/kslice_trace.hip: per-wave timeline (100 MHz wall clock) + hardware id,
+// and the shader-clock counter (s_memtime) at marks 1 and 2, i.e. around the streaming phase:
+// d(s_memtime) / d(wall clock) x 100 MHz is the clock the chip held meanwhile.  Record = 8 words:
+// marks 0..3, hardware id, s_memtime at marks 1 and 2.  The trace buffer rides in the dtab field
+// (unused by MODE_COUNTS); no output value depends on a stamp.
 #define skl_trace ((uint64_t *)g.dtab)
+#define SKL_TRACE_WORDS 8u
 #define SKL_TRACE_MARK(SLOT)                                                                  \
     do {                                                                                      \
-        if (lane == 0) skl_trace[((size_t)blockIdx.x * WAVES_PER_WG + wave) * 5u + (SLOT)] = wall_clock64(); \
+        if (lane == 0) {                                                                      \
+            uint64_t *rec_ = &skl_trace[((size_t)blockIdx.x * WAVES_PER_WG + wave) * SKL_TRACE_WORDS]; \
+            rec_[(SLOT)] = wall_clock64();                                                    \
+            if ((SLOT) == 1 || (SLOT) == 2) rec_[4 + (SLOT)] = __builtin_amdgcn_s_memtime();  \
+        }                                                                                     \
     } while (0)
 #else
 #define SKL_TRACE_MARK(SLOT) do { } while (0)
@@ -88,9 +96,16 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
     constexpr int SLOTS = PX / W;                 // packed slots finished by each wave
     static_assert(P % 2 == 0 && PX % W == 0, "packed slots must split over the waves");
     static_assert(PPL * LANES - PIECES < PIECES, "tail pieces wrap at most once");
-    static_assert(PPL * LANES * 16 >= PX * LANES * 4, "the reduction words fit one row buffer");
     static_assert(!KSL || MODE != MODE_COREACC, "k-sliced core/acc runs COUNTS + the epilogue kernel");
-    __shared__ uint4 lds_rows[W][2][PPL * LANES];
+    // LDS: the row buffers [W][2][PPL * LANES] x 16 B, then -- only when the per-k reduction words
+    // of a wave (PX * LANES) do not fit the row buffer it has just finished with (3 and 4 columns
+    // per lane) -- a reduction region [W][PX * LANES] x 4 B behind them.
+    constexpr uint32_t BUF_U4 = PPL * LANES;
+    constexpr uint32_t ROWS_U4 = W * 2 * BUF_U4;
+    constexpr bool RED_IN_ROWS = BUF_U4 * 4 >= PX * LANES;
+    constexpr uint32_t RED_U4 = RED_IN_ROWS ? 0u : (uint32_t)(W * PX * LANES) / 4u;
+    __shared__ uint4 lds_all[ROWS_U4 + RED_U4];
+    uint4 (*lds_rows)[2][BUF_U4] = reinterpret_cast<uint4 (*)[2][BUF_U4]>(&lds_all[0]);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        skl_trace[((size_t)blockIdx.x * W + wave) * 5u + 4] = ((uint64_t)xcc << 32) | hw;
+        skl_trace[((size_t)blockIdx.x * W + wave) * SKL_TRACE_WORDS + 4] = ((uint64_t)xcc << 32) | hw;
     }
 #endif
     SKL_TRACE_MARK(0);
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
         }                                                                                    \
     } while (0)
 
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(skl_lds_addr(&lds_rows[0][0][0]));
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(skl_lds_addr(&lds_all[0]));
     SKL_STAGE_DMA(0u, 0);
 
     // Next valid chunk of this wave after (kl, ts, ci) in its walk over k-mer lengths, stages
@@ -292,11 +307,13 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
         // The buffer this wave consumed last is dead (the next stage was prefetched into the
         // other one), so every wave publishes into its own: [wave][buf][PX][LANES] words.
         const uint32_t dead = (t - 1u) & 1u;
-        uint32_t *red = reinterpret_cast<uint32_t *>(&lds_rows[0][0][0]);
-        constexpr uint32_t BUF_WORDS = PPL * LANES * 4u;
+        // wave w's words start at red[w * RED_STRIDE + red_off]
+        uint32_t *red = reinterpret_cast<uint32_t *>(&lds_all[RED_IN_ROWS ? 0u : ROWS_U4]);
+        constexpr uint32_t RED_STRIDE = RED_IN_ROWS ? 2u * BUF_U4 * 4u : (uint32_t)(PX * LANES);
+        const uint32_t red_off = RED_IN_ROWS ? dead * BUF_U4 * 4u : 0u;
 #pragma unroll
         for (int x = 0; x < PX; ++x) {
-            red[((uint32_t)wave * 2u + dead) * BUF_WORDS + (uint32_t)x * LANES + lane] =
+            red[(uint32_t)wave * RED_STRIDE + red_off + (uint32_t)x * LANES + lane] =
                 cnt[2 * x] | (cnt[2 * x + 1] << 16);
             cnt[2 * x] = 0;
             cnt[2 * x + 1] = 0;
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
             const uint32_t x = (uint32_t)i * W + wave;
             uint32_t total = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) total += red[((uint32_t)w * 2u + dead) * BUF_WORDS + x * LANES + lane];
+            for (int w = 0; w < W; ++w) total += red[(uint32_t)w * RED_STRIDE + red_off + x * LANES + lane];
             if constexpr (MODE == MODE_COREACC) {
                 hist[i * MAX_FUSED_K + kl] = total;
             } else {
@@ -340,8 +357,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
             // leave as R/4 16-byte stores (one 64-byte run per column at R = 16).
             if (g.out_t != nullptr && min((jb0 + (uint32_t)JL) * 64u, g.nB) > g.t_col_begin) {   // workgroup-uniform
                 constexpr uint32_t TP = R + 4;   // padded column pitch (floats), keeps 16-byte alignment
-                static_assert(JL * 64 * TP * 4 <= W * 2 * PPL * LANES * 16, "the turned tile fits the row buffers");
-                float *tt = reinterpret_cast<float *>(&lds_rows[0][0][0]);
+                static_assert(JL * 64 * TP * 4 <= (ROWS_U4 + RED_U4) * 16, "the turned tile fits the LDS of the workgroup");
+                float *tt = reinterpret_cast<float *>(&lds_all[0]);
                 __syncthreads();   // every wave is done with the reduction words
 #pragma unroll
                 for (int i = 0; i < SLOTS; ++i) {
@@ -373,9 +390,9 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
     if constexpr (MODE == MODE_COREACC) {
         // symmetric self kNN: (core, acc) of columns >= t_col_begin also leave turned, see MODE_JACCARD
         constexpr uint32_t TP = R + 4;
-        static_assert(JL * 64 * TP * 8 <= W * 2 * PPL * LANES * 16, "the turned tile fits the row buffers");
+        static_assert(JL * 64 * TP * 8 <= (ROWS_U4 + RED_U4) * 16, "the turned tile fits the LDS of the workgroup");
         const bool turned = g.out_t != nullptr && min((jb0 + (uint32_t)JL) * 64u, g.nB) > g.t_col_begin;   // workgroup-uniform
-        float2 *tt = reinterpret_cast<float2 *>(&lds_rows[0][0][0]);
+        float2 *tt = reinterpret_cast<float2 *>(&lds_all[0]);
         if (turned) __syncthreads();   // every wave is done with the reduction words
         // store_coreacc() takes u16 fields, newest k lowest, as s2:s1:s0
 #pragma clang loop unroll(disable)
@@ -449,7 +466,7 @@ bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
     return mode == MODE_COUNTS || mode == MODE_JACCARD;
 }
 
-// shape = R*10 + JL; valid: 81, 82, 161, 162
+// shape = R*10 + JL; valid: 81, 82, 84, 161, 162, 163, 164
 hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shape, bool k_sliced,
                                      TileScratch &scratch, hipStream_t stream)
 {
@@ -485,6 +502,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         SKL_SHAPE(82, 8, 2)
         SKL_SHAPE(161, 16, 1)
         SKL_SHAPE(162, 16, 2)
+        SKL_SHAPE(163, 16, 3)
+        SKL_SHAPE(164, 16, 4)
+        SKL_SHAPE(84, 8, 4)
         default: return hipErrorInvalidValue;
     }
 #undef SKL_SHAPE
