@@ -41,7 +41,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # a 1-rank torchrun launch initialises RCCL too
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

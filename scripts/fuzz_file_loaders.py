@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Mutation fuzz of the file loaders under AddressSanitizer + UBSan (CPU only): the payload of a
 .ski built from the fixture genomes and of a fixture .skm is mutated (byte flips, truncation,
-insertions), re-framed with correct snappy checksums so that the CBOR / roaring layer sees it, and
-fed to `sketchlib inverted precluster --count` and `skl_dbtool info`.  Anything but a clean error
+insertions), re-framed with correct snappy checksums so that the MessagePack / CBOR / roaring layers see it, and
+fed to `sketchlib inverted precluster --count`, `skl_dbtool info` and (the .skm, next to its .skd)
+`sketchlib dist --ref-completeness-file`, which indexes per-sample arrays with what the .skm says.  Anything but a clean error
 exit (sanitizer report, signal, time-out) is printed.
 
 Build the two sanitised binaries first (from sketchlib.rust_amd/csrc):
@@ -30,8 +31,12 @@ def crc32c_masked(b):
     c^=0xFFFFFFFF
     return ((((c>>15)|(c<<17))&0xFFFFFFFF)+0xA282EAD8)&0xFFFFFFFF
 def frame(raw):
-    body=crc32c_masked(raw).to_bytes(4,'little')+raw
-    return b"\xff\x06\x00\x00sNaPpY"+b"\x01"+len(body).to_bytes(3,'little')+body
+    out=b"\xff\x06\x00\x00sNaPpY"
+    for o in range(0,max(len(raw),1),60000):   # the format caps a chunk at 65536 uncompressed bytes
+        part=raw[o:o+60000]
+        body=crc32c_masked(part).to_bytes(4,'little')+part
+        out+=b"\x01"+len(body).to_bytes(3,'little')+body
+    return out
 fx=os.path.abspath('tests/golden/reference_fixtures')
 tmp='/tmp/skifuzz'; shutil.rmtree(tmp,ignore_errors=True); os.makedirs(tmp)
 env={**os.environ,'ASAN_OPTIONS':'detect_leaks=0','LD_LIBRARY_PATH':'/root/repo/sketchlib.rust_amd/csrc/_build'}
@@ -47,6 +52,8 @@ run(['/tmp/dbtool_asan','unframe','idx.ski','rawski'])
 raw=open(os.path.join(tmp,'rawski'),'rb').read()
 run(['/tmp/dbtool_asan','unframe',os.path.join(fx,'sketches1.skm'),'rawskm'])
 rawskm=open(os.path.join(tmp,'rawskm'),'rb').read()
+shutil.copy(os.path.join(fx,'sketches1.skd'),os.path.join(tmp,'m.skd'))
+open(os.path.join(tmp,'comp.txt'),'w').write(''.join(f"{n}\t0.9\n" for n in names))
 def mutate(data):
     b=bytearray(data); kind=random.random()
     if kind<0.7:
@@ -58,8 +65,9 @@ def mutate(data):
 seen={}; bad=0
 for it in range(N):
     for kind,(payload,cmd) in {'ski':(raw,['/tmp/sketchlib_asan','inverted','precluster','m.ski','--count']),
-                               'skm':(rawskm,['/tmp/dbtool_asan','info','m'])}.items():
-        open(os.path.join(tmp,'m.'+kind),'wb').write(frame(mutate(payload)))
+                               'skm':(rawskm,['/tmp/dbtool_asan','info','m']),
+                               'skm+completeness':(rawskm,['/tmp/sketchlib_asan','dist','m','--ref-completeness-file','comp.txt'])}.items():
+        open(os.path.join(tmp,'m.'+kind.split('+')[0]),'wb').write(frame(mutate(payload)))
         rc,err=run(cmd)
         if 'Sanitizer' in err or rc<0 or 'runtime error' in err:
             bad+=1

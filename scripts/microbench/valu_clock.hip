@@ -86,13 +86,42 @@ KERNEL(k_bcnt, I_BCNT)
 KERNEL(k_fma, I_FMA)
 KERNEL(k_or3, I_OR3)
 
+// the same v_bitop3 stream with D accumulators instead of 8: instruction i depends on i - D
+#define I_BITOP_D1(i) "v_bitop3_b32 %0, %10, %9, %0 bitop3:0xbe\n"
+#define I_BITOP_D2(i) "v_bitop3_b32 %" #i ", %10, %9, %" #i " bitop3:0xbe\n"
+#define KERNEL_D(NAME, I0, I1, I2, I3, I4, I5, I6, I7)                                            \
+    __global__ __launch_bounds__(256) void NAME(Stamp *stamps, uint32_t *sink, uint32_t sa_in, int iters) \
+    {                                                                                             \
+        uint32_t m[8];                                                                            \
+        for (int i = 0; i < 8; ++i) m[i] = threadIdx.x * 2654435761u + i;                         \
+        uint32_t sa = __builtin_amdgcn_readfirstlane(sa_in);                                      \
+        uint32_t vb = threadIdx.x ^ 0x5bd1e995u, vc = threadIdx.x * 7u + 3u;                      \
+        uint64_t t0, r0;                                                                          \
+        stamp_begin(t0, r0);                                                                      \
+        for (int it = 0; it < iters; ++it) {                                                      \
+            REP8(asm volatile(I_BITOP_D2(I0) I_BITOP_D2(I1) I_BITOP_D2(I2) I_BITOP_D2(I3) I_BITOP_D2(I4) I_BITOP_D2(I5) I_BITOP_D2(I6) I_BITOP_D2(I7) \
+                              : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), \
+                                "+v"(m[6]), "+v"(m[7])                                            \
+                              : "s"(sa), "v"(vb), "v"(vc));)                                      \
+        }                                                                                         \
+        stamp_end(stamps, t0, r0);                                                                \
+        uint32_t r = 0;                                                                           \
+        for (int i = 0; i < 8; ++i) r ^= m[i];                                                    \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = r;                                          \
+    }
+KERNEL_D(k_bitop_d1, 0, 0, 0, 0, 0, 0, 0, 0)
+KERNEL_D(k_bitop_d2, 0, 1, 0, 1, 0, 1, 0, 1)
+KERNEL_D(k_bitop_d3, 0, 1, 2, 0, 1, 2, 0, 1)
+KERNEL_D(k_bitop_d4, 0, 1, 2, 3, 0, 1, 2, 3)
+KERNEL_D(k_bitop_pairs, 0, 0, 1, 1, 2, 2, 3, 3)   // the compiler's order in the pair kernel: dependent pairs back to back
+
 // ---- part 2: the pair kernel's inner loop, operands already on chip ----
 __device__ __forceinline__ uint32_t bitop_vvv(uint32_t m, uint32_t a, uint32_t b)
 {
     return __builtin_amdgcn_bitop3_b32(a, b, m, 0xBE);   // m | (a ^ b)
 }
 
-template <int R, int JL, bool LDS_ROWS>
+template <int R, int JL, bool LDS_ROWS, int ORD = 0>
 __global__ __launch_bounds__(256) void k_inner(Stamp *stamps, uint32_t *sink, uint32_t seed, int iters)
 {
     __shared__ uint4 lds_rows[4][R * 7];
@@ -125,17 +154,37 @@ __global__ __launch_bounds__(256) void k_inner(Stamp *stamps, uint32_t *sink, ui
             uint32_t mlo[JL], mhi[JL];
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
+                if constexpr (ORD == 0) {
 #pragma unroll
-                for (int j = 0; j < JL; ++j) {
-                    if (q == 0) {
-                        mlo[j] = a[0].x ^ b[j][0].y;
-                        mhi[j] = a[0].y ^ b[j][0].x;
-                    } else {
-                        mlo[j] = bitop_vvv(mlo[j], a[q].x, b[j][q].y);
-                        mhi[j] = bitop_vvv(mhi[j], a[q].y, b[j][q].x);
+                    for (int j = 0; j < JL; ++j) {
+                        if (q == 0) {
+                            mlo[j] = a[0].x ^ b[j][0].y;
+                            mhi[j] = a[0].y ^ b[j][0].x;
+                        } else {
+                            mlo[j] = bitop_vvv(mlo[j], a[q].x, b[j][q].y);
+                            mhi[j] = bitop_vvv(mhi[j], a[q].y, b[j][q].x);
+                        }
+                        mlo[j] = bitop_vvv(mlo[j], a[q].z, b[j][q].w);
+                        mhi[j] = bitop_vvv(mhi[j], a[q].w, b[j][q].z);
                     }
-                    mlo[j] = bitop_vvv(mlo[j], a[q].z, b[j][q].w);
-                    mhi[j] = bitop_vvv(mhi[j], a[q].w, b[j][q].z);
+                } else {
+                    // every chain advances once, then every chain again: dependency distance 2 JL
+#pragma unroll
+                    for (int j = 0; j < JL; ++j) {
+                        if (q == 0) {
+                            mlo[j] = a[0].x ^ b[j][0].y;
+                            mhi[j] = a[0].y ^ b[j][0].x;
+                        } else {
+                            mlo[j] = bitop_vvv(mlo[j], a[q].x, b[j][q].y);
+                            mhi[j] = bitop_vvv(mhi[j], a[q].y, b[j][q].x);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < JL; ++j) {
+                        mlo[j] = bitop_vvv(mlo[j], a[q].z, b[j][q].w);
+                        mhi[j] = bitop_vvv(mhi[j], a[q].w, b[j][q].z);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (LDS_ROWS) {
@@ -242,7 +291,10 @@ int main(int argc, char **argv)
     struct { const char *name; kern_t k; } ks[] = {
         {"v_add_u32 v,v,v", k_add},       {"v_xor_b32 v,v,v", k_xor_v},   {"v_xor_b32 v,s,v", k_xor_s},
         {"v_bitop3_b32 v,v,v,v", k_bitop_v}, {"v_bcnt_u32_b32 v,v,v", k_bcnt}, {"v_fma_f32 v,v,v,v", k_fma},
-        {"v_or3_b32 v,v,v,v", k_or3}};
+        {"v_or3_b32 v,v,v,v", k_or3},
+        {"v_bitop3 dep. distance 1", k_bitop_d1}, {"v_bitop3 dep. distance 2", k_bitop_d2},
+        {"v_bitop3 dep. distance 3", k_bitop_d3}, {"v_bitop3 dep. distance 4", k_bitop_d4},
+        {"v_bitop3 dependent pairs", k_bitop_pairs}};
     const int iters = 20000;
     for (auto &kk : ks) {
         for (int w : {1, 2, 3, 4}) {
@@ -258,6 +310,8 @@ int main(int argc, char **argv)
     struct { const char *name; kern_t k; int R, JL; int max_w; } ps[] = {
         {"R=16 JL=2 rows from LDS", k_inner<16, 2, true>, 16, 2, 4},
         {"R=16 JL=2 rows in regs ", k_inner<16, 2, false>, 16, 2, 3},
+        {"R=16 JL=2 LDS, chains interleaved", k_inner<16, 2, true, 1>, 16, 2, 4},
+        {"R=16 JL=3 LDS, chains interleaved", k_inner<16, 3, true, 1>, 16, 3, 2},
         {"R=16 JL=3 rows from LDS", k_inner<16, 3, true>, 16, 3, 2},
         {"R=16 JL=4 rows from LDS", k_inner<16, 4, true>, 16, 4, 2},
         {"R=16 JL=4 rows in regs ", k_inner<16, 4, false>, 16, 4, 2},

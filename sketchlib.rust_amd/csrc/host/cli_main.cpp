@@ -72,6 +72,9 @@ void print_help()
         "Options:\n"
         "  -o <OUTPUT>                     Output filename (omit to output to stdout)\n"
         "      --knn <KNN>                 Calculate sparse distances with k nearest-neighbours (ref-vs-ref or ref-vs-query)\n"
+        "                                  [neighbours at EQUAL distance are kept lowest index first; the reference's\n"
+        "                                  BinaryHeap keeps an unspecified subset of them, so tied rows can list other\n"
+        "                                  ids in another order -- the distances per row are the same]\n"
         "      --subset <SUBSET>           Sample names to analyse\n"
         "  -k <KMER>                       K-mer length (if provided only calculate Jaccard distance)\n"
         "      --ani                       Calculate ANI rather than Jaccard dists, using Poisson model\n"
@@ -250,6 +253,8 @@ int run_dist(const DistArgs &a)
     std::vector<std::string> warnings;
     std::optional<std::vector<double>> ref_comp;
     if (a.ref_completeness_file) {
+        // an unreadable / malformed file is an Err returned from main in the reference (lib.rs:334-339,
+        // `?`): "Error: ..." and exit code 1, which is what main() here does with std::exception
         ref_comp = read_completeness_file(*a.ref_completeness_file, references, &warnings);
     }
 
@@ -270,7 +275,11 @@ int run_dist(const DistArgs &a)
             throw Panic("Could not read sketch metadata from " + *a.query_db + ".skm");
         }
         log.info("Loading query sketch data from " + query_db_name + ".skd");
-        queries->read_sketch_data(query_db_name);
+        try {
+            queries->read_sketch_data(query_db_name);   // panics in the reference too (lib.rs:351)
+        } catch (const std::exception &e) {
+            throw Panic(e.what());
+        }
     }
     std::optional<std::vector<double>> query_comp;
     if (queries && a.query_completeness_file) {

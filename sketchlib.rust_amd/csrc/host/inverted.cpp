@@ -10,6 +10,8 @@
 #include <thread>
 
 #include "cbor.hpp"
+#include "msgpack.hpp"
+#include "msgpack.hpp"
 #include "snappy_frame.hpp"
 
 namespace skl_host {
@@ -147,9 +149,11 @@ Inverted Inverted::from_sketches(const std::vector<std::vector<uint16_t>> &sketc
     return inv;
 }
 
+// `.ski` = snappy frame around the MessagePack form of struct Inverted that rmp-serde writes
+// (inverted.rs:194-201): an ARRAY of the nine fields in declaration order (msgpack.hpp).
 void Inverted::save(const std::string &file_prefix) const
 {
-    CborValue root = CborValue::object();
+    CborValue root = CborValue::array();
     CborValue idx = CborValue::array();
     for (const auto &bin : index) {
         CborValue m = CborValue::object();
@@ -161,24 +165,24 @@ void Inverted::save(const std::string &file_prefix) const
         }
         idx.arr.push_back(std::move(m));
     }
-    root.put("index", std::move(idx));
-    root.put("n_samples", CborValue::uint(n_samples));
+    root.arr.push_back(std::move(idx));                                   // index
+    root.arr.push_back(CborValue::uint(n_samples));                       // n_samples
     CborValue names = CborValue::array();
     for (const auto &n : sample_names) names.arr.push_back(CborValue::text(n));
-    root.put("sample_names", std::move(names));
+    root.arr.push_back(std::move(names));                                 // sample_names
     auto opt_list = [](const std::optional<std::vector<std::string>> &v) {
         if (!v) return CborValue::null();
         CborValue a = CborValue::array();
         for (const auto &s : *v) a.arr.push_back(CborValue::text(s));
         return a;
     };
-    root.put("metadata", opt_list(metadata));
-    root.put("labels", opt_list(labels));
-    root.put("kmer_size", CborValue::uint(kmer_size));
-    root.put("sketch_version", CborValue::text(sketch_version));
-    root.put("rc", CborValue::boolean(rc));
-    root.put("hash_type", CborValue::text(hash_type));
-    const std::vector<uint8_t> framed = snappy_frame_encode(cbor_encode(root));
+    root.arr.push_back(opt_list(metadata));
+    root.arr.push_back(opt_list(labels));
+    root.arr.push_back(CborValue::uint(kmer_size));
+    root.arr.push_back(CborValue::text(sketch_version));
+    root.arr.push_back(CborValue::boolean(rc));
+    root.arr.push_back(CborValue::text(hash_type));                       // unit variant HashType::DNA -> "DNA"
+    const std::vector<uint8_t> framed = snappy_frame_encode(msgpack_encode(root));
     std::ofstream f(file_prefix + ".ski", std::ios::binary);
     if (!f) throw std::runtime_error("Couldn't write to " + file_prefix + ".ski");
     f.write(reinterpret_cast<const char *>(framed.data()), (std::streamsize)framed.size());
@@ -203,21 +207,40 @@ Inverted Inverted::load(const std::string &file_prefix, bool with_index)
     const std::string path = file_prefix + ".ski";
     const std::vector<uint8_t> framed = slurp(path);
     uint64_t n_bins = 0;
-    const CborValue root = with_index ? cbor_decode(snappy_frame_decode(framed))
-                                      : cbor_decode_map_skipping(snappy_frame_decode(framed), "index", &n_bins);
+    const std::vector<uint8_t> doc = snappy_frame_decode(framed);
+    if (doc.empty()) throw std::runtime_error(path + ": empty document");
+    // rmp-serde writes the struct as a 9-element array (0x99).  Two other forms are read: the same
+    // fields as a string-keyed MessagePack map (rmp-serde's `with_struct_map`, 0x89), and the
+    // snappy-framed CBOR map that round 1 of this code base wrote (any other first byte).
+    static const char *const FIELDS[9] = {"index", "n_samples", "sample_names", "metadata", "labels",
+                                          "kmer_size", "sketch_version", "rc", "hash_type"};
+    CborValue root;
+    if (doc[0] == 0x99) {
+        const CborValue arr = with_index ? msgpack_decode(doc) : msgpack_decode_array_skipping(doc, 0, &n_bins);
+        root = CborValue::object();
+        for (size_t f = 0; f < 9; ++f) root.put(FIELDS[f], arr.arr[f]);
+    } else if (doc[0] == 0x89) {
+        root = msgpack_decode(doc);
+        if (!with_index && root.get("index")) n_bins = root.get("index")->arr.size();
+    } else {
+        root = with_index ? cbor_decode(doc) : cbor_decode_map_skipping(doc, "index", &n_bins);
+    }
     if (root.kind != CborValue::MAP) throw std::runtime_error(path + ": not an inverted index");
     auto need = [&](const char *k) -> const CborValue & {
         const CborValue *v = root.get(k);
         if (!v) throw std::runtime_error(path + ": missing field " + k);
         return *v;
     };
+    if (with_index && need("index").kind != CborValue::ARRAY) throw std::runtime_error(path + ": index is not an array");
     Inverted inv;
     inv.sketch_size_hint = (size_t)n_bins;
     if (with_index)
     for (const auto &bin : need("index").arr) {
+        if (bin.kind != CborValue::MAP) throw std::runtime_error(path + ": index entry is not a map");
         inv.index.emplace_back();
         for (const auto &kv : bin.map) {
-            // ciborium writes a Vec<u8> either as a byte string or (via serialize_bytes) as bytes
+            if (kv.first.as_u64("bin value") > 0xFFFFu) throw std::runtime_error(path + ": bin value does not fit u16");
+            // serde's serialize_bytes gives a bin / byte string; a generic Vec<u8> would be an array
             std::string bytes;
             if (kv.second.kind == CborValue::BYTES) {
                 bytes = kv.second.s;
@@ -230,7 +253,10 @@ Inverted Inverted::load(const std::string &file_prefix, bool with_index)
         }
     }
     inv.n_samples = need("n_samples").as_u64("n_samples");
-    for (const auto &n : need("sample_names").arr) inv.sample_names.push_back(n.s);
+    for (const auto &n : need("sample_names").arr) {
+        if (n.kind != CborValue::TEXT) throw std::runtime_error(path + ": sample name is not a string");
+        inv.sample_names.push_back(n.s);
+    }
     auto opt_list = [](const CborValue *v) -> std::optional<std::vector<std::string>> {
         if (!v || v->kind != CborValue::ARRAY) return std::nullopt;
         std::vector<std::string> out;
@@ -241,9 +267,17 @@ Inverted Inverted::load(const std::string &file_prefix, bool with_index)
     inv.labels = opt_list(root.get("labels"));
     inv.kmer_size = need("kmer_size").as_u64("kmer_size");
     inv.sketch_version = need("sketch_version").s;
+    if (need("rc").kind != CborValue::BOOL) throw std::runtime_error(path + ": rc is not a bool");
     inv.rc = need("rc").b;
+    // HashType: "DNA" / "PDB" (unit variants), {"AA": "LevelN"} (newtype variant)
     const CborValue &ht = need("hash_type");
-    inv.hash_type = ht.kind == CborValue::TEXT ? ht.s : "other";
+    if (ht.kind == CborValue::TEXT) {
+        inv.hash_type = ht.s;
+    } else if (ht.kind == CborValue::MAP && ht.map.size() == 1 && ht.map[0].first.kind == CborValue::TEXT) {
+        inv.hash_type = ht.map[0].first.s + "(" + (ht.map[0].second.kind == CborValue::TEXT ? ht.map[0].second.s : "?") + ")";
+    } else {
+        throw std::runtime_error(path + ": unexpected hash_type encoding");
+    }
     // a file is untrusted input: everything later indexes per-sample arrays with these ids
     if (inv.n_samples != inv.sample_names.size()) throw std::runtime_error(path + ": n_samples does not match sample_names");
     if (inv.metadata && inv.metadata->size() != inv.n_samples) throw std::runtime_error(path + ": metadata does not match n_samples");

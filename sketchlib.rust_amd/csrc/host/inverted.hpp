@@ -1,7 +1,8 @@
 // inverted.hpp -- the inverted index of single-k sketches the reference's precluster mode uses
 // to pick kNN candidates: `Inverted` (src/inverted.rs:46-58), its on-disk
-// forms `.ski` (snappy-framed CBOR, bitmaps in Roaring's portable serialisation,
-// inverted.rs:194-216) and `.skq` (raw little-endian u16 bins, [sample][sketch_size],
+// forms `.ski` (snappy frame around the MessagePack document rmp-serde writes for the struct: a
+// 9-element array in field order, bitmaps as bin blobs in Roaring's portable serialisation,
+// inverted.rs:194-216; msgpack.hpp) and `.skq` (raw little-endian u16 bins, [sample][sketch_size],
 // inverted.rs:88-98), `any_shared_bins` (:259-268) and the pair count of
 // `precluster --count` (:271-300).
 #pragma once
@@ -17,7 +18,7 @@
 namespace skl_host {
 
 // Roaring "portable" serialisation of an ascending list of u32 (the format `roaring` 0.10's
-// serde impl wraps in a CBOR byte string; RoaringFormatSpec).  The reader takes array, bitmap
+// serde impl hands to the serialiser as bytes; RoaringFormatSpec).  The reader takes array, bitmap
 // and run containers; the writer emits array / bitmap containers without the run cookie.
 std::string roaring_serialize(const std::vector<uint32_t> &sorted_values);
 std::vector<uint32_t> roaring_deserialize(const std::string &bytes);

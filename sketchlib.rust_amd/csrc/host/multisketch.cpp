@@ -177,6 +177,11 @@ MultiSketch MultiSketch::load_metadata(const std::string &file_prefix)
     for (const auto &sm : m.sketch_metadata_) {
         if (sm.index && *sm.index >= m.sketch_metadata_.size()) throw std::runtime_error(filename + ": sample index out of range");
     }
+    // name_map values (the samples' block indices, multisketch.rs:55-58) index per-sample arrays
+    // later (get_sample_index -> the completeness vectors of io.cpp read_completeness_file)
+    for (const auto &kv : m.name_map_order_) {
+        if (kv.second >= m.sketch_metadata_.size()) throw std::runtime_error(filename + ": name_map index out of range");
+    }
     return m;
 }
 

@@ -162,6 +162,9 @@ std::vector<uint8_t> snappy_frame_decode(const std::vector<uint8_t> &f)
             c.compressed = type == 0x00;
             uint64_t ulen = c.len;
             if (c.compressed) snappy_raw_length(c.body, c.len, ulen);
+            // the framing format caps a chunk at 65536 uncompressed bytes (and the `snap` crate the
+            // reference uses enforces it): a 25-byte file may not claim gigabytes of output
+            if (ulen > 65536) throw std::runtime_error("snappy frame: chunk claims more than 65536 uncompressed bytes");
             c.out_off = total;
             c.out_len = (size_t)ulen;
             total += c.out_len;

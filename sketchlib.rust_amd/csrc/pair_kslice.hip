@@ -84,8 +84,9 @@ __device__ __forceinline__ uint32_t skl_lds_addr(const void *p)
 #define SKL_TRACE_MARK(SLOT) do { } while (0)
 #endif
 
+// (3 columns per lane: the register allocator is held to 3 waves per SIMD, 168 VGPRs)
 template <int R, int JL, int MODE, bool KSL, int ABL = 0>
-__global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const PairArgs g)
+__global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_kernel_kslice(const PairArgs g)
 {
     constexpr int W = WAVES_PER_WG;
     constexpr int CH = 2;                         // chunks per wave per stage
@@ -97,13 +98,14 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
     static_assert(P % 2 == 0 && PX % W == 0, "packed slots must split over the waves");
     static_assert(PPL * LANES - PIECES < PIECES, "tail pieces wrap at most once");
     static_assert(!KSL || MODE != MODE_COREACC, "k-sliced core/acc runs COUNTS + the epilogue kernel");
-    // LDS: the row buffers [W][2][PPL * LANES] x 16 B, then -- only when the per-k reduction words
-    // of a wave (PX * LANES) do not fit the row buffer it has just finished with (3 and 4 columns
-    // per lane) -- a reduction region [W][PX * LANES] x 4 B behind them.
+    // LDS: the row buffers [W][2][PPL * LANES] x 16 B.  The per-k reduction words of a wave
+    // (PX per lane) go into the row buffer it has just finished with, XIN per lane; with 3 and 4
+    // columns per lane the rest (PX - XIN per lane) go to an overflow region behind the row buffers.
     constexpr uint32_t BUF_U4 = PPL * LANES;
     constexpr uint32_t ROWS_U4 = W * 2 * BUF_U4;
-    constexpr bool RED_IN_ROWS = BUF_U4 * 4 >= PX * LANES;
-    constexpr uint32_t RED_U4 = RED_IN_ROWS ? 0u : (uint32_t)(W * PX * LANES) / 4u;
+    constexpr int XIN = (BUF_U4 * 4 / LANES) < (uint32_t)PX ? (int)(BUF_U4 * 4 / LANES) : PX;
+    constexpr int XOV = PX - XIN;
+    constexpr uint32_t RED_U4 = (uint32_t)(W * XOV * LANES) / 4u;
     __shared__ uint4 lds_all[ROWS_U4 + RED_U4];
     uint4 (*lds_rows)[2][BUF_U4] = reinterpret_cast<uint4 (*)[2][BUF_U4]>(&lds_all[0]);
 
@@ -140,9 +142,39 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
     const uint32_t stages_per_k = (g.ss64 + W * CH - 1) / (W * CH);
     const uint32_t n_stages = stages_per_k * nkk;
 
-    uint32_t cnt[P];   // this wave's partial mismatch counts of the current k (its chunks only)
+    // This wave's partial mismatch counts of the current k (its chunks only).  One register per
+    // pair, except with 3 columns per lane, where registers are what decides between 2 and 3 waves
+    // per SIMD: columns 0 and 1 of a row then share one register as u16 fields (a wave's share of
+    // one k-mer length is at most 64 * 256 mismatches per pair: kslice_supported) and column 2 has
+    // its own -- 2 R registers instead of 3 R, for one v_lshl_add_u32 more per (row, chunk).
+    constexpr bool PACK01 = JL == 3;
+    constexpr int NCNT = PACK01 ? 2 * R : P;
+    uint32_t cnt[NCNT];
 #pragma unroll
-    for (int x = 0; x < P; ++x) cnt[x] = 0;
+    for (int x = 0; x < NCNT; ++x) cnt[x] = 0;
+    // packed word x (two u16 fields) of the per-k reduction, and the pair its field h stands for
+    auto packed_word = [&](int x) -> uint32_t {
+        if constexpr (PACK01) {
+            return x < R ? cnt[x] : (cnt[R + 2 * (x - R)] | (cnt[R + 2 * (x - R) + 1] << 16));
+        } else {
+            return cnt[2 * x] | (cnt[2 * x + 1] << 16);
+        }
+    };
+    auto field_pair = [](uint32_t x, uint32_t h, uint32_t &r, uint32_t &j) {
+        if constexpr (PACK01) {
+            if (x < (uint32_t)R) {
+                r = x;
+                j = h;
+            } else {
+                r = 2u * (x - (uint32_t)R) + h;
+                j = 2u;
+            }
+        } else {
+            const uint32_t pair = 2u * x + h;
+            r = pair / JL;
+            j = pair % JL;
+        }
+    };
     // MODE_COREACC: totals of this wave's packed slots, one word per k-mer length (two u16
     // fields per word: the slot's two pairs).  Private (scratch) memory on purpose: written
     // once per k-mer length, read once at the end, and 24 registers cheaper.
@@ -251,33 +283,40 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
 #pragma unroll
                 for (int j = 0; j < JL; ++j) bn[j] = column_ptr(j, kn, cn);
                 const uint4 *rows = &lds_rows[wave][buf][(size_t)ci * R * 7];
-                uint4 a[7];
+                // Row operand: a ring of AD plane pairs.  Step s = r * 7 + q of the chunk reads
+                // rows[s]; right after its use the register is re-loaded with step s + AD.  AD = 7
+                // (a whole row ahead) with up to 2 columns per lane; 4 with 3 or more, where a step
+                // is 12+ VALU instructions long and the 12 registers decide the occupancy.
+                constexpr int AD = JL >= 3 ? 4 : 7;
+                uint4 a[AD];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) a[q] = rows[q];
+                for (int q = 0; q < AD; ++q) a[q] = rows[q];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     uint32_t mlo[JL], mhi[JL];
 #pragma unroll
                     for (int q = 0; q < 7; ++q) {
+                        const int s_ = r * 7 + q;      // compile-time after unrolling
+                        uint4 &ar = a[s_ % AD];
 #pragma unroll
                         for (int j = 0; j < JL; ++j) {
                             // b is stored (hi, lo) per plane: see device_common.hpp "VGPR banks"
                             if (q == 0) {
-                                mlo[j] = a[0].x ^ b[j][0].y;
-                                mhi[j] = a[0].y ^ b[j][0].x;
+                                mlo[j] = ar.x ^ b[j][0].y;
+                                mhi[j] = ar.y ^ b[j][0].x;
                             } else {
-                                mlo[j] = acc_mismatch_vvv(mlo[j], a[q].x, b[j][q].y);
-                                mhi[j] = acc_mismatch_vvv(mhi[j], a[q].y, b[j][q].x);
+                                mlo[j] = acc_mismatch_vvv(mlo[j], ar.x, b[j][q].y);
+                                mhi[j] = acc_mismatch_vvv(mhi[j], ar.y, b[j][q].x);
                             }
-                            mlo[j] = acc_mismatch_vvv(mlo[j], a[q].z, b[j][q].w);
-                            mhi[j] = acc_mismatch_vvv(mhi[j], a[q].w, b[j][q].z);
+                            mlo[j] = acc_mismatch_vvv(mlo[j], ar.z, b[j][q].w);
+                            mhi[j] = acc_mismatch_vvv(mhi[j], ar.w, b[j][q].z);
                         }
-                        // rolling prefetch of the next row's plane pair (no extra registers)
+                        // rolling prefetch of the plane pair AD steps ahead (no extra registers)
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (ABL & 1) {   // timing-only: no re-read, but opaque to CSE
-                            asm volatile("" : "+v"(a[q].x), "+v"(a[q].y), "+v"(a[q].z), "+v"(a[q].w));
+                            asm volatile("" : "+v"(ar.x), "+v"(ar.y), "+v"(ar.z), "+v"(ar.w));
                         } else {
-                            if (r + 1 < R) a[q] = rows[(r + 1) * 7 + q];
+                            if (s_ + AD < R * 7) ar = rows[s_ + AD];
                         }
                         if constexpr (!(ABL & 2)) {
                             if (r == R - 1) {   // last use of b[.][q] in this chunk: fetch the next chunk's
@@ -287,11 +326,22 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    // popcount with the add fused (v_bcnt_u32_b32 d, m, d)
+                    if constexpr (PACK01) {
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mlo[0]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mhi[0]));
+                        uint32_t t1;
+                        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(t1) : "v"(mlo[1]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(t1) : "v"(mhi[1]));
+                        cnt[r] = (t1 << 16) + cnt[r];   // v_lshl_add_u32
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mlo[2]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mhi[2]));
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < JL; ++j) {
-                        // popcount with the add fused (v_bcnt_u32_b32 d, m, d)
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[j]));
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[j]));
+                        for (int j = 0; j < JL; ++j) {
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[j]));
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[j]));
+                        }
                     }
                     if (r == 0 && ci == 0 && want_dma) {
                         SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
@@ -307,17 +357,17 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
         // The buffer this wave consumed last is dead (the next stage was prefetched into the
         // other one), so every wave publishes into its own: [wave][buf][PX][LANES] words.
         const uint32_t dead = (t - 1u) & 1u;
-        // wave w's words start at red[w * RED_STRIDE + red_off]
-        uint32_t *red = reinterpret_cast<uint32_t *>(&lds_all[RED_IN_ROWS ? 0u : ROWS_U4]);
-        constexpr uint32_t RED_STRIDE = RED_IN_ROWS ? 2u * BUF_U4 * 4u : (uint32_t)(PX * LANES);
-        const uint32_t red_off = RED_IN_ROWS ? dead * BUF_U4 * 4u : 0u;
+        // word x of wave w: red_at(w, x)
+        uint32_t *red_rows = reinterpret_cast<uint32_t *>(&lds_all[0]);
+        uint32_t *red_over = reinterpret_cast<uint32_t *>(&lds_all[ROWS_U4]);
+        auto red_at = [&](uint32_t w, uint32_t x) -> uint32_t & {
+            return x < (uint32_t)XIN ? red_rows[(w * 2u + dead) * (BUF_U4 * 4u) + x * LANES + lane]
+                                     : red_over[(w * (uint32_t)XOV + (x - (uint32_t)XIN)) * LANES + lane];
+        };
 #pragma unroll
-        for (int x = 0; x < PX; ++x) {
-            red[(uint32_t)wave * RED_STRIDE + red_off + (uint32_t)x * LANES + lane] =
-                cnt[2 * x] | (cnt[2 * x + 1] << 16);
-            cnt[2 * x] = 0;
-            cnt[2 * x + 1] = 0;
-        }
+        for (int x = 0; x < PX; ++x) red_at(wave, (uint32_t)x) = packed_word(x);
+#pragma unroll
+        for (int x = 0; x < NCNT; ++x) cnt[x] = 0;
         __syncthreads();
         // wave w finishes packed slots x = w (mod 4); fields stay below 2^16 (ss64 <= 1023)
         float tval[(MODE == MODE_JACCARD && KSL) ? SLOTS * 2 : 1];   // this wave's keys, for out_t
@@ -326,14 +376,14 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
             const uint32_t x = (uint32_t)i * W + wave;
             uint32_t total = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) total += red[(uint32_t)w * RED_STRIDE + red_off + x * LANES + lane];
+            for (int w = 0; w < W; ++w) total += red_at((uint32_t)w, x);
             if constexpr (MODE == MODE_COREACC) {
                 hist[i * MAX_FUSED_K + kl] = total;
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const uint32_t pair = 2u * x + h;
-                    const uint32_t r = pair / JL, j = pair % JL;
+                    uint32_t r, j;
+                    field_pair(x, (uint32_t)h, r, j);
                     const uint32_t mism = h ? (total >> 16) : (total & 0xFFFFu);
                     if constexpr (MODE == MODE_COUNTS) {
                         store_count(g, a0 + r, (jb0 + j) * 64u + lane, kk, mism);
@@ -364,8 +414,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
                 for (int i = 0; i < SLOTS; ++i) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const uint32_t pair = 2u * ((uint32_t)i * W + wave) + h;
-                        const uint32_t r = pair / JL, j = pair % JL;
+                        uint32_t r, j;
+                        field_pair((uint32_t)i * W + wave, (uint32_t)h, r, j);
                         tt[(j * 64u + lane) * TP + r] = tval[i * 2 + h];
                     }
                 }
@@ -405,8 +455,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_kslice(const 
             }
 #pragma clang loop unroll(disable)
             for (int h = 0; h < 2; ++h) {
-                const uint32_t pair = 2u * x + h;
-                const uint32_t r = pair / JL, j = pair % JL;
+                uint32_t r, j;
+                field_pair(x, (uint32_t)h, r, j);
                 const uint32_t sh = h * 16u;
                 const uint32_t s0 = ((word[0] >> sh) & 0xFFFFu) | (((word[1] >> sh) & 0xFFFFu) << 16);
                 const uint32_t s1 = ((word[2] >> sh) & 0xFFFFu) | (((word[3] >> sh) & 0xFFFFu) << 16);

@@ -96,17 +96,25 @@ class PipelinedGather:
     receives of consecutive steps are ordered by the communicator.
     """
 
-    def __init__(self, full, slices, rank, world, dist, root=0, depth=2):
+    def __init__(self, full, slices, rank, world, dist, root=0, depth=2, loopback=False):
+        """loopback: the root also SENDS its own band to itself (a separate `local` buffer received
+        into its slice of `full`) -- with one rank that is the whole exchange, which lets a 1-GPU box
+        run the RCCL send/recv path of the N > 1 gather (tests/test_bench_gpu.py)."""
         import collections
 
         self.full, self.slices, self.rank, self.world, self.dist, self.root = full, slices, rank, world, dist, root
         self.depth = max(1, depth)
         self.pending = collections.deque()
+        self.loopback = loopback
 
     def submit(self, local):
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             return
         ops = []
+        if self.rank == self.root and self.loopback and self.slices[self.root][3] > 0:
+            p0, cnt = self.slices[self.root][2], self.slices[self.root][3]
+            ops.append(self.dist.P2POp(self.dist.isend, local, self.root))
+            ops.append(self.dist.P2POp(self.dist.irecv, self.full[p0:p0 + cnt], self.root))
         if self.rank == self.root:
             for w in range(self.world):
                 if w == self.root or self.slices[w][3] == 0:
@@ -154,9 +162,9 @@ def exchange_knn_states(states, bounds, rank, world, dist):
             continue
         knn = t.shape[1]
         recv = torch.empty((world * rows[rank], knn), dtype=t.dtype, device=t.device)
-        if world == 1:
+        if dist is None:
             recv.copy_(t[bounds[0]:bounds[1]])
-        else:
+        else:   # (also with one rank: the collective then runs against itself)
             dist.all_to_all_single(recv, t.contiguous(), output_split_sizes=[rows[rank]] * world,
                                    input_split_sizes=rows)
         out.append(recv.view(world, rows[rank], knn))

@@ -134,30 +134,37 @@ def set_u_device(n, nk, ss64, device, first_sample=0, seed=SEED_U, chunk=4096):
     return out
 
 
-def set_clustered_device(n, nk, ss64, device, cluster_size=200, keep=0.9, seed=SEED_R, chunk=2048):
-    """Clustered sketches generated on `device` for large kNN benchmarks: sample s belongs to
-    cluster s % (n / cluster_size) and keeps each of its cluster's bin values with probability
-    `keep` (an independent 14-bit value otherwise), so a row has ~cluster_size close neighbours
-    scattered over the whole id range and every other distance sits at ~1.  Returns an int64
-    tensor [n, words] whose bit pattern is the uint64 slab (fill_usigs layout,
-    src/sketch/mod.rs:215-223)."""
+def set_clustered_device(n, nk, ss64, device, cluster_size=200, keep=0.9, seed=SEED_R, chunk=2048,
+                         first_sample=0, n_clusters=None):
+    """Clustered sketches generated on `device` for large runs: sample s belongs to cluster
+    s % n_clusters (default n / cluster_size) and keeps each of its cluster's bin values with
+    probability `keep` -- one number, or one per k-mer length so that J falls with k and the
+    core/accessory regression has a slope to fit -- and an independent 14-bit value otherwise, so a
+    row has ~cluster_size close neighbours scattered over the whole id range and every other
+    distance sits at ~1.  `first_sample` offsets the ids the samples' own draws come from (a query
+    set drawn from the same clusters as a reference set).  Returns an int64 tensor [n, words]
+    whose bit pattern is the uint64 slab (fill_usigs layout, src/sketch/mod.rs:215-223)."""
     import torch
 
     nb = ss64 * 64
     words = nk * ss64 * BBITS
-    n_clusters = max(1, n // cluster_size)
+    if n_clusters is None:
+        n_clusters = max(1, n // cluster_size)
     out = torch.empty((n, words), dtype=torch.int64, device=device)
     gold = _GOLD - (1 << 64)
     w = torch.arange(1, nk * nb + 1, dtype=torch.int64, device=device) * gold
     bit = torch.arange(64, dtype=torch.int64, device=device)
-    thresh = int(keep * 65536)
+    keeps = [keep] * nk if np.isscalar(keep) else list(keep)
+    assert len(keeps) == nk
+    thresh = torch.tensor([int(k * 65536) for k in keeps], dtype=torch.int64, device=device).view(1, nk, 1, 1)
     for s0 in range(0, n, chunk):
         s1 = min(n, s0 + chunk)
-        ids = torch.arange(s0, s1, dtype=torch.int64, device=device)
+        ids = torch.arange(first_sample + s0, first_sample + s1, dtype=torch.int64, device=device)
         own = _mix_t(_mix_t(ids + seed, torch)[:, None] + w[None, :], torch)
         par = _mix_t(_mix_t((ids % n_clusters) + (seed ^ 0xA5A5), torch)[:, None] + w[None, :], torch)
-        coin = (own >> 14) & 0xFFFF
-        vals = torch.where(coin < thresh, par & 0x3FFF, own & 0x3FFF).view(s1 - s0, nk, ss64, 64)
+        coin = ((own >> 14) & 0xFFFF).view(s1 - s0, nk, ss64, 64)
+        vals = torch.where(coin < thresh, (par & 0x3FFF).view(s1 - s0, nk, ss64, 64),
+                           (own & 0x3FFF).view(s1 - s0, nk, ss64, 64))
         planes = [(((vals >> p) & 1) << bit).sum(dim=-1) for p in range(BBITS)]   # disjoint bits: sum == or
         out[s0:s1] = torch.stack(planes, dim=-1).view(s1 - s0, words)
     return out

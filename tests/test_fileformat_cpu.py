@@ -95,6 +95,30 @@ def _py_unframe(data):
     return out
 
 
+def _py_frame(raw):
+    """The inverse: a snappy frame of uncompressed chunks (<= 65536 bytes each, as the format requires)."""
+    table = []
+    for n in range(256):
+        c = n
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        table.append(c)
+
+    def crc32c(b):
+        c = 0xFFFFFFFF
+        for x in b:
+            c = table[(c ^ x) & 0xFF] ^ (c >> 8)
+        return c ^ 0xFFFFFFFF
+
+    framed = b"\xff\x06\x00\x00sNaPpY"
+    for o in range(0, max(len(raw), 1), 60000):
+        chunk = raw[o:o + 60000]
+        c = crc32c(chunk)
+        masked = ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+        framed += b"\x01" + (len(chunk) + 4).to_bytes(3, "little") + masked.to_bytes(4, "little") + chunk
+    return framed
+
+
 @pytest.mark.parametrize("name", sorted(FIXTURE_DBS))
 def test_roundtrip_write_read(tmp_path, name):
     src = os.path.join(REF_FIXTURES, name)
@@ -274,20 +298,44 @@ def test_untrusted_files_are_refused_cleanly(tmp_path):
         (tmp_path / "x.skm").write_bytes(_frame(raw))
         res = subprocess.run([DBTOOL, "info", prefix], capture_output=True, text=True)
         assert res.returncode > 0, raw
+    # name_map values index the completeness vectors (io.cpp): an out-of-range one used to write 400 MB
+    # past a 2-element array in `dist --ref-completeness-file` (exit 139); now the .skm is refused
+    import shutil
+    for ext in (".skm", ".skd"):
+        shutil.copy(os.path.join(REF_FIXTURES, "legacy_db" + ext), tmp_path / ("nm" + ext))
+    subprocess.run([DBTOOL, "unframe", str(tmp_path / "nm.skm"), str(tmp_path / "nm.raw")], check=True)
+    rawm = (tmp_path / "nm.raw").read_bytes()
+    key = b"\x6bTIGR4.fa.gz\x01"                 # name_map entry "TIGR4.fa.gz": 1
+    assert rawm.count(key) == 1
+    (tmp_path / "nm.skm").write_bytes(_frame(rawm.replace(key, b"\x6bTIGR4.fa.gz\x1a\x02\xfa\xf0\x80")))   # 50 000 000
+    (tmp_path / "comp.txt").write_text("TIGR4.fa.gz\t0.9\nR6.fa.gz\t0.8\n")
+    for cmd in ([DBTOOL, "info", str(tmp_path / "nm")],
+                [CLI, "dist", str(tmp_path / "nm"), "--ref-completeness-file", str(tmp_path / "comp.txt")]):
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        # (the CLI reports it as the reference does a .skm it cannot read: a panic, exit 101)
+        assert res.returncode > 0 and ("name_map index out of range" in res.stderr or
+                                       (res.returncode == 101 and "Could not read sketch metadata" in res.stderr)), \
+            (cmd, res.returncode, res.stderr)
+    # a chunk that claims more than the format's 65536 uncompressed bytes (here 3 GiB from 25 bytes)
+    bomb = b"\xff\x06\x00\x00sNaPpY" + b"\x00" + (4 + 7).to_bytes(3, "little") + b"\x00\x00\x00\x00" + \
+        b"\x80\x80\x80\x80\x0c" + b"\x00\x61"
+    (tmp_path / "nm.skm").write_bytes(bomb)
+    res = subprocess.run([DBTOOL, "info", str(tmp_path / "nm")], capture_output=True, text=True)
+    assert res.returncode > 0 and "65536" in res.stderr, res.stderr
     # a real index, then its n_samples / a bitmap entry patched in the (re-framed) payload
     wd = tmp_path / "idx"
     wd.mkdir()
-    import shutil
     for f in FIXTURE_NAMES:
         shutil.copy(os.path.join(REF_FIXTURES, f), wd / f)
     subprocess.run([CLI, "inverted", "build", "-o", "i", "-k", "21", "-s", "20", *FIXTURE_NAMES], cwd=wd, check=True)
     subprocess.run([DBTOOL, "unframe", str(wd / "i.ski"), str(wd / "i.raw")], check=True)
     raw = (wd / "i.raw").read_bytes()
-    key = b"\x69n_samples\x04"
-    assert raw.count(key) == 1
+    # MessagePack array of struct Inverted: n_samples (4) sits between the index and the 4 names
+    key = b"\x04\x94\xbf14412_3#82"
+    assert raw[0] == 0x99 and raw.count(key) == 1
     ok = subprocess.run([CLI, "inverted", "precluster", "i.ski", "--count"], cwd=wd, capture_output=True, text=True)
     assert ok.returncode == 0 and "prefilter pairs" in ok.stdout
-    (wd / "bad.ski").write_bytes(_frame(raw.replace(key, b"\x69n_samples\x05")))
+    (wd / "bad.ski").write_bytes(_frame(raw.replace(key, b"\x05" + key[1:])))
     res = subprocess.run([CLI, "inverted", "precluster", "bad.ski", "--count"], cwd=wd, capture_output=True, text=True)
     assert res.returncode > 0 and "n_samples" in res.stderr
     # roaring array container of one value [cookie 12346, 1 container, key 0, card-1 = 0, offset, value]:

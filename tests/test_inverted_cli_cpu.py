@@ -1,12 +1,15 @@
 """`sketchlib inverted build` and the `.ski` / `.skq` formats without a GPU:
 the `.skq` our native sketcher writes is byte-identical to the reference's golden
 (tests/inverted.rs:260-270), `precluster --count` prints the reference's line (:279-285), and
-the `.ski` is decoded here by an independent Python reader (snappy frame -> CBOR -> Roaring
-portable format) and compared with the index built from the `.skq`."""
+the `.ski` is decoded here by independent Python readers (snappy frame -> MessagePack via the
+`msgpack` package -> Roaring portable format) and compared with the index built from the `.skq`.
+The reference writes the index with rmp_serde::encode::write (inverted.rs:194-201): struct Inverted
+as a 9-element MessagePack array in field order."""
 import os
 import shutil
 import subprocess
 
+import msgpack
 import numpy as np
 import pytest
 
@@ -34,6 +37,20 @@ def run(wd, *args, ok=True):
     if ok:
         assert res.returncode == 0, res.stderr
     return res
+
+
+FIELDS = ["index", "n_samples", "sample_names", "metadata", "labels", "kmer_size", "sketch_version", "rc",
+          "hash_type"]                     # field order of struct Inverted (inverted.rs:46-58)
+
+
+def ski_decode(path):
+    """.ski -> dict by field name; asserts the document is rmp-serde's array form in its canonical
+    (shortest) encodings: re-packing the decoded document gives the same bytes."""
+    doc = _py_unframe(path.read_bytes())
+    arr = msgpack.unpackb(doc, raw=False, strict_map_key=False)
+    assert isinstance(arr, list) and len(arr) == 9 and doc[0] == 0x99
+    assert msgpack.packb(arr, use_bin_type=True) == doc
+    return dict(zip(FIELDS, arr))
 
 
 def cbor_decode(b, i=0):
@@ -96,9 +113,7 @@ def test_build_writes_reference_skq_and_a_decodable_ski(wd):
     assert (wd / "inverted.skq").read_bytes() == open(os.path.join(REF_FIXTURES, "inverted.skq"), "rb").read()
     res = run(wd, "inverted", "precluster", "-v", "--count", "inverted.ski")
     assert res.stdout == "Identified 2 prefilter pairs from a max of 6\n"
-    ski, _ = cbor_decode(_py_unframe((wd / "inverted.ski").read_bytes()))
-    assert list(ski) == ["index", "n_samples", "sample_names", "metadata", "labels", "kmer_size", "sketch_version",
-                         "rc", "hash_type"]                     # field order of struct Inverted (inverted.rs:46-58)
+    ski = ski_decode(wd / "inverted.ski")
     assert ski["sample_names"] == FIXTURE_NAMES and ski["n_samples"] == 4 and ski["kmer_size"] == 21
     assert ski["rc"] is True and ski["hash_type"] == "DNA" and ski["metadata"] is None and ski["labels"] is None
     skq = np.fromfile(wd / "inverted.skq", dtype="<u2").reshape(4, 10)
@@ -107,13 +122,16 @@ def test_build_writes_reference_skq_and_a_decodable_ski(wd):
         expect = {}
         for s in range(4):
             expect.setdefault(int(skq[s, b]), []).append(s)
+            assert all(isinstance(v, bytes) for v in table.values())      # bin blobs, as serde's serialize_bytes gives
         assert {k: roaring_decode(v) for k, v in table.items()} == expect
 
 
 def test_large_bitmaps_round_trip_through_the_cli(wd, tmp_path):
     """A bin value shared by > 4096 samples is a bitmap container; ids beyond 65535 need a second
-    container.  A .ski with both is assembled here from the documented layout (CBOR of struct
-    Inverted, Roaring portable bitmaps, snappy frame) and read by the C++ loader via --count."""
+    container.  A .ski with both is assembled here from the documented layout (struct Inverted as
+    rmp-serde's MessagePack array, Roaring portable bitmaps, snappy frame) and read by the C++ loader
+    via --count -- and once more as the snappy-framed CBOR map that round 1 of this repository wrote,
+    which the loader still accepts."""
     # 70 000 samples x 2 bins: bin 0 is the same for everyone, bin 1 is shared by neighbours
     n = 70000
 
@@ -170,7 +188,6 @@ def test_large_bitmaps_round_trip_through_the_cli(wd, tmp_path):
     index[1] = {k: roaring_encode(v) for k, v in index[1].items()}
     ski = {"index": index, "n_samples": n, "sample_names": [f"s{i}" for i in range(n)], "metadata": None,
            "labels": None, "kmer_size": 21, "sketch_version": "0.3.0", "rc": True, "hash_type": "DNA"}
-    raw = enc(ski)
     # snappy frame, uncompressed chunks
     table = []
     for i in range(256):
@@ -185,22 +202,27 @@ def test_large_bitmaps_round_trip_through_the_cli(wd, tmp_path):
             c = table[(c ^ x) & 0xFF] ^ (c >> 8)
         return c ^ 0xFFFFFFFF
 
-    framed = b"\xff\x06\x00\x00sNaPpY"
-    for o in range(0, len(raw), 60000):
-        chunk = raw[o:o + 60000]
-        c = crc32c(chunk)
-        masked = ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
-        framed += b"\x01" + (len(chunk) + 4).to_bytes(3, "little") + masked.to_bytes(4, "little") + chunk
-    (tmp_path / "big.ski").write_bytes(framed)
-    res = run(tmp_path, "inverted", "precluster", "--count", "big.ski", "--threads", "4")
-    assert res.stdout == f"Identified {n * (n - 1) // 2} prefilter pairs from a max of {n * (n - 1) // 2}\n"
+    def frame(raw):
+        framed = b"\xff\x06\x00\x00sNaPpY"
+        for o in range(0, len(raw), 60000):
+            chunk = raw[o:o + 60000]
+            c = crc32c(chunk)
+            masked = ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+            framed += b"\x01" + (len(chunk) + 4).to_bytes(3, "little") + masked.to_bytes(4, "little") + chunk
+        return framed
+
+    expect = f"Identified {n * (n - 1) // 2} prefilter pairs from a max of {n * (n - 1) // 2}\n"
+    (tmp_path / "big.ski").write_bytes(frame(msgpack.packb([ski[f] for f in FIELDS], use_bin_type=True)))
+    assert run(tmp_path, "inverted", "precluster", "--count", "big.ski", "--threads", "4").stdout == expect
+    (tmp_path / "legacy.ski").write_bytes(frame(enc(ski)))
+    assert run(tmp_path, "inverted", "precluster", "--count", "legacy.ski", "--threads", "4").stdout == expect
 
 
 def test_species_names_reorder_the_index(wd):
     (wd / "species.txt").write_text("R6.fa.gz\tpneumo\n14412_3#84.contigs_velvet.fa.gz\tother\nTIGR4.fa.gz\tpneumo\n")
     run(wd, "inverted", "build", "-o", "reordered", "-k", "21", "-s", "10", "-f", "rfile.txt", "--write-skq",
         "--species-names", "species.txt")
-    ski, _ = cbor_decode(_py_unframe((wd / "reordered.ski").read_bytes()))
+    ski = ski_decode(wd / "reordered.ski")
     # labels in order of first appearance, unlabelled inputs last (io.rs:40-115)
     assert ski["sample_names"] == ["R6.fa.gz", "TIGR4.fa.gz", "14412_3#84.contigs_velvet.fa.gz",
                                    "14412_3#82.contigs_velvet.fa.gz"]
@@ -220,7 +242,7 @@ def test_metadata_is_stored_in_index_order(wd):
     (wd / "species.txt").write_text("R6.fa.gz\tpneumo\nTIGR4.fa.gz\tpneumo\n")
     run(wd, "inverted", "build", "-o", "meta", "-k", "31", "-f", "rfile.txt", "--species-names", "species.txt",
         "--metadata", "metadata.txt")
-    ski, _ = cbor_decode(_py_unframe((wd / "meta.ski").read_bytes()))
+    ski = ski_decode(wd / "meta.ski")
     assert ski["sample_names"][:2] == ["R6.fa.gz", "TIGR4.fa.gz"]
     assert ski["metadata"] == ["Metadata of " + {"R6.fa.gz": "R6", "TIGR4.fa.gz": "TIGR4",
                                                   "14412_3#82.contigs_velvet.fa.gz": "14412_3 82",
@@ -253,3 +275,51 @@ def test_gpu_paths_refuse_without_a_device(wd, skl):
     for extra in ((), ("--host-candidates",)):
         res = run(wd, "inverted", "precluster", "idx.ski", "--skd", "db", *extra, ok=False)
         assert res.returncode != 0 and "no CPU path" in res.stderr
+
+
+def test_rmp_serde_byte_layout_is_read(tmp_path):
+    """A `.ski` document typed out byte by byte from rmp-serde's encoding rules (no encoder of ours or
+    of the msgpack package involved): 2 bins, 3 samples, metadata None, labels Some, HashType::DNA.
+    Also the newtype-variant form of hash_type ({"AA": "Level2"}) and rmp-serde's struct-as-map form."""
+    from test_fileformat_cpu import _py_frame
+
+    def roaring(vals):   # one array container, portable format without run cookie
+        return ((12346).to_bytes(4, "little") + (1).to_bytes(4, "little") + (0).to_bytes(2, "little") +
+                (len(vals) - 1).to_bytes(2, "little") + (16).to_bytes(4, "little") +
+                b"".join(v.to_bytes(2, "little") for v in vals))
+
+    def binblob(b):
+        return b"\xc4" + bytes([len(b)]) + b
+
+    def fixstr(t):
+        return bytes([0xa0 | len(t)]) + t.encode()
+
+    def body(hash_type):
+        return (b"\x92"                                                     # index: array(2)
+                + b"\x82" + b"\x05" + binblob(roaring([0, 2])) + b"\xcd\x12\x34" + binblob(roaring([1]))   # {5: .., 0x1234: ..}
+                + b"\x81" + b"\xcc\xc8" + binblob(roaring([0, 1, 2]))         # {200: ..}   (u8 form)
+                + b"\x03"                                                   # n_samples
+                + b"\x93" + fixstr("a") + fixstr("b") + fixstr("c")         # sample_names
+                + b"\xc0"                                                   # metadata: None
+                + b"\x93" + fixstr("x") + fixstr("x") + fixstr("y")         # labels: Some
+                + b"\x15" + fixstr("0.3.0") + b"\xc3" + hash_type)          # kmer_size 21, version, rc true
+
+    for name, ht, ok in [("dna", fixstr("DNA"), True), ("aa", b"\x81" + fixstr("AA") + fixstr("Level2"), True),
+                         ("bad", b"\x07", False)]:
+        (tmp_path / f"{name}.ski").write_bytes(_py_frame(b"\x99" + body(ht)))
+        res = run(tmp_path, "inverted", "precluster", "--count", f"{name}.ski", ok=ok)
+        if ok:
+            assert res.stdout == "Identified 3 prefilter pairs from a max of 3\n", name
+        else:
+            assert res.returncode == 1 and "hash_type" in res.stderr
+    # with_struct_map: the same nine values keyed by field name
+    vals = msgpack.unpackb(b"\x99" + body(fixstr("DNA")), raw=False, strict_map_key=False)
+    (tmp_path / "map.ski").write_bytes(_py_frame(msgpack.packb(dict(zip(FIELDS, vals)), use_bin_type=True)))
+    assert run(tmp_path, "inverted", "precluster", "--count", "map.ski").stdout == \
+        "Identified 3 prefilter pairs from a max of 3\n"
+    # malformed: truncated document, container length beyond the input
+    doc = b"\x99" + body(fixstr("DNA"))
+    for bad in (doc[:-3], b"\x99\xdd\xff\xff\xff\xff", b"\x99\x92\x81\x05\xc6\xff\xff\xff\xff"):
+        (tmp_path / "trunc.ski").write_bytes(_py_frame(bad))
+        res = run(tmp_path, "inverted", "precluster", "--count", "trunc.ski", ok=False)
+        assert res.returncode == 1 and "MessagePack" in res.stderr, res.stderr
