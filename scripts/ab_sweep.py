@@ -18,6 +18,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# kernel selection / tile shapes / ablations exist only in the A/B build of the library (make AB=1)
+os.environ.setdefault("SKL_LIBRARY", os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build_ab", "libsketchlib_dist_hip.so"))
 import torch  # noqa: E402
 
 from sketchlib.rust_amd import capi, synth  # noqa: E402

@@ -8,6 +8,6 @@ for t in valu_rates valu_clock vgpr_banks lds_bcast; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value $t.hip -o _build/$t
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Wno-unused-value -I../../include -I$CSRC \
-  kslice_trace.hip -L$CSRC/_build -lsketchlib_dist_hip -Wl,-rpath,'$ORIGIN/../../../sketchlib.rust_amd/csrc/_build' \
+  kslice_trace.hip -L$CSRC/_build_ab -lsketchlib_dist_hip -Wl,-rpath,'$ORIGIN/../../../sketchlib.rust_amd/csrc/_build_ab' \
   -o _build/kslice_trace
 ls _build

@@ -4,6 +4,7 @@
 // launch go": dispatch ramp, rounds, tail.  (Measurement tool, not product code.)
 // Build: see scripts/microbench/build.sh
 #define SKL_TRACE 1
+#define SKL_AB 1   // every tile shape and the timing-only ablations (SKL_KSLICE_ABLATE)
 // distinct symbol names: the product library exports the untraced kernel under the original ones
 #define pair_kernel_kslice pair_kernel_kslice_traced
 #define launch_pair_kernel_kslice launch_pair_kernel_kslice_traced
@@ -60,13 +61,14 @@ int main(int argc, char **argv)
     fprintf(stderr, "launch\n");
     // argv[4]: untimed launches before the traced one (the clock settles under sustained load)
     const int warm = argc > 4 ? atoi(argv[4]) : 3;
-    for (int i = 0; i < warm; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ts, 0));
+    const int ablate = getenv("SKL_KSLICE_ABLATE") ? atoi(getenv("SKL_KSLICE_ABLATE")) : 0;
+    for (int i = 0; i < warm; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
     CK(hipDeviceSynchronize());
     fprintf(stderr, "warm done\n");
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ts, 0));
+    CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
     hipEventRecord(e1);
     CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -117,6 +117,7 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
     HIP_TRY(hipSetDevice(device));
     skl_ctx *ctx = new skl_ctx();
     ctx->device = device;
+    ctx->knobs = read_knobs();
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -223,85 +224,111 @@ extern "C" int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches)
     return SKL_OK;
 }
 
-long long env_int(const char *name, long long dflt)
+static long long env_int(const char *name, long long dflt)
 {
     const char *e = getenv(name);
     return (e && *e) ? atoll(e) : dflt;
 }
 
-// SKL_KERNEL = smem | lds | ksplit | kslice forces one implementation (0: dispatcher's choice)
-int forced_kernel()
+Knobs read_knobs()
 {
-    const char *e = getenv("SKL_KERNEL");
-    if (!e) return 0;
-    if (strcmp(e, "smem") == 0) return 1;
-    if (strcmp(e, "lds") == 0) return 2;
-    if (strcmp(e, "ksplit") == 0) return 3;
-    if (strcmp(e, "kslice") == 0) return 4;
-    return 0;
+    Knobs k;
+    k.timing_every = std::max(1ll, env_int("SKL_TIMING_EVERY", 1));
+    k.sliced_max_pairs = env_int("SKL_SLICED_MAX_PAIRS", -1);
+    k.knn_band_rows = std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));
+    k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
+    k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
+    k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
+    k.cand_symmetric = env_int("SKL_CAND_SYMMETRIC", 1) != 0;
+    const char *sk = getenv("SKL_SKETCH_KERNEL");
+    k.sketch_global = sk && strcmp(sk, "global") == 0;
+#ifdef SKL_AB
+    // SKL_KERNEL = smem | lds | ksplit | kslice forces one implementation (0: dispatcher's choice)
+    if (const char *e = getenv("SKL_KERNEL")) {
+        k.kernel = strcmp(e, "smem") == 0 ? 1 : strcmp(e, "lds") == 0 ? 2 : strcmp(e, "ksplit") == 0 ? 3
+                   : strcmp(e, "kslice") == 0 ? 4 : 0;
+    }
+    k.kslice_shape = (int)env_int("SKL_KSLICE_SHAPE", 0);
+    k.ksplit_rows = (int)env_int("SKL_KSPLIT_ROWS", 0);
+    k.kslice_ablate = (int)env_int("SKL_KSLICE_ABLATE", 0);
+#endif
+    return k;
 }
 
-// One tile computation, four implementations (the dispatcher's rule is in DESIGN.md 4.2):
-//   kslice (pair_kslice.hip)  default: 16 x 128 tiles, chunks split over the 4 waves, rows by
-//                             LDS DMA; one workgroup per (tile, k) for small launches and for
-//                             single-k Jaccard, all k + fused regression otherwise
-//   ksplit (pair_ksplit.hip)  fallback for shapes kslice does not take (ss64 > 1023)
-//   lds    (pair_lds.hip)     R x 256/512 tiles, rows broadcast from LDS (A/B only)
-//   smem   (kernels.hip)      rows through the scalar cache (A/B only)
-// SKL_KERNEL = kslice | ksplit | lds | smem forces one.
-static hipError_t dispatch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream,
-                                       std::string *name, TileScratch &tiles)
+int forced_kernel(const skl_ctx *ctx)
+{
+#ifdef SKL_AB
+    return ctx->knobs.kernel;
+#else
+    (void)ctx;
+    return 0;
+#endif
+}
+
+// One tile computation.  Product library: the chunk-split kernel (pair_kslice.hip: 16 x 128 tiles,
+// chunks split over the 4 waves, rows by LDS DMA; one workgroup per (tile, k) for small launches
+// and for single-k Jaccard, all k + fused regression otherwise) and, for the shapes it does not
+// take (sketches beyond 65 535 bins), pair_ksplit.hip.  The A/B build adds the earlier kernels
+// (pair_lds.hip, pair_smem.hip) and the other tile shapes behind SKL_KERNEL / SKL_KSLICE_SHAPE.
+static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args, int mode, hipStream_t stream)
 {
     static const char *mode_names[] = {"COUNTS", "JACCARD", "COREACC"};
     const std::string m = mode_names[mode];
-    // (tuning knobs are read on every call so an A/B run can interleave variants in one
-    // process: scripts/ab_sweep.py)
-    const int forced = forced_kernel();
-    const int forced_kslice_shape = env_int("SKL_KSLICE_SHAPE", 0);  // 81, 82, 161, 162
-    const int forced_rows = env_int("SKL_KSPLIT_ROWS", 0);           // 4 or 8
+    std::string *name = &ctx->last_kernel;
+    TileScratch &tiles = ctx->tile_scratch;
     const uint64_t rows = args.row_end - args.row_begin;
     const uint64_t pairs = args.self_mode ? rows * args.nB / 2 : rows * (uint64_t)args.nB;
     const bool small = pairs < (8ull << 20);
-    if (forced == 1) {
+    int shape = 162, ksplit_rows = 8;   // 8 >= 4 rows from n = 1000 up once XCDs are balanced
+#ifdef SKL_AB
+    const Knobs &kn = ctx->knobs;
+    if (kn.kslice_shape) shape = kn.kslice_shape;
+    if (kn.ksplit_rows) ksplit_rows = kn.ksplit_rows;
+    if (kn.kernel == 1) {
+        const int na = choose_na(rows, args.nB, args.self_mode, mode);
         *name = "skl::pair_kernel<NA=" + std::to_string(na) + ", " + m + "> (scalar-cache rows)";
         return launch_pair_kernel(args, mode, na, stream);
     }
-    // SKL_KERNEL=kslice (or no override): the chunk-split kernel, k-sliced for small launches
-    // (core/acc then arrives here as MODE_COUNTS from dense_band), all-k fused otherwise.
-    if (forced == 0 || forced == 4) {
+    if (kn.kernel == 2) {
+        const int ls = choose_lds_shape(rows, args.nB, args.self_mode, mode);
+        *name = "skl::pair_kernel_lds<R=" + std::to_string(ls / 10) + ", JL=" + std::to_string(ls % 10) + ", " + m +
+                "> (" + std::to_string(ls / 10) + "x" + std::to_string((ls % 10) * 256) + " tiles)";
+        return launch_pair_kernel_lds(args, mode, ls, tiles, stream);
+    }
+    const bool try_kslice = kn.kernel != 3;
+    const int ablate = kn.kslice_ablate;
+#else
+    const bool try_kslice = true;
+    const int ablate = 0;
+#endif
+    if (try_kslice) {
         // single-k Jaccard: the sliced and the all-k form are the same work, the sliced one
-        // compiles to fewer registers
+        // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
         const bool sliced = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
         if (kslice_supported(args, mode, sliced)) {
-            const int shape = forced_kslice_shape ? forced_kslice_shape : 162;
             *name = "skl::pair_kernel_kslice<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(shape % 10) +
                     ", " + m + (sliced ? ", k-sliced" : ", all k") + "> (" + std::to_string(shape / 10) + "x" +
                     std::to_string((shape % 10) * 64) + " tiles, chunks split over 4 waves)";
-            return launch_pair_kernel_kslice(args, mode, shape, sliced, tiles, stream);
+            return launch_pair_kernel_kslice(args, mode, shape, sliced, ablate, tiles, stream);
         }
     }
-    if (forced == 3 || (forced != 2 && small)) {
-        int r = forced_rows ? forced_rows : 8;  // 8 >= 4 from n = 1000 up once XCDs are balanced (sweep 18)
-        *name = "skl::pair_kernel_ksplit<R=" + std::to_string(r) + ", " + m + "> (" + std::to_string(r) +
-                "x64 tiles, chunks split over 4 waves)";
-        return launch_pair_kernel_ksplit(args, mode, r, tiles, stream);
-    }
-    const int shape = choose_lds_shape(rows, args.nB, args.self_mode, mode);
-    *name = "skl::pair_kernel_lds<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(shape % 10) +
-            ", " + m + "> (" + std::to_string(shape / 10) + "x" + std::to_string((shape % 10) * 256) + " tiles)";
-    return launch_pair_kernel_lds(args, mode, shape, tiles, stream);
+    *name = "skl::pair_kernel_ksplit<R=" + std::to_string(ksplit_rows) + ", " + m + "> (" + std::to_string(ksplit_rows) +
+            "x64 tiles, chunks split over 4 waves)";
+    return launch_pair_kernel_ksplit(args, mode, ksplit_rows, tiles, stream);
 }
 
 // Launch the pair kernel bracketed by HIP events on the context's stream.
-int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int na)
+int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode)
 {
     constexpr size_t MAX_EVENTS = 4096;
+#ifdef SKL_AB
+    ctx->knobs = read_knobs();   // A/B build only: one process interleaves variants (scripts/ab_sweep.py)
+#endif
     // SKL_TIMING_EVERY = N brackets every N-th launch only (default 1 = all): an event record is
     // a barrier packet on the queue, and two per launch cost a sub-millisecond launch ~5 us
-    const long long every = std::max(1ll, env_int("SKL_TIMING_EVERY", 1));
-    const bool sampled = (ctx->launches_seen++ % (size_t)every) == 0;
+    const bool sampled = (ctx->launches_seen++ % (size_t)ctx->knobs.timing_every) == 0;
     if (!sampled || ctx->events_used >= MAX_EVENTS) {
-        HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel, ctx->tile_scratch));
+        HIP_TRY(dispatch_pair_kernel(ctx, args, mode, ctx->stream));
         return SKL_OK;
     }
     if (ctx->events_used == ctx->events.size()) {
@@ -316,7 +343,7 @@ int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode, int na)
     }
     auto &ev = ctx->events[ctx->events_used++];
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    HIP_TRY(dispatch_pair_kernel(args, mode, na, ctx->stream, &ctx->last_kernel, ctx->tile_scratch));
+    HIP_TRY(dispatch_pair_kernel(ctx, args, mode, ctx->stream));
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     return SKL_OK;
 }
@@ -682,11 +709,11 @@ int fill_args(const skl_sketches *rows, const skl_sketches *cols, const skl_dist
 // Launch-size rule shared with dispatch_pair_kernel: core/acc launches below this many pairs
 // run k-sliced (counts + epilogue kernel), larger ones as one fused kernel.
 constexpr long long SLICED_MAX_PAIRS = 32ll << 20;   // n ~ 8000 all-vs-all: equal there (scripts/ab_sweep.py)
-static bool coreacc_runs_sliced(const skl_sketches *s, uint64_t pairs)
+static bool coreacc_runs_sliced(const skl_ctx *ctx, const skl_sketches *s, uint64_t pairs)
 {
-    const int forced = forced_kernel();
+    const int forced = forced_kernel(ctx);
     if (s->ss64 > 1023 || (forced != 0 && forced != 4)) return false;   // another kernel forced: never slice
-    const long long limit = env_int("SKL_SLICED_MAX_PAIRS", SLICED_MAX_PAIRS);
+    const long long limit = ctx->knobs.sliced_max_pairs >= 0 ? ctx->knobs.sliced_max_pairs : SLICED_MAX_PAIRS;
     return pairs < (uint64_t)limit;
 }
 
@@ -720,7 +747,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
     const bool coreacc = mode == MODE_COREACC;
     // Small core/acc launches run as (tile, k) workgroups producing counts + the epilogue
     // kernel (pair_kslice.hip): 5x the workgroups of the fused kernel and two columns per lane.
-    const bool sliced = coreacc && coreacc_runs_sliced(rows, pairs);
+    const bool sliced = coreacc && coreacc_runs_sliced(ctx, rows, pairs);
     if (coreacc && (sliced || !fused_coreacc_ok(rows))) {
         // unfused: counts -> scratch2 -> epilogue kernel
         PairArgs g;
@@ -737,8 +764,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         g.self_mode = self_mode;
         g.out_base = base;
         g.out = counts;
-        const int na = choose_na(r1 - r0, n_cols, self_mode, MODE_COUNTS);
-        SKL_TRY(timed_pair_launch(ctx, g, MODE_COUNTS, na));
+        SKL_TRY(timed_pair_launch(ctx, g, MODE_COUNTS));
         SKL_TRY(ensure_ytab(rows));
         EpilogueArgs e;
         memset(&e, 0, sizeof e);
@@ -773,8 +799,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
     g.self_mode = self_mode;
     g.out_base = base;
     g.out = dst_dev;
-    const int na = choose_na(r1 - r0, n_cols, self_mode, mode);
-    return timed_pair_launch(ctx, g, mode, na);
+    return timed_pair_launch(ctx, g, mode);
 }
 
 static size_t record_bytes(const skl_sketches *s, int mode)

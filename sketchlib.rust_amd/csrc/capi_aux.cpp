@@ -52,8 +52,7 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
     // the LDS-staged kernel takes every k-mer length up to its span + 1 (SKL_SKETCH_KERNEL=global: A/B)
     size_t kmax = 0;
     for (size_t ki = 0; ki < nk; ++ki) kmax = std::max(kmax, kmers[ki]);
-    const char *forced = getenv("SKL_SKETCH_KERNEL");
-    const bool lds_form = kmax <= (size_t)sketch_span_lds() + 1 && !(forced && strcmp(forced, "global") == 0);
+    const bool lds_form = kmax <= (size_t)sketch_span_lds() + 1 && !ctx->knobs.sketch_global;
     const uint64_t span = (uint64_t)(lds_form ? sketch_span_lds() : sketch_span());
     std::vector<uint64_t> span_begin(n_samples + 1, 0);
     for (size_t s = 0; s < n_samples; ++s) {
@@ -127,7 +126,7 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
 {
     const size_t n = s->n;
     const uint64_t total = host_offsets[n];
-    const bool symmetric = symmetric_lists && env_int("SKL_CAND_SYMMETRIC", 1) != 0;
+    const bool symmetric = symmetric_lists && ctx->knobs.cand_symmetric;
     // symmetric lists: only the candidates with a larger id than the row are evaluated (the
     // kernel stores each key for both rows), so a row's work items start at its first such candidate
     std::vector<uint64_t> first;

@@ -37,6 +37,28 @@ SKL_INTERNAL int fail(int code, const char *fmt, ...);
 
 struct skl_sketches;
 
+// Environment switches.  They are read ONCE, when a context is created (skl_ctx_create), never on
+// the launch path.  The product library knows the few below (timing cadence for benchmarks, test
+// knobs that force the banded / sliced forms on small inputs, A/B of the kNN drivers); kernel
+// selection, tile shapes and timing-only ablations exist only in the A/B build (-DSKL_AB).
+struct Knobs {
+    long long timing_every = 1;       // SKL_TIMING_EVERY: bracket every N-th pair-kernel launch with events
+    long long sliced_max_pairs = -1;  // SKL_SLICED_MAX_PAIRS: core/acc launches below this run k-sliced (-1: default)
+    long long knn_band_rows = 0;      // SKL_KNN_BAND_ROWS: force the band height of the kNN drivers (tests)
+    bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
+    bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
+    bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
+    bool cand_symmetric = true;       // SKL_CAND_SYMMETRIC=0: evaluate symmetric candidate lists in full
+    bool sketch_global = false;       // SKL_SKETCH_KERNEL=global: the unstaged sketching kernel
+#ifdef SKL_AB
+    int kernel = 0;                   // SKL_KERNEL: 0 none, 1 smem, 2 lds, 3 ksplit, 4 kslice
+    int kslice_shape = 0;             // SKL_KSLICE_SHAPE: R*10 + JL
+    int ksplit_rows = 0;              // SKL_KSPLIT_ROWS: 4 or 8
+    int kslice_ablate = 0;            // SKL_KSLICE_ABLATE: timing only, outputs wrong by construction
+#endif
+};
+SKL_INTERNAL Knobs read_knobs();
+
 struct skl_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -53,6 +75,7 @@ struct skl_ctx {
     size_t events_used = 0;
     size_t launches_seen = 0;           // pair-kernel launches since the last skl_ctx_timing_reset
     std::string last_kernel;
+    Knobs knobs;                        // environment switches as of skl_ctx_create
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration
     std::set<skl_sketches *> sketches;  // slabs created on this context
 };
@@ -88,11 +111,9 @@ SKL_INTERNAL int ctx_bind(skl_ctx *ctx);
 SKL_INTERNAL int host_log_variant();
 // grow-only scratch slot `which` of the context, at least `bytes` large
 SKL_INTERNAL int ctx_scratch(skl_ctx *ctx, size_t bytes, void **out, int which = 0);
-// tuning knobs are read on every call so an A/B run can interleave variants in one process
-SKL_INTERNAL long long env_int(const char *name, long long dflt);
-SKL_INTERNAL int forced_kernel();   // SKL_KERNEL: 0 none, 1 smem, 2 lds, 3 ksplit, 4 kslice
+SKL_INTERNAL int forced_kernel(const skl_ctx *ctx);   // A/B build: SKL_KERNEL; product library: always 0
 // the pair kernel bracketed by HIP events on the context's stream (skl_ctx_kernel_ms)
-SKL_INTERNAL int timed_pair_launch(skl_ctx *ctx, const skl::PairArgs &args, int mode, int na);
+SKL_INTERNAL int timed_pair_launch(skl_ctx *ctx, const skl::PairArgs &args, int mode);
 // records [first, second) events around a launch of another kernel the same way; returns the
 // slot to record into or null when the event budget is used up
 SKL_INTERNAL std::pair<hipEvent_t, hipEvent_t> *timing_slot(skl_ctx *ctx);

@@ -58,10 +58,9 @@ static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
 {
     if (s->ss64 > 1023) return false;
     if (p->dist_type == SKL_DIST_COREACC && !fused_coreacc_ok(s)) return false;
-    const int forced = forced_kernel();
+    const int forced = forced_kernel(s->ctx);
     if (forced != 0 && forced != 4) return false;          // the turned store lives in pair_kslice.hip
-    const long long shape = env_int("SKL_KSLICE_SHAPE", 0);
-    return shape == 0 || shape == 81 || shape == 82 || shape == 161 || shape == 162;
+    return true;
 }
 
 // The bands `bands` (ascending indices; band b = rows [b*band_rows, (b+1)*band_rows)) merged into
@@ -112,7 +111,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         g.out_t = b1 < n ? (float *)tband[buf] : nullptr;
         g.t_col_begin = (uint32_t)(b1 - col0);
         g.t_stride = (uint32_t)t_stride;
-        SKL_TRY(timed_pair_launch(ctx, g, mode, choose_na(b1 - b0, g.nB, 0, mode)));
+        SKL_TRY(timed_pair_launch(ctx, g, mode));
         if (overlap) {
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
             HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
@@ -124,7 +123,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         m.run_key = st.key;
         m.run_idx = st.idx;
         m.run_d1 = st.d1;
-        m.streaming = env_int("SKL_TOPK_STREAM", 1) != 0;
+        m.streaming = ctx->knobs.topk_stream;
         // rows of the band: columns [b0, n) minus themselves (the view's first b0 - col0 columns
         // reached them turned, from earlier bands)
         m.keys = (const float *)kband[buf];
@@ -213,7 +212,7 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
         m.run_key = st.key;
         m.run_idx = st.idx;
         m.run_d1 = st.d1;
-        m.streaming = env_int("SKL_TOPK_STREAM", 1) != 0;
+        m.streaming = ctx->knobs.topk_stream;
         m.key_stride = (uint64_t)n_cand * m.stride2;
         m.rows = (uint32_t)(b1 - b0);
         m.self_id_base = self_mode ? (uint32_t)b0 : 0xFFFFFFFFu;
@@ -260,14 +259,14 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         band_bytes = std::max(band_bytes, std::min<size_t>(free_b / 4, 8ull << 30));
     }
     size_t band_rows = std::max<size_t>(1, band_bytes / 2 / (n_cand * rec));   // two key bands
-    const size_t forced_band_rows = (size_t)std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));  // test knob: force several bands
+    const size_t forced_band_rows = (size_t)ctx->knobs.knn_band_rows;  // test knob: force several bands
     if (forced_band_rows) band_rows = forced_band_rows;
     band_rows = std::min(band_rows, r1 - r0);
     // The whole self matrix: evaluate each pair once (knn_self_symmetric) when that leaves bands
     // worth launching -- about 8 of them (7/16 of the pair evaluations saved), each at least 32 M
     // pairs, within four band buffers of up to half the free HBM (<= 32 GiB) together.
     bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p) &&
-                     env_int("SKL_KNN_SYMMETRIC", 1) != 0;   // (0: A/B against the row-by-row form)
+                     ctx->knobs.knn_symmetric;   // (SKL_KNN_SYMMETRIC=0: A/B against the row-by-row form)
     if (symmetric) {
         size_t budget = band_bytes;
         if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, 32ull << 30));
@@ -275,7 +274,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         if (want >= n_cand) symmetric = false;
         else band_rows = want;
     }
-    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && band_rows < r1 - r0;
+    const bool overlap = ctx->knobs.knn_overlap && band_rows < r1 - r0;
 
     // device staging for host-destined results
     uint64_t *d_idx = out_idx;
@@ -329,7 +328,7 @@ extern "C" size_t skl_knn_band_rows(const skl_sketches *s, const skl_dist_params
 {
     if (!s || !p || s->n == 0) return 0;
     const size_t rec = p->dist_type == SKL_DIST_COREACC ? 2 * sizeof(float) : sizeof(float);
-    const long long forced = env_int("SKL_KNN_BAND_ROWS", 0);   // test knob (the same for every participant)
+    const long long forced = s->ctx->knobs.knn_band_rows;   // test knob (the same for every participant)
     if (forced > 0) return std::min<size_t>(s->n, (size_t)forced);
     // a fixed budget (no free-memory query): every participant must arrive at the same number
     return std::min(s->n, symmetric_band_rows(s->n, rec, 32ull << 30, n_participants));
@@ -361,7 +360,7 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     }
     KnnState st;
     SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
-    const bool overlap = env_int("SKL_KNN_OVERLAP", 1) != 0 && list.size() > 1;
+    const bool overlap = ctx->knobs.knn_overlap && list.size() > 1;
     SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
     const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     const size_t items = n * knn;

@@ -75,10 +75,11 @@ struct PairArgs {
     double kf[MAX_FUSED_K];       // k-mer lengths as f64
 };
 
-// Choose rows-per-wave for a launch of `pairs` pairs.
+#ifdef SKL_AB
+// pair_smem.hip (A/B build only): rows-per-wave for a launch, and the scalar-cache kernel.
 int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
-
 hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream);
+#endif
 
 // Device buffer the launchers may use for the tile-prefix table (owned by the context).
 struct TileScratch {
@@ -95,21 +96,24 @@ struct TileScratch {
 hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_group,
                       TileScratch &scratch, hipStream_t stream, uint64_t *grid_out);
 
-// LDS-staged variant (pair_lds.hip).  shape = R*10 + JL: R rows per workgroup tile, JL
-// 64-column blocks per lane; valid shapes: 41, 81, 82, 162.
+#ifdef SKL_AB
+// LDS-staged variant (pair_lds.hip, A/B build only).  shape = R*10 + JL: R rows per workgroup tile,
+// JL 64-column blocks per lane; valid shapes: 41, 81, 82, 162.
 hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, TileScratch &scratch,
                                   hipStream_t stream);
+int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
+#endif
 // K-split variant for small launches (pair_ksplit.hip): rows_per_tile in {4, 8}.
 hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_per_tile,
                                      TileScratch &scratch, hipStream_t stream);
 // Chunk-split kernel (pair_kslice.hip): R x 64*JL tiles, the 4 waves of a workgroup split the
 // chunks.  k_sliced = one workgroup per (tile, k-mer length), MODE_COUNTS / MODE_JACCARD only;
 // otherwise one workgroup walks all k-mer lengths and runs the fused epilogue.
-// shape = R*10 + JL in {81, 82, 161, 162}.
-hipError_t launch_pair_kernel_kslice(const PairArgs &args, int mode, int shape, bool k_sliced,
+// shape = R*10 + JL: 162 (16 x 128 tiles) in the product library; the A/B build also has 81, 82, 84,
+// 161, 163, 164 and the timing-only ablations (ablate != 0: outputs wrong by construction).
+hipError_t launch_pair_kernel_kslice(const PairArgs &args, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream);
 bool kslice_supported(const PairArgs &args, int mode, bool k_sliced);
-int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
 
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
 hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint32_t n,

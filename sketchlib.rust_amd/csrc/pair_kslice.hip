@@ -516,8 +516,8 @@ bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
     return mode == MODE_COUNTS || mode == MODE_JACCARD;
 }
 
-// shape = R*10 + JL; valid: 81, 82, 84, 161, 162, 163, 164
-hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shape, bool k_sliced,
+// shape = R*10 + JL; the product library has 162 only, the A/B build (-DSKL_AB) the others and the ablations
+hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream)
 {
     PairArgs args = args_in;
@@ -531,30 +531,33 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (k_sliced) n_wg *= args.k_count;
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);
+#ifdef SKL_AB
     // timing-only ablations of the sliced COUNTS kernel (outputs wrong by construction):
     // SKL_KSLICE_ABLATE = 1 no row re-reads from LDS, 2 no column reloads, 3 both
-    if (const char *e = getenv("SKL_KSLICE_ABLATE")) {
-        const int abl = atoi(e);
-        if (abl && shape == 162 && k_sliced && mode == MODE_COUNTS) {
-            const dim3 block(LANES * WAVES_PER_WG);
-            if (abl == 1) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 1>), grid, block, 0, stream, args);
-            else if (abl == 2) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 2>), grid, block, 0, stream, args);
-            else hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 3>), grid, block, 0, stream, args);
-            return hipGetLastError();
-        }
+    if (ablate && shape == 162 && k_sliced && mode == MODE_COUNTS) {
+        const dim3 block(LANES * WAVES_PER_WG);
+        if (ablate == 1) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 1>), grid, block, 0, stream, args);
+        else if (ablate == 2) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 2>), grid, block, 0, stream, args);
+        else hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 3>), grid, block, 0, stream, args);
+        return hipGetLastError();
     }
+#else
+    (void)ablate;
+#endif
 #define SKL_SHAPE(SH, RR, JJ)                                                                  \
     case SH:                                                                                   \
         return k_sliced ? launch_rjk<RR, JJ, true>(args, mode, grid, stream)                   \
                         : launch_rjk<RR, JJ, false>(args, mode, grid, stream);
     switch (shape) {
+        SKL_SHAPE(162, 16, 2)
+#ifdef SKL_AB
         SKL_SHAPE(81, 8, 1)
         SKL_SHAPE(82, 8, 2)
+        SKL_SHAPE(84, 8, 4)
         SKL_SHAPE(161, 16, 1)
-        SKL_SHAPE(162, 16, 2)
         SKL_SHAPE(163, 16, 3)
         SKL_SHAPE(164, 16, 4)
-        SKL_SHAPE(84, 8, 4)
+#endif
         default: return hipErrorInvalidValue;
     }
 #undef SKL_SHAPE

@@ -245,9 +245,11 @@ hipError_t launch_pair_kernel_ksplit(const PairArgs &args_in, int mode, int rows
     if (n_wg == 0) return hipSuccess;
     const dim3 grid((unsigned)n_wg);
     switch (rows_per_tile) {
-        case 4: return launch_r<4>(args, mode, grid, stream);
         case 8: return launch_r<8>(args, mode, grid, stream);
+#ifdef SKL_AB
+        case 4: return launch_r<4>(args, mode, grid, stream);
         case 16: return launch_r<16>(args, mode, grid, stream);
+#endif
         default: return hipErrorInvalidValue;
     }
 }

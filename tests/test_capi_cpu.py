@@ -30,6 +30,34 @@ def test_header_symbols_all_exported(skl):
     assert sorted(skl.DECLARED_SYMBOLS) == declared
 
 
+def test_product_library_has_no_ab_kernels_or_switches():
+    """The kernels kept for A/B timing (pair_lds, pair_smem, the other tile shapes of the chunk-split
+    kernel) and the timing-only ablations, whose outputs are wrong by construction, exist only in the
+    -DSKL_AB build; the product library has neither the instantiations nor the environment switches."""
+    import sketchlib.rust_amd as pkg
+
+    pkg.build_library()
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", pkg.library_path()], text=True)
+    demangled = subprocess.check_output(["c++filt"], input=syms, text=True)
+    kernels = sorted(set(re.findall(r"skl::(pair_kernel\w*<[^>]*>)", demangled)))
+    assert kernels, "no pair kernel exported?"
+    for k in kernels:
+        # chunk-split kernel: 16 x 128 tiles only, ablation parameter 0; ksplit fallback: 8-row tiles
+        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [012], (true|false), 0>|pair_kernel_ksplit<8, [012], 8, false>", k), k
+    blob = open(pkg.library_path(), "rb").read()
+    for needle in (b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
+                   b"SKL_LDS_SHAPE", b"SKL_FORCE_NA", b"SKL_PAIR_VARIANT"):
+        assert needle not in blob, needle
+    # and no getenv on the launch path: what remains is read by read_knobs(), once per context
+    src = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "capi.cpp")).read()
+    lo, hi = src.index("static long long env_int"), src.index("int forced_kernel(const skl_ctx *ctx)")
+    assert "getenv(" not in src[:lo] + src[hi:]
+    assert src.count("read_knobs()") == 3      # definition, skl_ctx_create, and the A/B build's per-launch refresh
+    for f in ("capi_knn.cpp", "capi_aux.cpp", "pair_kslice.hip", "pair_ksplit.hip", "kernels.hip", "topk.hip"):
+        text = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", f)).read()
+        assert "getenv" not in text and "env_int(" not in text, f
+
+
 def test_library_has_gfx950_code_object():
     import sketchlib.rust_amd as pkg
 

@@ -115,13 +115,16 @@ def test_large_launch_spot_checks(oracle, skl, gpu_ctx, n):
     assert np.array_equal(dj[:, 0], exp)
 
 
-def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx, monkeypatch):
-    """4.5e8 pairs into a NaN-filled device buffer, alternating the kernel implementations and
-    their tile shapes on one context: every launch must write every pair, and all of them the
-    same values.  (A per-launch tile table that was uploaded from a dying host buffer once left
-    0.6 % of a 5e9-pair launch unwritten when two tile shapes alternated; the table is now a
-    closed form evaluated on the device.)"""
+def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx):
+    """4.5e8 pairs into NaN-filled device buffers while the forms of the pair kernel alternate on ONE
+    context, as they do in a caller's process: all-k fused core/accessory, k-sliced single-k Jaccard,
+    raw counts, core/accessory over row bands small enough to run k-sliced + epilogue.  Every launch
+    must write every pair, and the banded results must equal the whole.  (A per-launch tile table that
+    was uploaded from a dying host buffer once left 0.6 % of a 5e9-pair launch unwritten when two tile
+    shapes alternated; the table is now a closed form evaluated on the device.)"""
     import torch
+
+    from sketchlib.rust_amd import multi_gpu
 
     n = 30000
     dev = torch.device("cuda", 0)
@@ -129,21 +132,29 @@ def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx, monkeypatch):
     gpu_ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     g = gpu_ctx.sketches(synth.set_u_device(n, 5, SS64, dev), n, K5, SS64)
     pairs = n * (n - 1) // 2
-    first = None
-    for env in ({}, {"SKL_KERNEL": "lds"}, {"SKL_SLICED_MAX_PAIRS": "100000000000"}, {"SKL_KERNEL": "ksplit"},
-                {"SKL_KERNEL": "lds", "SKL_LDS_SHAPE": "82"}, {}):
-        for k in ("SKL_KERNEL", "SKL_SLICED_MAX_PAIRS", "SKL_LDS_SHAPE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        out = torch.full((pairs, 2), float("nan"), dtype=torch.float32, device=dev)
-        skl.self_dists_all(gpu_ctx, g, g.set_k(), out=out)
+    whole = torch.full((pairs, 2), float("nan"), dtype=torch.float32, device=dev)
+    skl.self_dists_all(gpu_ctx, g, g.set_k(), out=whole)
+    assert "all k" in gpu_ctx.last_kernel()
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(whole).any().item())
+    seen = set()
+    for round_ in range(2):
+        jac = torch.full((pairs, 1), float("nan"), dtype=torch.float32, device=dev)
+        skl.self_dists_all(gpu_ctx, g, g.set_k(23), out=jac)
+        seen.add(gpu_ctx.last_kernel().split(" (")[0])
         torch.cuda.synchronize()
-        assert not bool(torch.isnan(out).any().item()), (env, gpu_ctx.last_kernel())
-        if first is None:
-            first = out
-        else:
-            assert bool((out == first).all().item()), (env, gpu_ctx.last_kernel())
-            del out
+        assert not bool(torch.isnan(jac).any().item()), gpu_ctx.last_kernel()
+        del jac
+        banded = torch.full((pairs, 2), float("nan"), dtype=torch.float32, device=dev)
+        for r0, r1, p0, cnt in multi_gpu.self_band_slices(n, 40):       # 1.1e7 pairs per band: k-sliced + epilogue
+            skl.self_dists_rows(gpu_ctx, g, g.set_k(), r0, r1, out=banded[p0:p0 + cnt])
+            seen.add(gpu_ctx.last_kernel().split(" (")[0])
+        again = torch.full((pairs, 2), float("nan"), dtype=torch.float32, device=dev)
+        skl.self_dists_all(gpu_ctx, g, g.set_k(), out=again)
+        seen.add(gpu_ctx.last_kernel().split(" (")[0])
+        torch.cuda.synchronize()
+        assert bool((banded == whole).all().item()) and bool((again == whole).all().item()), round_
+        del banded, again
+    assert len(seen) >= 3, seen      # COREACC all k, JACCARD k-sliced, COUNTS k-sliced
     g.close()
     gpu_ctx.set_stream(None)

@@ -1,8 +1,10 @@
-"""Every pair-kernel implementation the library ships, not only the one the dispatcher picks:
-the chunk-split kernel in both forms (k-sliced + epilogue kernel, all-k fused) and its tile
-shapes, and the A/B kernels kept behind SKL_KERNEL (lds, ksplit, smem).  The knobs are read
-once per process, so each variant runs in a child process; results must equal the oracle
-bit for bit (counts, Jaccard f32, regression outputs without completeness correction)."""
+"""Every pair-kernel implementation that is built, not only the one the dispatcher picks.  The
+PRODUCT library has the chunk-split kernel in both forms (k-sliced + epilogue kernel, all-k fused)
+and the ksplit fallback; the A/B library (`make AB=1`, -DSKL_AB; never loaded by the product) adds
+the other tile shapes and the earlier kernels behind SKL_KERNEL (lds, ksplit, smem).  The switches
+are read when a context is created, so each variant runs in a child process; results must equal the
+oracle bit for bit (counts, Jaccard f32, regression outputs) and, with a completeness correction,
+within 1e-6 on EVERY pair."""
 import os
 import subprocess
 import sys
@@ -66,22 +68,34 @@ for ani in (False, True):
 print("VARIANT_OK", ctx.last_kernel())
 """ % {"root": ROOT}
 
+AB = {"SKL_LIBRARY": os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build_ab", "libsketchlib_dist_hip.so")}
 VARIANTS = [
+    # product library
     ({}, "k-sliced"),                                              # dispatcher's choice at this size
     ({"SKL_SLICED_MAX_PAIRS": "0"}, "all k"),                      # all-k fused form
-    ({"SKL_KSLICE_SHAPE": "82"}, "R=8, JL=2"),
-    ({"SKL_KSLICE_SHAPE": "81", "SKL_SLICED_MAX_PAIRS": "0"}, "R=8, JL=1"),
-    ({"SKL_KSLICE_SHAPE": "161"}, "R=16, JL=1"),
-    ({"SKL_KERNEL": "lds"}, "pair_kernel_lds"),
-    ({"SKL_KERNEL": "lds", "SKL_LDS_SHAPE": "82"}, "pair_kernel_lds"),
-    ({"SKL_KERNEL": "ksplit"}, "pair_kernel_ksplit"),
-    ({"SKL_KERNEL": "smem"}, "pair_kernel<"),
+    # A/B library
+    ({**AB}, "k-sliced"),
+    ({**AB, "SKL_KSLICE_SHAPE": "82"}, "R=8, JL=2"),
+    ({**AB, "SKL_KSLICE_SHAPE": "81", "SKL_SLICED_MAX_PAIRS": "0"}, "R=8, JL=1"),
+    ({**AB, "SKL_KSLICE_SHAPE": "161"}, "R=16, JL=1"),
+    ({**AB, "SKL_KSLICE_SHAPE": "163"}, "R=16, JL=3"),             # packed counts, 4-deep row ring
+    ({**AB, "SKL_KSLICE_SHAPE": "163", "SKL_SLICED_MAX_PAIRS": "0"}, "R=16, JL=3"),
+    ({**AB, "SKL_KSLICE_SHAPE": "164"}, "R=16, JL=4"),
+    ({**AB, "SKL_KSLICE_SHAPE": "84", "SKL_SLICED_MAX_PAIRS": "0"}, "R=8, JL=4"),
+    ({**AB, "SKL_KERNEL": "lds"}, "pair_kernel_lds"),
+    ({**AB, "SKL_KERNEL": "lds", "SKL_LDS_SHAPE": "82"}, "pair_kernel_lds"),
+    ({**AB, "SKL_KERNEL": "ksplit"}, "pair_kernel_ksplit"),
+    ({**AB, "SKL_KERNEL": "smem"}, "pair_kernel<"),
 ]
 
 
-@pytest.mark.parametrize("env,expect", VARIANTS, ids=[",".join(f"{k}={v}" for k, v in e.items()) or "default"
-                                                      for e, _ in VARIANTS])
+@pytest.mark.parametrize("env,expect", VARIANTS,
+                         ids=[",".join("AB" if k == "SKL_LIBRARY" else f"{k}={v}" for k, v in e.items()) or "default"
+                              for e, _ in VARIANTS])
 def test_kernel_variant_parity(gpu_ctx, env, expect):
+    if "SKL_LIBRARY" in env:
+        import sketchlib.rust_amd as pkg
+        pkg.build_ab_library()
     res = subprocess.run([sys.executable, "-c", CHILD, expect], env={**os.environ, **env}, capture_output=True,
                          text=True, timeout=600)
     assert res.returncode == 0 and "VARIANT_OK" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
