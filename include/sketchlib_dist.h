@@ -81,6 +81,10 @@ int skl_ctx_set_stream(skl_ctx *ctx, void *hip_stream);
  * synchronise explicitly wants this. */
 int skl_ctx_use_default_stream(skl_ctx *ctx);
 int skl_ctx_synchronize(skl_ctx *ctx);
+/* The library's few environment switches (INTEGRATION.md "Building") are read when a context is
+ * created and never on the launch path; this re-reads them for an existing context (tests and
+ * benchmarks that compare two drivers inside one process). */
+int skl_ctx_reload_env(skl_ctx *ctx);
 /* Pair-kernel timing.  Every dense / binmatch / knn call brackets each launch of the
  * pair kernel with HIP events recorded on the context's stream.  reset() forgets them;
  * kernel_ms() synchronises and returns the summed device time and the number of

@@ -53,6 +53,7 @@ _SIG = [
     ("skl_ctx_set_stream", C.c_int, [_P, _P]),
     ("skl_ctx_use_default_stream", C.c_int, [_P]),
     ("skl_ctx_synchronize", C.c_int, [_P]),
+    ("skl_ctx_reload_env", C.c_int, [_P]),
     ("skl_ctx_timing_reset", C.c_int, [_P]),
     ("skl_ctx_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     ("skl_ctx_last_kernel", C.c_char_p, [_P]),
@@ -116,13 +117,37 @@ def load():
             import torch  # noqa: F401
         except Exception:
             pass
-        L = C.CDLL(path)
-        for name, restype, argtypes in _SIG:
-            fn = getattr(L, name)  # AttributeError if the export is missing
-            fn.restype = restype
-            fn.argtypes = argtypes
-        _lib = L
+        _lib = _open(path)
     return _lib
+
+
+def _open(path):
+    L = C.CDLL(path)
+    for name, restype, argtypes in _SIG:
+        fn = getattr(L, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return L
+
+
+class using_library:
+    """with using_library(path): ...  -- the binding calls into another build of the library (the A/B
+    build) inside the block.  Handles created inside belong to that build: close them before leaving."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        load()
+        self.saved = _lib
+        _lib = _open(self.path)
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def _check(rc):
@@ -180,6 +205,10 @@ class Context:
 
     def synchronize(self):
         _check(load().skl_ctx_synchronize(self._h))
+
+    def reload_env(self):
+        """Re-read the SKL_* environment switches (they are otherwise read when the context is created)."""
+        _check(load().skl_ctx_reload_env(self._h))
 
     def timing_reset(self):
         _check(load().skl_ctx_timing_reset(self._h))

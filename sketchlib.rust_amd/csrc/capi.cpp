@@ -197,6 +197,13 @@ extern "C" int skl_ctx_synchronize(skl_ctx *ctx)
     return SKL_OK;
 }
 
+extern "C" int skl_ctx_reload_env(skl_ctx *ctx)
+{
+    SKL_TRY(ctx_bind(ctx));
+    ctx->knobs = read_knobs();
+    return SKL_OK;
+}
+
 extern "C" const char *skl_ctx_last_kernel(skl_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
 
 extern "C" int skl_ctx_timing_reset(skl_ctx *ctx)

@@ -125,8 +125,17 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
     // blockIdx -> (XCD, tile slot on that XCD[, k-mer length]): the k slices of a tile are
     // neighbours in the per-XCD order
     const uint32_t xcd = blockIdx.x & 7u, s_idx = blockIdx.x >> 3;
+#ifdef SKL_EXP_KORDER
+    // experiment: blocks of SKL_EXP_KORDER consecutive tiles walk one k-mer length together, so that
+    // the workgroups resident on an XCD at one time share a (column group, k) plane of the lane slab
+    constexpr uint32_t KB = SKL_EXP_KORDER;
+    const uint32_t per_blk = KB * g.k_count;
+    const uint32_t slot = KSL ? (s_idx / per_blk) * KB + (s_idx % per_blk) % KB : s_idx;
+    const uint32_t kk0 = KSL ? (s_idx % per_blk) / KB : 0u;
+#else
     const uint32_t slot = KSL ? s_idx / g.k_count : s_idx;
     const uint32_t kk0 = KSL ? s_idx - slot * g.k_count : 0u;   // first k index of this workgroup
+#endif
     const uint32_t nkk = KSL ? 1u : g.k_count;                  // k-mer lengths it walks
     uint32_t jg, at;  // column group (JL blocks of 64), row tile
     if (!lookup_tile_at(g, xcd, slot, jg, at)) return;
@@ -347,6 +356,30 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
                         SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
                         b_younger = 0;
                     }
+#ifdef SKL_EXP_L2PREFETCH
+                    // experiment: touch the column lines of the chunk AFTER the next one (one dword per
+                    // 128-byte line, result never read) so that its loads find them in L2.  Issued after
+                    // row 0, when no column load is in flight: older than every load the compiler counts.
+                    if (r == 0) {
+                        uint32_t k2 = kn, c2 = cn;
+                        // position after (kn, cn) in this wave's walk
+                        {
+                            uint32_t kl2 = kn - g.k_begin - kk0, ts2 = (cn - wave * CH) / (W * CH);
+                            int ci2 = (int)((cn - wave * CH) % (W * CH));
+                            if (next_chunk(kl2, ts2, ci2, k2, c2)) {
+#pragma unroll
+                                for (int j = 0; j < JL; ++j) {
+                                    const uint32_t jb = (jb0 + j) < g.n_jblocks ? (jb0 + j) : (g.n_jblocks - 1u);
+                                    const char *line = reinterpret_cast<const char *>(
+                                        g.B + (((size_t)jb * g.nk + k2) * g.ss64 + c2) * (7 * LANES)) + (lane < 56u ? lane : 55u) * 128u;
+                                    uint32_t sink;
+                                    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(line) : "memory");
+                                }
+                                b_younger += 0;   // (hidden loads are older than the next column loads: the counted waits stay exact)
+                            }
+                        }
+                    }
+#endif
                 }
                 if constexpr (!(ABL & 2)) ++b_younger;
             }
@@ -528,6 +561,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     const hipError_t pe = plan_tiles(args, (uint32_t)R, (uint32_t)JL * 64u, scratch, stream, &n_wg);
     if (pe != hipSuccess) return pe;
     if (n_wg == 0) return hipSuccess;
+#ifdef SKL_EXP_KORDER
+    if (k_sliced) n_wg = 8ull * ((args.tiles_per_xcd + SKL_EXP_KORDER - 1) / SKL_EXP_KORDER) * SKL_EXP_KORDER;
+#endif
     if (k_sliced) n_wg *= args.k_count;
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);

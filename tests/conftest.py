@@ -35,6 +35,27 @@ def skl():
     return capi
 
 
+@pytest.fixture(autouse=True)
+def _switches_follow_the_environment(request):
+    """The library reads its SKL_* switches when a context is created; the session-wide context is
+    brought back in line with the (restored) environment after every test that changed it."""
+    yield
+    if "gpu_ctx" in request.fixturenames and "monkeypatch" in request.fixturenames:
+        request.getfixturevalue("gpu_ctx").reload_env()
+
+
+@pytest.fixture()
+def set_switch(gpu_ctx, monkeypatch):
+    """set_switch("SKL_X", "value" | None): change a library switch for the rest of this test."""
+    def _set(name, value):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(value))
+        gpu_ctx.reload_env()
+    return _set
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx(skl):
     if skl.device_count() == 0:

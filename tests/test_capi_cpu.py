@@ -52,7 +52,7 @@ def test_product_library_has_no_ab_kernels_or_switches():
     src = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "capi.cpp")).read()
     lo, hi = src.index("static long long env_int"), src.index("int forced_kernel(const skl_ctx *ctx)")
     assert "getenv(" not in src[:lo] + src[hi:]
-    assert src.count("read_knobs()") == 3      # definition, skl_ctx_create, and the A/B build's per-launch refresh
+    assert src.count("read_knobs()") == 4      # definition, skl_ctx_create, skl_ctx_reload_env, the A/B build's per-launch refresh
     for f in ("capi_knn.cpp", "capi_aux.cpp", "pair_kslice.hip", "pair_ksplit.hip", "kernels.hip", "topk.hip"):
         text = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", f)).read()
         assert "getenv" not in text and "env_int(" not in text, f

@@ -366,3 +366,31 @@ def test_short_skd_and_wrong_strides_are_refused(tmp_path):
     (tmp_path / "s.skm").write_bytes(_frame(raw.replace(key, b"\x6bkmer_stride\x18\xe1")))
     res = subprocess.run([DBTOOL, "info", str(tmp_path / "s")], capture_output=True, text=True)
     assert res.returncode > 0 and "strides" in res.stderr
+
+
+@pytest.mark.parametrize("name", ["sketches1", "sketches2", "sketches3"])
+def test_skm_writer_emits_the_reference_cbor(tmp_path, name):
+    """What our .skm writer puts inside the snappy frame is, byte for byte, the CBOR document that
+    ciborium wrote into the reference's own file (multisketch.rs:80-88): same field order, same
+    shortest-form integers, definite lengths, name_map in the file's order.  (The frames differ: the
+    reference's chunks are snappy-compressed, ours are stored -- type 0x01 -- which every framing-format
+    reader, `snap::read::FrameDecoder` included, must accept.)  The `.skm` the native sketcher writes
+    from the genomes decodes to the same document up to the order of name_map, a HashMap."""
+    src = os.path.join(REF_FIXTURES, name)
+    subprocess.check_call([DBTOOL, "unframe", src + ".skm", str(tmp_path / "ref.raw")])
+    subprocess.check_call([DBTOOL, "roundtrip", src, str(tmp_path / "copy")])
+    ours = _py_unframe((tmp_path / "copy.skm").read_bytes())
+    assert ours == (tmp_path / "ref.raw").read_bytes()
+    from test_inverted_cli_cpu import cbor_decode
+    doc, end = cbor_decode(ours)
+    assert end == len(ours) and list(doc)[:3] == ["sketch_size", "sketchsize64", "kmer_lengths"]
+    k, size = {"sketches1": ("31", "1000"), "sketches2": ("31", "10000"), "sketches3": ("21", "1000")}[name]
+    subprocess.check_call([CLI, "sketch", "-o", str(tmp_path / "fresh"), "-k", k, "-s", size, *FIXTURE_NAMES], cwd=REF_FIXTURES,
+                          stderr=subprocess.DEVNULL)
+    fresh, _ = cbor_decode(_py_unframe((tmp_path / "fresh.skm").read_bytes()))
+    assert list(fresh) == list(doc)
+    for key in doc:
+        if key == "sketch_version":
+            continue
+        assert fresh[key] == doc[key], key        # dict comparison ignores name_map's order
+    assert (tmp_path / "fresh.skd").read_bytes() == open(src + ".skd", "rb").read()

@@ -106,7 +106,8 @@ def test_cross_large_launch_ragged_tiles(oracle, skl, gpu_ctx, monkeypatch, slic
     qb = np.concatenate([synth.set_r(min(500, nq - s), kmers, ss64, n_clusters=50, first_sample=20000 + s) for s in range(0, nq, 500)])
     o_r, g_r = oracle.Sketches(rb, nr, kmers, ss64), gpu_ctx.sketches(rb, nr, kmers, ss64)
     o_q, g_q = oracle.Sketches(qb, nq, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
-    monkeypatch.setenv("SKL_SLICED_MAX_PAIRS", sliced_max)   # the knob is read on every call
+    monkeypatch.setenv("SKL_SLICED_MAX_PAIRS", sliced_max)
+    gpu_ctx.reload_env()
     got = skl.cross_dists_all(gpu_ctx, g_r, g_q, g_r.set_k())
     assert "pair_kernel_kslice" in gpu_ctx.last_kernel()
     assert ("all k" if sliced_max == "0" else "k-sliced") in gpu_ctx.last_kernel()

@@ -17,6 +17,7 @@ TOL = 1e-6
 def _knn(skl, ctx, g, p, knn, monkeypatch, band_rows, symmetric, with_d1=False):
     monkeypatch.setenv("SKL_KNN_BAND_ROWS", str(band_rows))
     monkeypatch.setenv("SKL_KNN_SYMMETRIC", "1" if symmetric else "0")
+    ctx.reload_env()
     idx, d0, d1 = skl.self_dists_knn(ctx, g, p, knn)
     return (idx, d0, d1) if with_d1 else (idx, d0)
 
@@ -116,6 +117,7 @@ def test_partial_states_of_every_rank_merge_to_the_whole(skl, gpu_ctx, monkeypat
     g = gpu_ctx.sketches(bins, n, kmers, ss64)
     p = g.set_k() if dist == "coreacc" else g.set_k(23, dist == "ani")
     monkeypatch.setenv("SKL_KNN_SYMMETRIC", "0")
+    gpu_ctx.reload_env()
     whole = skl.self_dists_knn(gpu_ctx, g, p, knn)
     n_bands = (n + band_rows - 1) // band_rows
     deal = multi_gpu.knn_band_deal(n_bands, world)
@@ -182,6 +184,7 @@ def test_streaming_merge_against_the_radix_select(oracle, skl, gpu_ctx, monkeypa
         got = {}
         for stream in ("1", "0"):
             monkeypatch.setenv("SKL_TOPK_STREAM", stream)
+            gpu_ctx.reload_env()
             got[stream] = skl.cross_dists_knn(gpu_ctx, g, q, g.set_k(21), knn)
         assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1]), name
         o_r, o_q = oracle.Sketches(bins, n, kmers, ss64), oracle.Sketches(bins[:1].copy(), 1, kmers, ss64)
@@ -244,20 +247,26 @@ def test_random_knn_configuration(oracle, skl, gpu_ctx, monkeypatch, seed):
     assert np.array_equal(runs["once"][0], runs["rows"][0]) and np.array_equal(runs["once"][0], runs["split"][0])
 
 
-@pytest.mark.parametrize("shape", ["81", "82", "161"])
+@pytest.mark.parametrize("shape", ["81", "82", "161", "163", "164"])
 def test_other_tile_shapes_turn_their_tiles_too(oracle, skl, gpu_ctx, monkeypatch, shape):
-    """The turned second store for the tile shapes that are not the default (8 rows, one column
-    block per lane), single-k and core/accessory records."""
+    """The turned second store for the tile shapes of the A/B build (8 rows, one / three / four
+    column blocks per lane), single-k and core/accessory records."""
+    import sketchlib.rust_amd as pkg
+
     kmers, ss64, n, knn = [15, 19, 23], 4, 301, 8
     bins = synth.set_r(n, kmers, ss64, n_clusters=6)
-    g = gpu_ctx.sketches(bins, n, kmers, ss64)
     o = oracle.Sketches(bins, n, kmers, ss64)
     monkeypatch.setenv("SKL_KSLICE_SHAPE", shape)
-    for p, oargs in ((g.set_k(19), (oracle.JACCARD, 1, False)), (g.set_k(), (oracle.COREACC, 0, False))):
-        idx, d0, d1 = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, 40, True, with_d1=True)
-        assert f"R={shape[:-1]}, JL={shape[-1]}" in gpu_ctx.last_kernel()
-        exp = oracle.self_dists_knn(o, knn, *oargs, ties=oracle.TIES_CANONICAL, threads=8)
-        assert np.array_equal(idx, exp["idx"])
-        np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
-        if oargs[0] == oracle.COREACC:
-            np.testing.assert_allclose(d1, exp["d1"], atol=TOL, rtol=0)
+    with skl.using_library(pkg.build_ab_library()):
+        ctx = skl.Context(0)
+        g = ctx.sketches(bins, n, kmers, ss64)
+        for p, oargs in ((g.set_k(19), (oracle.JACCARD, 1, False)), (g.set_k(), (oracle.COREACC, 0, False))):
+            idx, d0, d1 = _knn(skl, ctx, g, p, knn, monkeypatch, 40, True, with_d1=True)
+            assert f"R={shape[:-1]}, JL={shape[-1]}" in ctx.last_kernel()
+            exp = oracle.self_dists_knn(o, knn, *oargs, ties=oracle.TIES_CANONICAL, threads=8)
+            assert np.array_equal(idx, exp["idx"])
+            np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
+            if oargs[0] == oracle.COREACC:
+                np.testing.assert_allclose(d1, exp["d1"], atol=TOL, rtol=0)
+        g.close()
+        ctx.close()

@@ -122,10 +122,12 @@ def test_both_kernel_forms_and_bin_counts(skl, gpu_ctx, monkeypatch, num_bins):
     got = skl.sketch_signs(gpu_ctx, *pack(samples), kmers, num_bins, True)
     assert "lds_kernel" in gpu_ctx.last_kernel()
     monkeypatch.setenv("SKL_SKETCH_KERNEL", "global")
+    gpu_ctx.reload_env()
     ref = skl.sketch_signs(gpu_ctx, *pack(samples), kmers, num_bins, True)
     assert "lds_kernel" not in gpu_ctx.last_kernel()
     assert np.array_equal(got, ref)
     monkeypatch.delenv("SKL_SKETCH_KERNEL")
+    gpu_ctx.reload_env()
     big_k = skl.sketch_signs(gpu_ctx, *pack(samples), [130], num_bins, True)      # past the staged limit
     assert "lds_kernel" not in gpu_ctx.last_kernel()
     for s_, (codes, offsets) in enumerate(samples):
