@@ -72,10 +72,10 @@ int main(int argc, char **argv)
     hipEventRecord(e1);
     CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const int R = shape / 10, JL = shape % 10;
+    const int R = shape / 10, JL = shape == 165 ? 2 : shape % 10;
     PairArgs gp = g; uint64_t n_wg = 0;
     CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
-    n_wg *= nk;
+    n_wg = 8ull * ((gp.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * nk;   // as launch_pair_kernel_kslice pads it
     const int wpw = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
     const size_t n_waves = n_wg * wpw;
     fprintf(stderr, "n_wg %llu\n", (unsigned long long)n_wg);
@@ -163,7 +163,7 @@ int main(int argc, char **argv)
             const size_t wg = w / wpw_;
             auto add = [&](std::map<int, std::pair<double, int>> &m, int key) { m[key].first += st; m[key].second++; };
             add(by_xcc, (int)xcc);
-            add(by_k, (int)((wg >> 3) % nk));
+            add(by_k, (int)(((wg >> 3) % (KSL_TILE_BLOCK * nk)) / KSL_TILE_BLOCK));
             add(by_wave, (int)(w % wpw_));
             add(by_se, (int)((hw >> 13) & 0x7));
         }

@@ -115,6 +115,36 @@ KERNEL_D(k_bitop_d3, 0, 1, 2, 0, 1, 2, 0, 1)
 KERNEL_D(k_bitop_d4, 0, 1, 2, 3, 0, 1, 2, 3)
 KERNEL_D(k_bitop_pairs, 0, 0, 1, 1, 2, 2, 3, 3)   // the compiler's order in the pair kernel: dependent pairs back to back
 
+// does a non-VALU instruction between VALU instructions cost the SIMD an issue slot?  The same 64
+// v_bitop3 per iteration with one extra instruction after every 4th (16 per iteration)
+#define I_BITOP_X(i, EXTRA) "v_bitop3_b32 %" #i ", %10, %9, %" #i " bitop3:0xbe\n" EXTRA
+#define KERNEL_X(NAME, EXTRA)                                                                     \
+    __global__ __launch_bounds__(256) void NAME(Stamp *stamps, uint32_t *sink, uint32_t sa_in, int iters) \
+    {                                                                                             \
+        uint32_t m[8];                                                                            \
+        for (int i = 0; i < 8; ++i) m[i] = threadIdx.x * 2654435761u + i;                         \
+        uint32_t sa = __builtin_amdgcn_readfirstlane(sa_in);                                      \
+        uint32_t vb = threadIdx.x ^ 0x5bd1e995u, vc = threadIdx.x * 7u + 3u;                      \
+        uint64_t t0, r0;                                                                          \
+        stamp_begin(t0, r0);                                                                      \
+        for (int it = 0; it < iters; ++it) {                                                      \
+            REP8(asm volatile(I_BITOP_X(0, "") I_BITOP_X(1, "") I_BITOP_X(2, "") I_BITOP_X(3, EXTRA)      \
+                              I_BITOP_X(4, "") I_BITOP_X(5, "") I_BITOP_X(6, "") I_BITOP_X(7, EXTRA)      \
+                              : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), \
+                                "+v"(m[6]), "+v"(m[7])                                            \
+                              : "s"(sa), "v"(vb), "v"(vc));)                                      \
+        }                                                                                         \
+        stamp_end(stamps, t0, r0);                                                                \
+        uint32_t r = 0;                                                                           \
+        for (int i = 0; i < 8; ++i) r ^= m[i];                                                    \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = r;                                          \
+    }
+KERNEL_X(k_x_none, "")
+KERNEL_X(k_x_waitcnt, "s_waitcnt lgkmcnt(0)\n")
+KERNEL_X(k_x_nop, "s_nop 0\n")
+KERNEL_X(k_x_salu, "s_add_u32 s40, s40, 1\n")
+KERNEL_X(k_x_vmov, "v_mov_b32 v60, v61\n")
+
 // ---- part 2: the pair kernel's inner loop, operands already on chip ----
 __device__ __forceinline__ uint32_t bitop_vvv(uint32_t m, uint32_t a, uint32_t b)
 {
@@ -294,7 +324,9 @@ int main(int argc, char **argv)
         {"v_or3_b32 v,v,v,v", k_or3},
         {"v_bitop3 dep. distance 1", k_bitop_d1}, {"v_bitop3 dep. distance 2", k_bitop_d2},
         {"v_bitop3 dep. distance 3", k_bitop_d3}, {"v_bitop3 dep. distance 4", k_bitop_d4},
-        {"v_bitop3 dependent pairs", k_bitop_pairs}};
+        {"v_bitop3 dependent pairs", k_bitop_pairs},
+        {"64 bitop3 (reference)", k_x_none}, {"64 bitop3 + 16 s_waitcnt", k_x_waitcnt}, {"64 bitop3 + 16 s_nop", k_x_nop},
+        {"64 bitop3 + 16 s_add_u32", k_x_salu}, {"64 bitop3 + 16 v_mov_b32", k_x_vmov}};
     const int iters = 20000;
     for (auto &kk : ks) {
         for (int w : {1, 2, 3, 4}) {

@@ -11,21 +11,21 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("SKL_LIBRARY", os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build_ab", "libsketchlib_dist_hip.so"))
 from sketchlib.rust_amd import capi, synth  # noqa: E402
 
-shapes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "163,164,84").split(",")]
+shapes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "162,163,164,84,82,161").split(",")]
 ok = True
 for (n, ss64, kmers) in [(1000, 64, [15, 19, 23, 27, 31]), (777, 32, [13, 17, 21, 25, 29]), (2500, 5, [15, 19, 23])]:
     bins = synth.set_r(n, kmers, ss64, n_clusters=max(2, n // 40))
     ctx = capi.Context(0)
     g = ctx.sketches(bins, n, kmers, ss64)
     ref = {}
-    for shape in [162] + shapes:
+    for shape in [165] + shapes:
         os.environ["SKL_KSLICE_SHAPE"] = str(shape)
         for sliced in ("0", str(1 << 40)):
             os.environ["SKL_SLICED_MAX_PAIRS"] = sliced
             got = (capi.self_binmatch(ctx, g), capi.self_dists_all(ctx, g, g.set_k()),
                    capi.self_dists_all(ctx, g, g.set_k(kmers[1])))
             kern = ctx.last_kernel()
-            if shape == 162 and sliced == "0":
+            if shape == 165 and sliced == "0":
                 ref = got
             same = all(np.array_equal(a, b) for a, b in zip(got, ref))
             ok &= same

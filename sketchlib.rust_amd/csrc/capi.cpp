@@ -286,7 +286,9 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args, int m
     const uint64_t rows = args.row_end - args.row_begin;
     const uint64_t pairs = args.self_mode ? rows * args.nB / 2 : rows * (uint64_t)args.nB;
     const bool small = pairs < (8ull << 20);
-    int shape = 162, ksplit_rows = 8;   // 8 >= 4 rows from n = 1000 up once XCDs are balanced
+    // 165 = 16 x 128 tiles in the 128-register form (4 waves per SIMD): +3.5 % at n = 16 000 over the
+    // 141-register form 162 (3 waves), equal at n = 1 000 (profiles/r02_ab_tight.jsonl)
+    int shape = 165, ksplit_rows = 8;   // 8 >= 4 rows from n = 1000 up once XCDs are balanced
 #ifdef SKL_AB
     const Knobs &kn = ctx->knobs;
     if (kn.kslice_shape) shape = kn.kslice_shape;
@@ -313,9 +315,10 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args, int m
         // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
         const bool sliced = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
         if (kslice_supported(args, mode, sliced)) {
-            *name = "skl::pair_kernel_kslice<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(shape % 10) +
-                    ", " + m + (sliced ? ", k-sliced" : ", all k") + "> (" + std::to_string(shape / 10) + "x" +
-                    std::to_string((shape % 10) * 64) + " tiles, chunks split over 4 waves)";
+            const int jl = shape == 165 ? 2 : shape % 10;
+            *name = "skl::pair_kernel_kslice<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(jl) +
+                    ", " + m + (sliced ? ", k-sliced" : ", all k") + (shape == 165 ? ", tight" : "") + "> (" +
+                    std::to_string(shape / 10) + "x" + std::to_string(jl * 64) + " tiles, chunks split over 4 waves)";
             return launch_pair_kernel_kslice(args, mode, shape, sliced, ablate, tiles, stream);
         }
     }

@@ -109,8 +109,9 @@ hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_pe
 // Chunk-split kernel (pair_kslice.hip): R x 64*JL tiles, the 4 waves of a workgroup split the
 // chunks.  k_sliced = one workgroup per (tile, k-mer length), MODE_COUNTS / MODE_JACCARD only;
 // otherwise one workgroup walks all k-mer lengths and runs the fused epilogue.
-// shape = R*10 + JL: 162 (16 x 128 tiles) in the product library; the A/B build also has 81, 82, 84,
-// 161, 163, 164 and the timing-only ablations (ablate != 0: outputs wrong by construction).
+// shape: 165 (16 x 128 tiles, the 128-register form) in the product library; the A/B build also has
+// R*10 + JL = 81, 82, 84, 161, 162, 163, 164 and the timing-only ablations (ablate != 0: outputs wrong
+// by construction).
 hipError_t launch_pair_kernel_kslice(const PairArgs &args, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream);
 bool kslice_supported(const PairArgs &args, int mode, bool k_sliced);

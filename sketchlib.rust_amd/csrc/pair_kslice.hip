@@ -32,6 +32,8 @@
 
 namespace skl {
 
+constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk a k-mer length together
+
 // 16 bytes per lane, global -> LDS, no VGPR destination (global_load_lds_dwordx4): lane l's
 // 16 bytes land at LDS byte address m0 + 16*l.  Issued through inline asm ON PURPOSE: the
 // compiler treats the builtin form as an LDS write it cannot disambiguate and puts
@@ -84,9 +86,10 @@ __device__ __forceinline__ uint32_t skl_lds_addr(const void *p)
 #define SKL_TRACE_MARK(SLOT) do { } while (0)
 #endif
 
-// (3 columns per lane: the register allocator is held to 3 waves per SIMD, 168 VGPRs)
-template <int R, int JL, int MODE, bool KSL, int ABL = 0>
-__global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_kernel_kslice(const PairArgs g)
+// (3 columns per lane: the register allocator is held to 3 waves per SIMD, 168 VGPRs.  TIGHT: the
+// 2-column form squeezed into 128 VGPRs -- packed counts, 4-deep row ring -- for 4 waves per SIMD.)
+template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false>
+__global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1)) void pair_kernel_kslice(const PairArgs g)
 {
     constexpr int W = WAVES_PER_WG;
     constexpr int CH = 2;                         // chunks per wave per stage
@@ -125,17 +128,14 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
     // blockIdx -> (XCD, tile slot on that XCD[, k-mer length]): the k slices of a tile are
     // neighbours in the per-XCD order
     const uint32_t xcd = blockIdx.x & 7u, s_idx = blockIdx.x >> 3;
-#ifdef SKL_EXP_KORDER
-    // experiment: blocks of SKL_EXP_KORDER consecutive tiles walk one k-mer length together, so that
-    // the workgroups resident on an XCD at one time share a (column group, k) plane of the lane slab
-    constexpr uint32_t KB = SKL_EXP_KORDER;
+    // k-sliced: blocks of KSL_TILE_BLOCK consecutive tiles of an XCD walk one k-mer length together
+    // (tile index fastest, then k, then block), so that the workgroups resident on an XCD at one time
+    // share a (column group, k) plane of the lane slab in its L2: 2 % at n = 4 000 ... 8 000 against
+    // k fastest (profiles/r02_ab_korder_l2prefetch.jsonl)
+    constexpr uint32_t KB = KSL_TILE_BLOCK;
     const uint32_t per_blk = KB * g.k_count;
     const uint32_t slot = KSL ? (s_idx / per_blk) * KB + (s_idx % per_blk) % KB : s_idx;
-    const uint32_t kk0 = KSL ? (s_idx % per_blk) / KB : 0u;
-#else
-    const uint32_t slot = KSL ? s_idx / g.k_count : s_idx;
-    const uint32_t kk0 = KSL ? s_idx - slot * g.k_count : 0u;   // first k index of this workgroup
-#endif
+    const uint32_t kk0 = KSL ? (s_idx % per_blk) / KB : 0u;   // first k index of this workgroup
     const uint32_t nkk = KSL ? 1u : g.k_count;                  // k-mer lengths it walks
     uint32_t jg, at;  // column group (JL blocks of 64), row tile
     if (!lookup_tile_at(g, xcd, slot, jg, at)) return;
@@ -156,21 +156,27 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
     // per SIMD: columns 0 and 1 of a row then share one register as u16 fields (a wave's share of
     // one k-mer length is at most 64 * 256 mismatches per pair: kslice_supported) and column 2 has
     // its own -- 2 R registers instead of 3 R, for one v_lshl_add_u32 more per (row, chunk).
-    constexpr bool PACK01 = JL == 3;
-    constexpr int NCNT = PACK01 ? 2 * R : P;
+    static_assert(!TIGHT || JL == 2, "the tight form exists for 2 columns per lane");
+    constexpr bool PACK01 = JL == 3 || TIGHT;
+    constexpr int NCNT = PACK01 ? (JL == 3 ? 2 * R : R) : P;
     uint32_t cnt[NCNT];
 #pragma unroll
     for (int x = 0; x < NCNT; ++x) cnt[x] = 0;
     // packed word x (two u16 fields) of the per-k reduction, and the pair its field h stands for
     auto packed_word = [&](int x) -> uint32_t {
-        if constexpr (PACK01) {
+        if constexpr (PACK01 && JL == 2) {
+            return cnt[x];
+        } else if constexpr (PACK01) {
             return x < R ? cnt[x] : (cnt[R + 2 * (x - R)] | (cnt[R + 2 * (x - R) + 1] << 16));
         } else {
             return cnt[2 * x] | (cnt[2 * x + 1] << 16);
         }
     };
     auto field_pair = [](uint32_t x, uint32_t h, uint32_t &r, uint32_t &j) {
-        if constexpr (PACK01) {
+        if constexpr (PACK01 && JL == 2) {
+            r = x;
+            j = h;
+        } else if constexpr (PACK01) {
             if (x < (uint32_t)R) {
                 r = x;
                 j = h;
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
                 // rows[s]; right after its use the register is re-loaded with step s + AD.  AD = 7
                 // (a whole row ahead) with up to 2 columns per lane; 4 with 3 or more, where a step
                 // is 12+ VALU instructions long and the 12 registers decide the occupancy.
-                constexpr int AD = JL >= 3 ? 4 : 7;
+                constexpr int AD = (JL >= 3 || TIGHT) ? 4 : 7;
                 uint4 a[AD];
 #pragma unroll
                 for (int q = 0; q < AD; ++q) a[q] = rows[q];
@@ -343,8 +349,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
                         asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(t1) : "v"(mlo[1]));
                         asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(t1) : "v"(mhi[1]));
                         cnt[r] = (t1 << 16) + cnt[r];   // v_lshl_add_u32
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mlo[2]));
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mhi[2]));
+                        if constexpr (JL == 3) {
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mlo[2]));
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mhi[2]));
+                        }
                     } else {
 #pragma unroll
                         for (int j = 0; j < JL; ++j) {
@@ -356,30 +364,6 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
                         SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
                         b_younger = 0;
                     }
-#ifdef SKL_EXP_L2PREFETCH
-                    // experiment: touch the column lines of the chunk AFTER the next one (one dword per
-                    // 128-byte line, result never read) so that its loads find them in L2.  Issued after
-                    // row 0, when no column load is in flight: older than every load the compiler counts.
-                    if (r == 0) {
-                        uint32_t k2 = kn, c2 = cn;
-                        // position after (kn, cn) in this wave's walk
-                        {
-                            uint32_t kl2 = kn - g.k_begin - kk0, ts2 = (cn - wave * CH) / (W * CH);
-                            int ci2 = (int)((cn - wave * CH) % (W * CH));
-                            if (next_chunk(kl2, ts2, ci2, k2, c2)) {
-#pragma unroll
-                                for (int j = 0; j < JL; ++j) {
-                                    const uint32_t jb = (jb0 + j) < g.n_jblocks ? (jb0 + j) : (g.n_jblocks - 1u);
-                                    const char *line = reinterpret_cast<const char *>(
-                                        g.B + (((size_t)jb * g.nk + k2) * g.ss64 + c2) * (7 * LANES)) + (lane < 56u ? lane : 55u) * 128u;
-                                    uint32_t sink;
-                                    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(line) : "memory");
-                                }
-                                b_younger += 0;   // (hidden loads are older than the next column loads: the counted waits stay exact)
-                            }
-                        }
-                    }
-#endif
                 }
                 if constexpr (!(ABL & 2)) ++b_younger;
             }
@@ -520,20 +504,20 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, JL == 3 ? 3 : 1) void pair_ker
     SKL_TRACE_MARK(3);
 }
 
-template <int R, int JL, bool KSL>
+template <int R, int JL, bool KSL, bool TIGHT = false>
 static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
 {
     const dim3 block(LANES * WAVES_PER_WG);
     switch (mode) {
         case MODE_COUNTS:
-            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL, 0, TIGHT>), grid, block, 0, stream, args);
             break;
         case MODE_JACCARD:
-            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, KSL>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, KSL, 0, TIGHT>), grid, block, 0, stream, args);
             break;
         case MODE_COREACC:
             if constexpr (!KSL) {
-                hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COREACC, false>), grid, block, 0, stream, args);
+                hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COREACC, false, 0, TIGHT>), grid, block, 0, stream, args);
                 break;
             }
             return hipErrorInvalidValue;
@@ -549,28 +533,27 @@ bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
     return mode == MODE_COUNTS || mode == MODE_JACCARD;
 }
 
-// shape = R*10 + JL; the product library has 162 only, the A/B build (-DSKL_AB) the others and the ablations
+// shape = R*10 + JL, or 165 = the tight form of 16 x 128 (the product library's only shape); the A/B
+// build (-DSKL_AB) has the others and the ablations
 hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream)
 {
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     if (!kslice_supported(args, mode, k_sliced)) return hipErrorInvalidValue;
-    const int R = shape / 10, JL = shape % 10;
+    const int R = shape / 10, JL = shape == 165 ? 2 : shape % 10;   // 165: the tight 16 x 128 form
     uint64_t n_wg = 0;
     const hipError_t pe = plan_tiles(args, (uint32_t)R, (uint32_t)JL * 64u, scratch, stream, &n_wg);
     if (pe != hipSuccess) return pe;
     if (n_wg == 0) return hipSuccess;
-#ifdef SKL_EXP_KORDER
-    if (k_sliced) n_wg = 8ull * ((args.tiles_per_xcd + SKL_EXP_KORDER - 1) / SKL_EXP_KORDER) * SKL_EXP_KORDER;
-#endif
-    if (k_sliced) n_wg *= args.k_count;
+    // k-sliced: whole blocks of KSL_TILE_BLOCK tile slots per XCD (slots past the last tile exit at once)
+    if (k_sliced) n_wg = 8ull * ((args.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * args.k_count;
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);
 #ifdef SKL_AB
     // timing-only ablations of the sliced COUNTS kernel (outputs wrong by construction):
     // SKL_KSLICE_ABLATE = 1 no row re-reads from LDS, 2 no column reloads, 3 both
-    if (ablate && shape == 162 && k_sliced && mode == MODE_COUNTS) {
+    if (ablate && (shape == 162 || shape == 165) && k_sliced && mode == MODE_COUNTS) {
         const dim3 block(LANES * WAVES_PER_WG);
         if (ablate == 1) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 1>), grid, block, 0, stream, args);
         else if (ablate == 2) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 2>), grid, block, 0, stream, args);
@@ -585,8 +568,11 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         return k_sliced ? launch_rjk<RR, JJ, true>(args, mode, grid, stream)                   \
                         : launch_rjk<RR, JJ, false>(args, mode, grid, stream);
     switch (shape) {
-        SKL_SHAPE(162, 16, 2)
+        case 165:   // the product shape: 16 x 128 tiles, 128 VGPRs
+            return k_sliced ? launch_rjk<16, 2, true, true>(args, mode, grid, stream)
+                            : launch_rjk<16, 2, false, true>(args, mode, grid, stream);
 #ifdef SKL_AB
+        SKL_SHAPE(162, 16, 2)
         SKL_SHAPE(81, 8, 1)
         SKL_SHAPE(82, 8, 2)
         SKL_SHAPE(84, 8, 4)

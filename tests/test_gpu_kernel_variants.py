@@ -75,6 +75,8 @@ VARIANTS = [
     ({"SKL_SLICED_MAX_PAIRS": "0"}, "all k"),                      # all-k fused form
     # A/B library
     ({**AB}, "k-sliced"),
+    ({**AB, "SKL_KSLICE_SHAPE": "162"}, "R=16, JL=2, COUNTS, k-sliced>"),   # the 141-register form
+    ({**AB, "SKL_KSLICE_SHAPE": "162", "SKL_SLICED_MAX_PAIRS": "0"}, "R=16, JL=2, COREACC, all k>"),
     ({**AB, "SKL_KSLICE_SHAPE": "82"}, "R=8, JL=2"),
     ({**AB, "SKL_KSLICE_SHAPE": "81", "SKL_SLICED_MAX_PAIRS": "0"}, "R=8, JL=1"),
     ({**AB, "SKL_KSLICE_SHAPE": "161"}, "R=16, JL=1"),
