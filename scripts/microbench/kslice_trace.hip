@@ -46,12 +46,13 @@ int main(int argc, char **argv)
     fprintf(stderr, "relayout done\n");
     const uint64_t pairs = (uint64_t)n * (n - 1) / 2;
     uint32_t *dOut;
-    CK(hipMalloc(&dOut, pairs * nk * 4));
+    CK(hipMalloc(&dOut, pairs * nk * 4 * (argc > 5 ? (size_t)atoi(argv[5]) : 1)));
     PairArgs g;
     memset(&g, 0, sizeof g);
     g.A = dA; g.B = dB; g.nA = n; g.nB = n; g.nk = nk; g.ss64 = ss64;
     g.k_begin = 0; g.k_count = nk; g.row_begin = 0; g.row_end = n - 1; g.self_mode = 1;
     g.out_base = 0; g.out = dOut; g.cnt_pair_stride = 1; g.cnt_k_stride = pairs;
+    g.k_slices = argc > 5 ? (uint32_t)atoi(argv[5]) : 1u;
     uint64_t *dTrace;
     const size_t trace_words = (size_t)TW << 20;   // up to 1 M waves
     CK(hipMalloc(&dTrace, trace_words * 8));
@@ -62,6 +63,8 @@ int main(int argc, char **argv)
     // argv[4]: untimed launches before the traced one (the clock settles under sustained load)
     const int warm = argc > 4 ? atoi(argv[4]) : 3;
     const int ablate = getenv("SKL_KSLICE_ABLATE") ? atoi(getenv("SKL_KSLICE_ABLATE")) : 0;
+    // argv[5]: chunk slices per k-mer length (k_slices of the k-sliced COUNTS launch)
+    const uint32_t slices = argc > 5 ? (uint32_t)atoi(argv[5]) : 1u;
     for (int i = 0; i < warm; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
     CK(hipDeviceSynchronize());
     fprintf(stderr, "warm done\n");
@@ -75,7 +78,7 @@ int main(int argc, char **argv)
     const int R = shape / 10, JL = shape == 165 ? 2 : shape % 10;
     PairArgs gp = g; uint64_t n_wg = 0;
     CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
-    n_wg = 8ull * ((gp.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * nk;   // as launch_pair_kernel_kslice pads it
+    n_wg = 8ull * ((gp.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * nk * slices;   // as launch_pair_kernel_kslice pads it
     const int wpw = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
     const size_t n_waves = n_wg * wpw;
     fprintf(stderr, "n_wg %llu\n", (unsigned long long)n_wg);
@@ -105,7 +108,7 @@ int main(int argc, char **argv)
         std::sort(clk.begin(), clk.end());
         std::sort(cyc.begin(), cyc.end());
         // one wave of a k-sliced workgroup: ss64 / 4 chunks x R rows x JL columns x (28 + 2 half-rate) = 32 issue slots each
-        const double slots = (double)(ss64 / 4) * R * JL * 32.0;
+        const double slots = (double)(ss64 / 4 / slices) * R * JL * 32.0;
         printf("  in-kernel clock while streaming: p10 %.3f median %.3f p90 %.3f GHz; streaming phase of a wave: median %.0f cycles = %.2f cycles per issue slot per wave (%.0f slots)\n",
                clk[clk.size() / 10], clk[clk.size() / 2], clk[clk.size() * 9 / 10], cyc[cyc.size() / 2],
                cyc[cyc.size() / 2] / slots, slots);

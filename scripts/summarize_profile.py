@@ -27,8 +27,11 @@ for log in ("bench_stats.log",):
                 print("bench line (under the profiler):")
                 print(f"- workload: {d['config']['workload']}")
                 print(f"- value: {d['value']:.4g} {d['unit']}, ms_per_step {d['ms_per_step']:.4f}")
-                print(f"- roofline (live HIP events): kernel_avg_ms {d['roofline']['kernel_avg_ms']:.4f}, "
-                      f"achieved {d['roofline']['achieved']:.1f} GB/s, frac {d['roofline']['frac']:.3f}\n")
+                rf = d["roofline"]
+                print(f"- roofline (live HIP events): kernel_avg_ms {rf['kernel_avg_ms']:.4f} over {rf['kernel_launches_timed']} "
+                      f"launches; bound {rf['bound']}: achieved {rf['achieved']:.2f} of {rf['peak']:.2f} {rf['unit']}, "
+                      f"frac {rf['frac']:.3f}; no-reuse HBM model: {rf['hbm_no_reuse']['achieved_GBs']:.0f} GB/s "
+                      f"(reuse factor {rf['hbm_no_reuse']['reuse_factor']:.1f})\n")
 
 st = find("stats", "*kernel_stats.csv")
 if st:
@@ -44,7 +47,7 @@ print("## PMC (per launch, pair kernel only)\n")
 print("| counter | launches | mean per launch |")
 print("|---|---|---|")
 vals = {}
-for sub in ("fetch", "write", "sq", "tcc"):
+for sub in ("fetch", "write", "sq", "tcc", "stall_a", "stall_b"):
     f = find(sub, "*counter_collection.csv")
     if not f:
         continue

@@ -118,6 +118,10 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
     skl_ctx *ctx = new skl_ctx();
     ctx->device = device;
     ctx->knobs = read_knobs();
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    }
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -243,6 +247,7 @@ Knobs read_knobs()
     k.timing_every = std::max(1ll, env_int("SKL_TIMING_EVERY", 1));
     k.sliced_max_pairs = env_int("SKL_SLICED_MAX_PAIRS", -1);
     k.knn_band_rows = std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));
+    k.k_slices = (int)env_int("SKL_K_SLICES", 0);
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
@@ -743,6 +748,20 @@ static uint64_t self_rows_pairs(uint64_t r0, uint64_t r1, uint64_t n)
 }
 
 
+// k-sliced core/accessory launches: into how many chunk slices to cut each k-mer length (the kernel
+// then runs one workgroup per (tile, k, slice) and the epilogue sums the partial counts).  Default: 1.
+// Measured on MI355X (profiles/r02_k_slices_experiment.txt): at BASELINE's 1 000 genomes -- 1 400
+// whole-k workgroups on 1 024 resident slots, 1.37 rounds that cost 2 -- 2 slices keep every SIMD at 4
+// waves for 100 of 163 us instead of 60 of 157 us, but each workgroup pays its fixed 7 + 2 us (first
+// row DMA under load, reduction and stores) on half the work, and the launch ends at the same time
+// (0.1601 vs 0.1600 ms per step); 4 slices are 3 % slower, and from n = 1 400 up slices only cost.
+// SKL_K_SLICES forces a value (tests keep the sliced form bit-exact; A/B runs).
+static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
+{
+    const uint32_t S = ctx->knobs.k_slices > 0 ? (uint32_t)ctx->knobs.k_slices : 1u;
+    return (S == 1 || ((S == 2 || S == 4 || S == 8) && ss64 % (8 * S) == 0)) ? S : 1u;
+}
+
 // Core of every dense call: rows [r0, r1) of the pair space into `dst` (device).
 // elem_bytes is the output record size per pair.
 int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
@@ -763,11 +782,13 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         PairArgs g;
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
         void *counts = nullptr;
-        SKL_TRY(ctx_scratch(ctx, pairs * rows->nk * sizeof(uint32_t), &counts, 1));
-        if (sliced) {   // k-major scratch: coalesced stores from the (tile, k) workgroups
+        const uint32_t k_slices = sliced ? choose_k_slices(ctx, rows->ss64) : 1u;
+        SKL_TRY(ctx_scratch(ctx, pairs * rows->nk * k_slices * sizeof(uint32_t), &counts, 1));
+        if (sliced) {   // k-major scratch: coalesced stores from the (tile, k[, chunk slice]) workgroups
             g.cnt_pair_stride = 1;
             g.cnt_k_stride = pairs;
             g.k_sliced = 1;
+            g.k_slices = k_slices;
         }
         g.row_begin = (uint32_t)r0;
         g.row_end = (uint32_t)r1;
@@ -784,6 +805,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.n_pairs = pairs;
         e.nk = (uint32_t)rows->nk;
         e.ss64 = (uint32_t)rows->ss64;
+        e.n_slices = k_slices;
         e.nA_rows = (uint32_t)rows->n;
         e.nB_cols = (uint32_t)cols->n;
         e.row_begin = (uint32_t)r0;

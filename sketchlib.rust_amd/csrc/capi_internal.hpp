@@ -45,6 +45,7 @@ struct Knobs {
     long long timing_every = 1;       // SKL_TIMING_EVERY: bracket every N-th pair-kernel launch with events
     long long sliced_max_pairs = -1;  // SKL_SLICED_MAX_PAIRS: core/acc launches below this run k-sliced (-1: default)
     long long knn_band_rows = 0;      // SKL_KNN_BAND_ROWS: force the band height of the kNN drivers (tests)
+    int k_slices = 0;                 // SKL_K_SLICES: chunk slices per k of k-sliced core/acc launches (0: chosen per launch)
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
@@ -61,6 +62,7 @@ SKL_INTERNAL Knobs read_knobs();
 
 struct skl_ctx {
     int device = 0;
+    int n_cu = 256;                     // compute units of the device (MI355X: 256)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only scratch

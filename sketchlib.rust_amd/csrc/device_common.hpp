@@ -139,13 +139,14 @@ __device__ __forceinline__ uint64_t pair_out_index(const PairArgs &g, uint32_t i
            g.out_base;
 }
 
-// MODE_COUNTS: samebits of k index kk (jaccard.rs:15-25)
+// MODE_COUNTS: samebits of k index kk (jaccard.rs:15-25) over `bins` bins (the whole sketch, or one
+// chunk slice of it: pair_kslice.hip, k_slices)
 __device__ __forceinline__ void store_count(const PairArgs &g, uint32_t i, uint32_t jcol,
-                                            uint32_t kk, uint32_t mismatches)
+                                            uint32_t kk, uint32_t bins, uint32_t mismatches)
 {
     if (pair_valid(g, i, jcol)) {
         ((uint32_t *)g.out)[pair_out_index(g, i, jcol) * g.cnt_pair_stride + kk * g.cnt_k_stride] =
-            g.ss64 * 64u - mismatches;
+            bins - mismatches;
     }
 }
 

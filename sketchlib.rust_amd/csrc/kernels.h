@@ -56,6 +56,8 @@ struct PairArgs {
     // ([pair][k] for the public bin-match calls, k-major for the internal counts scratch)
     uint64_t cnt_pair_stride, cnt_k_stride;
     uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
+    uint32_t k_slices;            // k-sliced MODE_COUNTS: chunk slices per k-mer length (0/1: none); slice s of k index kk
+                                  // stores the matches of ITS bins at "k index" s * k_count + kk
     // Symmetric self kNN (pair_kslice.hip: k-sliced MODE_JACCARD and all-k MODE_COREACC): besides
     // out, the record of (row i, column j >= t_col_begin) also goes to record
     // (j - t_col_begin) * t_stride + (i - row_begin) of out_t, i.e. as a candidate of row j.
@@ -126,6 +128,7 @@ struct EpilogueArgs {
     uint64_t pair_stride, k_stride;
     uint64_t n_pairs;
     uint32_t nk, ss64;
+    uint32_t n_slices;          // counts come in this many chunk slices per k (k index s * nk + t): summed here
     uint32_t nA_rows, nB_cols;  // to recover (i, j) for completeness lookups
     uint32_t row_begin;
     uint32_t self_mode;

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
     double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
     const uint32_t *cnt = g.counts + p * g.pair_stride;
     for (uint32_t t = 0; t < g.nk; ++t) {
-        const uint32_t same = cnt[t * g.k_stride];
+        uint32_t same = cnt[t * g.k_stride];
+        for (uint32_t sl = 1; sl < g.n_slices; ++sl) same += cnt[((uint64_t)sl * g.nk + t) * g.k_stride];
         double y;
         if (!g.has_comp) {
             y = g.ytab[same <= maxnbits ? same : maxnbits];

@@ -133,10 +133,18 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
     // share a (column group, k) plane of the lane slab in its L2: 2 % at n = 4 000 ... 8 000 against
     // k fastest (profiles/r02_ab_korder_l2prefetch.jsonl)
     constexpr uint32_t KB = KSL_TILE_BLOCK;
-    const uint32_t per_blk = KB * g.k_count;
+    // (MODE_COUNTS launches may also cut a k-mer length into g.k_slices chunk ranges, one workgroup
+    // each -- more, shorter workgroups for launches that would otherwise fill the chip 1.4 times;
+    // slice s of k index kk stores its counts as "k index" s * k_count + kk, summed by the epilogue)
+    const uint32_t n_slices = KSL && MODE == MODE_COUNTS ? g.k_slices : 1u;
+    const uint32_t per_blk = KB * g.k_count * n_slices;
     const uint32_t slot = KSL ? (s_idx / per_blk) * KB + (s_idx % per_blk) % KB : s_idx;
-    const uint32_t kk0 = KSL ? (s_idx % per_blk) / KB : 0u;   // first k index of this workgroup
+    const uint32_t kslot = KSL ? (s_idx % per_blk) / KB : 0u;
+    const uint32_t kk0 = kslot / n_slices;                      // first k index of this workgroup
+    const uint32_t slice = kslot - kk0 * n_slices;
     const uint32_t nkk = KSL ? 1u : g.k_count;                  // k-mer lengths it walks
+    const uint32_t c_begin = slice * (g.ss64 / n_slices);       // chunk range of this workgroup
+    const uint32_t c_end = n_slices > 1u ? c_begin + g.ss64 / n_slices : g.ss64;
     uint32_t jg, at;  // column group (JL blocks of 64), row tile
     if (!lookup_tile_at(g, xcd, slot, jg, at)) return;
     const uint32_t jb0 = jg * JL;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
     const size_t kmer_stride = (size_t)g.ss64 * BBITS;
     const size_t sample_stride = kmer_stride * g.nk;
     // wave w owns chunks w*CH + i + ts*(W*CH), i < CH, of every k-mer length
-    const uint32_t stages_per_k = (g.ss64 + W * CH - 1) / (W * CH);
+    const uint32_t stages_per_k = (c_end - c_begin + W * CH - 1) / (W * CH);
     const uint32_t n_stages = stages_per_k * nkk;
 
     // This wave's partial mismatch counts of the current k (its chunks only).  One register per
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
 #define SKL_STAGE_DMA(T, BUF)                                                                \
     do {                                                                                     \
         const uint32_t k_ = g.k_begin + kk0 + (T) / stages_per_k;                            \
-        const uint32_t c0_ = ((T) % stages_per_k) * (W * CH) + wave * CH;                    \
+        const uint32_t c0_ = c_begin + ((T) % stages_per_k) * (W * CH) + wave * CH;          \
         _Pragma("unroll") for (int u = 0; u < PPL; ++u)                                      \
         {                                                                                    \
             const uint32_t pp_ = lane + u * 64u;                                             \
@@ -230,8 +238,8 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
                 }
             }
             if (kl_ >= nkk) return false;
-            const uint32_t c_ = ts_ * (W * CH) + wave * CH + (uint32_t)ci_;
-            if (c_ < g.ss64) {
+            const uint32_t c_ = c_begin + ts_ * (W * CH) + wave * CH + (uint32_t)ci_;
+            if (c_ < c_end) {
                 k_out = g.k_begin + kk0 + kl_;
                 c_out = c_;
                 return true;
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
     // the loads return in order, and the compiler's counted vmcnt before each use is exact).
     uint4 b[JL][7];
     {
-        uint32_t k1 = g.k_begin + kk0, c1 = 0;
+        uint32_t k1 = g.k_begin + kk0, c1 = c_begin;
         next_chunk(0u, 0u, -1, k1, c1);
 #pragma unroll
         for (int j = 0; j < JL; ++j) {
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
         const uint32_t kk = kk0 + kl;
         for (uint32_t ts = 0; ts < stages_per_k; ++ts, ++t) {
             const uint32_t buf = t & 1u;
-            const uint32_t c0 = ts * (W * CH) + wave * CH;
+            const uint32_t c0 = c_begin + ts * (W * CH) + wave * CH;
             // This wave's DMA of stage t must have landed.  VMEM returns in order, so it is
             // enough that only the younger column loads may still be in flight.
             if (b_younger == 0) {
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
             // column registers consumed once, so no column load is in flight then); a stage
             // in which this wave has no chunk requests them here.
             const bool want_dma = t + 1 < n_stages;
-            if (want_dma && c0 >= g.ss64) {
+            if (want_dma && c0 >= c_end) {
                 SKL_STAGE_DMA(t + 1, buf ^ 1u);
                 b_younger = 0;
             }
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
             // instead of the vmcnt(0) it falls back to across a loop back-edge)
 #pragma unroll
             for (uint32_t ci = 0; ci < (uint32_t)CH; ++ci) {
-                if (c0 + ci >= g.ss64) break;
+                if (c0 + ci >= c_end) break;
                 // where the columns of the next chunk are (the current ones again if none follows)
                 uint32_t kn = g.k_begin + kk, cn = c0 + ci;
                 next_chunk(kl, ts, (int)ci, kn, cn);
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
                     field_pair(x, (uint32_t)h, r, j);
                     const uint32_t mism = h ? (total >> 16) : (total & 0xFFFFu);
                     if constexpr (MODE == MODE_COUNTS) {
-                        store_count(g, a0 + r, (jb0 + j) * 64u + lane, kk, mism);
+                        store_count(g, a0 + r, (jb0 + j) * 64u + lane, slice * g.k_count + kk, (c_end - c_begin) * 64u, mism);
                     } else if constexpr (KSL) {
                         const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
                         float v = __builtin_inff();
@@ -547,7 +555,12 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (pe != hipSuccess) return pe;
     if (n_wg == 0) return hipSuccess;
     // k-sliced: whole blocks of KSL_TILE_BLOCK tile slots per XCD (slots past the last tile exit at once)
-    if (k_sliced) n_wg = 8ull * ((args.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * args.k_count;
+    if (!(k_sliced && mode == MODE_COUNTS) || args.k_slices == 0) args.k_slices = 1;
+    if (args.ss64 % (args.k_slices * 8u) != 0 && args.k_slices != 1) return hipErrorInvalidValue;   // whole stages per slice
+    if (k_sliced) {
+        n_wg = 8ull * ((args.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * args.k_count *
+               args.k_slices;
+    }
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);
 #ifdef SKL_AB

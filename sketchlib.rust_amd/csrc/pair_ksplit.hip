@@ -183,7 +183,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_ksplit(const 
 #pragma unroll
                 for (int w = 0; w < WAVES_PER_WG; ++w) total += lds_red[kk & 1u][w][x][lane];
                 if constexpr (MODE == MODE_COUNTS) {
-                    store_count(g, a0 + x, jcol, kk, total);
+                    store_count(g, a0 + x, jcol, kk, g.ss64 * 64u, total);
                 } else if constexpr (MODE == MODE_JACCARD) {
                     store_jaccard(g, a0 + x, jcol, total);
                 } else {

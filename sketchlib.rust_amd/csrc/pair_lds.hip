@@ -217,7 +217,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel_lds(const Pai
                 for (int x = 0; x < P; ++x) {
                     const uint32_t r = (uint32_t)x / JL, j = (uint32_t)x % JL;
                     if constexpr (MODE == MODE_COUNTS) {
-                        store_count(g, a0 + r, (jb0 + j) * 64u + lane, kk, cnt[0]);
+                        store_count(g, a0 + r, (jb0 + j) * 64u + lane, kk, g.ss64 * 64u, cnt[0]);
                     } else {
                         store_jaccard(g, a0 + r, (jb0 + j) * 64u + lane, cnt[0]);
                     }

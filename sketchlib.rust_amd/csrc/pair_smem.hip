@@ -139,7 +139,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_kernel(const PairArg
         // ---- per-k epilogue ----
         if constexpr (MODE == MODE_COUNTS) {
 #pragma unroll
-            for (int ia = 0; ia < NA; ++ia) store_count(g, a0 + ia, jcol, kk, st0[ia]);
+            for (int ia = 0; ia < NA; ++ia) store_count(g, a0 + ia, jcol, kk, g.ss64 * 64u, st0[ia]);
         } else if constexpr (MODE == MODE_JACCARD) {
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia) store_jaccard(g, a0 + ia, jcol, st0[ia]);

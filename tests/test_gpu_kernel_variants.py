@@ -73,6 +73,10 @@ VARIANTS = [
     # product library
     ({}, "k-sliced"),                                              # dispatcher's choice at this size
     ({"SKL_SLICED_MAX_PAIRS": "0"}, "all k"),                      # all-k fused form
+    ({"SKL_K_SLICES": "1"}, "k-sliced"),                           # k-sliced, whole k-mer lengths
+    ({"SKL_K_SLICES": "2"}, "k-sliced"),                           # ... cut into 2 / 4 / 8 chunk slices
+    ({"SKL_K_SLICES": "4"}, "k-sliced"),
+    ({"SKL_K_SLICES": "8"}, "k-sliced"),
     # A/B library
     ({**AB}, "k-sliced"),
     ({**AB, "SKL_KSLICE_SHAPE": "162"}, "R=16, JL=2, COUNTS, k-sliced>"),   # the 141-register form
