@@ -10,6 +10,10 @@
 #define launch_pair_kernel_kslice launch_pair_kernel_kslice_traced
 #define kslice_supported kslice_supported_traced
 #include "../../sketchlib.rust_amd/csrc/pair_kslice.hip"
+#define pair_kernel_kpersist pair_kernel_kpersist_traced
+#define launch_pair_kernel_kpersist launch_pair_kernel_kpersist_traced
+#define kpersist_supported kpersist_supported_traced
+#include "../../sketchlib.rust_amd/csrc/pair_kpersist.hip"
 
 #include <algorithm>
 #include <cstdio>
@@ -25,7 +29,7 @@ using namespace skl;
 int main(int argc, char **argv)
 {
     const uint32_t n = argc > 1 ? atoi(argv[1]) : 1000;
-    const int shape = argc > 2 ? atoi(argv[2]) : 162;
+    int shape = argc > 2 ? atoi(argv[2]) : 162;
     const uint32_t nk = 5, ss64 = 64;
     constexpr size_t TW = 8;   // words per trace record (SKL_TRACE_WORDS)
     const size_t sample_words = (size_t)nk * ss64 * BBITS;
@@ -46,7 +50,7 @@ int main(int argc, char **argv)
     fprintf(stderr, "relayout done\n");
     const uint64_t pairs = (uint64_t)n * (n - 1) / 2;
     uint32_t *dOut;
-    CK(hipMalloc(&dOut, pairs * nk * 4 * (argc > 5 ? (size_t)atoi(argv[5]) : 1)));
+    CK(hipMalloc(&dOut, pairs * nk * 4 * std::max<size_t>(2, argc > 5 ? (size_t)atoi(argv[5]) : 1)));
     PairArgs g;
     memset(&g, 0, sizeof g);
     g.A = dA; g.B = dB; g.nA = n; g.nB = n; g.nk = nk; g.ss64 = ss64;
@@ -65,20 +69,34 @@ int main(int argc, char **argv)
     const int ablate = getenv("SKL_KSLICE_ABLATE") ? atoi(getenv("SKL_KSLICE_ABLATE")) : 0;
     // argv[5]: chunk slices per k-mer length (k_slices of the k-sliced COUNTS launch)
     const uint32_t slices = argc > 5 ? (uint32_t)atoi(argv[5]) : 1u;
-    for (int i = 0; i < warm; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
+    int pflags = 1;
+    if (shape >= 980 && shape <= 999) { pflags = shape == 999 ? 1 : shape - 980; shape = 999; }   // 991 queue, 993 +priority rotation, 995 equal split, 997 both
+    const bool persistent = shape == 999;
+    uint32_t *dCtr = nullptr;
+    CK(hipMalloc(&dCtr, 8 * 32 * 4));
+    CK(hipMemset(dCtr, 0, 8 * 32 * 4));
+    if (persistent) { g.k_sliced = 1; g.k_slices = 2; g.persistent_ok = (uint32_t)pflags; g.work_counter = dCtr; CK(hipMemset(dOut, 0, pairs * nk * 4 * 2)); }
+    bool used = false;
+    for (int i = 0; i < warm; ++i) {
+        if (persistent) { CK(hipMemsetAsync(dCtr, 0, 8 * 32 * 4, 0)); CK(launch_pair_kernel_kpersist(g, 1024, ts, 0, &used)); }
+        else CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
+    }
+    if (persistent) { CK(hipMemsetAsync(dCtr, 0, 8 * 32 * 4, 0)); CK(hipMemsetAsync(dTrace, 0, trace_words * 8, 0)); }
     CK(hipDeviceSynchronize());
     fprintf(stderr, "warm done\n");
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
+    if (persistent) CK(launch_pair_kernel_kpersist(g, 1024, ts, 0, &used));
+    else CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
     hipEventRecord(e1);
     CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const int R = shape / 10, JL = shape == 165 ? 2 : shape % 10;
+    const int R = shape == 999 ? 16 : shape / 10, JL = (shape == 165 || shape == 999) ? 2 : shape % 10;
     PairArgs gp = g; uint64_t n_wg = 0;
     CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
     n_wg = 8ull * ((gp.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * nk * slices;   // as launch_pair_kernel_kslice pads it
+    if (shape == 999) n_wg = 1024;
     const int wpw = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
     const size_t n_waves = n_wg * wpw;
     fprintf(stderr, "n_wg %llu\n", (unsigned long long)n_wg);
@@ -108,7 +126,21 @@ int main(int argc, char **argv)
         std::sort(clk.begin(), clk.end());
         std::sort(cyc.begin(), cyc.end());
         // one wave of a k-sliced workgroup: ss64 / 4 chunks x R rows x JL columns x (28 + 2 half-rate) = 32 issue slots each
-        const double slots = (double)(ss64 / 4 / slices) * R * JL * 32.0;
+        double slots = (double)(ss64 / 4 / slices) * R * JL * 32.0;
+        if (shape == 999) {   // a wave walks tr[7] stages of 2 chunks each (median over waves)
+            std::vector<double> st;
+            for (size_t w = 0; w < n_waves; ++w) if (tr[w * TW + 3]) st.push_back((double)tr[w * TW + 7]);
+            std::sort(st.begin(), st.end());
+            slots = st[st.size() / 2] * 2.0 * R * JL * 32.0;
+            printf("  persistent: stages per wave min %.0f median %.0f max %.0f\n", st.front(), st[st.size() / 2], st.back());
+            // part-end accounting (second trace region): mean cycles per wave in each section
+            std::vector<uint64_t> ext(4096 * 8);
+            CK(hipMemcpy(ext.data(), (uint64_t *)dTrace + 4096 * 8, ext.size() * 8, hipMemcpyDeviceToHost));
+            double sums[5] = {0, 0, 0, 0, 0};
+            for (size_t w = 0; w < 4096; ++w) for (int x = 0; x < 5; ++x) sums[x] += (double)ext[w * 8 + x];
+            printf("  persistent part ends, mean per wave: parts %.2f; cycles to barrier 1 %.0f, reduce+store %.0f, to barrier 2 %.0f, next-part setup %.0f\n",
+                   sums[4] / 4096, sums[0] / 4096, sums[1] / 4096, sums[2] / 4096, sums[3] / 4096);
+        }
         printf("  in-kernel clock while streaming: p10 %.3f median %.3f p90 %.3f GHz; streaming phase of a wave: median %.0f cycles = %.2f cycles per issue slot per wave (%.0f slots)\n",
                clk[clk.size() / 10], clk[clk.size() / 2], clk[clk.size() * 9 / 10], cyc[cyc.size() / 2],
                cyc[cyc.size() / 2] / slots, slots);

@@ -128,7 +128,9 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
         return fail(SKL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
-    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    e = hipMalloc((void **)&ctx->work_counter, 8 * 32 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 8 * 32 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     for (int x = 0; x < 2 && e == hipSuccess; ++x) {
         e = hipEventCreateWithFlags(&ctx->knn_pair_done[x], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->knn_topk_done[x], hipEventDisableTiming);
@@ -165,6 +167,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     for (void *buf : ctx->scratch) {
         if (buf) (void)hipFree(buf);
     }
+    if (ctx->work_counter) (void)hipFree(ctx->work_counter);
     if (ctx->tile_scratch.d_prefix) (void)hipFree(ctx->tile_scratch.d_prefix);
     if (ctx->tile_scratch.h_staging) (void)hipHostFree(ctx->tile_scratch.h_staging);
     if (ctx->tile_scratch.staged) (void)hipEventDestroy(ctx->tile_scratch.staged);
@@ -248,6 +251,7 @@ Knobs read_knobs()
     k.sliced_max_pairs = env_int("SKL_SLICED_MAX_PAIRS", -1);
     k.knn_band_rows = std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));
     k.k_slices = (int)env_int("SKL_K_SLICES", 0);
+    k.persist = env_int("SKL_PERSIST", 1);
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
@@ -270,6 +274,8 @@ Knobs read_knobs()
 int forced_kernel(const skl_ctx *ctx)
 {
 #ifdef SKL_AB
+    // a forced tile shape or ablation counts as a forced kernel for the persistent form (it has one shape)
+    if (ctx->knobs.kernel == 0 && (ctx->knobs.kslice_shape || ctx->knobs.kslice_ablate)) return 4;
     return ctx->knobs.kernel;
 #else
     (void)ctx;
@@ -315,6 +321,22 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args, int m
     const bool try_kslice = true;
     const int ablate = 0;
 #endif
+    ctx->last_count_planes = std::max(1u, args.k_slices);
+    ctx->last_persistent = false;
+    if (try_kslice && args.k_slices == 2u && args.persistent_ok && kpersist_supported(args, mode, 4u * (uint32_t)ctx->n_cu)) {
+        // k-sliced core/acc (counts + epilogue) with fewer (tile, k) units than resident workgroup
+        // slots: the persistent form, the workgroups share the stages of all units
+        bool used = false;
+        const hipError_t e = launch_pair_kernel_kpersist(args, 4u * (uint32_t)ctx->n_cu, tiles, stream, &used);
+        if (e != hipSuccess) return e;
+        if (used) {
+            ctx->last_count_planes = 2;
+            ctx->last_persistent = true;
+            *name = "skl::pair_kernel_kpersist (16x128 tiles, chunks split over 4 waves; persistent: " +
+                    std::to_string(4 * ctx->n_cu) + " workgroups share the (tile, k, stage) sequence, " + m + ")";
+            return hipSuccess;
+        }
+    }
     if (try_kslice) {
         // single-k Jaccard: the sliced and the all-k form are the same work, the sliced one
         // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
@@ -783,12 +805,33 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
         void *counts = nullptr;
         const uint32_t k_slices = sliced ? choose_k_slices(ctx, rows->ss64) : 1u;
-        SKL_TRY(ctx_scratch(ctx, pairs * rows->nk * k_slices * sizeof(uint32_t), &counts, 1));
+        // the persistent form of the k-sliced launch (pair_kpersist.hip): two planes, plane 1 zero on entry
+        // It pays when the launch has fewer (tile, k) units than ~0.6 of the resident workgroup slots
+        // (a chip the one-workgroup-per-unit launch cannot fill: 3x faster at 200 genomes, 1.45x at 500,
+        // equal from ~700; profiles/r02_ab_persist.jsonl).  SKL_PERSIST=0 never, 2 whenever it is supported.
+        const uint64_t est_units = pairs * rows->nk / 2048;
+        const bool persist_pays = ctx->knobs.persist >= 2 || est_units * 10 <= 6ull * 4ull * (uint64_t)ctx->n_cu;
+        const bool persistent = sliced && ctx->knobs.persist && persist_pays && k_slices == 1u && rows->ss64 % 8 == 0 &&
+                                forced_kernel(ctx) == 0;
+        const size_t plane_bytes = pairs * rows->nk * sizeof(uint32_t);
+        SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(persistent ? 2u : 1u, k_slices), &counts, 1));
         if (sliced) {   // k-major scratch: coalesced stores from the (tile, k[, chunk slice]) workgroups
             g.cnt_pair_stride = 1;
             g.cnt_k_stride = pairs;
             g.k_sliced = 1;
-            g.k_slices = k_slices;
+            g.k_slices = persistent ? 2u : k_slices;
+            g.persistent_ok = persistent ? 1u : 0u;
+            g.work_counter = ctx->work_counter;
+        }
+        if (persistent) {
+            void *plane1 = (char *)counts + plane_bytes;
+            if (ctx->clean_plane1 != plane1 || ctx->clean_plane1_bytes != plane_bytes) {
+                HIP_TRY(hipMemsetAsync(plane1, 0, plane_bytes, ctx->stream));
+                ctx->clean_plane1 = plane1;
+                ctx->clean_plane1_bytes = plane_bytes;
+            }
+        } else {
+            ctx->clean_plane1 = nullptr;   // this launch writes the scratch in another layout
         }
         g.row_begin = (uint32_t)r0;
         g.row_end = (uint32_t)r1;
@@ -799,13 +842,16 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         SKL_TRY(ensure_ytab(rows));
         EpilogueArgs e;
         memset(&e, 0, sizeof e);
-        e.counts = (const uint32_t *)counts;
+        e.counts = (uint32_t *)counts;
         e.pair_stride = g.cnt_pair_stride;
         e.k_stride = g.cnt_k_stride;
         e.n_pairs = pairs;
         e.nk = (uint32_t)rows->nk;
         e.ss64 = (uint32_t)rows->ss64;
-        e.n_slices = k_slices;
+        e.n_slices = sliced ? ctx->last_count_planes : 1u;
+        e.rezero_plane1 = sliced && ctx->last_persistent ? 1u : 0u;
+        e.work_counter = e.rezero_plane1 ? ctx->work_counter : nullptr;
+        if (persistent && !ctx->last_persistent) ctx->clean_plane1 = nullptr;   // (an empty launch: nothing ran)
         e.nA_rows = (uint32_t)rows->n;
         e.nB_cols = (uint32_t)cols->n;
         e.row_begin = (uint32_t)r0;

@@ -46,6 +46,7 @@ struct Knobs {
     long long sliced_max_pairs = -1;  // SKL_SLICED_MAX_PAIRS: core/acc launches below this run k-sliced (-1: default)
     long long knn_band_rows = 0;      // SKL_KNN_BAND_ROWS: force the band height of the kNN drivers (tests)
     int k_slices = 0;                 // SKL_K_SLICES: chunk slices per k of k-sliced core/acc launches (0: chosen per launch)
+    int persist = 1;                    // SKL_PERSIST=0: k-sliced core/acc launches never take the persistent form
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
@@ -77,6 +78,13 @@ struct skl_ctx {
     size_t events_used = 0;
     size_t launches_seen = 0;           // pair-kernel launches since the last skl_ctx_timing_reset
     std::string last_kernel;
+    uint32_t last_count_planes = 1;     // planes the last MODE_COUNTS k-sliced launch wrote (epilogue: n_slices)
+    bool last_persistent = false;       // ... and whether it was the persistent form (plane 1 added to, re-zeroed by the epilogue)
+    // plane 1 of the counts scratch as the persistent form needs it: all zero.  Valid for exactly
+    // this (pointer, bytes) until anything else writes the scratch.
+    const void *clean_plane1 = nullptr;
+    size_t clean_plane1_bytes = 0;
+    uint32_t *work_counter = nullptr;   // 8 x 32 u32 queue counters of pair_kpersist.hip (zero between launches)
     Knobs knobs;                        // environment switches as of skl_ctx_create
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration
     std::set<skl_sketches *> sketches;  // slabs created on this context

@@ -33,6 +33,38 @@ __device__ __forceinline__ uint32_t acc_mismatch_vvv(uint32_t m, uint32_t a, uin
     return __builtin_amdgcn_bitop3_b32(a, b, m, 0xBE);
 }
 
+// 16 bytes per lane, global -> LDS, no VGPR destination (global_load_lds_dwordx4): lane l's
+// 16 bytes land at LDS byte address m0 + 16*l.  Issued through inline asm ON PURPOSE: the
+// compiler treats the builtin form as an LDS write it cannot disambiguate and puts
+// `s_waitcnt vmcnt(0)` in front of every later LDS read -- which also waits for the NEXT
+// stage's DMA and the column prefetch, i.e. exposes their full latency once per chunk.
+// Hidden from its bookkeeping, the ordering is ours: the explicit counted vmcnt wait at the
+// top of each stage (VMEM returns in order).  Hidden VMEM ops can only make the compiler's
+// own counted waits stricter, never laxer, and the issue points below keep every hidden op
+// OLDER than the column loads in flight, so they stay exact.
+__device__ __forceinline__ void skl_dma16(const void *src, uint32_t lds_byte_addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr))
+                 : "memory");   // m0 is reserved (cannot be listed); nothing else in these kernels uses it
+#else
+    (void)src;
+    (void)lds_byte_addr;
+#endif
+}
+
+__device__ __forceinline__ uint32_t skl_lds_addr(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+#else
+    (void)p;
+    return 0;
+#endif
+}
+
 // jaccard.rs:14,26-44 on the device (used when a completeness correction makes the
 // host-built tables inapplicable).
 __device__ __forceinline__ double jaccard_from_samebits_dev(uint32_t samebits, uint32_t ss64,

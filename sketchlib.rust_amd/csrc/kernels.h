@@ -58,6 +58,8 @@ struct PairArgs {
     uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
     uint32_t k_slices;            // k-sliced MODE_COUNTS: chunk slices per k-mer length (0/1: none); slice s of k index kk
                                   // stores the matches of ITS bins at "k index" s * k_count + kk
+    uint32_t persistent_ok;       // the caller prepared two planes with plane 1 zeroed: pair_kpersist.hip may run
+    uint32_t *work_counter;       // pair_kpersist.hip: 8 x 32 u32, entry [xcd * 32] = stages of that XCD handed out; zero on entry
     // Symmetric self kNN (pair_kslice.hip: k-sliced MODE_JACCARD and all-k MODE_COREACC): besides
     // out, the record of (row i, column j >= t_col_begin) also goes to record
     // (j - t_col_begin) * t_stride + (i - row_begin) of out_t, i.e. as a candidate of row j.
@@ -117,6 +119,13 @@ hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_pe
 hipError_t launch_pair_kernel_kslice(const PairArgs &args, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream);
 bool kslice_supported(const PairArgs &args, int mode, bool k_sliced);
+// Persistent form of the k-sliced MODE_COUNTS launch (pair_kpersist.hip): grid = `slots` resident
+// workgroups, each walking an equal share of its XCD's stages; counts land in TWO planes ("k index"
+// plane * k_count + kk) that the epilogue sums.  *used = false when the launch was not taken
+// (fewer units than slots): the caller then launches the one-workgroup-per-unit form.
+bool kpersist_supported(const PairArgs &args, int mode, uint32_t slots);
+hipError_t launch_pair_kernel_kpersist(const PairArgs &args, uint32_t slots, TileScratch &scratch,
+                                       hipStream_t stream, bool *used);
 
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
 hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint32_t n,
@@ -124,11 +133,13 @@ hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint3
 
 // Unfused core/acc epilogue: counts [pair][nk] u32 -> (core, acc) f32 pairs.
 struct EpilogueArgs {
-    const uint32_t *counts;     // count of (pair p, k t) at counts[p*pair_stride + t*k_stride]
+    uint32_t *counts;           // count of (pair p, k t) at counts[p*pair_stride + t*k_stride]
     uint64_t pair_stride, k_stride;
     uint64_t n_pairs;
     uint32_t nk, ss64;
     uint32_t n_slices;          // counts come in this many chunk slices per k (k index s * nk + t): summed here
+    uint32_t rezero_plane1;     // 1: after reading, write 0 to the slice-1 records (pair_kpersist.hip adds into them)
+    uint32_t *work_counter;     // ... and reset these 8 x 32 queue counters (or null)
     uint32_t nA_rows, nB_cols;  // to recover (i, j) for completeness lookups
     uint32_t row_begin;
     uint32_t self_mode;

@@ -148,6 +148,7 @@ hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint3
 __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArgs g)
 {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g.work_counter && p < 8u) g.work_counter[p * 32u] = 0u;   // the persistent pair kernel's queues, for its next launch
     if (p >= g.n_pairs) return;
     double c1 = 0.0, c2 = 0.0;
     if (g.has_comp) {
@@ -176,17 +177,23 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
     }
     const uint32_t maxnbits = g.ss64 * 64u;
     double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
-    const uint32_t *cnt = g.counts + p * g.pair_stride;
+    uint32_t *cnt = g.counts + p * g.pair_stride;
     for (uint32_t t = 0; t < g.nk; ++t) {
         uint32_t same = cnt[t * g.k_stride];
         for (uint32_t sl = 1; sl < g.n_slices; ++sl) same += cnt[((uint64_t)sl * g.nk + t) * g.k_stride];
+        if (g.rezero_plane1) cnt[((uint64_t)g.nk + t) * g.k_stride] = 0u;
         double y;
         if (!g.has_comp) {
             y = g.ytab[same <= maxnbits ? same : maxnbits];
         } else {
             y = glibc_log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff), g.log_variant);
         }
-        if (y < g.tolerance) break;
+        if (y < g.tolerance) {   // jaccard.rs:89-91: break (the plane-1 records of the k not read are zeroed all the same)
+            if (g.rezero_plane1) {
+                for (uint32_t t2 = t + 1u; t2 < g.nk; ++t2) cnt[((uint64_t)g.nk + t2) * g.k_stride] = 0u;
+            }
+            break;
+        }
         const double k_fl = g.kf[t];
         xsum += k_fl;
         ysum += y;

@@ -34,38 +34,6 @@ namespace skl {
 
 constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk a k-mer length together
 
-// 16 bytes per lane, global -> LDS, no VGPR destination (global_load_lds_dwordx4): lane l's
-// 16 bytes land at LDS byte address m0 + 16*l.  Issued through inline asm ON PURPOSE: the
-// compiler treats the builtin form as an LDS write it cannot disambiguate and puts
-// `s_waitcnt vmcnt(0)` in front of every later LDS read -- which also waits for the NEXT
-// stage's DMA and the column prefetch, i.e. exposes their full latency once per chunk.
-// Hidden from its bookkeeping, the ordering is ours: the explicit counted vmcnt wait at the
-// top of each stage (VMEM returns in order).  Hidden VMEM ops can only make the compiler's
-// own counted waits stricter, never laxer, and the issue points below keep every hidden op
-// OLDER than the column loads in flight, so they stay exact.
-__device__ __forceinline__ void skl_dma16_ks(const void *src, uint32_t lds_byte_addr)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :
-                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr))
-                 : "memory");   // m0 is reserved (cannot be listed); nothing else in this kernel uses it
-#else
-    (void)src;
-    (void)lds_byte_addr;
-#endif
-}
-
-__device__ __forceinline__ uint32_t skl_lds_addr(const void *p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-#else
-    (void)p;
-    return 0;
-#endif
-}
-
 #ifdef SKL_TRACE
 // scripts/microbench/kslice_trace.hip: per-wave timeline (100 MHz wall clock) + hardware id,
 // and the shader-clock counter (s_memtime) at marks 1 and 2, i.e. around the streaming phase:
@@ -219,7 +187,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1))
             const uint32_t cc_ = (c0_ + c_) < g.ss64 ? (c0_ + c_) : (g.ss64 - 1u);           \
             const uint64_t *src_ = g.A + (size_t)(a0 + r_) * sample_stride +                 \
                                    (size_t)k_ * kmer_stride + (size_t)cc_ * BBITS + 2u * q_; \
-            skl_dma16_ks(src_, lds_base + (((uint32_t)wave * 2u + (BUF)) * (PPL * LANES) + u * 64u) * 16u); \
+            skl_dma16(src_, lds_base + (((uint32_t)wave * 2u + (BUF)) * (PPL * LANES) + u * 64u) * 16u); \
         }                                                                                    \
     } while (0)
 

@@ -71,14 +71,15 @@ print("VARIANT_OK", ctx.last_kernel())
 AB = {"SKL_LIBRARY": os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build_ab", "libsketchlib_dist_hip.so")}
 VARIANTS = [
     # product library
-    ({}, "k-sliced"),                                              # dispatcher's choice at this size
+    ({}, "kpersist"),                                              # dispatcher's choice at this size: fewer units than workgroup slots
+    ({"SKL_PERSIST": "0"}, "k-sliced"),                            # one workgroup per (tile, k)
     ({"SKL_SLICED_MAX_PAIRS": "0"}, "all k"),                      # all-k fused form
-    ({"SKL_K_SLICES": "1"}, "k-sliced"),                           # k-sliced, whole k-mer lengths
+    ({"SKL_K_SLICES": "1", "SKL_PERSIST": "0"}, "k-sliced"),       # k-sliced, whole k-mer lengths
     ({"SKL_K_SLICES": "2"}, "k-sliced"),                           # ... cut into 2 / 4 / 8 chunk slices
     ({"SKL_K_SLICES": "4"}, "k-sliced"),
     ({"SKL_K_SLICES": "8"}, "k-sliced"),
     # A/B library
-    ({**AB}, "k-sliced"),
+    ({**AB}, "kpersist"),
     ({**AB, "SKL_KSLICE_SHAPE": "162"}, "R=16, JL=2, COUNTS, k-sliced>"),   # the 141-register form
     ({**AB, "SKL_KSLICE_SHAPE": "162", "SKL_SLICED_MAX_PAIRS": "0"}, "R=16, JL=2, COREACC, all k>"),
     ({**AB, "SKL_KSLICE_SHAPE": "82"}, "R=8, JL=2"),
