@@ -252,6 +252,8 @@ Knobs read_knobs()
     k.knn_band_rows = std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));
     k.k_slices = (int)env_int("SKL_K_SLICES", 0);
     k.persist = env_int("SKL_PERSIST", 1);
+    k.tile32_min = env_int("SKL_TILE32_MIN", 16ll << 20);
+    k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 4)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
@@ -288,8 +290,10 @@ int forced_kernel(const skl_ctx *ctx)
 // and for single-k Jaccard, all k + fused regression otherwise) and, for the shapes it does not
 // take (sketches beyond 65 535 bins), pair_ksplit.hip.  The A/B build adds the earlier kernels
 // (pair_lds.hip, pair_smem.hip) and the other tile shapes behind SKL_KERNEL / SKL_KSLICE_SHAPE.
-static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args, int mode, hipStream_t stream)
+static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, int mode, hipStream_t stream)
 {
+    PairArgs args = args_in;
+    args.group_span = (uint32_t)ctx->knobs.group_span;
     static const char *mode_names[] = {"COUNTS", "JACCARD", "COREACC"};
     const std::string m = mode_names[mode];
     std::string *name = &ctx->last_kernel;
@@ -299,7 +303,18 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args, int m
     const bool small = pairs < (8ull << 20);
     // 165 = 16 x 128 tiles in the 128-register form (4 waves per SIMD): +3.5 % at n = 16 000 over the
     // 141-register form 162 (3 waves), equal at n = 1 000 (profiles/r02_ab_tight.jsonl)
+    // 325 = 32 x 128 tiles (130-168 registers, 3 waves per SIMD) for launches of at least
+    // tile32_min pair x k-mer-length evaluations (~4 096 units of 32 x 128): every column register is
+    // used against 32 rows instead of 16, which halves the lane-slab traffic per pair -- HBM bytes per
+    // launch at n = 16 000 fall from 59.5 GB to 32.0 GB and the kernel gains 1.5-6 %
+    // (profiles/r02_tile32_*.md); smaller launches lose to the coarser tail (n = 1 000: +32 %).
+    // Launches that also write the transposed band (symmetric kNN) keep the 16-row tile their band
+    // layout is built on.
     int shape = 165, ksplit_rows = 8;   // 8 >= 4 rows from n = 1000 up once XCDs are balanced
+    {
+        const uint64_t k_walked = mode == MODE_JACCARD ? 1u : args.k_count;
+        if (args.out_t == nullptr && ctx->knobs.tile32_min >= 0 && pairs * k_walked >= (uint64_t)ctx->knobs.tile32_min) shape = 325;
+    }
 #ifdef SKL_AB
     const Knobs &kn = ctx->knobs;
     if (kn.kslice_shape) shape = kn.kslice_shape;
@@ -342,9 +357,9 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args, int m
         // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
         const bool sliced = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
         if (kslice_supported(args, mode, sliced)) {
-            const int jl = shape == 165 ? 2 : shape % 10;
+            const int jl = (shape == 165 || shape == 325) ? 2 : shape % 10;
             *name = "skl::pair_kernel_kslice<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(jl) +
-                    ", " + m + (sliced ? ", k-sliced" : ", all k") + (shape == 165 ? ", tight" : "") + "> (" +
+                    ", " + m + (sliced ? ", k-sliced" : ", all k") + ((shape == 165 || shape == 325) ? ", tight" : "") + "> (" +
                     std::to_string(shape / 10) + "x" + std::to_string(jl * 64) + " tiles, chunks split over 4 waves)";
             return launch_pair_kernel_kslice(args, mode, shape, sliced, ablate, tiles, stream);
         }

@@ -129,10 +129,58 @@ __device__ __forceinline__ uint64_t square_to_condensed_dev(uint64_t i, uint64_t
 
 
 // Balanced, XCD-aware tile lookup.  Workgroups are dealt round-robin to the 8 XCDs, so
+// Row tiles column group `group` needs in self mode: those with some i < j, i.e. first row below the
+// group's last column (the host's plan_tiles counts the same way).
+__device__ __forceinline__ uint32_t group_row_tiles(const PairArgs &g, uint32_t group)
+{
+    const uint64_t last_col = (uint64_t)(group + 1u) * g.group_cols - 1u;
+    const uint32_t lim = last_col < g.row_end ? (uint32_t)last_col : g.row_end;
+    return lim > g.row_begin ? (lim - g.row_begin + g.tile_rows - 1u) / g.tile_rows : 0u;
+}
+
+// Tile u of super-group sg, self mode.  A super-group is group_span consecutive column groups; its
+// tiles are numbered row tile by row tile, the groups that need that row tile side by side.  Later
+// groups need more row tiles (the triangle), so row tile `at` belongs to the LAST groups of the
+// super-group: all of them up to the first group's count, one fewer up to the second's, ...
+__device__ __forceinline__ void tile_in_supergroup_self(const PairArgs &g, uint32_t sg, uint32_t u, uint32_t &group,
+                                                        uint32_t &row_tile)
+{
+    const uint32_t first = sg * g.group_span;
+    const uint32_t gcount = min(g.group_span, g.n_groups - first);
+    uint32_t lo_at = 0;
+    for (uint32_t gi = 0; gi + 1u < gcount; ++gi) {
+        const uint32_t width = gcount - gi;
+        const uint32_t n_gi = group_row_tiles(g, first + gi);
+        const uint32_t span = (n_gi - lo_at) * width;
+        if (u < span) {
+            row_tile = lo_at + u / width;
+            group = first + gi + (u - (u / width) * width);
+            return;
+        }
+        u -= span;
+        lo_at = n_gi;
+    }
+    row_tile = lo_at + u;
+    group = first + gcount - 1u;
+}
+
+// ... cross mode: every group needs all a_tiles row tiles
+__device__ __forceinline__ void tile_in_supergroup_cross(const PairArgs &g, uint32_t t, uint32_t &group, uint32_t &row_tile)
+{
+    const uint32_t per = g.group_span * g.a_tiles;
+    const uint32_t sg = t / per, u = t - sg * per;
+    const uint32_t first = sg * g.group_span;
+    const uint32_t gcount = min(g.group_span, g.n_groups - first);
+    row_tile = u / gcount;
+    group = first + (u - row_tile * gcount);
+}
+
 // blockIdx % 8 labels the XCD (MI355X_MICROARCH.md); XCD x takes tiles
-// [x*tiles_per_xcd, (x+1)*tiles_per_xcd) of the column-group-major numbering of the ACTIVE
-// tiles: every XCD gets the same number of (equal-cost) tiles, and the tiles of one XCD
-// share at most ceil(groups/8)+1 column groups, whose lane slab then stays in its L2.
+// [x*tiles_per_xcd, (x+1)*tiles_per_xcd) of the super-group-major numbering of the ACTIVE
+// tiles: every XCD gets the same number of (equal-cost) tiles.  The 128 workgroups resident on an
+// XCD are 128 consecutive tiles = 128 / group_span row tiles x group_span column groups: with
+// group_span = 4 they bring 32 row tiles (18 MB at cfg 3) and 4 column groups (18 MB) through that
+// XCD's L2 instead of 128 row tiles (73 MB) and 1 column group (4.6 MB).
 // Returns false when this workgroup has no tile.
 __device__ __forceinline__ bool lookup_tile_at(const PairArgs &g, uint32_t xcd, uint32_t slot,
                                                uint32_t &group, uint32_t &row_tile)
@@ -141,17 +189,16 @@ __device__ __forceinline__ bool lookup_tile_at(const PairArgs &g, uint32_t xcd, 
     const uint32_t t = xcd * g.tiles_per_xcd + slot;
     if (t >= g.n_active_tiles) return false;
     if (!g.self_mode) {
-        group = t / g.a_tiles;
-        row_tile = t - group * g.a_tiles;
+        tile_in_supergroup_cross(g, t, group, row_tile);
         return true;
     }
-    uint32_t lo = 0, hi = g.n_groups;  // largest lo with prefix[lo] <= t
+    const uint32_t n_super = (g.n_groups + g.group_span - 1u) / g.group_span;
+    uint32_t lo = 0, hi = n_super;  // largest lo with prefix[lo] <= t
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
         if (g.tile_prefix[mid] <= t) lo = mid; else hi = mid;
     }
-    group = lo;
-    row_tile = t - g.tile_prefix[lo];
+    tile_in_supergroup_self(g, lo, t - g.tile_prefix[lo], group, row_tile);
     return true;
 }
 

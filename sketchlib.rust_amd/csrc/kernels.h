@@ -49,7 +49,10 @@ struct PairArgs {
     uint32_t n_active_tiles;
     uint32_t tiles_per_xcd;       // ceil(n_active_tiles / 8)
     uint32_t n_groups;            // column groups
-    const uint32_t *tile_prefix;  // [n_groups + 1] first tile number of each group (self mode)
+    uint32_t group_span;          // column groups per super-group: the tiles of a super-group are numbered row tile by
+                                  // row tile, its groups side by side (1: column group by column group)
+    uint32_t tile_rows, group_cols;   // tile height / columns per group the numbering was planned for
+    const uint32_t *tile_prefix;  // [ceil(n_groups / group_span) + 1] first tile number of each super-group (self mode)
     uint64_t out_base;            // flat index of the first pair of this launch
     void *out;
     // MODE_COUNTS record layout: count of (pair p, k index kk) at out[p*cnt_pair_stride + kk*cnt_k_stride]

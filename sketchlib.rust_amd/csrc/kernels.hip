@@ -31,6 +31,9 @@ hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_
                       TileScratch &scratch, hipStream_t stream, uint64_t *grid_out)
 {
     *grid_out = 0;
+    if (args.group_span == 0) args.group_span = 1;
+    args.tile_rows = rows_per_tile;
+    args.group_cols = cols_per_group;
     const uint32_t rows = args.row_end - args.row_begin;
     args.a_tiles = (rows + rows_per_tile - 1) / rows_per_tile;
     args.n_jblocks = (args.nB + 63u) / 64u;
@@ -41,17 +44,18 @@ hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_
         total = (uint64_t)args.a_tiles * args.n_groups;
     } else {
         // group g is needed by the row tiles with a0 < (g+1)*W - 1 (some i < j exists)
-        std::vector<uint32_t> prefix(args.n_groups + 1);
+        const uint32_t n_super = (args.n_groups + args.group_span - 1) / args.group_span;
+        std::vector<uint32_t> prefix(n_super + 1);
         total = 0;
         for (uint32_t gi = 0; gi < args.n_groups; ++gi) {
-            prefix[gi] = (uint32_t)total;
+            if (gi % args.group_span == 0) prefix[gi / args.group_span] = (uint32_t)total;
             const uint64_t last_col = (uint64_t)(gi + 1) * cols_per_group - 1;
             const uint32_t lim = (uint32_t)std::min<uint64_t>(args.row_end, last_col);
             total += lim > args.row_begin ? (lim - args.row_begin + rows_per_tile - 1) / rows_per_tile : 0u;
         }
-        prefix[args.n_groups] = (uint32_t)total;
+        prefix[n_super] = (uint32_t)total;
         if (total >= (1ull << 32)) return hipErrorInvalidValue;
-        const uint64_t key[4] = {((uint64_t)args.row_begin << 32) | args.row_end, args.nB,
+        const uint64_t key[4] = {((uint64_t)args.row_begin << 32) | args.row_end, ((uint64_t)args.group_span << 32) | args.nB,
                                  ((uint64_t)rows_per_tile << 32) | cols_per_group, total};
         if (prefix.size() > scratch.capacity) {
             if (scratch.d_prefix) (void)hipFree(scratch.d_prefix);          // (synchronises the device)

@@ -94,9 +94,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, 4) void pair_kernel_kpersist(c
     const size_t kmer_stride = (size_t)g.ss64 * BBITS;
     const size_t sample_stride = kmer_stride * g.nk;
 
-    // self mode, up to 64 column groups (every k-sliced launch up to n = 8 192): the whole tile
+    // self mode, up to 64 super-groups of column groups (every k-sliced launch): the whole tile
     // prefix table in one register, one entry per lane
-    const uint32_t prefix_lane = (g.self_mode && g.n_groups <= 64u) ? g.tile_prefix[lane < g.n_groups ? lane : g.n_groups - 1u] : 0u;
+    const uint32_t n_super = (g.n_groups + g.group_span - 1u) / g.group_span;
+    const uint32_t prefix_lane = (g.self_mode && n_super <= 64u) ? g.tile_prefix[lane < n_super ? lane : n_super - 1u] : 0u;
 
     // unit index on this XCD -> (tile, k): blocks of KP_TILE_BLOCK tiles walk one k-mer length
     // together (tile fastest, then k, then block), as in the k-sliced launch of pair_kslice.hip
@@ -108,22 +109,20 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, 4) void pair_kernel_kpersist(c
         uint32_t jg = 0, at = 0;
         const uint32_t t = t_lo + slot;
         if (!g.self_mode) {
-            jg = t / g.a_tiles;
-            at = t - jg * g.a_tiles;
-        } else if (g.n_groups <= 64u) {
-            // no memory access: lane l holds the first tile of group l (loaded once, below); the
-            // groups' first tiles ascend
-            const uint64_t below = __ballot(lane < g.n_groups && prefix_lane <= t);
-            jg = (uint32_t)__popcll(below) - 1u;
-            at = t - (uint32_t)__builtin_amdgcn_readlane((int)prefix_lane, (int)jg);
+            tile_in_supergroup_cross(g, t, jg, at);
+        } else if (n_super <= 64u) {
+            // no memory access: lane l holds the first tile of super-group l (loaded once, above); the
+            // super-groups' first tiles ascend
+            const uint64_t below = __ballot(lane < n_super && prefix_lane <= t);
+            const uint32_t sg = (uint32_t)__popcll(below) - 1u;
+            tile_in_supergroup_self(g, sg, t - (uint32_t)__builtin_amdgcn_readlane((int)prefix_lane, (int)sg), jg, at);
         } else {
-            uint32_t lo = 0, hi = g.n_groups;   // largest lo with prefix[lo] <= t
+            uint32_t lo = 0, hi = n_super;   // largest lo with prefix[lo] <= t
             while (hi - lo > 1u) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (g.tile_prefix[mid] <= t) lo = mid; else hi = mid;
             }
-            jg = lo;
-            at = t - g.tile_prefix[lo];
+            tile_in_supergroup_self(g, lo, t - g.tile_prefix[lo], jg, at);
         }
         Unit d;
         d.a0 = __builtin_amdgcn_readfirstlane(g.row_begin + at * R);

@@ -57,10 +57,10 @@ constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk 
 // (3 columns per lane: the register allocator is held to 3 waves per SIMD, 168 VGPRs.  TIGHT: the
 // 2-column form squeezed into 128 VGPRs -- packed counts, 4-deep row ring -- for 4 waves per SIMD.)
 template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false>
-__global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? 4 : (JL == 3 ? 3 : 1)) void pair_kernel_kslice(const PairArgs g)
+__global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL == 3 ? 3 : 1)) void pair_kernel_kslice(const PairArgs g)
 {
     constexpr int W = WAVES_PER_WG;
-    constexpr int CH = 2;                         // chunks per wave per stage
+    constexpr int CH = R > 16 ? 1 : 2;            // chunks per wave per stage
     constexpr int PIECES = R * CH * 7;            // 16-byte pieces per wave-stage
     constexpr int PPL = (PIECES + LANES - 1) / LANES;   // DMA instructions per wave-stage
     constexpr int P = R * JL;                     // pairs per lane
@@ -509,7 +509,7 @@ bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
     return mode == MODE_COUNTS || mode == MODE_JACCARD;
 }
 
-// shape = R*10 + JL, or 165 = the tight form of 16 x 128 (the product library's only shape); the A/B
+// shape = R*10 + JL, or 165 / 325 = the tight forms of 16 x 128 and 32 x 128 (the product library's shapes); the A/B
 // build (-DSKL_AB) has the others and the ablations
 hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream)
@@ -517,7 +517,7 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     if (!kslice_supported(args, mode, k_sliced)) return hipErrorInvalidValue;
-    const int R = shape / 10, JL = shape == 165 ? 2 : shape % 10;   // 165: the tight 16 x 128 form
+    const int R = shape / 10, JL = (shape == 165 || shape == 325) ? 2 : shape % 10;   // 165: the tight 16 x 128 form; 325: 32 x 128
     uint64_t n_wg = 0;
     const hipError_t pe = plan_tiles(args, (uint32_t)R, (uint32_t)JL * 64u, scratch, stream, &n_wg);
     if (pe != hipSuccess) return pe;
@@ -552,6 +552,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         case 165:   // the product shape: 16 x 128 tiles, 128 VGPRs
             return k_sliced ? launch_rjk<16, 2, true, true>(args, mode, grid, stream)
                             : launch_rjk<16, 2, false, true>(args, mode, grid, stream);
+        case 325:   // large launches: 32 x 128 tiles, packed counts, 3 waves per SIMD, half the column traffic per pair
+            return k_sliced ? launch_rjk<32, 2, true, true>(args, mode, grid, stream)
+                            : launch_rjk<32, 2, false, true>(args, mode, grid, stream);
 #ifdef SKL_AB
         SKL_SHAPE(162, 16, 2)
         SKL_SHAPE(81, 8, 1)
