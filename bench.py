@@ -144,10 +144,44 @@ def static_profile(name):
         return {}
 
 
+LIVE_CLOCK = {"enabled": True, "cache": {}}
+
+
+def live_clock(clock_key):
+    """The shader clock the chip holds under this kernel ON THIS BOX, NOW: the diagnostic build of the
+    pair kernel (scripts/microbench/kslice_trace: s_memtime / s_memrealtime stamps in every wave) run as
+    a child process after the timed region, on the workload's shape -- cfg 2 itself after 200
+    back-to-back launches, or an 8 000-genome slice of the large launches with their 32 x 128 tiles.
+    None when the tool is not built or the run is under a profiler."""
+    if not LIVE_CLOCK["enabled"] or any(k.startswith("ROCPROF") for k in os.environ):
+        return None
+    if clock_key in LIVE_CLOCK["cache"]:
+        return LIVE_CLOCK["cache"][clock_key]
+    exe = os.path.join(ROOT, "scripts", "microbench", "_build", "kslice_trace")
+    argv = {"cfg2": [exe, "1000", "165", "rand", "200", "1"], "large_n": [exe, "8000", "325", "rand", "5", "1"]}[clock_key]
+    res = None
+    if os.path.exists(exe):
+        try:
+            import re
+            import subprocess
+            out = subprocess.run(argv, capture_output=True, text=True, timeout=300).stdout
+            m = re.search(r"in-kernel clock while streaming: p10 ([\d.]+) median ([\d.]+) p90 ([\d.]+) GHz", out)
+            if m:
+                res = {"ghz": float(m.group(2)), "p10": float(m.group(1)), "p90": float(m.group(3)),
+                       "source": "live: " + " ".join(["scripts/microbench/_build/kslice_trace"] + argv[1:]) +
+                                 " run after the timed region on this GPU (median over waves of d(s_memtime)/d(s_memrealtime) "
+                                 "while streaming; diagnostic build of the same kernel)"}
+        except Exception:
+            res = None
+    LIVE_CLOCK["cache"][clock_key] = res
+    return res
+
+
 def valu_block(pairs_per_launch, avg_kernel_s, nk, ss64, clock_key):
     slots = issue_slots_per_pair(nk, ss64)
     achieved = slots * pairs_per_launch / avg_kernel_s if avg_kernel_s > 0 else 0.0
     clk = static_profile("in_kernel_clock.json").get(clock_key)
+    live = live_clock(clock_key)
     blk = {
         "achieved": achieved / 1e12,
         "peak": VALU_PEAK_LANE_OPS / 1e12,
@@ -158,7 +192,10 @@ def valu_block(pairs_per_launch, avg_kernel_s, nk, ss64, clock_key):
         "peak_definition": "256 CUs x 4 SIMD-32 x 32 lanes/cycle (one wave64 instruction per 2 cycles) x 2.4 GHz "
                            "datasheet clock",
     }
-    if clk:
+    if live:
+        blk["in_kernel_clock"] = live
+        blk["frac_at_in_kernel_clock"] = achieved / (VALU_PEAK_LANE_OPS * live["ghz"] / DATASHEET_CLOCK_GHZ)
+    elif clk:
         f = clk["clock_ghz_median"]
         blk["in_kernel_clock"] = {"ghz": f, "source": clk["source"] + " (static: s_memtime / s_memrealtime stamps "
                                                                       "of a diagnostic build, not this run)"}
@@ -180,12 +217,15 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip assembling the output on rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the Set R and cfg3 legs")
+    ap.add_argument("--no-live-clock", action="store_true",
+                    help="quote the committed in-kernel clock instead of measuring it after the timed region")
     ap.add_argument("--loopback", action="store_true",
                     help="distributed launch: rank 0 also sends its own band to itself over RCCL (lets one rank "
                          "exercise the send/recv gather)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: finish each step's gather before the next step's kernel (default: one step of overlap)")
     args = ap.parse_args()
+    LIVE_CLOCK["enabled"] = not args.no_live_clock
 
     # The library brackets pair-kernel launches with HIP events for skl_ctx_kernel_ms(); an event
     # record is a barrier packet on the queue and two per launch cost a 0.16 ms step ~5 us.  The
@@ -210,6 +250,7 @@ def main():
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
     dist = None
     if distributed:
+        LIVE_CLOCK["enabled"] = False   # the clock probe is a 1-GPU diagnostic: N > 1 lines quote the committed figure
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -442,6 +483,7 @@ def main():
                              "pairs": pairs3, "pairs_per_s": pairs3 / wall, "s_per_step": wall,
                              "kernel": ctx.last_kernel(), "kernel_avg_ms": ksec * 1e3, "valu_frac": v3["frac"],
                              "valu_frac_at_in_kernel_clock": v3.get("frac_at_in_kernel_clock"),
+                             "in_kernel_clock": v3.get("in_kernel_clock"),
                              "verified_pairs": cnt, "max_abs_err": worst}
         out["config"]["secondary"] = secondary
         sk3.close()

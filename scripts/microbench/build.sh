@@ -4,7 +4,10 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p _build
 CSRC=../../sketchlib.rust_amd/csrc
+# usage: build.sh [kslice_trace]  (no argument: every tool)
+ONLY=${1:-}
 for t in valu_rates valu_clock vgpr_banks lds_bcast; do
+  [ -n "$ONLY" ] && continue
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value $t.hip -o _build/$t
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Wno-unused-value -I../../include -I$CSRC \

@@ -92,7 +92,7 @@ int main(int argc, char **argv)
     hipEventRecord(e1);
     CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const int R = shape == 999 ? 16 : shape / 10, JL = (shape == 165 || shape == 999) ? 2 : shape % 10;
+    const int R = shape == 999 ? 16 : shape / 10, JL = (shape == 165 || shape == 325 || shape == 999) ? 2 : shape % 10;
     PairArgs gp = g; uint64_t n_wg = 0;
     CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
     n_wg = 8ull * ((gp.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * nk * slices;   // as launch_pair_kernel_kslice pads it

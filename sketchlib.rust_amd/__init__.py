@@ -7,6 +7,6 @@ the tests and bench.py, a synthetic sketch generator, and the multi-GPU row part
 over torch.distributed.  Nothing here computes distances on the CPU.
 """
 from . import build as _build_mod  # noqa: F401
-from .build import ab_library_path, build_ab_library, build_library, library_path  # noqa: F401
+from .build import ab_library_path, build_ab_library, build_clock_probe, build_library, library_path  # noqa: F401
 
-__all__ = ["build_library", "library_path", "build_ab_library", "ab_library_path"]
+__all__ = ["build_library", "library_path", "build_ab_library", "ab_library_path", "build_clock_probe"]

@@ -68,3 +68,27 @@ def build_library(force=False, verbose=False):
 def build_ab_library(force=False, verbose=False):
     """make -C csrc AB=1: the A/B library (tests/test_gpu_kernel_variants.py, scripts/ab_sweep.py)."""
     return _build(True, force, verbose)
+
+
+PROBE_DIR = os.path.join(os.path.dirname(_HERE), "scripts", "microbench")
+CLOCK_PROBE = os.path.join(PROBE_DIR, "_build", "kslice_trace")
+
+
+def build_clock_probe(force=False):
+    """scripts/microbench/kslice_trace: the pair kernels built with s_memtime / wall-clock stamps (a
+    diagnostic binary, linked against the A/B library for the host-side helpers).  bench.py runs it
+    after its timed region to quote the shader clock the chip holds under the kernel on that box."""
+    build_ab_library()
+    h = hashlib.sha256(source_hash().encode())
+    with open(os.path.join(PROBE_DIR, "kslice_trace.hip"), "rb") as fh:
+        h.update(fh.read())
+    want = h.hexdigest()
+    stamp = os.path.join(PROBE_DIR, "_build", ".kslice_trace_sha256")
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or have != want or not os.path.exists(CLOCK_PROBE):
+        res = subprocess.run(["bash", os.path.join(PROBE_DIR, "build.sh"), "kslice_trace"], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("building scripts/microbench/kslice_trace failed:\n" + res.stdout + res.stderr)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
+    return CLOCK_PROBE

@@ -44,6 +44,10 @@ def test_bench_default_line(gpu_ctx):
     assert rf["kernel_launches_timed"] >= 10
     # the kernel time the roofline uses is consistent with the step time the value uses
     assert rf["kernel_avg_ms"] <= line["ms_per_step"] * 1.05
+    # the in-kernel clock beside the fraction is measured on this box, after the timed region
+    clk = rf["in_kernel_clock"]
+    assert clk["source"].startswith("live:") and 1.0 < clk["ghz"] < 2.6, clk
+    assert abs(rf["frac_at_in_kernel_clock"] - rf["frac"] * 2.4 / clk["ghz"]) < 1e-9
 
 
 def test_bench_rccl_path_with_one_rank(gpu_ctx):
