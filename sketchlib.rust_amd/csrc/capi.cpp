@@ -357,10 +357,11 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
         // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
         const bool sliced = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
         if (kslice_supported(args, mode, sliced)) {
-            const int jl = (shape == 165 || shape == 325) ? 2 : shape % 10;
-            *name = "skl::pair_kernel_kslice<R=" + std::to_string(shape / 10) + ", JL=" + std::to_string(jl) +
-                    ", " + m + (sliced ? ", k-sliced" : ", all k") + ((shape == 165 || shape == 325) ? ", tight" : "") + "> (" +
-                    std::to_string(shape / 10) + "x" + std::to_string(jl * 64) + " tiles, chunks split over 4 waves)";
+            const int jl = (shape == 165 || shape == 325 || shape > 1000) ? 2 : shape % 10;
+            const int rr = shape > 1000 ? shape / 100 : shape / 10;
+            *name = "skl::pair_kernel_kslice<R=" + std::to_string(rr) + ", JL=" + std::to_string(jl) +
+                    ", " + m + (sliced ? ", k-sliced" : ", all k") + ((shape == 165 || shape == 325 || shape > 1000) ? ", tight" : "") + "> (" +
+                    std::to_string(rr) + "x" + std::to_string(jl * 64) + " tiles, chunks split over 4 waves)";
             return launch_pair_kernel_kslice(args, mode, shape, sliced, ablate, tiles, stream);
         }
     }

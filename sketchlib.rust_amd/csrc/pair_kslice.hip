@@ -56,7 +56,15 @@ constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk 
 
 // (3 columns per lane: the register allocator is held to 3 waves per SIMD, 168 VGPRs.  TIGHT: the
 // 2-column form squeezed into 128 VGPRs -- packed counts, 4-deep row ring -- for 4 waves per SIMD.)
-template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false>
+// MB: rows walked plane by plane together (1: row by row).  A chunk is walked in blocks of MB rows, and
+// inside a block plane pair q of all MB rows comes before plane pair q + 1 of any.  Column register
+// b[.][q] is then free -- and re-loaded with the next chunk's data -- 6/7 of a BLOCK before its first
+// use there instead of one row before: 3.4 rows of VALU work with MB = 4.  Costs 4 (MB - 1) registers
+// for the blocks' mismatch accumulators, so only the 32-row form (3 waves per SIMD, registers to
+// spare) has it.  Worth 1.2-1.4 % at n = 8 000 ... 16 000 (MB = 1 / 2 / 4 / 8: 30.34 / 29.95 / 29.98 /
+// 30.07 ms at n = 16 000, profiles/r02_ab_row_blocks.jsonl): the s_waitcnt share of the SQ counters is
+// mostly the LDS reads of a kernel that runs at the LDS's rate, not the column loads.
+template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL == 3 ? 3 : 1)) void pair_kernel_kslice(const PairArgs g)
 {
     constexpr int W = WAVES_PER_WG;
@@ -280,63 +288,73 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
                 // is 12+ VALU instructions long and the 12 registers decide the occupancy.
                 constexpr int AD = (JL >= 3 || TIGHT) ? 4 : 7;
                 uint4 a[AD];
+                static_assert(R % MB == 0, "rows per tile must be a multiple of the block height");
+                // step s of the chunk -> index of its plane pair in the row buffer ([row][plane pair])
+                auto row_slot = [](int s) constexpr { return ((s / (7 * MB)) * MB + s % MB) * 7 + (s % (7 * MB)) / MB; };
 #pragma unroll
-                for (int q = 0; q < AD; ++q) a[q] = rows[q];
+                for (int q = 0; q < AD; ++q) a[q] = rows[row_slot(q)];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    uint32_t mlo[JL], mhi[JL];
+                for (int rb = 0; rb < R / MB; ++rb) {
+                    uint32_t mlo[MB][JL], mhi[MB][JL];
 #pragma unroll
                     for (int q = 0; q < 7; ++q) {
-                        const int s_ = r * 7 + q;      // compile-time after unrolling
-                        uint4 &ar = a[s_ % AD];
 #pragma unroll
-                        for (int j = 0; j < JL; ++j) {
-                            // b is stored (hi, lo) per plane: see device_common.hpp "VGPR banks"
-                            if (q == 0) {
-                                mlo[j] = ar.x ^ b[j][0].y;
-                                mhi[j] = ar.y ^ b[j][0].x;
+                        for (int m = 0; m < MB; ++m) {
+                            const int s_ = (rb * 7 + q) * MB + m;      // compile-time after unrolling
+                            uint4 &ar = a[s_ % AD];
+#pragma unroll
+                            for (int j = 0; j < JL; ++j) {
+                                // b is stored (hi, lo) per plane: see device_common.hpp "VGPR banks"
+                                if (q == 0) {
+                                    mlo[m][j] = ar.x ^ b[j][0].y;
+                                    mhi[m][j] = ar.y ^ b[j][0].x;
+                                } else {
+                                    mlo[m][j] = acc_mismatch_vvv(mlo[m][j], ar.x, b[j][q].y);
+                                    mhi[m][j] = acc_mismatch_vvv(mhi[m][j], ar.y, b[j][q].x);
+                                }
+                                mlo[m][j] = acc_mismatch_vvv(mlo[m][j], ar.z, b[j][q].w);
+                                mhi[m][j] = acc_mismatch_vvv(mhi[m][j], ar.w, b[j][q].z);
+                            }
+                            // rolling prefetch of the plane pair AD steps ahead (no extra registers)
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (ABL & 1) {   // timing-only: no re-read, but opaque to CSE
+                                asm volatile("" : "+v"(ar.x), "+v"(ar.y), "+v"(ar.z), "+v"(ar.w));
                             } else {
-                                mlo[j] = acc_mismatch_vvv(mlo[j], ar.x, b[j][q].y);
-                                mhi[j] = acc_mismatch_vvv(mhi[j], ar.y, b[j][q].x);
+                                if (s_ + AD < R * 7) ar = rows[row_slot(s_ + AD)];
                             }
-                            mlo[j] = acc_mismatch_vvv(mlo[j], ar.z, b[j][q].w);
-                            mhi[j] = acc_mismatch_vvv(mhi[j], ar.w, b[j][q].z);
-                        }
-                        // rolling prefetch of the plane pair AD steps ahead (no extra registers)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (ABL & 1) {   // timing-only: no re-read, but opaque to CSE
-                            asm volatile("" : "+v"(ar.x), "+v"(ar.y), "+v"(ar.z), "+v"(ar.w));
-                        } else {
-                            if (s_ + AD < R * 7) ar = rows[s_ + AD];
-                        }
-                        if constexpr (!(ABL & 2)) {
-                            if (r == R - 1) {   // last use of b[.][q] in this chunk: fetch the next chunk's
+                            if constexpr (!(ABL & 2)) {
+                                if (rb == R / MB - 1 && m == MB - 1) {   // last use of b[.][q] in this chunk: fetch the next chunk's
 #pragma unroll
-                                for (int j = 0; j < JL; ++j) b[j][q] = bn[j][q * LANES];
+                                    for (int j = 0; j < JL; ++j) b[j][q] = bn[j][q * LANES];
+                                }
                             }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+#pragma unroll
+                  for (int m = 0; m < MB; ++m) {
+                    const int r = rb * MB + m;
                     // popcount with the add fused (v_bcnt_u32_b32 d, m, d)
                     if constexpr (PACK01) {
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mlo[0]));
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mhi[0]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mlo[m][0]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mhi[m][0]));
                         uint32_t t1;
-                        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(t1) : "v"(mlo[1]));
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(t1) : "v"(mhi[1]));
+                        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(t1) : "v"(mlo[m][1]));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(t1) : "v"(mhi[m][1]));
                         cnt[r] = (t1 << 16) + cnt[r];   // v_lshl_add_u32
                         if constexpr (JL == 3) {
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mlo[2]));
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mhi[2]));
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mlo[m][2]));
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mhi[m][2]));
                         }
                     } else {
 #pragma unroll
                         for (int j = 0; j < JL; ++j) {
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[j]));
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[j]));
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[m][j]));
+                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[m][j]));
                         }
                     }
-                    if (r == 0 && ci == 0 && want_dma) {
+                  }
+                    if (rb == 0 && ci == 0 && want_dma) {
                         SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
                         b_younger = 0;
                     }
@@ -480,20 +498,20 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
     SKL_TRACE_MARK(3);
 }
 
-template <int R, int JL, bool KSL, bool TIGHT = false>
+template <int R, int JL, bool KSL, bool TIGHT = false, int MB = 1>
 static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
 {
     const dim3 block(LANES * WAVES_PER_WG);
     switch (mode) {
         case MODE_COUNTS:
-            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL, 0, TIGHT>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL, 0, TIGHT, MB>), grid, block, 0, stream, args);
             break;
         case MODE_JACCARD:
-            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, KSL, 0, TIGHT>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, KSL, 0, TIGHT, MB>), grid, block, 0, stream, args);
             break;
         case MODE_COREACC:
             if constexpr (!KSL) {
-                hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COREACC, false, 0, TIGHT>), grid, block, 0, stream, args);
+                hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COREACC, false, 0, TIGHT, MB>), grid, block, 0, stream, args);
                 break;
             }
             return hipErrorInvalidValue;
@@ -517,7 +535,8 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     if (!kslice_supported(args, mode, k_sliced)) return hipErrorInvalidValue;
-    const int R = shape / 10, JL = (shape == 165 || shape == 325) ? 2 : shape % 10;   // 165: the tight 16 x 128 form; 325: 32 x 128
+    const int R = shape > 1000 ? shape / 100 : shape / 10;   // 165 / 325 (and 1652, 325x in the A/B build): the tight forms of 16 x 128 and 32 x 128
+    const int JL = (shape == 165 || shape == 325 || shape > 1000) ? 2 : shape % 10;
     uint64_t n_wg = 0;
     const hipError_t pe = plan_tiles(args, (uint32_t)R, (uint32_t)JL * 64u, scratch, stream, &n_wg);
     if (pe != hipSuccess) return pe;
@@ -553,9 +572,12 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
             return k_sliced ? launch_rjk<16, 2, true, true>(args, mode, grid, stream)
                             : launch_rjk<16, 2, false, true>(args, mode, grid, stream);
         case 325:   // large launches: 32 x 128 tiles, packed counts, 3 waves per SIMD, half the column traffic per pair
-            return k_sliced ? launch_rjk<32, 2, true, true>(args, mode, grid, stream)
-                            : launch_rjk<32, 2, false, true>(args, mode, grid, stream);
+            return k_sliced ? launch_rjk<32, 2, true, true, 4>(args, mode, grid, stream)
+                            : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
 #ifdef SKL_AB
+        case 3251:   // ... walked row by row
+            return k_sliced ? launch_rjk<32, 2, true, true, 1>(args, mode, grid, stream)
+                            : launch_rjk<32, 2, false, true, 1>(args, mode, grid, stream);
         SKL_SHAPE(162, 16, 2)
         SKL_SHAPE(81, 8, 1)
         SKL_SHAPE(82, 8, 2)

@@ -43,7 +43,7 @@ def test_product_library_has_no_ab_kernels_or_switches():
     assert kernels, "no pair kernel exported?"
     for k in kernels:
         # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only, ablation parameter 0; ksplit fallback: 8-row tiles
-        assert re.fullmatch(r"pair_kernel_kslice<(16|32), 2, [012], (true|false), 0, true>|pair_kernel_ksplit<8, [012], 8, false>", k), k
+        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [012], (true|false), 0, true, 1>|pair_kernel_kslice<32, 2, [012], (true|false), 0, true, 4>|pair_kernel_ksplit<8, [012], 8, false>", k), k
     assert "skl::pair_kernel_kpersist(" in demangled    # the persistent form of the k-sliced launch (not a template)
     blob = open(pkg.library_path(), "rb").read()
     for needle in (b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
