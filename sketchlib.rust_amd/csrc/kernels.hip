@@ -182,29 +182,49 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
     const uint32_t maxnbits = g.ss64 * 64u;
     double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
     uint32_t *cnt = g.counts + p * g.pair_stride;
-    for (uint32_t t = 0; t < g.nk; ++t) {
-        uint32_t same = cnt[t * g.k_stride];
-        for (uint32_t sl = 1; sl < g.n_slices; ++sl) same += cnt[((uint64_t)sl * g.nk + t) * g.k_stride];
-        if (g.rezero_plane1) cnt[((uint64_t)g.nk + t) * g.k_stride] = 0u;
-        double y;
-        if (!g.has_comp) {
-            y = g.ytab[same <= maxnbits ? same : maxnbits];
-        } else {
-            y = glibc_log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff), g.log_variant);
-        }
-        if (y < g.tolerance) {   // jaccard.rs:89-91: break (the plane-1 records of the k not read are zeroed all the same)
-            if (g.rezero_plane1) {
-                for (uint32_t t2 = t + 1u; t2 < g.nk; ++t2) cnt[((uint64_t)g.nk + t2) * g.k_stride] = 0u;
+    // The reference's loop leaves at the first k-mer length whose ln J is below the tolerance
+    // (jaccard.rs:89-91), so a literal loop is a chain of 2 nk dependent loads (count, then table
+    // entry) -- 10 L2 round trips at cfg 2, which is what this kernel's 10 us were.  The counts of up
+    // to KB k-mer lengths and their table entries are therefore loaded up front, independent of each
+    // other; the sums then stop at the same k-mer length as before.
+    constexpr uint32_t KB = 8;
+    bool stopped = false;
+    for (uint32_t t0 = 0; t0 < g.nk; t0 += KB) {
+        uint32_t same[KB];
+        double yt[KB];
+#pragma unroll
+        for (uint32_t u = 0; u < KB; ++u) {
+            const uint32_t t = t0 + u;
+            same[u] = 0u;
+            if (t < g.nk) {
+                same[u] = cnt[t * g.k_stride];
+                for (uint32_t sl = 1; sl < g.n_slices; ++sl) same[u] += cnt[((uint64_t)sl * g.nk + t) * g.k_stride];
+                // plane 1 goes back to zero for the persistent pair kernel's next launch, whether or not k index t is used
+                if (g.rezero_plane1) cnt[((uint64_t)g.nk + t) * g.k_stride] = 0u;
             }
-            break;
         }
-        const double k_fl = g.kf[t];
-        xsum += k_fl;
-        ysum += y;
-        xysum += k_fl * y;
-        xsquaresum += k_fl * k_fl;
-        ysquaresum += y * y;
-        n += 1.0;
+        if (!g.has_comp) {
+#pragma unroll
+            for (uint32_t u = 0; u < KB; ++u) yt[u] = g.ytab[same[u] <= maxnbits ? same[u] : maxnbits];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < KB; ++u) {
+            const uint32_t t = t0 + u;
+            if (t >= g.nk || stopped) continue;
+            const double y = g.has_comp ? glibc_log(jaccard_from_samebits_dev(same[u], g.ss64, true, c1, c2, g.cutoff), g.log_variant)
+                                        : yt[u];
+            if (y < g.tolerance) {   // jaccard.rs:89-91: break
+                stopped = true;
+                continue;
+            }
+            const double k_fl = g.kf[t];
+            xsum += k_fl;
+            ysum += y;
+            xysum += k_fl * y;
+            xsquaresum += k_fl * k_fl;
+            ysquaresum += y * y;
+            n += 1.0;
+        }
     }
     ((float2 *)g.out)[p] =
         simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
