@@ -253,7 +253,7 @@ Knobs read_knobs()
     k.k_slices = (int)env_int("SKL_K_SLICES", 0);
     k.persist = env_int("SKL_PERSIST", 1);
     k.tile32_min = env_int("SKL_TILE32_MIN", 16ll << 20);
-    k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 4)));
+    k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;

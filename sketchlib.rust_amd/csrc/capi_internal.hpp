@@ -46,7 +46,7 @@ struct Knobs {
     long long sliced_max_pairs = -1;  // SKL_SLICED_MAX_PAIRS: core/acc launches below this run k-sliced (-1: default)
     long long knn_band_rows = 0;      // SKL_KNN_BAND_ROWS: force the band height of the kNN drivers (tests)
     int k_slices = 0;                 // SKL_K_SLICES: chunk slices per k of k-sliced core/acc launches (0: chosen per launch)
-    int group_span = 4;                 // SKL_GROUP_SPAN: column groups whose tiles are numbered side by side (device_common.hpp lookup_tile_at)
+    int group_span = 2;                 // SKL_GROUP_SPAN: column groups whose tiles are numbered side by side (device_common.hpp lookup_tile_at)
     long long tile32_min = 16ll << 20;  // SKL_TILE32_MIN: pair x k evaluations from which launches use 32 x 128 tiles (-1: never, 0: always)
     int persist = 1;                    // SKL_PERSIST=0: k-sliced core/acc launches never take the persistent form
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN

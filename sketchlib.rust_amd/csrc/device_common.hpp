@@ -177,10 +177,11 @@ __device__ __forceinline__ void tile_in_supergroup_cross(const PairArgs &g, uint
 
 // blockIdx % 8 labels the XCD (MI355X_MICROARCH.md); XCD x takes tiles
 // [x*tiles_per_xcd, (x+1)*tiles_per_xcd) of the super-group-major numbering of the ACTIVE
-// tiles: every XCD gets the same number of (equal-cost) tiles.  The 128 workgroups resident on an
-// XCD are 128 consecutive tiles = 128 / group_span row tiles x group_span column groups: with
-// group_span = 4 they bring 32 row tiles (18 MB at cfg 3) and 4 column groups (18 MB) through that
-// XCD's L2 instead of 128 row tiles (73 MB) and 1 column group (4.6 MB).
+// tiles: every XCD gets the same number of (equal-cost) tiles.  The ~100 workgroups resident on an
+// XCD are consecutive tiles = row tiles x group_span column groups, each row tile shared by
+// group_span neighbouring workgroups.  HBM bytes per launch at n = 16 000 with 32 x 128 tiles:
+// 44.8 GB numbered group by group, 31.6 GB with group_span = 2 (the default), 32.0 GB with 4; at
+// cfg 2 (k-sliced, 16 x 128): 261 / 257 / 321 MB (profiles/r02_tile32_*.md, r02c_*).
 // Returns false when this workgroup has no tile.
 __device__ __forceinline__ bool lookup_tile_at(const PairArgs &g, uint32_t xcd, uint32_t slot,
                                                uint32_t &group, uint32_t &row_tile)

@@ -78,7 +78,8 @@ VARIANTS = [
     ({"SKL_TILE32_MIN": "0", "SKL_PERSIST": "0"}, "R=32, JL=2, COUNTS, k-sliced"),   # 32 x 128 tiles (large launches' shape)
     ({"SKL_TILE32_MIN": "0", "SKL_SLICED_MAX_PAIRS": "0"}, "R=32, JL=2, COREACC, all k"),
     ({"SKL_GROUP_SPAN": "1"}, "kpersist"),                         # tile numbering: column group by column group
-    ({"SKL_GROUP_SPAN": "3", "SKL_PERSIST": "0"}, "k-sliced"),     # ... 3 groups side by side
+    ({"SKL_GROUP_SPAN": "3", "SKL_PERSIST": "0"}, "k-sliced"),     # ... 3 groups side by side (default: 2)
+    ({"SKL_GROUP_SPAN": "4"}, "kpersist"),
     ({"SKL_K_SLICES": "2"}, "k-sliced"),                           # ... cut into 2 / 4 / 8 chunk slices
     ({"SKL_K_SLICES": "4"}, "k-sliced"),
     ({"SKL_K_SLICES": "8"}, "k-sliced"),
