@@ -308,12 +308,10 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     // used against 32 rows instead of 16, which halves the lane-slab traffic per pair -- HBM bytes per
     // launch at n = 16 000 fall from 59.5 GB to 32.0 GB and the kernel gains 1.5-6 %
     // (profiles/r02_tile32_*.md); smaller launches lose to the coarser tail (n = 1 000: +32 %).
-    // Launches that also write the transposed band (symmetric kNN) keep the 16-row tile their band
-    // layout is built on.
     int shape = 165, ksplit_rows = 8;   // 8 >= 4 rows from n = 1000 up once XCDs are balanced
     {
         const uint64_t k_walked = mode == MODE_JACCARD ? 1u : args.k_count;
-        if (args.out_t == nullptr && ctx->knobs.tile32_min >= 0 && pairs * k_walked >= (uint64_t)ctx->knobs.tile32_min) shape = 325;
+        if (ctx->knobs.tile32_min >= 0 && pairs * k_walked >= (uint64_t)ctx->knobs.tile32_min) shape = 325;
     }
 #ifdef SKL_AB
     const Knobs &kn = ctx->knobs;

@@ -73,7 +73,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
     const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
     const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
-    const size_t t_stride = (band_rows + 15) / 16 * 16;
+    const size_t t_stride = (band_rows + 31) / 32 * 32;   // whole tiles of either height (16 or 32 rows: dispatch_pair_kernel)
     void *kband[2] = {nullptr, nullptr}, *tband[2] = {nullptr, nullptr};
     SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[0], 0));
     SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[0], 4));

@@ -22,29 +22,35 @@ def _knn(skl, ctx, g, p, knn, monkeypatch, band_rows, symmetric, with_d1=False):
     return (idx, d0, d1) if with_d1 else (idx, d0)
 
 
+@pytest.mark.parametrize("tile_rows", [16, 32])
 @pytest.mark.parametrize("band_rows", [7, 16, 40, 64, 100, 332])
 @pytest.mark.parametrize("ani", [False, True], ids=["dist", "ani"])
-def test_bands_of_every_shape_match_the_oracle(oracle, skl, gpu_ctx, monkeypatch, band_rows, ani):
+def test_bands_of_every_shape_match_the_oracle(oracle, skl, gpu_ctx, monkeypatch, band_rows, ani, tile_rows):
+    """Both tile heights of the pair kernel turn their tiles into the transposed band (large bands take
+    32 x 128 tiles: SKL_TILE32_MIN; forced here either way)."""
     kmers, ss64, n, knn = [17, 21, 25], 8, 333, 11
     bins = synth.set_r(n, kmers, ss64, n_clusters=9)
     o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
     p = g.set_k(21, ani)
+    monkeypatch.setenv("SKL_TILE32_MIN", "0" if tile_rows == 32 else "-1")
     idx, d0 = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True)
-    assert "k-sliced" in gpu_ctx.last_kernel()
+    assert "k-sliced" in gpu_ctx.last_kernel() and f"R={tile_rows}," in gpu_ctx.last_kernel()
     exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, ani, ties=oracle.TIES_CANONICAL, threads=8)
     assert np.array_equal(idx, exp["idx"])
     np.testing.assert_allclose(d0, exp["d0"], atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("tile_rows", [16, 32])
 @pytest.mark.parametrize("band_rows", [7, 16, 50, 128])
-def test_core_accessory_keys(oracle, skl, gpu_ctx, monkeypatch, band_rows):
+def test_core_accessory_keys(oracle, skl, gpu_ctx, monkeypatch, band_rows, tile_rows):
     """(core, acc) records: the key is the core distance, the accessory distance rides along
     (distance_matrix.rs:245-248), through both copies of a record and the running top-k."""
     kmers, ss64, n, knn = [15, 19, 23, 27, 31], 8, 211, 9
     bins = synth.set_r(n, kmers, ss64, n_clusters=6)
     o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    monkeypatch.setenv("SKL_TILE32_MIN", "0" if tile_rows == 32 else "-1")
     idx, d0, d1 = _knn(skl, gpu_ctx, g, g.set_k(), knn, monkeypatch, band_rows, True, with_d1=True)
-    assert "COREACC, all k" in gpu_ctx.last_kernel()
+    assert "COREACC, all k" in gpu_ctx.last_kernel() and f"R={tile_rows}," in gpu_ctx.last_kernel()
     ref = _knn(skl, gpu_ctx, g, g.set_k(), knn, monkeypatch, band_rows, False, with_d1=True)
     assert np.array_equal(idx, ref[0]) and np.array_equal(d0, ref[1]) and np.array_equal(d1, ref[2])
     exp = oracle.self_dists_knn(o, knn, oracle.COREACC, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
