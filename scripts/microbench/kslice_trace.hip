@@ -72,6 +72,12 @@ int main(int argc, char **argv)
     int pflags = 1;
     if (shape >= 980 && shape <= 999) { pflags = shape == 999 ? 1 : shape - 980; shape = 999; }   // 991 queue, 993 +priority rotation, 995 equal split, 997 both
     const bool persistent = shape == 999;
+    // KT_TAIL=S: tail slicing of the one-workgroup-per-unit launch (pair_kslice.hip, PairArgs::tail_slices)
+    if (getenv("KT_TAIL") && !persistent) {
+        g.tail_slices = (uint32_t)atoi(getenv("KT_TAIL"));
+        g.tail_resident = (shape == 325 ? 3u : 4u) * 256u / 8u;
+        CK(hipMemset(dOut, 0, pairs * nk * 4 * 2));
+    }
     uint32_t *dCtr = nullptr;
     CK(hipMalloc(&dCtr, 8 * 32 * 4));
     CK(hipMemset(dCtr, 0, 8 * 32 * 4));
@@ -97,6 +103,7 @@ int main(int argc, char **argv)
     CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
     n_wg = 8ull * ((gp.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * nk * slices;   // as launch_pair_kernel_kslice pads it
     if (shape == 999) n_wg = 1024;
+    if (g.tail_slices > 1) n_wg *= g.tail_slices;   // upper bound: workgroup indices beyond the launch have empty records
     const int wpw = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;
     const size_t n_waves = n_wg * wpw;
     fprintf(stderr, "n_wg %llu\n", (unsigned long long)n_wg);

@@ -251,7 +251,8 @@ Knobs read_knobs()
     k.sliced_max_pairs = env_int("SKL_SLICED_MAX_PAIRS", -1);
     k.knn_band_rows = std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));
     k.k_slices = (int)env_int("SKL_K_SLICES", 0);
-    k.persist = env_int("SKL_PERSIST", 1);
+    k.tail_slices = (int)std::min(8ll, std::max(0ll, env_int("SKL_TAIL_SLICES", 4)));
+    k.tail_max_pct = env_int("SKL_TAIL_MAX_PCT", 90);
     k.tile32_min = env_int("SKL_TILE32_MIN", 16ll << 20);
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
@@ -261,6 +262,7 @@ Knobs read_knobs()
     const char *sk = getenv("SKL_SKETCH_KERNEL");
     k.sketch_global = sk && strcmp(sk, "global") == 0;
 #ifdef SKL_AB
+    k.persist = (int)env_int("SKL_PERSIST", 0);   // 2: the persistent form (pair_kpersist.hip) whenever it is supported
     // SKL_KERNEL = smem | lds | ksplit | kslice forces one implementation (0: dispatcher's choice)
     if (const char *e = getenv("SKL_KERNEL")) {
         k.kernel = strcmp(e, "smem") == 0 ? 1 : strcmp(e, "lds") == 0 ? 2 : strcmp(e, "ksplit") == 0 ? 3
@@ -336,6 +338,15 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
 #endif
     ctx->last_count_planes = std::max(1u, args.k_slices);
     ctx->last_persistent = false;
+    ctx->last_tail = false;
+    if (args.tail_slices > 1u) {
+        // tail-sliced one-workgroup-per-unit launch: two planes whatever kernel ends up running (a
+        // kernel without the slices leaves plane 1 as it found it: zero)
+        args.tail_resident = (shape == 325 ? 3u : 4u) * (uint32_t)ctx->n_cu / 8u;
+        ctx->last_count_planes = 2;
+        ctx->last_tail = true;
+    }
+#ifdef SKL_AB
     if (try_kslice && args.k_slices == 2u && args.persistent_ok && kpersist_supported(args, mode, 4u * (uint32_t)ctx->n_cu)) {
         // k-sliced core/acc (counts + epilogue) with fewer (tile, k) units than resident workgroup
         // slots: the persistent form, the workgroups share the stages of all units
@@ -350,6 +361,7 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
             return hipSuccess;
         }
     }
+#endif
     if (try_kslice) {
         // single-k Jaccard: the sliced and the all-k form are the same work, the sliced one
         // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
@@ -359,7 +371,9 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
             const int rr = shape > 1000 ? shape / 100 : shape / 10;
             *name = "skl::pair_kernel_kslice<R=" + std::to_string(rr) + ", JL=" + std::to_string(jl) +
                     ", " + m + (sliced ? ", k-sliced" : ", all k") + ((shape == 165 || shape == 325 || shape > 1000) ? ", tight" : "") + "> (" +
-                    std::to_string(rr) + "x" + std::to_string(jl * 64) + " tiles, chunks split over 4 waves)";
+                    std::to_string(rr) + "x" + std::to_string(jl * 64) + " tiles, chunks split over 4 waves" +
+                    (sliced && mode == MODE_COUNTS && args.tail_slices > 1u
+                         ? "; " + std::to_string(args.tail_slices) + " chunk slices per unit in the last round of workgroups" : "") + ")";
             return launch_pair_kernel_kslice(args, mode, shape, sliced, ablate, tiles, stream);
         }
     }
@@ -819,16 +833,28 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
         void *counts = nullptr;
         const uint32_t k_slices = sliced ? choose_k_slices(ctx, rows->ss64) : 1u;
-        // the persistent form of the k-sliced launch (pair_kpersist.hip): two planes, plane 1 zero on entry
-        // It pays when the launch has fewer (tile, k) units than ~0.6 of the resident workgroup slots
-        // (a chip the one-workgroup-per-unit launch cannot fill: 3x faster at 200 genomes, 1.45x at 500,
-        // equal from ~700; profiles/r02_ab_persist.jsonl).  SKL_PERSIST=0 never, 2 whenever it is supported.
+        // A launch with fewer (tile, k) units than resident workgroup slots cannot fill the chip with one
+        // workgroup per unit: most SIMDs hold 0-2 waves and the launch takes the time of ONE unit at a
+        // lone wave's issue rate whatever its size (0.100 ms from 100 to 600 genomes).  Such launches are
+        // cut into tail_slices chunk slices per unit -- and so is the last, partial round of any launch
+        // SKL_TAIL_MAX_PCT lets through (default 90: launches of up to 0.9 estimated rounds, where the
+        // whole launch is that partial round; the partial round of a longer launch gains nothing,
+        // profiles/r02_ab_tail_slices.jsonl).  Slice 0 of a unit stores, the others add into a second
+        // plane that is zero on entry and re-zeroed by the epilogue.
         const uint64_t est_units = pairs * rows->nk / 2048;
-        const bool persist_pays = ctx->knobs.persist >= 2 || est_units * 10 <= 6ull * 4ull * (uint64_t)ctx->n_cu;
-        const bool persistent = sliced && ctx->knobs.persist && persist_pays && k_slices == 1u && rows->ss64 % 8 == 0 &&
-                                forced_kernel(ctx) == 0;
+        const uint64_t slots = 4ull * (uint64_t)ctx->n_cu;
+#ifdef SKL_AB
+        // the persistent form of the k-sliced launch (pair_kpersist.hip, A/B build): same two planes
+        const bool persistent = sliced && ctx->knobs.persist >= 2 && k_slices == 1u && rows->ss64 % 8 == 0 && forced_kernel(ctx) == 0;
+#else
+        const bool persistent = false;
+#endif
+        const uint32_t tail_slices = (uint32_t)ctx->knobs.tail_slices;
+        const bool tail = sliced && !persistent && k_slices == 1u && tail_slices > 1u && rows->ss64 % (8u * tail_slices) == 0 &&
+                          forced_kernel(ctx) == 0 && est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
+        const bool two_planes = persistent || tail;
         const size_t plane_bytes = pairs * rows->nk * sizeof(uint32_t);
-        SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(persistent ? 2u : 1u, k_slices), &counts, 1));
+        SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(two_planes ? 2u : 1u, k_slices), &counts, 1));
         if (sliced) {   // k-major scratch: coalesced stores from the (tile, k[, chunk slice]) workgroups
             g.cnt_pair_stride = 1;
             g.cnt_k_stride = pairs;
@@ -836,8 +862,9 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             g.k_slices = persistent ? 2u : k_slices;
             g.persistent_ok = persistent ? 1u : 0u;
             g.work_counter = ctx->work_counter;
+            g.tail_slices = tail ? tail_slices : 0u;
         }
-        if (persistent) {
+        if (two_planes) {
             void *plane1 = (char *)counts + plane_bytes;
             if (ctx->clean_plane1 != plane1 || ctx->clean_plane1_bytes != plane_bytes) {
                 HIP_TRY(hipMemsetAsync(plane1, 0, plane_bytes, ctx->stream));
@@ -863,9 +890,9 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.nk = (uint32_t)rows->nk;
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
-        e.rezero_plane1 = sliced && ctx->last_persistent ? 1u : 0u;
-        e.work_counter = e.rezero_plane1 ? ctx->work_counter : nullptr;
-        if (persistent && !ctx->last_persistent) ctx->clean_plane1 = nullptr;   // (an empty launch: nothing ran)
+        e.rezero_plane1 = sliced && (ctx->last_persistent || ctx->last_tail) ? 1u : 0u;
+        e.work_counter = sliced && ctx->last_persistent ? ctx->work_counter : nullptr;
+        if (two_planes && !(ctx->last_persistent || ctx->last_tail)) ctx->clean_plane1 = nullptr;   // (an empty launch, or another kernel took it: plane 1 is not known to be zero)
         e.nA_rows = (uint32_t)rows->n;
         e.nB_cols = (uint32_t)cols->n;
         e.row_begin = (uint32_t)r0;

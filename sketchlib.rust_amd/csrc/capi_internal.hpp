@@ -48,7 +48,8 @@ struct Knobs {
     int k_slices = 0;                 // SKL_K_SLICES: chunk slices per k of k-sliced core/acc launches (0: chosen per launch)
     int group_span = 2;                 // SKL_GROUP_SPAN: column groups whose tiles are numbered side by side (device_common.hpp lookup_tile_at)
     long long tile32_min = 16ll << 20;  // SKL_TILE32_MIN: pair x k evaluations from which launches use 32 x 128 tiles (-1: never, 0: always)
-    int persist = 1;                    // SKL_PERSIST=0: k-sliced core/acc launches never take the persistent form
+    int tail_slices = 4;                // SKL_TAIL_SLICES: chunk slices per unit in the last, partial round of a k-sliced core/acc launch (0/1: off)
+    long long tail_max_pct = 90;        // SKL_TAIL_MAX_PCT: ... for launches of up to this many estimated rounds of workgroups (in percent)
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
@@ -56,6 +57,7 @@ struct Knobs {
     bool sketch_global = false;       // SKL_SKETCH_KERNEL=global: the unstaged sketching kernel
 #ifdef SKL_AB
     int kernel = 0;                   // SKL_KERNEL: 0 none, 1 smem, 2 lds, 3 ksplit, 4 kslice
+    int persist = 0;                  // SKL_PERSIST=2: k-sliced core/acc launches take the persistent form (pair_kpersist.hip)
     int kslice_shape = 0;             // SKL_KSLICE_SHAPE: R*10 + JL
     int ksplit_rows = 0;              // SKL_KSPLIT_ROWS: 4 or 8
     int kslice_ablate = 0;            // SKL_KSLICE_ABLATE: timing only, outputs wrong by construction
@@ -81,6 +83,7 @@ struct skl_ctx {
     size_t launches_seen = 0;           // pair-kernel launches since the last skl_ctx_timing_reset
     std::string last_kernel;
     uint32_t last_count_planes = 1;     // planes the last MODE_COUNTS k-sliced launch wrote (epilogue: n_slices)
+    bool last_tail = false;             // ... or the tail-sliced one-workgroup-per-unit launch (plane 1 added to as well)
     bool last_persistent = false;       // ... and whether it was the persistent form (plane 1 added to, re-zeroed by the epilogue)
     // plane 1 of the counts scratch as the persistent form needs it: all zero.  Valid for exactly
     // this (pointer, bytes) until anything else writes the scratch.

@@ -61,6 +61,12 @@ struct PairArgs {
     uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
     uint32_t k_slices;            // k-sliced MODE_COUNTS: chunk slices per k-mer length (0/1: none); slice s of k index kk
                                   // stores the matches of ITS bins at "k index" s * k_count + kk
+    // Tail slicing of a k-sliced MODE_COUNTS launch (pair_kslice.hip): on every XCD the workgroups from
+    // index tail_first on are chunk slices of units (tail_slices per unit, adjacent) instead of whole
+    // units; slice 0 stores its counts to plane 0, the others ADD theirs to plane 1 (k index
+    // k_count + kk: zero on entry, summed and re-zeroed by the epilogue, as for pair_kpersist.hip).
+    // tail_slices <= 1: off.  The launcher sets tail_first from tail_resident = workgroups resident per XCD.
+    uint32_t tail_slices, tail_first, tail_resident;
     uint32_t persistent_ok;       // the caller prepared two planes with plane 1 zeroed: pair_kpersist.hip may run
     uint32_t *work_counter;       // pair_kpersist.hip: 8 x 32 u32, entry [xcd * 32] = stages of that XCD handed out; zero on entry
     // Symmetric self kNN (pair_kslice.hip: k-sliced MODE_JACCARD and all-k MODE_COREACC): besides

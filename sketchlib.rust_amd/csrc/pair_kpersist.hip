@@ -1,6 +1,9 @@
 // pair_kpersist.hip -- the chunk-split pair kernel as a PERSISTENT launch (gfx950), for SMALL
 // launches of the k-sliced core/accessory form (bin-match counts into a k-major scratch array +
-// epilogue kernel).
+// epilogue kernel).  A/B BUILD ONLY (-DSKL_AB, SKL_PERSIST=2): plain chunk slices of such launches
+// (pair_kslice.hip, PairArgs::tail_slices) do the same job as well or better with a tenth of the code
+// (profiles/r02_ab_tail_slices.jsonl), so that is what the product library ships;
+// this kernel stays as the measured answer to "a dynamic work queue, one atomic per fetch".
 //
 // Why.  pair_kslice.hip's k-sliced form launches one workgroup per (tile, k-mer length): U units of
 // equal cost on G = 4 x CUs resident workgroup slots.  A unit is 8 stages of 4 waves (sketchsize64 =
@@ -11,7 +14,7 @@
 // the STAGES of all units, so every SIMD has 4 waves however few units there are: 0.033 ms at 100
 // genomes, 0.041 at 200, 0.070 at 500 (profiles/r02_ab_persist.jsonl).  From U ~ 0.7 G on the
 // one-workgroup-per-unit launch fills the chip by itself and is as fast or faster (the parts a unit
-// is cut into cost a reduction each), so the dispatcher takes this form for U <= 0.6 G only.
+// is cut into cost a reduction each).
 //
 // Work distribution.  The workgroups of an XCD (gx of them) walk that XCD's stage sequence (a stage =
 // 8 chunks of one unit, 2 per wave; units in the k-sliced launch's order) in PIECES, a fixed function

@@ -28,6 +28,7 @@
 // Wave timelines of this kernel: scripts/microbench/kslice_trace.hip.
 #include "device_common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace skl {
@@ -112,12 +113,21 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
     // (MODE_COUNTS launches may also cut a k-mer length into g.k_slices chunk ranges, one workgroup
     // each -- more, shorter workgroups for launches that would otherwise fill the chip 1.4 times;
     // slice s of k index kk stores its counts as "k index" s * k_count + kk, summed by the epilogue)
-    const uint32_t n_slices = KSL && MODE == MODE_COUNTS ? g.k_slices : 1u;
-    const uint32_t per_blk = KB * g.k_count * n_slices;
-    const uint32_t slot = KSL ? (s_idx / per_blk) * KB + (s_idx % per_blk) % KB : s_idx;
-    const uint32_t kslot = KSL ? (s_idx % per_blk) / KB : 0u;
-    const uint32_t kk0 = kslot / n_slices;                      // first k index of this workgroup
-    const uint32_t slice = kslot - kk0 * n_slices;
+    // TAIL SLICING (g.tail_slices > 1, instead of the uniform slices): the workgroups of an XCD up to
+    // index tail_first -- its whole rounds of resident workgroups -- are whole units, the ones after
+    // are chunk slices of the remaining units.  The last round of a launch is then made of short
+    // workgroups that spread over all SIMDs instead of a few long ones that run 1-2 per SIMD at a lone
+    // wave's issue interval, and the rounds before it pay nothing.  Slice 0 stores, the others add
+    // into plane 1 (see kernels.h).
+    const bool tail_mode = KSL && MODE == MODE_COUNTS && g.tail_slices > 1u;
+    const bool in_tail = tail_mode && s_idx >= g.tail_first;
+    const uint32_t n_slices = in_tail ? g.tail_slices : (KSL && MODE == MODE_COUNTS && !tail_mode ? g.k_slices : 1u);
+    const uint32_t u_idx = in_tail ? g.tail_first + (s_idx - g.tail_first) / n_slices : s_idx;   // unit index (tail mode) / workgroup index
+    const uint32_t per_blk = KB * g.k_count * (tail_mode ? 1u : n_slices);
+    const uint32_t slot = KSL ? (u_idx / per_blk) * KB + (u_idx % per_blk) % KB : s_idx;
+    const uint32_t kslot = KSL ? (u_idx % per_blk) / KB : 0u;
+    const uint32_t kk0 = tail_mode ? kslot : kslot / n_slices;  // first k index of this workgroup
+    const uint32_t slice = in_tail ? (s_idx - g.tail_first) % n_slices : (tail_mode ? 0u : kslot - kk0 * n_slices);
     const uint32_t nkk = KSL ? 1u : g.k_count;                  // k-mer lengths it walks
     const uint32_t c_begin = slice * (g.ss64 / n_slices);       // chunk range of this workgroup
     const uint32_t c_end = n_slices > 1u ? c_begin + g.ss64 / n_slices : g.ss64;
@@ -397,7 +407,16 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
                     field_pair(x, (uint32_t)h, r, j);
                     const uint32_t mism = h ? (total >> 16) : (total & 0xFFFFu);
                     if constexpr (MODE == MODE_COUNTS) {
-                        store_count(g, a0 + r, (jb0 + j) * 64u + lane, slice * g.k_count + kk, (c_end - c_begin) * 64u, mism);
+                        if (in_tail && slice != 0u) {   // tail slices 1.. add into plane 1
+                            const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
+                            if (pair_valid(g, i_, jc_)) {
+                                atomicAdd(&((uint32_t *)g.out)[pair_out_index(g, i_, jc_) * g.cnt_pair_stride +
+                                                               (uint64_t)(g.k_count + kk) * g.cnt_k_stride],
+                                          (c_end - c_begin) * 64u - mism);
+                            }
+                        } else {
+                            store_count(g, a0 + r, (jb0 + j) * 64u + lane, (tail_mode ? 0u : slice * g.k_count) + kk, (c_end - c_begin) * 64u, mism);
+                        }
                     } else if constexpr (KSL) {
                         const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
                         float v = __builtin_inff();
@@ -543,10 +562,24 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (n_wg == 0) return hipSuccess;
     // k-sliced: whole blocks of KSL_TILE_BLOCK tile slots per XCD (slots past the last tile exit at once)
     if (!(k_sliced && mode == MODE_COUNTS) || args.k_slices == 0) args.k_slices = 1;
+    if (!(k_sliced && mode == MODE_COUNTS)) args.tail_slices = 0;
+    if (args.tail_slices > 1u) {
+        // whole units for the XCD's whole rounds of resident workgroups, slices for the rest
+        // (counted on the real units: the padding slots of the last tile block exit at once)
+        if (args.ss64 % (args.tail_slices * 8u) != 0 || args.tail_resident == 0) return hipErrorInvalidValue;   // whole stages per slice
+        const uint32_t units_x = args.tiles_per_xcd * args.k_count;
+        args.tail_first = units_x / args.tail_resident * args.tail_resident;
+        args.k_slices = 1;
+    }
     if (args.ss64 % (args.k_slices * 8u) != 0 && args.k_slices != 1) return hipErrorInvalidValue;   // whole stages per slice
     if (k_sliced) {
-        n_wg = 8ull * ((args.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * args.k_count *
-               args.k_slices;
+        const uint64_t units_pad = (uint64_t)((args.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * args.k_count;
+        n_wg = 8ull * units_pad * args.k_slices;
+        if (args.tail_slices > 1u) {
+            const uint64_t first = std::min<uint64_t>(args.tail_first, units_pad);
+            args.tail_first = (uint32_t)first;
+            n_wg = 8ull * (first + (units_pad - first) * args.tail_slices);
+        }
     }
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);

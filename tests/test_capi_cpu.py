@@ -44,10 +44,10 @@ def test_product_library_has_no_ab_kernels_or_switches():
     for k in kernels:
         # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only, ablation parameter 0; ksplit fallback: 8-row tiles
         assert re.fullmatch(r"pair_kernel_kslice<16, 2, [012], (true|false), 0, true, 1>|pair_kernel_kslice<32, 2, [012], (true|false), 0, true, 4>|pair_kernel_ksplit<8, [012], 8, false>", k), k
-    assert "skl::pair_kernel_kpersist(" in demangled    # the persistent form of the k-sliced launch (not a template)
+    assert "pair_kernel_kpersist" not in demangled      # the persistent form of the k-sliced launch: A/B build only
     blob = open(pkg.library_path(), "rb").read()
     for needle in (b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
-                   b"SKL_LDS_SHAPE", b"SKL_FORCE_NA", b"SKL_PAIR_VARIANT"):
+                   b"SKL_LDS_SHAPE", b"SKL_FORCE_NA", b"SKL_PAIR_VARIANT", b"SKL_PERSIST"):
         assert needle not in blob, needle
     # and no getenv on the launch path: what remains is read by read_knobs(), once per context
     src = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "capi.cpp")).read()

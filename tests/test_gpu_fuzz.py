@@ -96,13 +96,14 @@ print("BANDS_OK")
     assert res.returncode == 0 and "BANDS_OK" in res.stdout, res.stderr[-2000:]
 
 
-@pytest.mark.parametrize("sliced_max,persist,tile32", [("0", "1", None), ("1000000000000", "0", None), ("1000000000000", "2", None),
-                                                        ("0", "1", "-1"), ("1000000000000", "0", "-1")],
-                         ids=["fused", "k_sliced", "persistent", "fused_16_rows", "k_sliced_16_rows"])
-def test_cross_large_launch_ragged_tiles(oracle, skl, gpu_ctx, monkeypatch, sliced_max, persist, tile32):
+@pytest.mark.parametrize("sliced_max,tail,tile32", [("0", "0", None), ("1000000000000", "0", None), ("1000000000000", "1", None),
+                                                     ("0", "0", "-1"), ("1000000000000", "0", "-1"), ("1000000000000", "1", "-1")],
+                         ids=["fused", "k_sliced", "k_sliced_tail", "fused_16_rows", "k_sliced_16_rows", "k_sliced_16_rows_tail"])
+def test_cross_large_launch_ragged_tiles(oracle, skl, gpu_ctx, monkeypatch, sliced_max, tail, tile32):
     """5 000 refs x 2 000 queries = 1e7 pairs in cross mode, ragged on both axes: the large-launch kernel
-    (all k-mer lengths fused in one workgroup), the one-workgroup-per-(tile, k) launch, and the persistent
-    form forced onto a launch of 24 units per workgroup slot (whole-unit rounds, then the guided tail).
+    (all k-mer lengths fused in one workgroup), the one-workgroup-per-(tile, k) launch, and that launch
+    with its last, partial round of workgroups cut into chunk slices (whole units before it, slices that
+    add into the second counts plane after: forced, the default rule takes it for short launches only).
     At this size the dispatcher takes 32 x 128 tiles; SKL_TILE32_MIN=-1 keeps the 16 x 128 ones."""
     kmers, ss64 = [15, 19, 23, 27, 31], 64
     nr, nq = 5003, 2001
@@ -111,15 +112,15 @@ def test_cross_large_launch_ragged_tiles(oracle, skl, gpu_ctx, monkeypatch, slic
     o_r, g_r = oracle.Sketches(rb, nr, kmers, ss64), gpu_ctx.sketches(rb, nr, kmers, ss64)
     o_q, g_q = oracle.Sketches(qb, nq, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
     monkeypatch.setenv("SKL_SLICED_MAX_PAIRS", sliced_max)
-    monkeypatch.setenv("SKL_PERSIST", persist)
+    monkeypatch.setenv("SKL_TAIL_MAX_PCT", "100000000" if tail == "1" else "90")
     if tile32 is not None:
         monkeypatch.setenv("SKL_TILE32_MIN", tile32)
     gpu_ctx.reload_env()
     got = skl.cross_dists_all(gpu_ctx, g_r, g_q, g_r.set_k())
     name = gpu_ctx.last_kernel()
-    assert ("all k" if sliced_max == "0" else "kpersist" if persist == "2" else "k-sliced") in name, name
-    if persist != "2":
-        assert ("R=16" if tile32 == "-1" else "R=32") in name, name
+    assert ("all k" if sliced_max == "0" else "k-sliced") in name, name
+    assert ("chunk slices" in name) == (tail == "1"), name
+    assert ("R=16" if tile32 == "-1" else "R=32") in name, name
     rng = np.random.default_rng(3)
     pairs = list(zip(rng.integers(0, nr, 2500), rng.integers(0, nq, 2500))) + [(0, 0), (nr - 1, nq - 1), (nr - 1, 0),
                                                                                (0, nq - 1), (15, 511), (16, 512), (4999, 1999)]

@@ -71,20 +71,22 @@ print("VARIANT_OK", ctx.last_kernel())
 AB = {"SKL_LIBRARY": os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build_ab", "libsketchlib_dist_hip.so")}
 VARIANTS = [
     # product library
-    ({}, "kpersist"),                                              # dispatcher's choice at this size: fewer units than workgroup slots
-    ({"SKL_PERSIST": "0"}, "k-sliced"),                            # one workgroup per (tile, k)
+    ({}, "4 chunk slices"),                                        # dispatcher's choice at this size: less than one round of workgroups
+    ({"SKL_TAIL_SLICES": "0"}, "k-sliced"),                        # one workgroup per (tile, k)
+    ({"SKL_TAIL_SLICES": "2"}, "2 chunk slices"),
     ({"SKL_SLICED_MAX_PAIRS": "0"}, "all k"),                      # all-k fused form
-    ({"SKL_K_SLICES": "1", "SKL_PERSIST": "0"}, "k-sliced"),       # k-sliced, whole k-mer lengths
-    ({"SKL_TILE32_MIN": "0", "SKL_PERSIST": "0"}, "R=32, JL=2, COUNTS, k-sliced"),   # 32 x 128 tiles (large launches' shape)
+    ({"SKL_K_SLICES": "1"}, "k-sliced"),                           # k-sliced, whole k-mer lengths
+    ({"SKL_TILE32_MIN": "0"}, "R=32, JL=2, COUNTS, k-sliced"),     # 32 x 128 tiles (large launches' shape)
     ({"SKL_TILE32_MIN": "0", "SKL_SLICED_MAX_PAIRS": "0"}, "R=32, JL=2, COREACC, all k"),
-    ({"SKL_GROUP_SPAN": "1"}, "kpersist"),                         # tile numbering: column group by column group
-    ({"SKL_GROUP_SPAN": "3", "SKL_PERSIST": "0"}, "k-sliced"),     # ... 3 groups side by side (default: 2)
-    ({"SKL_GROUP_SPAN": "4"}, "kpersist"),
+    ({"SKL_GROUP_SPAN": "1"}, "k-sliced"),                         # tile numbering: column group by column group
+    ({"SKL_GROUP_SPAN": "3", "SKL_TAIL_SLICES": "0"}, "k-sliced"), # ... 3 groups side by side (default: 2)
+    ({"SKL_GROUP_SPAN": "4"}, "k-sliced"),
     ({"SKL_K_SLICES": "2"}, "k-sliced"),                           # ... cut into 2 / 4 / 8 chunk slices
     ({"SKL_K_SLICES": "4"}, "k-sliced"),
     ({"SKL_K_SLICES": "8"}, "k-sliced"),
     # A/B library
-    ({**AB}, "kpersist"),
+    ({**AB}, "4 chunk slices"),
+    ({**AB, "SKL_PERSIST": "2"}, "kpersist"),                      # the persistent form of the k-sliced launch
     ({**AB, "SKL_KSLICE_SHAPE": "162"}, "R=16, JL=2, COUNTS, k-sliced>"),   # the 141-register form
     ({**AB, "SKL_KSLICE_SHAPE": "162", "SKL_SLICED_MAX_PAIRS": "0"}, "R=16, JL=2, COREACC, all k>"),
     ({**AB, "SKL_KSLICE_SHAPE": "82"}, "R=8, JL=2"),
