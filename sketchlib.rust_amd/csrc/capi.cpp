@@ -257,6 +257,7 @@ Knobs read_knobs()
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
+    k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
     k.cand_symmetric = env_int("SKL_CAND_SYMMETRIC", 1) != 0;
     const char *sk = getenv("SKL_SKETCH_KERNEL");

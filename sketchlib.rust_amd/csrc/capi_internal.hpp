@@ -51,6 +51,7 @@ struct Knobs {
     int tail_slices = 4;                // SKL_TAIL_SLICES: chunk slices per unit in the last, partial round of a k-sliced core/acc launch (0/1: off)
     long long tail_max_pct = 90;        // SKL_TAIL_MAX_PCT: ... for launches of up to this many estimated rounds of workgroups (in percent)
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
+    bool knn_row_flags = true;        // SKL_KNN_ROW_FLAGS=0: the merge of the transposed band visits every row (A/B only, results are identical)
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
     bool cand_symmetric = true;       // SKL_CAND_SYMMETRIC=0: evaluate symmetric candidate lists in full
@@ -71,8 +72,8 @@ struct skl_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only scratch
-    void *scratch[6] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN)
-    size_t scratch_bytes[6] = {};
+    void *scratch[7] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32)
+    size_t scratch_bytes[7] = {};
     hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
     // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
     // "producer finished buffer b" / "consumer finished buffer b"

@@ -83,6 +83,17 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[1], 3));
         SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[1], 5));
     }
+    // Row flags of the transposed band (one array per band buffer): the pair kernel marks the rows that
+    // received a record below their knn-th best so far with the band's number, and the merge of the
+    // transposed band (n - b1 workgroups reading band_rows records each: 2/3 of the merge time at cfg 5)
+    // returns at once for the others.  The threshold the pair kernel compares with is read from the
+    // running state while merges of earlier bands may still be updating it on the other stream: a
+    // stale value is a higher one (a row's knn-th best only ever improves), so it flags too many rows,
+    // never too few; ties never count (a band's sample ids are above every id a lower row holds).
+    void *flag_mem = nullptr;
+    SKL_TRY(ctx_scratch(ctx, 2 * n * sizeof(uint32_t), &flag_mem, 6));
+    uint32_t *flags[2] = {(uint32_t *)flag_mem, (uint32_t *)flag_mem + (overlap ? n : 0)};
+    HIP_TRY(hipMemsetAsync(flag_mem, 0, 2 * n * sizeof(uint32_t), ctx->stream));
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
     if (overlap) {   // the states were cleared on the context's stream, the merges run on the other one
         HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
@@ -111,6 +122,13 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         g.out_t = b1 < n ? (float *)tband[buf] : nullptr;
         g.t_col_begin = (uint32_t)(b1 - col0);
         g.t_stride = (uint32_t)t_stride;
+        const uint32_t flag_value = (uint32_t)(it + 1);      // never 0, distinct per band of this call
+        if (g.out_t && ctx->knobs.knn_row_flags) {
+            g.t_flag = flags[buf] + col0;                   // indexed by the view's column number, like t_col_begin
+            g.t_flag_value = flag_value;
+            g.t_thr = st.key + col0 * knn + (knn - 1);      // knn-th best of sample col0 + c
+            g.t_thr_stride = (uint32_t)knn;
+        }
         SKL_TRY(timed_pair_launch(ctx, g, mode));
         if (overlap) {
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
@@ -142,6 +160,8 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         m.id_base = (uint32_t)b0;
         m.skip_below = 0;
         m.self_id_base = m.state_row_base = (uint32_t)b1;
+        m.flag = ctx->knobs.knn_row_flags ? flags[buf] + b1 : nullptr;
+        m.flag_value = flag_value;
         HIP_TRY(launch_topk_merge(m, topk_stream));
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
         ++it;

@@ -175,6 +175,13 @@ __device__ __forceinline__ void tile_in_supergroup_cross(const PairArgs &g, uint
     group = first + (u - row_tile * gcount);
 }
 
+// f32 -> u32 whose unsigned order is the float order (the running top-k keeps its keys this way)
+__device__ __forceinline__ uint32_t sortable_bits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 // blockIdx % 8 labels the XCD (MI355X_MICROARCH.md); XCD x takes tiles
 // [x*tiles_per_xcd, (x+1)*tiles_per_xcd) of the super-group-major numbering of the ACTIVE
 // tiles: every XCD gets the same number of (equal-cost) tiles.  The ~100 workgroups resident on an

@@ -76,6 +76,14 @@ struct PairArgs {
     // tile height.  Null = off.
     float *out_t;
     uint32_t t_col_begin, t_stride;
+    // ... and the rows that receive such a candidate BELOW their current knn-th best are flagged, so
+    // that the merge of the transposed band visits only them: t_thr[c * t_thr_stride] is the sortable
+    // key (topk.hip) of column c's knn-th best so far (0xFFFFFFFF while it has fewer; it may be stale,
+    // i.e. too high, never too low), t_flag[c] is set to t_flag_value.  Column indices are the view's
+    // (like t_col_begin).  Null = off.
+    const uint32_t *t_thr;
+    uint32_t *t_flag;
+    uint32_t t_thr_stride, t_flag_value;
     // epilogue
     int32_t jout;                 // JaccardOut
     int32_t has_comp;
@@ -256,6 +264,8 @@ struct TopkMergeArgs {
     uint32_t *run_idx;        // [.][knn]
     float *run_d1;            // [.][knn] second values (stride2 == 2) or null
     uint32_t streaming;       // 1: one-pass streaming merge (default); 0: radix select only (A/B)
+    const uint32_t *flag;     // row r is merged only if flag[r] == flag_value (null: every row)
+    uint32_t flag_value;
 };
 hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream);
 // Union of up to MERGE_STATES_MAX partial states of the same rows (disjoint candidate sets) ->

@@ -458,6 +458,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
                         const float4 v = *reinterpret_cast<const float4 *>(&tt[c * TP + 4u * q]);
                         *reinterpret_cast<float4 *>(&g.out_t[(size_t)(jc - g.t_col_begin) * g.t_stride +
                                                              (a0 - g.row_begin) + 4u * q]) = v;
+                        if (g.t_flag != nullptr) {   // does any of the four beat column jc's knn-th best? (invalid records are +inf)
+                            const float best = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
+                            if (sortable_bits(best) < g.t_thr[(size_t)jc * g.t_thr_stride]) g.t_flag[jc] = g.t_flag_value;
+                        }
                     }
                 }
             }
@@ -510,6 +514,9 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
                     const float4 v = *reinterpret_cast<const float4 *>(&tt[c * TP + 2u * q]);
                     *reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(g.out_t) +
                                                 (size_t)(jc - g.t_col_begin) * g.t_stride + (a0 - g.row_begin) + 2u * q) = v;
+                    if (g.t_flag != nullptr) {   // two (core, acc) records: the key is the core distance
+                        if (sortable_bits(fminf(v.x, v.z)) < g.t_thr[(size_t)jc * g.t_thr_stride]) g.t_flag[jc] = g.t_flag_value;
+                    }
                 }
             }
         }

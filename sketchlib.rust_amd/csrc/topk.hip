@@ -19,6 +19,7 @@ namespace skl {
 constexpr int TOPK_THREADS = 256;
 constexpr int TOPK_MAX = 2048;  // knn upper bound handled on device
 
+// (the pair kernel compares with the same mapping: device_common.hpp)
 __device__ __forceinline__ uint32_t sortable_bits(float f)
 {
     const uint32_t u = __float_as_uint(f);
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
     __shared__ TopkShared sh;
     __shared__ float second[TOPK_MAX];   // second values of the new state (stride2 == 2)
     const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    // the pair kernel flagged the rows that received a record below their knn-th best: nothing to do for the others
+    if (g.flag != nullptr && g.flag[row] != g.flag_value) return;
     const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
     const uint32_t knn = g.knn;
     const size_t srow = (size_t)(g.state_row_base + row) * knn;

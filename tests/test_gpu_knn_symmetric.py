@@ -100,6 +100,27 @@ def test_same_as_row_by_row(oracle, skl, gpu_ctx, monkeypatch, n, band_rows, knn
     assert np.array_equal(idx, exp["idx"])
 
 
+@pytest.mark.parametrize("dist", ["jaccard", "coreacc"])
+def test_row_flags_skip_only_rows_without_news(oracle, skl, gpu_ctx, monkeypatch, dist):
+    """The pair kernel flags the rows a band improves and the merge of the transposed band skips the
+    rest (SKL_KNN_ROW_FLAGS=0: every row is visited).  Clustered data, many small bands: most rows are
+    final after their cluster's bands, so most visits are skipped -- and nothing may change."""
+    kmers, ss64, n, knn = ([21], 3, 2600, 12) if dist == "jaccard" else ([15, 19, 23], 8, 900, 7)
+    bins = synth.set_r(n, kmers, ss64, n_clusters=25)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21) if dist == "jaccard" else g.set_k()
+    monkeypatch.setenv("SKL_KNN_ROW_FLAGS", "1")
+    on = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, 48, True, with_d1=True)
+    monkeypatch.setenv("SKL_KNN_ROW_FLAGS", "0")
+    off = _knn(skl, gpu_ctx, g, p, knn, monkeypatch, 48, True, with_d1=True)
+    for a, b in zip(on, off):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    o = oracle.Sketches(bins, n, kmers, ss64)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD if dist == "jaccard" else oracle.COREACC, 0, False,
+                                ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(on[0], exp["idx"])
+
+
 def test_device_output_and_default_band_size(skl, gpu_ctx, monkeypatch):
     """No knobs: the driver sizes the bands itself; one band means the row-by-row form runs."""
     monkeypatch.delenv("SKL_KNN_BAND_ROWS", raising=False)
