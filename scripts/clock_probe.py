@@ -67,6 +67,23 @@ def main():
     for t, s in samples:
         print(f"t={t - t0:5.2f}s", json.dumps(s))
     print("ms per launch over time:", [f"{t:.1f}s:{ms:.2f}" for t, ms in times[::4]])
+    # energy per pair: mean package power over the samples taken after the first second, mean launch time likewise
+    watts = []
+    for t, smp in samples:
+        if t - t0 < 1.0:
+            continue
+        for k, v in smp.items():
+            if "power" in k.lower():
+                try:
+                    watts.append(float(v))
+                except ValueError:
+                    pass
+    ms = [m for t, m in times if t >= 1.0]
+    if watts and ms:
+        w, m = sum(watts) / len(watts), sum(ms) / len(ms)
+        print(json.dumps({"kernel": ctx.last_kernel().split(" (")[0], "switches": {k: v for k, v in os.environ.items() if k.startswith("SKL_")},
+                          "n": n, "ms_per_launch": m, "pairs_per_s": pairs / (m / 1e3), "package_power_W": w,
+                          "pairs_per_joule": pairs / (m / 1e3) / w, "power_samples": len(watts)}))
 
 
 if __name__ == "__main__":
