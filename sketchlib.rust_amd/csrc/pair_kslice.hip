@@ -203,8 +203,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
             const uint32_t q_ = p_ % 7u, rc_ = p_ / 7u;                                      \
             const uint32_t r_ = rc_ % R, c_ = rc_ / R;                                       \
             const uint32_t cc_ = (c0_ + c_) < g.ss64 ? (c0_ + c_) : (g.ss64 - 1u);           \
-            const uint64_t *src_ = g.A + (size_t)(a0 + r_) * sample_stride +                 \
-                                   (size_t)k_ * kmer_stride + (size_t)cc_ * BBITS + 2u * q_; \
+            const uint64_t *src_ = (ABL & 4)                                                 \
+                ? g.A + ((((size_t)(a0 / R) * g.nk + k_) * g.ss64 + cc_) * R + r_) * BBITS + 2u * q_ /* timing only: a tile-major row slab */ \
+                : g.A + (size_t)(a0 + r_) * sample_stride +                                  \
+                      (size_t)k_ * kmer_stride + (size_t)cc_ * BBITS + 2u * q_;               \
             skl_dma16(src_, lds_base + (((uint32_t)wave * 2u + (BUF)) * (PPL * LANES) + u * 64u) * 16u); \
         }                                                                                    \
     } while (0)
@@ -591,6 +593,16 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)n_wg);
 #ifdef SKL_AB
+    // timing-only: rows read as if the row slab were tile-major ([row tile][k][chunk][row][plane]: a wave's
+    // stage is one contiguous 3.5 KB run instead of 16-32 runs of 112 B, one per sample)
+    if (ablate == 4 && (shape == 165 || shape == 325)) {
+        const dim3 block(LANES * WAVES_PER_WG);
+        if (shape == 165 && k_sliced && mode == MODE_COUNTS) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 4, true, 1>), grid, block, 0, stream, args);
+        else if (shape == 325 && k_sliced && mode == MODE_COUNTS) hipLaunchKernelGGL((pair_kernel_kslice<32, 2, MODE_COUNTS, true, 4, true, 4>), grid, block, 0, stream, args);
+        else if (shape == 325 && !k_sliced && mode == MODE_COREACC) hipLaunchKernelGGL((pair_kernel_kslice<32, 2, MODE_COREACC, false, 4, true, 4>), grid, block, 0, stream, args);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     // timing-only ablations of the sliced COUNTS kernel (outputs wrong by construction):
     // SKL_KSLICE_ABLATE = 1 no row re-reads from LDS, 2 no column reloads, 3 both
     if (ablate && (shape == 162 || shape == 165) && k_sliced && mode == MODE_COUNTS) {
