@@ -133,6 +133,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
     const uint32_t c_end = n_slices > 1u ? c_begin + g.ss64 / n_slices : g.ss64;
     uint32_t jg, at;  // column group (JL blocks of 64), row tile
     if (!lookup_tile_at(g, xcd, slot, jg, at)) return;
+    if constexpr ((ABL & 8) != 0) {   // timing only: every workgroup computes tile (0, group 1): all operands cache-hot
+        jg = 1;
+        at = 0;
+    }
     const uint32_t jb0 = jg * JL;
     const uint32_t a0 = g.row_begin + at * R;
     if (jb0 >= g.n_jblocks) return;
@@ -595,6 +599,10 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
 #ifdef SKL_AB
     // timing-only: rows read as if the row slab were tile-major ([row tile][k][chunk][row][plane]: a wave's
     // stage is one contiguous 3.5 KB run instead of 16-32 runs of 112 B, one per sample)
+    if (ablate == 8 && shape == 165 && k_sliced && mode == MODE_COUNTS) {   // timing only: all workgroups on one hot tile
+        hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 8, true, 1>), grid, dim3(LANES * WAVES_PER_WG), 0, stream, args);
+        return hipGetLastError();
+    }
     if (ablate == 4 && (shape == 165 || shape == 325)) {
         const dim3 block(LANES * WAVES_PER_WG);
         if (shape == 165 && k_sliced && mode == MODE_COUNTS) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 4, true, 1>), grid, block, 0, stream, args);
