@@ -919,6 +919,64 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
     g.self_mode = self_mode;
     g.out_base = base;
     g.out = dst_dev;
+    if (mode == MODE_JACCARD) {
+        // A single-k launch smaller than the chip has the same problem as a small core/accessory one
+        // (one workgroup per tile on a quarter of the SIMDs, each wave at its own issue interval: 0.058
+        // ms from 200 to 1 000 genomes) and takes the same cure: bin-match counts in tail_slices chunk
+        // slices per tile + an epilogue launch that turns the summed counts into the f32 output.
+        const uint32_t tail_slices = (uint32_t)ctx->knobs.tail_slices;
+        const uint64_t est_units = pairs / 2048;
+        const uint64_t slots = 4ull * (uint64_t)ctx->n_cu;
+        const bool tail = tail_slices > 1u && rows->ss64 <= 1023 && rows->ss64 % (8u * tail_slices) == 0 && forced_kernel(ctx) == 0 &&
+                          est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
+        if (tail) {
+            void *counts = nullptr;
+            const size_t plane_bytes = pairs * sizeof(uint32_t);
+            SKL_TRY(ctx_scratch(ctx, plane_bytes * 2, &counts, 1));
+            void *plane1 = (char *)counts + plane_bytes;
+            if (ctx->clean_plane1 != plane1 || ctx->clean_plane1_bytes != plane_bytes) {
+                HIP_TRY(hipMemsetAsync(plane1, 0, plane_bytes, ctx->stream));
+                ctx->clean_plane1 = plane1;
+                ctx->clean_plane1_bytes = plane_bytes;
+            }
+            g.cnt_pair_stride = 1;
+            g.cnt_k_stride = pairs;
+            g.k_sliced = 1;
+            g.k_slices = 1;
+            g.tail_slices = tail_slices;
+            g.out = counts;
+            SKL_TRY(timed_pair_launch(ctx, g, MODE_COUNTS));
+            if (!ctx->last_tail) ctx->clean_plane1 = nullptr;
+            EpilogueArgs e;
+            memset(&e, 0, sizeof e);
+            e.counts = (uint32_t *)counts;
+            e.pair_stride = 1;
+            e.k_stride = pairs;
+            e.n_pairs = pairs;
+            e.nk = 1;
+            e.ss64 = (uint32_t)rows->ss64;
+            e.n_slices = 2;
+            e.rezero_plane1 = 1;
+            e.nA_rows = (uint32_t)rows->n;
+            e.nB_cols = (uint32_t)cols->n;
+            e.row_begin = (uint32_t)r0;
+            e.self_mode = self_mode;
+            e.n_total = (uint32_t)cols->n;
+            e.out_base = base;
+            e.has_comp = g.has_comp;
+            e.log_variant = g.log_variant;
+            e.compA = rows->d_comp;
+            e.compB = cols->d_comp;
+            e.cutoff = p->completeness_cutoff;
+            e.jaccard_out = 1;
+            e.jout = jout;
+            e.kf0 = g.kf[0];
+            e.dtab = g.dtab;
+            e.out = (float *)dst_dev;
+            HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));
+            return SKL_OK;
+        }
+    }
     return timed_pair_launch(ctx, g, mode);
 }
 

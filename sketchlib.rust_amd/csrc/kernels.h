@@ -169,6 +169,12 @@ struct EpilogueArgs {
     double cutoff, tolerance;
     const double *kf;           // device array [nk]
     float *out;
+    // single-k Jaccard launches that ran as counts (chunk slices of launches smaller than the chip):
+    // nk == 1, and the output is one f32 per pair as pair_kslice.hip's MODE_JACCARD would have stored it
+    int32_t jaccard_out;        // 0: core/accessory; 1: f32 per pair, value chosen by jout
+    int32_t jout;               // JaccardOut
+    double kf0;                 // k-mer length of the one k (ANI outputs)
+    const float *dtab;          // [64*ss64 + 1] f32 output per bin-match count (no completeness correction)
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
 // y[i] = glibc_log(x[i], variant) on the device (glibc_log.hpp)

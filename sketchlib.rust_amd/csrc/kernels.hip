@@ -180,8 +180,27 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
         c2 = g.compB[j];
     }
     const uint32_t maxnbits = g.ss64 * 64u;
-    double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
     uint32_t *cnt = g.counts + p * g.pair_stride;
+    if (g.jaccard_out) {
+        // one k-mer length, counted in chunk slices: the value pair_kslice.hip's MODE_JACCARD stores
+        // (device_common.hpp jaccard_out_value; mod.rs:83-100, :173-176)
+        uint32_t same = cnt[0];
+        for (uint32_t sl = 1; sl < g.n_slices; ++sl) same += cnt[(uint64_t)sl * g.k_stride];
+        if (g.rezero_plane1) cnt[g.k_stride] = 0u;
+        if (same > maxnbits) same = maxnbits;
+        float v;
+        if (!g.has_comp) {
+            v = g.dtab[same];
+        } else {
+            const double jac = jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff);
+            if (g.jout == JOUT_DIST) v = (float)(1.0 - jac);
+            else if (g.jout == JOUT_ANI) v = (float)ani_pois_dev(jac, g.kf0, g.log_variant);
+            else v = (float)(1.0 - ani_pois_dev(jac, g.kf0, g.log_variant));
+        }
+        g.out[p] = v;
+        return;
+    }
+    double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
     // The reference's loop leaves at the first k-mer length whose ln J is below the tolerance
     // (jaccard.rs:89-91), so a literal loop is a chain of 2 nk dependent loads (count, then table
     // entry) -- 10 L2 round trips at cfg 2, which is what this kernel's 10 us were.  The counts of up

@@ -117,3 +117,33 @@ def test_unsupported_shapes_run_plain(oracle, skl, gpu_ctx, set_switch):
     assert "chunk slices" not in gpu_ctx.last_kernel()
     assert np.array_equal(got, oracle.self_dists_all(oracle.Sketches(bins, n, kmers, ss64), threads=8))
     g.close()
+
+
+@pytest.mark.parametrize("ss64,slices", [(64, 4), (32, 4), (32, 2), (128, 8)])
+def test_single_k_launches_smaller_than_the_chip(oracle, skl, gpu_ctx, set_switch, ss64, slices):
+    """Single-k Jaccard / ANI launches of less than a round of workgroups run as bin-match counts in
+    chunk slices + an epilogue launch; same values as the one-workgroup-per-tile kernel and the oracle,
+    with and without a completeness correction, self, cross and row bands."""
+    kmers, n, nq = [17, 21, 25], 317, 90
+    rb = synth.set_r(n, kmers, ss64, n_clusters=6)
+    qb = synth.set_r(nq, kmers, ss64, n_clusters=6, first_sample=2000)
+    for comp in (False, True):
+        rc = np.linspace(0.6, 1.0, n) if comp else None
+        qc = np.linspace(1.0, 0.7, nq) if comp else None
+        o_r, g_r = oracle.Sketches(rb, n, kmers, ss64, rc), gpu_ctx.sketches(rb, n, kmers, ss64, rc)
+        o_q, g_q = oracle.Sketches(qb, nq, kmers, ss64, qc), gpu_ctx.sketches(qb, nq, kmers, ss64, qc)
+        for ani in (False, True):
+            p = g_r.set_k(21, ani)
+            got = {}
+            for form, env in (("sliced", str(slices)), ("plain", "0")):
+                set_switch("SKL_TAIL_SLICES", env)
+                got[form] = (skl.self_dists_all(gpu_ctx, g_r, p), skl.cross_dists_all(gpu_ctx, g_r, g_q, p),
+                             skl.self_dists_rows(gpu_ctx, g_r, p, 100, 171))
+                assert ("JACCARD" in gpu_ctx.last_kernel()) == (form == "plain"), gpu_ctx.last_kernel()
+            for a, b in zip(got["sliced"], got["plain"]):
+                assert np.array_equal(a, b), (ss64, slices, comp, ani)
+            np.testing.assert_allclose(got["sliced"][0], oracle.self_dists_all(o_r, oracle.JACCARD, 1, ani, threads=8), atol=1e-6, rtol=0)
+            np.testing.assert_allclose(got["sliced"][1], oracle.cross_dists_all(o_r, o_q, oracle.JACCARD, 1, ani, threads=8),
+                                       atol=1e-6, rtol=0)
+        g_r.close()
+        g_q.close()
