@@ -23,6 +23,14 @@
 //     that size run MODE_COUNTS into a k-major scratch array followed by
 //     coreacc_epilogue_kernel (kernels.hip) -- 28 bytes per pair of extra traffic.
 //
+// Two tile heights in the product library: R = 16 in 128 registers (4 waves per
+// SIMD) for launches below 16 M pair x k evaluations, R = 32 (130-162 registers, 3 waves, one chunk
+// per wave and stage, chunks walked in plane-major blocks of MB = 4 rows) above: every column
+// register then meets 32 rows, which halves the lane-slab bytes per pair.
+// Launches smaller than the chip (k-sliced counts): the units of the last, partial round of
+// workgroups are cut into chunk slices, slice 0 storing and the others adding into a second counts
+// plane (PairArgs::tail_slices).
+//
 // Per (row, column, chunk) the instruction stream is 2 v_xor + 26 v_bitop3 (all-VGPR,
 // bank-conflict-free, see device_common.hpp) + 2 fused v_bcnt.
 // Wave timelines of this kernel: scripts/microbench/kslice_trace.hip.
