@@ -26,7 +26,7 @@ def _case(seed):
     return rng, kmers, ss64, n, nq, comp
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SKL_FUZZ_SEEDS", "24"))))   # a soak run sets SKL_FUZZ_SEEDS=400
 def test_random_configuration(oracle, skl, gpu_ctx, seed):
     rng, kmers, ss64, n, nq, use_comp = _case(seed)
     clusters = int(rng.integers(1, 9))

@@ -9,6 +9,8 @@ sequences of launches in ONE context:
 Plane 1 must be found zero by every such launch whatever ran before (another size, the other form, a
 single-k launch or raw counts through the same scratch), and the persistent form's queue counters must
 be back at zero."""
+import os
+
 import numpy as np
 import pytest
 
@@ -36,6 +38,8 @@ def _sequence(oracle, skl, ctx, switch, seed, on, off, marker):
         nk = int(rng.integers(2, 7))
         kmers = sorted(rng.choice(np.arange(9, 40), size=nk, replace=False).tolist())
         ss64 = int(rng.choice([8, 16, 24, 32, 64, 64, 128]))
+        if step == 0:
+            ss64 = 128      # (every form under test applies to at least one launch of the sequence)
         n = int(rng.integers(3, 700))
         nq = int(rng.integers(1, 300))
         rb = synth.set_r(n, kmers, ss64, n_clusters=int(rng.integers(1, 12)), seed=seed * 31 + step)
@@ -64,8 +68,11 @@ def _sequence(oracle, skl, ctx, switch, seed, on, off, marker):
     return took
 
 
+SOAK = int(os.environ.get("SKL_FUZZ_SEEDS", "0"))   # a soak run sets SKL_FUZZ_SEEDS=400
+
+
 @pytest.mark.parametrize("slices", [2, 4, 8])
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(max(3, SOAK // 20)))
 def test_chunk_slices_in_sequences_of_launches(oracle, skl, gpu_ctx, monkeypatch, seed, slices):
     def switch(env):
         for k, v in env.items():
@@ -78,7 +85,7 @@ def test_chunk_slices_in_sequences_of_launches(oracle, skl, gpu_ctx, monkeypatch
     assert took >= 1, took     # (sketch sizes that are not a multiple of 8 x slices run plain)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(max(3, SOAK // 40)))
 def test_persistent_form_in_sequences_of_launches(oracle, skl, monkeypatch, seed):
     import sketchlib.rust_amd as pkg
 
