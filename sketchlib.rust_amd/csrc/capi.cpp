@@ -94,6 +94,7 @@ int ctx_scratch(skl_ctx *ctx, size_t bytes, void **out, int which)
         }
         HIP_TRY(hipMalloc(&buf, bytes));
         cap = bytes;
+        if (which == 1) ctx->clean_plane1 = nullptr;   // a new counts scratch: nothing is known to be zero in it
     }
     *out = buf;
     return SKL_OK;
