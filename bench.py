@@ -409,7 +409,8 @@ def main():
                 "kmers": KMERS,
                 "dataset": "Set U (uniform random bins)" if args.dataset == "U" else "Set R (related clusters)",
                 "partition": f"{world} row band(s) of equal pair count"
-                             + ("" if dist is None or args.no_gather else ", grouped send/recv gather to rank 0 (RCCL)"
+                             + ("" if dist is None or args.no_gather else (", grouped send/recv gather to rank 0 (RCCL)" if not host_staged else
+                                                                         ", gather to rank 0 staged through host memory (gloo: debugging backend)")
                                 + (" overlapped with the next step's kernel" if pipe is not None else "")),
                 "output_checksum_first_1e8_pairs": checksum,
                 **(verified or {}),
