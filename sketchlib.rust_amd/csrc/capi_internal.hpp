@@ -72,8 +72,8 @@ struct skl_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only scratch
-    void *scratch[7] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32)
-    size_t scratch_bytes[7] = {};
+    void *scratch[8] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits
+    size_t scratch_bytes[8] = {};
     hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
     // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
     // "producer finished buffer b" / "consumer finished buffer b"

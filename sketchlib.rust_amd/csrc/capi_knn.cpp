@@ -94,6 +94,12 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     SKL_TRY(ctx_scratch(ctx, 2 * n * sizeof(uint32_t), &flag_mem, 6));
     uint32_t *flags[2] = {(uint32_t *)flag_mem, (uint32_t *)flag_mem + (overlap ? n : 0)};
     HIP_TRY(hipMemsetAsync(flag_mem, 0, 2 * n * sizeof(uint32_t), ctx->stream));
+    // ... and for the band's own rows one bit per 64-column block (the merge of the band reads only the
+    // marked stretches of a row): band_rows x ceil(columns / 2048) words per band buffer, behind the flags
+    const size_t bit_words = (n / 64 + 1 + 31) / 32;
+    void *bits_mem = nullptr;
+    SKL_TRY(ctx_scratch(ctx, 2 * band_rows * bit_words * sizeof(uint32_t), &bits_mem, 7));
+    uint32_t *row_bits[2] = {(uint32_t *)bits_mem, (uint32_t *)bits_mem + (overlap ? band_rows * bit_words : 0)};
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
     if (overlap) {   // the states were cleared on the context's stream, the merges run on the other one
         HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
@@ -123,6 +129,13 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         g.t_col_begin = (uint32_t)(b1 - col0);
         g.t_stride = (uint32_t)t_stride;
         const uint32_t flag_value = (uint32_t)(it + 1);      // never 0, distinct per band of this call
+        if (ctx->knobs.knn_row_flags) {
+            HIP_TRY(hipMemsetAsync(row_bits[buf], 0, band_rows * bit_words * sizeof(uint32_t), ctx->stream));
+            g.r_bits = row_bits[buf];
+            g.r_bits_stride = (uint32_t)bit_words;
+            g.r_thr = st.key + b0 * knn + (knn - 1);        // knn-th best of sample b0 + r
+            g.r_thr_stride = (uint32_t)knn;
+        }
         if (g.out_t && ctx->knobs.knn_row_flags) {
             g.t_flag = flags[buf] + col0;                   // indexed by the view's column number, like t_col_begin
             g.t_flag_value = flag_value;
@@ -151,7 +164,10 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         m.id_base = (uint32_t)col0;
         m.skip_below = (uint32_t)b0;
         m.self_id_base = m.state_row_base = (uint32_t)b0;
+        m.seg_bits = ctx->knobs.knn_row_flags ? row_bits[buf] : nullptr;
+        m.seg_bits_stride = (uint32_t)bit_words;
         HIP_TRY(launch_topk_merge(m, topk_stream));
+        m.seg_bits = nullptr;
         // rows below the band: the band's samples as their candidates
         m.keys = (const float *)tband[buf];
         m.key_stride = (uint64_t)t_stride * m.stride2;

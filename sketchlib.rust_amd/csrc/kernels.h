@@ -84,6 +84,13 @@ struct PairArgs {
     const uint32_t *t_thr;
     uint32_t *t_flag;
     uint32_t t_thr_stride, t_flag_value;
+    // The same for the band's OWN rows, per 64-column block: bit b of r_bits[(i - row_begin) * r_bits_stride
+    // + b / 32] is set when row i received a record in columns [64 b, 64 b + 64) of the view below its
+    // knn-th best so far, r_thr[(i - row_begin) * r_thr_stride]; the merge of the band skips the blocks
+    // without a bit.  Zeroed by the host before the launch.  Null = off.
+    const uint32_t *r_thr;
+    uint32_t *r_bits;
+    uint32_t r_thr_stride, r_bits_stride;
     // epilogue
     int32_t jout;                 // JaccardOut
     int32_t has_comp;
@@ -272,6 +279,8 @@ struct TopkMergeArgs {
     uint32_t streaming;       // 1: one-pass streaming merge (default); 0: radix select only (A/B)
     const uint32_t *flag;     // row r is merged only if flag[r] == flag_value (null: every row)
     uint32_t flag_value;
+    const uint32_t *seg_bits; // row r: bit b of seg_bits[r * seg_bits_stride + b / 32] clear = no record at positions
+    uint32_t seg_bits_stride; // [64 b, 64 b + 64) can enter the state: not read (null: everything is read)
 };
 hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream);
 // Union of up to MERGE_STATES_MAX partial states of the same rows (disjoint candidate sets) ->

@@ -434,9 +434,17 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
                     } else if constexpr (KSL) {
                         const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
                         float v = __builtin_inff();
-                        if (pair_valid(g, i_, jc_)) {
+                        const bool valid_ = pair_valid(g, i_, jc_);
+                        if (valid_) {
                             v = jaccard_out_value(g, i_, jc_, mism);
                             ((float *)g.out)[pair_out_index(g, i_, jc_)] = v;
+                        }
+                        if (g.r_bits != nullptr && i_ < g.row_end) {   // (wave-uniform: i_ is)
+                            // symmetric self kNN: does this 64-column block bring row i_ anything below its knn-th best?
+                            const uint32_t thr_ = g.r_thr[(size_t)(i_ - g.row_begin) * g.r_thr_stride];
+                            if (__ballot(valid_ && sortable_bits(v) < thr_) != 0ull && lane == 0u) {
+                                atomicOr(&g.r_bits[(size_t)(i_ - g.row_begin) * g.r_bits_stride + ((jb0 + j) >> 5)], 1u << ((jb0 + j) & 31u));
+                            }
                         }
                         tval[i * 2 + h] = v;
                     } else {
@@ -511,9 +519,16 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
                 const uint32_t s2 = ((word[4] >> sh) & 0xFFFFu) | (((word[5] >> sh) & 0xFFFFu) << 16);
                 const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
                 float2 v = make_float2(__builtin_inff(), __builtin_inff());
-                if (pair_valid(g, i_, jc_)) {
+                const bool valid_ = pair_valid(g, i_, jc_);
+                if (valid_) {
                     v = coreacc_value(g, i_, jc_, s0, s1, s2);
                     ((float2 *)g.out)[pair_out_index(g, i_, jc_)] = v;
+                }
+                if (g.r_bits != nullptr && i_ < g.row_end) {   // see MODE_JACCARD; the key is the core distance
+                    const uint32_t thr_ = g.r_thr[(size_t)(i_ - g.row_begin) * g.r_thr_stride];
+                    if (__ballot(valid_ && sortable_bits(v.x) < thr_) != 0ull && lane == 0u) {
+                        atomicOr(&g.r_bits[(size_t)(i_ - g.row_begin) * g.r_bits_stride + ((jb0 + j) >> 5)], 1u << ((jb0 + j) & 31u));
+                    }
                 }
                 if (turned) tt[(j * 64u + lane) * TP + r] = v;
             }

@@ -284,6 +284,20 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
             // walks a whole row, so its memory-level parallelism is what the scan runs at)
             constexpr uint32_t UNROLL = 4;
             for (uint32_t q0 = begin; q0 < begin + len; q0 += TOPK_THREADS * UNROLL) {
+                if (g.seg_bits != nullptr) {
+                    // the pair kernel marked the 64-record blocks that hold something below this row's knn-th
+                    // best (as of a moment ago: never too few): a stretch of 1 024 positions without a mark is not read
+                    const uint32_t *bits = g.seg_bits + (size_t)row * g.seg_bits_stride;
+                    const uint32_t b_lo = q0 >> 6, b_hi = (min(q0 + TOPK_THREADS * UNROLL, begin + len) - 1u) >> 6;
+                    bool any = false;
+                    for (uint32_t w = b_lo >> 5; w <= (b_hi >> 5); ++w) {
+                        uint32_t word = bits[w];
+                        if (w == (b_lo >> 5)) word &= ~0u << (b_lo & 31u);
+                        if (w == (b_hi >> 5) && (b_hi & 31u) != 31u) word &= (2u << (b_hi & 31u)) - 1u;
+                        any |= word != 0u;
+                    }
+                    if (!any) continue;   // (workgroup-uniform)
+                }
                 uint64_t item[UNROLL];
                 float raw[UNROLL];
 #pragma unroll
