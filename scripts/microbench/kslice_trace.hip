@@ -101,7 +101,7 @@ int main(int argc, char **argv)
     const int R = shape == 999 ? 16 : shape / 10, JL = (shape == 165 || shape == 325 || shape == 999) ? 2 : shape % 10;
     PairArgs gp = g; uint64_t n_wg = 0;
     CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
-    n_wg = 8ull * ((gp.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * nk * slices;   // as launch_pair_kernel_kslice pads it
+    n_wg = 8ull * gp.tiles_per_xcd * nk * slices;   // as launch_pair_kernel_kslice sizes it
     if (shape == 999) n_wg = 1024;
     if (g.tail_slices > 1) n_wg *= g.tail_slices;   // upper bound: workgroup indices beyond the launch have empty records
     const int wpw = getenv("SKL_KSLICE_WAVES") ? atoi(getenv("SKL_KSLICE_WAVES")) : 4;

@@ -131,9 +131,14 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
     const bool in_tail = tail_mode && s_idx >= g.tail_first;
     const uint32_t n_slices = in_tail ? g.tail_slices : (KSL && MODE == MODE_COUNTS && !tail_mode ? g.k_slices : 1u);
     const uint32_t u_idx = in_tail ? g.tail_first + (s_idx - g.tail_first) / n_slices : s_idx;   // unit index (tail mode) / workgroup index
+    // (the last block of an XCD may be short: the grid has exactly tiles_per_xcd x k x slices workgroups
+    // per XCD, no padding slots that would be dispatched only to exit)
     const uint32_t per_blk = KB * g.k_count * (tail_mode ? 1u : n_slices);
-    const uint32_t slot = KSL ? (u_idx / per_blk) * KB + (u_idx % per_blk) % KB : s_idx;
-    const uint32_t kslot = KSL ? (u_idx % per_blk) / KB : 0u;
+    const uint32_t blk_ = u_idx / per_blk, rem_ = u_idx - blk_ * per_blk;
+    const uint32_t in_blk = KSL ? min(KB, g.tiles_per_xcd - min(g.tiles_per_xcd, blk_ * KB)) : 1u;
+    if (KSL && in_blk == 0u) return;
+    const uint32_t slot = KSL ? blk_ * KB + rem_ % in_blk : s_idx;
+    const uint32_t kslot = KSL ? rem_ / in_blk : 0u;
     const uint32_t kk0 = tail_mode ? kslot : kslot / n_slices;  // first k index of this workgroup
     const uint32_t slice = in_tail ? (s_idx - g.tail_first) % n_slices : (tail_mode ? 0u : kslot - kk0 * n_slices);
     const uint32_t nkk = KSL ? 1u : g.k_count;                  // k-mer lengths it walks
@@ -596,7 +601,7 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     const hipError_t pe = plan_tiles(args, (uint32_t)R, (uint32_t)JL * 64u, scratch, stream, &n_wg);
     if (pe != hipSuccess) return pe;
     if (n_wg == 0) return hipSuccess;
-    // k-sliced: whole blocks of KSL_TILE_BLOCK tile slots per XCD (slots past the last tile exit at once)
+    // k-sliced: exactly tiles_per_xcd x k [x slices] workgroups per XCD (the last tile block is short)
     if (!(k_sliced && mode == MODE_COUNTS) || args.k_slices == 0) args.k_slices = 1;
     if (!(k_sliced && mode == MODE_COUNTS)) args.tail_slices = 0;
     if (args.tail_slices > 1u) {
@@ -609,7 +614,7 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     }
     if (args.ss64 % (args.k_slices * 8u) != 0 && args.k_slices != 1) return hipErrorInvalidValue;   // whole stages per slice
     if (k_sliced) {
-        const uint64_t units_pad = (uint64_t)((args.tiles_per_xcd + KSL_TILE_BLOCK - 1) / KSL_TILE_BLOCK) * KSL_TILE_BLOCK * args.k_count;
+        const uint64_t units_pad = (uint64_t)args.tiles_per_xcd * args.k_count;   // exact: the last tile block of an XCD is short
         n_wg = 8ull * units_pad * args.k_slices;
         if (args.tail_slices > 1u) {
             const uint64_t first = std::min<uint64_t>(args.tail_first, units_pad);
