@@ -254,6 +254,7 @@ Knobs read_knobs()
     k.k_slices = (int)env_int("SKL_K_SLICES", 0);
     k.tail_slices = (int)std::min(8ll, std::max(0ll, env_int("SKL_TAIL_SLICES", 4)));
     k.tail_max_pct = env_int("SKL_TAIL_MAX_PCT", 90);
+    k.round_priority = env_int("SKL_ROUND_PRIORITY", 1) != 0;
     k.tile32_min = env_int("SKL_TILE32_MIN", 16ll << 20);
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
@@ -338,6 +339,7 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     const bool try_kslice = true;
     const int ablate = 0;
 #endif
+    args.round_size = ctx->knobs.round_priority ? (shape == 325 ? 3u : 4u) * (uint32_t)ctx->n_cu / 8u : 0u;
     ctx->last_count_planes = std::max(1u, args.k_slices);
     ctx->last_persistent = false;
     ctx->last_tail = false;

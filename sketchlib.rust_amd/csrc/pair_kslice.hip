@@ -142,6 +142,21 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
     const uint32_t kk0 = tail_mode ? kslot : kslot / n_slices;  // first k index of this workgroup
     const uint32_t slice = in_tail ? (s_idx - g.tail_first) % n_slices : (tail_mode ? 0u : kslot - kk0 * n_slices);
     const uint32_t nkk = KSL ? 1u : g.k_count;                  // k-mer lengths it walks
+    // WAVE PRIORITY BY ROUND.  A SIMD issues for its oldest wave first, so the workgroups of a launch's
+    // second round -- dispatched into the slots the first round's oldest waves free -- get what three
+    // older waves leave them until those finish, and then run on alone at a lone wave's issue interval:
+    // that is the tail of every launch of 1-2.5 rounds.  Raising the priority of each later round by one
+    // (s_setprio, capped at 3) lets them work from the moment they arrive: -3 ... -4 % at 900-1 200
+    // genomes core/accessory, -7 % at 2 000 single-k (a second round of a few workgroups), +2 % at
+    // 2.5-2.7 rounds and nothing beyond, so the launcher asks for it up to 2.25 rounds
+    // (profiles/r02_ab_round_priority.jsonl).  Not for sliced launches (four quarter-rounds of short
+    // workgroups: +6 % at 800 genomes).
+    if (KSL && !tail_mode && g.round_size != 0u) {
+        const uint32_t round_ = s_idx / g.round_size;
+        if (round_ == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (round_ == 2u) __builtin_amdgcn_s_setprio(2);
+        else if (round_ >= 3u) __builtin_amdgcn_s_setprio(3);
+    }
     const uint32_t c_begin = slice * (g.ss64 / n_slices);       // chunk range of this workgroup
     const uint32_t c_end = n_slices > 1u ? c_begin + g.ss64 / n_slices : g.ss64;
     uint32_t jg, at;  // column group (JL blocks of 64), row tile
@@ -613,6 +628,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         args.k_slices = 1;
     }
     if (args.ss64 % (args.k_slices * 8u) != 0 && args.k_slices != 1) return hipErrorInvalidValue;   // whole stages per slice
+    // wave priority by round: for launches of up to 2.25 rounds of workgroups (it costs 2 % at 2.5-2.7 rounds
+    // and is neutral beyond; profiles/r02_ab_round_priority.jsonl)
+    if (!k_sliced || (uint64_t)args.tiles_per_xcd * args.k_count * args.k_slices * 4u > 9ull * args.round_size) args.round_size = 0;
     if (k_sliced) {
         const uint64_t units_pad = (uint64_t)args.tiles_per_xcd * args.k_count;   // exact: the last tile block of an XCD is short
         n_wg = 8ull * units_pad * args.k_slices;
