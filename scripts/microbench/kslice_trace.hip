@@ -72,6 +72,7 @@ int main(int argc, char **argv)
     int pflags = 1;
     if (shape >= 980 && shape <= 999) { pflags = shape == 999 ? 1 : shape - 980; shape = 999; }   // 991 queue, 993 +priority rotation, 995 equal split, 997 both
     const bool persistent = shape == 999;
+    if (getenv("KT_ROUND")) g.round_size = (uint32_t)atoi(getenv("KT_ROUND"));   // wave priority by round of workgroups (PairArgs::round_size)
     // KT_TAIL=S: tail slicing of the one-workgroup-per-unit launch (pair_kslice.hip, PairArgs::tail_slices)
     if (getenv("KT_TAIL") && !persistent) {
         g.tail_slices = (uint32_t)atoi(getenv("KT_TAIL"));
