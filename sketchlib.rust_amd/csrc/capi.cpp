@@ -853,7 +853,8 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
 #else
         const bool persistent = false;
 #endif
-        const uint32_t tail_slices = (uint32_t)ctx->knobs.tail_slices;
+        // (launches of less than 1/16 round -- ~200 genomes -- are cut twice as fine when the sketch allows it)
+        const uint32_t tail_slices = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 % 64 == 0 ? 8u : (uint32_t)ctx->knobs.tail_slices;
         const bool tail = sliced && !persistent && k_slices == 1u && tail_slices > 1u && rows->ss64 % (8u * tail_slices) == 0 &&
                           forced_kernel(ctx) == 0 && est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
         const bool two_planes = persistent || tail;
@@ -927,9 +928,9 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // (one workgroup per tile on a quarter of the SIMDs, each wave at its own issue interval: 0.058
         // ms from 200 to 1 000 genomes) and takes the same cure: bin-match counts in tail_slices chunk
         // slices per tile + an epilogue launch that turns the summed counts into the f32 output.
-        const uint32_t tail_slices = (uint32_t)ctx->knobs.tail_slices;
         const uint64_t est_units = pairs / 2048;
         const uint64_t slots = 4ull * (uint64_t)ctx->n_cu;
+        const uint32_t tail_slices = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 % 64 == 0 ? 8u : (uint32_t)ctx->knobs.tail_slices;
         const bool tail = tail_slices > 1u && rows->ss64 <= 1023 && rows->ss64 % (8u * tail_slices) == 0 && forced_kernel(ctx) == 0 &&
                           est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
         if (tail) {
