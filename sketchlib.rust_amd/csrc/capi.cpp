@@ -839,7 +839,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         const uint32_t k_slices = sliced ? choose_k_slices(ctx, rows->ss64) : 1u;
         // A launch with fewer (tile, k) units than resident workgroup slots cannot fill the chip with one
         // workgroup per unit: most SIMDs hold 0-2 waves and the launch takes the time of ONE unit at a
-        // lone wave's issue rate whatever its size (0.100 ms from 100 to 600 genomes).  Such launches are
+        // lone wave's issue rate whatever its size (0.055-0.064 ms from 100 to 500 genomes).  Such launches are
         // cut into tail_slices chunk slices per unit -- and so is the last, partial round of any launch
         // SKL_TAIL_MAX_PCT lets through (default 90: launches of up to 0.9 estimated rounds, where the
         // whole launch is that partial round; the partial round of a longer launch gains nothing,
