@@ -6,7 +6,7 @@ mkdir -p _build
 CSRC=../../sketchlib.rust_amd/csrc
 # usage: build.sh [kslice_trace]  (no argument: every tool)
 ONLY=${1:-}
-for t in valu_rates valu_clock vgpr_banks lds_bcast; do
+for t in valu_rates valu_clock vgpr_banks lds_bcast l2_retention; do
   [ -n "$ONLY" ] && continue
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value $t.hip -o _build/$t
 done
