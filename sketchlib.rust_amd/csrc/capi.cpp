@@ -78,6 +78,11 @@ int ctx_bind(skl_ctx *ctx)
 {
     if (!ctx) return fail(SKL_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
+#ifdef SKL_AB
+    // A/B build only: one process interleaves variants (scripts/ab_sweep.py), so the switches are read at
+    // every API entry -- before any dispatch decision of the call, not in the middle of it
+    ctx->knobs = read_knobs();
+#endif
     return SKL_OK;
 }
 
@@ -255,6 +260,7 @@ Knobs read_knobs()
     k.tail_slices = (int)std::min(8ll, std::max(0ll, env_int("SKL_TAIL_SLICES", 4)));
     k.tail_max_pct = env_int("SKL_TAIL_MAX_PCT", 90);
     k.round_priority = env_int("SKL_ROUND_PRIORITY", 1) != 0;
+    k.half_tiles = env_int("SKL_HALF_TILES", 1) != 0;
     k.tile32_min = env_int("SKL_TILE32_MIN", 16ll << 20);
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
@@ -339,14 +345,18 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     const bool try_kslice = true;
     const int ablate = 0;
 #endif
-    args.round_size = ctx->knobs.round_priority ? (shape == 325 ? 3u : 4u) * (uint32_t)ctx->n_cu / 8u : 0u;
+    args.no_half_tiles = ctx->knobs.half_tiles ? 0u : 1u;
+    // workgroups resident per CU: 4, except the all-k 32-row form (168 registers, 48 KB of LDS): 3
+    const bool sliced_launch = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
+    const uint32_t wg_per_cu = (shape == 325 && !sliced_launch) ? 3u : 4u;
+    args.round_size = ctx->knobs.round_priority ? wg_per_cu * (uint32_t)ctx->n_cu / 8u : 0u;
     ctx->last_count_planes = std::max(1u, args.k_slices);
     ctx->last_persistent = false;
     ctx->last_tail = false;
     if (args.tail_slices > 1u) {
         // tail-sliced one-workgroup-per-unit launch: two planes whatever kernel ends up running (a
         // kernel without the slices leaves plane 1 as it found it: zero)
-        args.tail_resident = (shape == 325 ? 3u : 4u) * (uint32_t)ctx->n_cu / 8u;
+        args.tail_resident = wg_per_cu * (uint32_t)ctx->n_cu / 8u;
         ctx->last_count_planes = 2;
         ctx->last_tail = true;
     }
@@ -369,7 +379,7 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     if (try_kslice) {
         // single-k Jaccard: the sliced and the all-k form are the same work, the sliced one
         // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
-        const bool sliced = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
+        const bool sliced = sliced_launch;
         if (kslice_supported(args, mode, sliced)) {
             const int jl = (shape == 165 || shape == 325 || shape > 1000) ? 2 : shape % 10;
             const int rr = shape > 1000 ? shape / 100 : shape / 10;
@@ -390,9 +400,6 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
 int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode)
 {
     constexpr size_t MAX_EVENTS = 4096;
-#ifdef SKL_AB
-    ctx->knobs = read_knobs();   // A/B build only: one process interleaves variants (scripts/ab_sweep.py)
-#endif
     // SKL_TIMING_EVERY = N brackets every N-th launch only (default 1 = all): an event record is
     // a barrier packet on the queue, and two per launch cost a sub-millisecond launch ~5 us
     const bool sampled = (ctx->launches_seen++ % (size_t)ctx->knobs.timing_every) == 0;
@@ -884,8 +891,12 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         g.self_mode = self_mode;
         g.out_base = base;
         g.out = counts;
+        SKL_TRY(ensure_ytab(rows));   // (before the pair launch: nothing may fail between it and the epilogue)
+        // Plane 1 holds partial counts from the pair launch until the epilogue has re-zeroed it: it is
+        // "clean" again only once that epilogue is enqueued.  Any early return in between leaves it marked dirty.
+        const void *const plane1_clean = ctx->clean_plane1;
+        ctx->clean_plane1 = nullptr;
         SKL_TRY(timed_pair_launch(ctx, g, MODE_COUNTS));
-        SKL_TRY(ensure_ytab(rows));
         EpilogueArgs e;
         memset(&e, 0, sizeof e);
         e.counts = (uint32_t *)counts;
@@ -897,7 +908,6 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
         e.rezero_plane1 = sliced && (ctx->last_persistent || ctx->last_tail) ? 1u : 0u;
         e.work_counter = sliced && ctx->last_persistent ? ctx->work_counter : nullptr;
-        if (two_planes && !(ctx->last_persistent || ctx->last_tail)) ctx->clean_plane1 = nullptr;   // (an empty launch, or another kernel took it: plane 1 is not known to be zero)
         e.nA_rows = (uint32_t)rows->n;
         e.nB_cols = (uint32_t)cols->n;
         e.row_begin = (uint32_t)r0;
@@ -914,6 +924,8 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.kf = rows->d_kf;
         e.out = (float *)dst_dev;
         HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));
+        // (an empty launch, or one another kernel took, leaves plane 1 not known to be zero)
+        if (two_planes && (ctx->last_persistent || ctx->last_tail)) ctx->clean_plane1 = plane1_clean;
         return SKL_OK;
     }
     PairArgs g;
@@ -949,8 +961,9 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             g.k_slices = 1;
             g.tail_slices = tail_slices;
             g.out = counts;
+            const void *const plane1_clean = ctx->clean_plane1;   // as above: dirty until the epilogue is enqueued
+            ctx->clean_plane1 = nullptr;
             SKL_TRY(timed_pair_launch(ctx, g, MODE_COUNTS));
-            if (!ctx->last_tail) ctx->clean_plane1 = nullptr;
             EpilogueArgs e;
             memset(&e, 0, sizeof e);
             e.counts = (uint32_t *)counts;
@@ -978,6 +991,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             e.dtab = g.dtab;
             e.out = (float *)dst_dev;
             HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));
+            if (ctx->last_tail) ctx->clean_plane1 = plane1_clean;
             return SKL_OK;
         }
     }

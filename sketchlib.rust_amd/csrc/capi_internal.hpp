@@ -49,6 +49,7 @@ struct Knobs {
     int group_span = 2;                 // SKL_GROUP_SPAN: column groups whose tiles are numbered side by side (device_common.hpp lookup_tile_at)
     long long tile32_min = 16ll << 20;  // SKL_TILE32_MIN: pair x k evaluations from which launches use 32 x 128 tiles (-1: never, 0: always)
     int tail_slices = 4;                // SKL_TAIL_SLICES: chunk slices per unit in the last, partial round of a k-sliced core/acc launch (0/1: off)
+    bool half_tiles = true;             // SKL_HALF_TILES=0: 64-column blocks of a tile without a pair of the launch are walked anyway (A/B only, results are identical)
     bool round_priority = true;         // SKL_ROUND_PRIORITY=0: k-sliced workgroups of later rounds keep the default wave priority (A/B only, results are identical)
     long long tail_max_pct = 90;        // SKL_TAIL_MAX_PCT: ... for launches of up to this many estimated rounds of workgroups (in percent)
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN

@@ -23,10 +23,11 @@
 //     that size run MODE_COUNTS into a k-major scratch array followed by
 //     coreacc_epilogue_kernel (kernels.hip) -- 28 bytes per pair of extra traffic.
 //
-// Two tile heights in the product library: R = 16 in 128 registers (4 waves per
-// SIMD) for launches below 16 M pair x k evaluations, R = 32 (130-162 registers, 3 waves, one chunk
-// per wave and stage, chunks walked in plane-major blocks of MB = 4 rows) above: every column
-// register then meets 32 rows, which halves the lane-slab bytes per pair.
+// Two tile heights in the product library: R = 16 in 128 registers (4 waves per SIMD) for
+// launches below 16 M pair x k evaluations, R = 32 above (one chunk per wave and stage; every column
+// register then meets 32 rows, which halves the lane-slab bytes per pair): k-sliced in 128 registers
+// and 32 KB of LDS (4 waves, chunks walked in plane-major blocks of MB = 2 rows), all k + fused
+// regression in 168 registers (3 waves, MB = 4).
 // Launches smaller than the chip (k-sliced counts): the units of the last, partial round of
 // workgroups are cut into chunk slices, slice 0 storing and the others adding into a second counts
 // plane (PairArgs::tail_slices).
@@ -73,8 +74,10 @@ constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk 
 // spare) has it.  Worth 1.2-1.4 % at n = 8 000 ... 16 000 (MB = 1 / 2 / 4 / 8: 30.34 / 29.95 / 29.98 /
 // 30.07 ms at n = 16 000, profiles/r02_ab_row_blocks.jsonl): the s_waitcnt share of the SQ counters is
 // mostly the LDS reads of a kernel that runs at the LDS's rate, not the column loads.
-template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1>
-__global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL == 3 ? 3 : 1)) void pair_kernel_kslice(const PairArgs g)
+// OCC: waves per SIMD the register allocator is held to (0: 4 for the tight 16-row form, 3 for the tight
+// 32-row form and for 3 columns per lane, 1 otherwise).
+template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1, int OCC = 0>
+__global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R > 16 ? 3 : 4) : (JL == 3 ? 3 : 1))) void pair_kernel_kslice(const PairArgs g)
 {
     constexpr int W = WAVES_PER_WG;
     constexpr int CH = R > 16 ? 1 : 2;            // chunks per wave per stage
@@ -91,7 +94,11 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
     // columns per lane the rest (PX - XIN per lane) go to an overflow region behind the row buffers.
     constexpr uint32_t BUF_U4 = PPL * LANES;
     constexpr uint32_t ROWS_U4 = W * 2 * BUF_U4;
-    constexpr int XIN = (BUF_U4 * 4 / LANES) < (uint32_t)PX ? (int)(BUF_U4 * 4 / LANES) : PX;
+    // (a k-sliced workgroup walks ONE k-mer length: no next stage is in flight when it reduces, so both row
+    // buffers of a wave are free -- the 32-row form then needs no overflow region: 32 KB instead of 48 KB of
+    // LDS per workgroup, i.e. room for 4 workgroups per CU)
+    constexpr uint32_t RED_BUFS = KSL ? 2u : 1u;
+    constexpr int XIN = (RED_BUFS * BUF_U4 * 4 / LANES) < (uint32_t)PX ? (int)(RED_BUFS * BUF_U4 * 4 / LANES) : PX;
     constexpr int XOV = PX - XIN;
     constexpr uint32_t RED_U4 = (uint32_t)(W * XOV * LANES) / 4u;
     __shared__ uint4 lds_all[ROWS_U4 + RED_U4];
@@ -170,423 +177,64 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, TIGHT ? (R > 16 ? 3 : 4) : (JL
     if (jb0 >= g.n_jblocks) return;
     if (a0 >= g.row_end) return;
     if (g.self_mode && a0 >= (jg + 1u) * JL * 64u - 1u) return;   // tile entirely on/below the diagonal
-
-    const size_t kmer_stride = (size_t)g.ss64 * BBITS;
-    const size_t sample_stride = kmer_stride * g.nk;
-    // wave w owns chunks w*CH + i + ts*(W*CH), i < CH, of every k-mer length
-    const uint32_t stages_per_k = (c_end - c_begin + W * CH - 1) / (W * CH);
-    const uint32_t n_stages = stages_per_k * nkk;
-
-    // This wave's partial mismatch counts of the current k (its chunks only).  One register per
-    // pair, except with 3 columns per lane, where registers are what decides between 2 and 3 waves
-    // per SIMD: columns 0 and 1 of a row then share one register as u16 fields (a wave's share of
-    // one k-mer length is at most 64 * 256 mismatches per pair: kslice_supported) and column 2 has
-    // its own -- 2 R registers instead of 3 R, for one v_lshl_add_u32 more per (row, chunk).
-    static_assert(!TIGHT || JL == 2, "the tight form exists for 2 columns per lane");
-    constexpr bool PACK01 = JL == 3 || TIGHT;
-    constexpr int NCNT = PACK01 ? (JL == 3 ? 2 * R : R) : P;
-    uint32_t cnt[NCNT];
-#pragma unroll
-    for (int x = 0; x < NCNT; ++x) cnt[x] = 0;
-    // packed word x (two u16 fields) of the per-k reduction, and the pair its field h stands for
-    auto packed_word = [&](int x) -> uint32_t {
-        if constexpr (PACK01 && JL == 2) {
-            return cnt[x];
-        } else if constexpr (PACK01) {
-            return x < R ? cnt[x] : (cnt[R + 2 * (x - R)] | (cnt[R + 2 * (x - R) + 1] << 16));
+    // HALF TILES (2 columns per lane).  A 64-column block of the tile that holds no pair of the launch is
+    // not walked: block 0 of a tile that straddles the diagonal when every column of it is <= the
+    // tile's first row (self mode: 4 of the 8 diagonal row tiles of every column group at 16 rows, 2 of
+    // 4 at 32 -- 6.5 % of a 1 000-genome launch's lane-pairs), block 1 when the launch's columns end
+    // in block 0 (an odd number of 64-column blocks).  The chunk walk below is instantiated for the
+    // three cases and chosen per workgroup (uniform branch); the skipped block's column registers are
+    // never loaded and its count fields stay 0 (its pairs are invalid and never stored).
+    constexpr bool HALF_TILES = R == 16 && JL == 2 && TIGHT && ABL == 0;
+    const bool skip0 = HALF_TILES && !g.no_half_tiles && g.self_mode && a0 + 1u >= (jb0 + 1u) * 64u;
+    const bool skip1 = HALF_TILES && !g.no_half_tiles && jb0 + 1u >= g.n_jblocks;
+    // The walk is TEXTUALLY included once per case (pair_kslice_walk.inc; SKL_J0 / SKL_J1 = the column blocks
+    // [J0, J1) it walks), not a lambda or a function template: wrapping it in either changes hipcc's register
+    // allocation of the 32-row form (168 VGPRs + 144 B of spills per lane instead of 144 VGPRs).  No value of
+    // one case is live in another, so the cases do not add to each other's register pressure.
+    if constexpr (HALF_TILES) {
+        if (skip0) {
+#define SKL_J0 1
+#define SKL_J1 JL
+#include "pair_kslice_walk.inc"
+#undef SKL_J0
+#undef SKL_J1
+        } else if (skip1) {
+#define SKL_J0 0
+#define SKL_J1 1
+#include "pair_kslice_walk.inc"
+#undef SKL_J0
+#undef SKL_J1
         } else {
-            return cnt[2 * x] | (cnt[2 * x + 1] << 16);
+#define SKL_J0 0
+#define SKL_J1 JL
+#include "pair_kslice_walk.inc"
+#undef SKL_J0
+#undef SKL_J1
         }
-    };
-    auto field_pair = [](uint32_t x, uint32_t h, uint32_t &r, uint32_t &j) {
-        if constexpr (PACK01 && JL == 2) {
-            r = x;
-            j = h;
-        } else if constexpr (PACK01) {
-            if (x < (uint32_t)R) {
-                r = x;
-                j = h;
-            } else {
-                r = 2u * (x - (uint32_t)R) + h;
-                j = 2u;
-            }
-        } else {
-            const uint32_t pair = 2u * x + h;
-            r = pair / JL;
-            j = pair % JL;
-        }
-    };
-    // MODE_COREACC: totals of this wave's packed slots, one word per k-mer length (two u16
-    // fields per word: the slot's two pairs).  Private (scratch) memory on purpose: written
-    // once per k-mer length, read once at the end, and 24 registers cheaper.
-    volatile uint32_t hist[(MODE == MODE_COREACC) ? SLOTS * MAX_FUSED_K : 1];
-
-    // Row staging: global -> LDS DMA (global_load_lds_dwordx4): piece p = (chunk*R + row)*7 + q
-    // of this wave's stage lands at slot p of the wave's buffer.  Chunks past the end of the
-    // sketch are clamped to the last one and never used.
-#define SKL_STAGE_DMA(T, BUF)                                                                \
-    do {                                                                                     \
-        const uint32_t k_ = g.k_begin + kk0 + (T) / stages_per_k;                            \
-        const uint32_t c0_ = c_begin + ((T) % stages_per_k) * (W * CH) + wave * CH;          \
-        _Pragma("unroll") for (int u = 0; u < PPL; ++u)                                      \
-        {                                                                                    \
-            const uint32_t pp_ = lane + u * 64u;                                             \
-            const uint32_t p_ = pp_ < (uint32_t)PIECES ? pp_ : pp_ - (uint32_t)PIECES;       \
-            const uint32_t q_ = p_ % 7u, rc_ = p_ / 7u;                                      \
-            const uint32_t r_ = rc_ % R, c_ = rc_ / R;                                       \
-            const uint32_t cc_ = (c0_ + c_) < g.ss64 ? (c0_ + c_) : (g.ss64 - 1u);           \
-            const uint64_t *src_ = (ABL & 4)                                                 \
-                ? g.A + ((((size_t)(a0 / R) * g.nk + k_) * g.ss64 + cc_) * R + r_) * BBITS + 2u * q_ /* timing only: a tile-major row slab */ \
-                : g.A + (size_t)(a0 + r_) * sample_stride +                                  \
-                      (size_t)k_ * kmer_stride + (size_t)cc_ * BBITS + 2u * q_;               \
-            skl_dma16(src_, lds_base + (((uint32_t)wave * 2u + (BUF)) * (PPL * LANES) + u * 64u) * 16u); \
-        }                                                                                    \
-    } while (0)
-
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(skl_lds_addr(&lds_all[0]));
-    SKL_STAGE_DMA(0u, 0);
-
-    // Next valid chunk of this wave after (kl, ts, ci) in its walk over k-mer lengths, stages
-    // and chunks (wave-uniform scalar code); false when the walk is over.
-    auto next_chunk = [&](uint32_t kl_, uint32_t ts_, int ci_, uint32_t &k_out, uint32_t &c_out) {
-        for (;;) {
-            if (++ci_ >= CH) {
-                ci_ = 0;
-                if (++ts_ >= stages_per_k) {
-                    ts_ = 0;
-                    ++kl_;
-                }
-            }
-            if (kl_ >= nkk) return false;
-            const uint32_t c_ = c_begin + ts_ * (W * CH) + wave * CH + (uint32_t)ci_;
-            if (c_ < c_end) {
-                k_out = g.k_begin + kk0 + kl_;
-                c_out = c_;
-                return true;
-            }
-        }
-    };
-    auto column_ptr = [&](int j, uint32_t k_, uint32_t c_) {
-        const uint32_t jb = (jb0 + j) < g.n_jblocks ? (jb0 + j) : (g.n_jblocks - 1u);   // clamped, never stored
-        return g.B + (((size_t)jb * g.nk + k_) * g.ss64 + c_) * (7 * LANES) + lane;
-    };
-
-    // Column operand: 2 x 7 x 16 B per lane and chunk, always ONE CHUNK AHEAD with no extra
-    // registers: during the last row of a chunk every b[j][q] is re-loaded with the next
-    // chunk's data right after its last use (the first of them gets most of a row of lead,
-    // the loads return in order, and the compiler's counted vmcnt before each use is exact).
-    uint4 b[JL][7];
-    {
-        uint32_t k1 = g.k_begin + kk0, c1 = c_begin;
-        next_chunk(0u, 0u, -1, k1, c1);
-#pragma unroll
-        for (int j = 0; j < JL; ++j) {
-            const uint4 *bp = column_ptr(j, k1, c1);
-#pragma unroll
-            for (int q = 0; q < 7; ++q) b[j][q] = bp[q * LANES];
-        }
-    }
-    uint32_t b_younger = 1;   // chunks' worth of column loads (JL*7 each) issued after the newest row DMA
-
-    uint32_t t = 0;   // flat stage counter (k-mer lengths x stages)
-    for (uint32_t kl = 0; kl < nkk; ++kl) {
-        const uint32_t kk = kk0 + kl;
-        for (uint32_t ts = 0; ts < stages_per_k; ++ts, ++t) {
-            const uint32_t buf = t & 1u;
-            const uint32_t c0 = c_begin + ts * (W * CH) + wave * CH;
-            // This wave's DMA of stage t must have landed.  VMEM returns in order, so it is
-            // enough that only the younger column loads may still be in flight.
-            if (b_younger == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else if (b_younger == 1) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JL * 7) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * JL * 7) : "memory");
-            }
-            if (t == 0) SKL_TRACE_MARK(1);
-            // The next stage's rows are requested after row 0 of this stage's first chunk (all
-            // column registers consumed once, so no column load is in flight then); a stage
-            // in which this wave has no chunk requests them here.
-            const bool want_dma = t + 1 < n_stages;
-            if (want_dma && c0 >= c_end) {
-                SKL_STAGE_DMA(t + 1, buf ^ 1u);
-                b_younger = 0;
-            }
-
-            // (unrolled: the column loads issued in the last row of chunk 0 and their first use
-            // in chunk 1 are then straight-line code, and the compiler's waits on them are counted
-            // instead of the vmcnt(0) it falls back to across a loop back-edge)
-#pragma unroll
-            for (uint32_t ci = 0; ci < (uint32_t)CH; ++ci) {
-                if (c0 + ci >= c_end) break;
-                // where the columns of the next chunk are (the current ones again if none follows)
-                uint32_t kn = g.k_begin + kk, cn = c0 + ci;
-                next_chunk(kl, ts, (int)ci, kn, cn);
-                const uint4 *bn[JL];
-#pragma unroll
-                for (int j = 0; j < JL; ++j) bn[j] = column_ptr(j, kn, cn);
-                const uint4 *rows = &lds_rows[wave][buf][(size_t)ci * R * 7];
-                // Row operand: a ring of AD plane pairs.  Step s = r * 7 + q of the chunk reads
-                // rows[s]; right after its use the register is re-loaded with step s + AD.  AD = 7
-                // (a whole row ahead) with up to 2 columns per lane; 4 with 3 or more, where a step
-                // is 12+ VALU instructions long and the 12 registers decide the occupancy.
-                constexpr int AD = (JL >= 3 || TIGHT) ? 4 : 7;
-                uint4 a[AD];
-                static_assert(R % MB == 0, "rows per tile must be a multiple of the block height");
-                // step s of the chunk -> index of its plane pair in the row buffer ([row][plane pair])
-                auto row_slot = [](int s) constexpr { return ((s / (7 * MB)) * MB + s % MB) * 7 + (s % (7 * MB)) / MB; };
-#pragma unroll
-                for (int q = 0; q < AD; ++q) a[q] = rows[row_slot(q)];
-#pragma unroll
-                for (int rb = 0; rb < R / MB; ++rb) {
-                    uint32_t mlo[MB][JL], mhi[MB][JL];
-#pragma unroll
-                    for (int q = 0; q < 7; ++q) {
-#pragma unroll
-                        for (int m = 0; m < MB; ++m) {
-                            const int s_ = (rb * 7 + q) * MB + m;      // compile-time after unrolling
-                            uint4 &ar = a[s_ % AD];
-#pragma unroll
-                            for (int j = 0; j < JL; ++j) {
-                                // b is stored (hi, lo) per plane: see device_common.hpp "VGPR banks"
-                                if (q == 0) {
-                                    mlo[m][j] = ar.x ^ b[j][0].y;
-                                    mhi[m][j] = ar.y ^ b[j][0].x;
-                                } else {
-                                    mlo[m][j] = acc_mismatch_vvv(mlo[m][j], ar.x, b[j][q].y);
-                                    mhi[m][j] = acc_mismatch_vvv(mhi[m][j], ar.y, b[j][q].x);
-                                }
-                                mlo[m][j] = acc_mismatch_vvv(mlo[m][j], ar.z, b[j][q].w);
-                                mhi[m][j] = acc_mismatch_vvv(mhi[m][j], ar.w, b[j][q].z);
-                            }
-                            // rolling prefetch of the plane pair AD steps ahead (no extra registers)
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (ABL & 1) {   // timing-only: no re-read, but opaque to CSE
-                                asm volatile("" : "+v"(ar.x), "+v"(ar.y), "+v"(ar.z), "+v"(ar.w));
-                            } else {
-                                if (s_ + AD < R * 7) ar = rows[row_slot(s_ + AD)];
-                            }
-                            if constexpr (!(ABL & 2)) {
-                                if (rb == R / MB - 1 && m == MB - 1) {   // last use of b[.][q] in this chunk: fetch the next chunk's
-#pragma unroll
-                                    for (int j = 0; j < JL; ++j) b[j][q] = bn[j][q * LANES];
-                                }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-#pragma unroll
-                  for (int m = 0; m < MB; ++m) {
-                    const int r = rb * MB + m;
-                    // popcount with the add fused (v_bcnt_u32_b32 d, m, d)
-                    if constexpr (PACK01) {
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mlo[m][0]));
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r]) : "v"(mhi[m][0]));
-                        uint32_t t1;
-                        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(t1) : "v"(mlo[m][1]));
-                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(t1) : "v"(mhi[m][1]));
-                        cnt[r] = (t1 << 16) + cnt[r];   // v_lshl_add_u32
-                        if constexpr (JL == 3) {
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mlo[m][2]));
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[R + r]) : "v"(mhi[m][2]));
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < JL; ++j) {
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mlo[m][j]));
-                            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r * JL + j]) : "v"(mhi[m][j]));
-                        }
-                    }
-                  }
-                    if (rb == 0 && ci == 0 && want_dma) {
-                        SKL_STAGE_DMA(t + 1, buf ^ 1u);  // lands under this stage's VALU work
-                        b_younger = 0;
-                    }
-                }
-                if constexpr (!(ABL & 2)) ++b_younger;
-            }
-        }
-
-        // ---- end of a k-mer length: sum the 4 partial counts per pair through LDS ----
-        if (kl + 1 == nkk) SKL_TRACE_MARK(2);
-        // The buffer this wave consumed last is dead (the next stage was prefetched into the
-        // other one), so every wave publishes into its own: [wave][buf][PX][LANES] words.
-        const uint32_t dead = (t - 1u) & 1u;
-        // word x of wave w: red_at(w, x)
-        uint32_t *red_rows = reinterpret_cast<uint32_t *>(&lds_all[0]);
-        uint32_t *red_over = reinterpret_cast<uint32_t *>(&lds_all[ROWS_U4]);
-        auto red_at = [&](uint32_t w, uint32_t x) -> uint32_t & {
-            return x < (uint32_t)XIN ? red_rows[(w * 2u + dead) * (BUF_U4 * 4u) + x * LANES + lane]
-                                     : red_over[(w * (uint32_t)XOV + (x - (uint32_t)XIN)) * LANES + lane];
-        };
-#pragma unroll
-        for (int x = 0; x < PX; ++x) red_at(wave, (uint32_t)x) = packed_word(x);
-#pragma unroll
-        for (int x = 0; x < NCNT; ++x) cnt[x] = 0;
-        __syncthreads();
-        // wave w finishes packed slots x = w (mod 4); fields stay below 2^16 (ss64 <= 1023)
-        float tval[(MODE == MODE_JACCARD && KSL) ? SLOTS * 2 : 1];   // this wave's keys, for out_t
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            const uint32_t x = (uint32_t)i * W + wave;
-            uint32_t total = 0;
-#pragma unroll
-            for (int w = 0; w < W; ++w) total += red_at((uint32_t)w, x);
-            if constexpr (MODE == MODE_COREACC) {
-                hist[i * MAX_FUSED_K + kl] = total;
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    uint32_t r, j;
-                    field_pair(x, (uint32_t)h, r, j);
-                    const uint32_t mism = h ? (total >> 16) : (total & 0xFFFFu);
-                    if constexpr (MODE == MODE_COUNTS) {
-                        if (in_tail && slice != 0u) {   // tail slices 1.. add into plane 1
-                            const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
-                            if (pair_valid(g, i_, jc_)) {
-                                atomicAdd(&((uint32_t *)g.out)[pair_out_index(g, i_, jc_) * g.cnt_pair_stride +
-                                                               (uint64_t)(g.k_count + kk) * g.cnt_k_stride],
-                                          (c_end - c_begin) * 64u - mism);
-                            }
-                        } else {
-                            store_count(g, a0 + r, (jb0 + j) * 64u + lane, (tail_mode ? 0u : slice * g.k_count) + kk, (c_end - c_begin) * 64u, mism);
-                        }
-                    } else if constexpr (KSL) {
-                        const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
-                        float v = __builtin_inff();
-                        const bool valid_ = pair_valid(g, i_, jc_);
-                        if (valid_) {
-                            v = jaccard_out_value(g, i_, jc_, mism);
-                            ((float *)g.out)[pair_out_index(g, i_, jc_)] = v;
-                        }
-                        if (g.r_bits != nullptr && i_ < g.row_end) {   // (wave-uniform: i_ is)
-                            // symmetric self kNN: does this 64-column block bring row i_ anything below its knn-th best?
-                            const uint32_t thr_ = g.r_thr[(size_t)(i_ - g.row_begin) * g.r_thr_stride];
-                            if (__ballot(valid_ && sortable_bits(v) < thr_) != 0ull && lane == 0u) {
-                                atomicOr(&g.r_bits[(size_t)(i_ - g.row_begin) * g.r_bits_stride + ((jb0 + j) >> 5)], 1u << ((jb0 + j) & 31u));
-                            }
-                        }
-                        tval[i * 2 + h] = v;
-                    } else {
-                        store_jaccard(g, a0 + r, (jb0 + j) * 64u + lane, mism);
-                    }
-                }
-            }
-        }
-        if constexpr (MODE == MODE_JACCARD && KSL) {
-            // Symmetric self kNN: the keys of columns >= t_col_begin are also candidates of the
-            // ROW with that sample id.  The tile is turned through LDS so that a column's R keys
-            // leave as R/4 16-byte stores (one 64-byte run per column at R = 16).
-            if (g.out_t != nullptr && min((jb0 + (uint32_t)JL) * 64u, g.nB) > g.t_col_begin) {   // workgroup-uniform
-                constexpr uint32_t TP = R + 4;   // padded column pitch (floats), keeps 16-byte alignment
-                static_assert(JL * 64 * TP * 4 <= (ROWS_U4 + RED_U4) * 16, "the turned tile fits the LDS of the workgroup");
-                float *tt = reinterpret_cast<float *>(&lds_all[0]);
-                __syncthreads();   // every wave is done with the reduction words
-#pragma unroll
-                for (int i = 0; i < SLOTS; ++i) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        uint32_t r, j;
-                        field_pair((uint32_t)i * W + wave, (uint32_t)h, r, j);
-                        tt[(j * 64u + lane) * TP + r] = tval[i * 2 + h];
-                    }
-                }
-                __syncthreads();
-                constexpr uint32_t QUADS = R / 4;
-                for (uint32_t item = tid; item < (uint32_t)JL * 64u * QUADS; item += LANES * W) {
-                    const uint32_t c = item / QUADS, q = item % QUADS;
-                    const uint32_t jc = jb0 * 64u + c;
-                    if (jc >= g.t_col_begin && jc < g.nB) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&tt[c * TP + 4u * q]);
-                        *reinterpret_cast<float4 *>(&g.out_t[(size_t)(jc - g.t_col_begin) * g.t_stride +
-                                                             (a0 - g.row_begin) + 4u * q]) = v;
-                        if (g.t_flag != nullptr) {   // does any of the four beat column jc's knn-th best? (invalid records are +inf)
-                            const float best = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
-                            if (sortable_bits(best) < g.t_thr[(size_t)jc * g.t_thr_stride]) g.t_flag[jc] = g.t_flag_value;
-                        }
-                    }
-                }
-            }
-        }
-        // the next stage's DMA of every wave goes into the buffer just read: fence the reads
-        if (kl + 1 < nkk) __syncthreads();
-    }
-#undef SKL_STAGE_DMA
-
-    if constexpr (MODE == MODE_COREACC) {
-        // symmetric self kNN: (core, acc) of columns >= t_col_begin also leave turned, see MODE_JACCARD
-        constexpr uint32_t TP = R + 4;
-        static_assert(JL * 64 * TP * 8 <= (ROWS_U4 + RED_U4) * 16, "the turned tile fits the LDS of the workgroup");
-        const bool turned = g.out_t != nullptr && min((jb0 + (uint32_t)JL) * 64u, g.nB) > g.t_col_begin;   // workgroup-uniform
-        float2 *tt = reinterpret_cast<float2 *>(&lds_all[0]);
-        if (turned) __syncthreads();   // every wave is done with the reduction words
-        // store_coreacc() takes u16 fields, newest k lowest, as s2:s1:s0
-#pragma clang loop unroll(disable)
-        for (int i = 0; i < SLOTS; ++i) {
-            const uint32_t x = (uint32_t)i * W + wave;
-            uint32_t word[MAX_FUSED_K];   // word[f]: totals of the k-mer length f steps from the newest
-#pragma unroll
-            for (int f = 0; f < MAX_FUSED_K; ++f) {
-                word[f] = (uint32_t)f < nkk ? hist[i * MAX_FUSED_K + (nkk - 1u - f)] : 0u;
-            }
-#pragma clang loop unroll(disable)
-            for (int h = 0; h < 2; ++h) {
-                uint32_t r, j;
-                field_pair(x, (uint32_t)h, r, j);
-                const uint32_t sh = h * 16u;
-                const uint32_t s0 = ((word[0] >> sh) & 0xFFFFu) | (((word[1] >> sh) & 0xFFFFu) << 16);
-                const uint32_t s1 = ((word[2] >> sh) & 0xFFFFu) | (((word[3] >> sh) & 0xFFFFu) << 16);
-                const uint32_t s2 = ((word[4] >> sh) & 0xFFFFu) | (((word[5] >> sh) & 0xFFFFu) << 16);
-                const uint32_t i_ = a0 + r, jc_ = (jb0 + j) * 64u + lane;
-                float2 v = make_float2(__builtin_inff(), __builtin_inff());
-                const bool valid_ = pair_valid(g, i_, jc_);
-                if (valid_) {
-                    v = coreacc_value(g, i_, jc_, s0, s1, s2);
-                    ((float2 *)g.out)[pair_out_index(g, i_, jc_)] = v;
-                }
-                if (g.r_bits != nullptr && i_ < g.row_end) {   // see MODE_JACCARD; the key is the core distance
-                    const uint32_t thr_ = g.r_thr[(size_t)(i_ - g.row_begin) * g.r_thr_stride];
-                    if (__ballot(valid_ && sortable_bits(v.x) < thr_) != 0ull && lane == 0u) {
-                        atomicOr(&g.r_bits[(size_t)(i_ - g.row_begin) * g.r_bits_stride + ((jb0 + j) >> 5)], 1u << ((jb0 + j) & 31u));
-                    }
-                }
-                if (turned) tt[(j * 64u + lane) * TP + r] = v;
-            }
-        }
-        if (turned) {
-            __syncthreads();
-            constexpr uint32_t DUOS = R / 2;   // two records = one 16-byte store
-            for (uint32_t item = tid; item < (uint32_t)JL * 64u * DUOS; item += LANES * W) {
-                const uint32_t c = item / DUOS, q = item % DUOS;
-                const uint32_t jc = jb0 * 64u + c;
-                if (jc >= g.t_col_begin && jc < g.nB) {
-                    const float4 v = *reinterpret_cast<const float4 *>(&tt[c * TP + 2u * q]);
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(g.out_t) +
-                                                (size_t)(jc - g.t_col_begin) * g.t_stride + (a0 - g.row_begin) + 2u * q) = v;
-                    if (g.t_flag != nullptr) {   // two (core, acc) records: the key is the core distance
-                        if (sortable_bits(fminf(v.x, v.z)) < g.t_thr[(size_t)jc * g.t_thr_stride]) g.t_flag[jc] = g.t_flag_value;
-                    }
-                }
-            }
-        }
+    } else {
+#define SKL_J0 0
+#define SKL_J1 JL
+#include "pair_kslice_walk.inc"
+#undef SKL_J0
+#undef SKL_J1
     }
     SKL_TRACE_MARK(3);
 }
 
-template <int R, int JL, bool KSL, bool TIGHT = false, int MB = 1>
+template <int R, int JL, bool KSL, bool TIGHT = false, int MB = 1, int OCC = 0>
 static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
 {
     const dim3 block(LANES * WAVES_PER_WG);
     switch (mode) {
         case MODE_COUNTS:
-            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL, 0, TIGHT, MB>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL, 0, TIGHT, MB, OCC>), grid, block, 0, stream, args);
             break;
         case MODE_JACCARD:
-            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, KSL, 0, TIGHT, MB>), grid, block, 0, stream, args);
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, KSL, 0, TIGHT, MB, OCC>), grid, block, 0, stream, args);
             break;
         case MODE_COREACC:
             if constexpr (!KSL) {
-                hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COREACC, false, 0, TIGHT, MB>), grid, block, 0, stream, args);
+                hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COREACC, false, 0, TIGHT, MB, OCC>), grid, block, 0, stream, args);
                 break;
             }
             return hipErrorInvalidValue;
@@ -677,10 +325,15 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         case 165:   // the product shape: 16 x 128 tiles, 128 VGPRs
             return k_sliced ? launch_rjk<16, 2, true, true>(args, mode, grid, stream)
                             : launch_rjk<16, 2, false, true>(args, mode, grid, stream);
-        case 325:   // large launches: 32 x 128 tiles, packed counts, 3 waves per SIMD, half the column traffic per pair
-            return k_sliced ? launch_rjk<32, 2, true, true, 4>(args, mode, grid, stream)
+        case 325:   // large launches: 32 x 128 tiles, packed counts, half the column traffic per pair.  k-sliced: blocks of 2
+                    // rows in 128 registers and 32 KB of LDS = 4 waves per SIMD (-3 ... -5 % against blocks of 4 rows at 3
+                    // waves, n = 8 000 ... 32 000 single-k, profiles/r03_ab_occ4.jsonl); all k: blocks of 4 rows, 3 waves
+            return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
 #ifdef SKL_AB
+        case 3254:   // the k-sliced 32 x 128 form of round 2: blocks of 4 rows, 143 registers, 3 waves per SIMD
+            return k_sliced ? launch_rjk<32, 2, true, true, 4>(args, mode, grid, stream)
+                            : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
         case 3251:   // ... walked row by row
             return k_sliced ? launch_rjk<32, 2, true, true, 1>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 1>(args, mode, grid, stream);

@@ -42,8 +42,10 @@ def test_product_library_has_no_ab_kernels_or_switches():
     kernels = sorted(set(re.findall(r"skl::(pair_kernel\w*<[^>]*>)", demangled)))
     assert kernels, "no pair kernel exported?"
     for k in kernels:
-        # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only, ablation parameter 0; ksplit fallback: 8-row tiles
-        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [012], (true|false), 0, true, 1>|pair_kernel_kslice<32, 2, [012], (true|false), 0, true, 4>|pair_kernel_ksplit<8, [012], 8, false>", k), k
+        # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only (32 x 128: k-sliced in blocks of 2 rows
+        # held to 4 waves per SIMD, all k in blocks of 4 rows), ablation parameter 0; ksplit fallback: 8-row tiles
+        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [012], (true|false), 0, true, 1, 0>|pair_kernel_kslice<32, 2, [01], true, 0, true, 2, 4>|"
+                            r"pair_kernel_kslice<32, 2, [012], false, 0, true, 4, 0>|pair_kernel_ksplit<8, [012], 8, false>", k), k
     assert "pair_kernel_kpersist" not in demangled      # the persistent form of the k-sliced launch: A/B build only
     blob = open(pkg.library_path(), "rb").read()
     for needle in (b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
@@ -53,7 +55,7 @@ def test_product_library_has_no_ab_kernels_or_switches():
     src = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "capi.cpp")).read()
     lo, hi = src.index("static long long env_int"), src.index("int forced_kernel(const skl_ctx *ctx)")
     assert "getenv(" not in src[:lo] + src[hi:]
-    assert src.count("read_knobs()") == 4      # definition, skl_ctx_create, skl_ctx_reload_env, the A/B build's per-launch refresh
+    assert src.count("read_knobs()") == 4      # definition, skl_ctx_create, skl_ctx_reload_env, the A/B build's refresh at every API entry
     for f in ("capi_knn.cpp", "capi_aux.cpp", "pair_kslice.hip", "pair_ksplit.hip", "kernels.hip", "topk.hip"):
         text = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", f)).read()
         assert "getenv" not in text and "env_int(" not in text, f
