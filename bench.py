@@ -8,14 +8,29 @@ the workload, inputs resident in HBM, output assembled on rank 0.
 
 Workloads:
   N = 1   BASELINE.json configs[1] ("cfg2"): 1 000 synthetic genomes all-vs-all, sketchsize64 = 64,
-          k = {15,19,23,27,31}, 499 500 pairs, Set U (random bins: what the north star names).  After
-          the timed region, untimed: 2 000 sampled pairs against the oracle, the same workload on
-          Set R (related genomes: the regression is exercised) with its own oracle check, and
-          configs[2] ("cfg3", 100 000 genomes, 5.0e9 pairs, 40 GB of output) as a secondary figure.
+          k = {15,19,23,27,31}, 499 500 pairs, Set U (random bins: what the north star names).
   N > 1   BASELINE.json configs[2] ("cfg3") STRONG-scaled: the 100 000-genome triangle is cut into
           N row bands of equal pair count (each one contiguous slice of the reference's condensed
           output array), every rank holds the whole slab (3.6 GB), computes its band, and the bands
-          are assembled on rank 0 with grouped send/recv over RCCL, one step behind the compute.
+          are assembled on rank 0 with grouped send/recv over RCCL in messages of at most 1 GiB, one
+          step behind the compute (`--gather host`: each rank copies its band into its offsets of a
+          shared host buffer instead).
+
+Order of a run (every phase is stated in the JSON line):
+  1. PRECONDITIONING (`config.preconditioning_s`, default 1 s, untimed): the workload's own launch,
+     back to back.  The chip's clock takes tens of milliseconds of sustained load to settle (the first
+     launches after idle run 10-20 % slower), and the driver's 5 + 20 steps of a 0.16 ms launch are over
+     in 4 ms -- without this the line measures the clock ramp, not the kernel.
+  2. W warm-up steps, barrier + device sync, EXACTLY K timed steps, barrier + device sync -> `value`.
+  3. ROOFLINE PASS (fixed size, independent of K and W; default 100 launches at cfg 2, 3 for the large
+     workloads): every launch bracketed by HIP events on the launch stream -> `roofline.kernel_avg_ms`;
+     then the same launches once more with a one-wave sampler on a second stream that reads the shader
+     clock the chip holds DURING them (`roofline.in_kernel_clock`: same launches, same launch history
+     as the timed region; the kernel time of that pass is reported beside it).
+  4. Untimed checks: sampled pairs of the timed output against the oracle; N > 1: the assembled matrix
+     against bands recomputed on rank 0.
+  5. N = 1: secondary legs (cfg 2 on Set R, cfg 3 / cfg 4 / cfg 5 at full size on this one GPU), HBM
+     traffic of the launch from two rocprofv3 --pmc child passes of this script, CPU baseline.
 
 Prints ONE JSON line on rank 0.
 """
@@ -34,6 +49,7 @@ KMERS = [15, 19, 23, 27, 31]
 SS64 = 64
 CFG2_N = 1000
 CFG3_N = 100_000
+K4, SS64_CFG45 = [13, 17, 21, 25, 29], 32          # BASELINE configs[3], [4]
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # Vector-ALU peak of the chip (the resource that binds this kernel: 32-bit integer bitwise work, no
 # MFMA shape).  MI355X_MICROARCH.md "Execution model": a wave64 VALU instruction issues over 2 cycles
@@ -42,21 +58,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MI
 N_SIMD = 256 * 4
 DATASHEET_CLOCK_GHZ = 2.4
 VALU_PEAK_LANE_OPS = N_SIMD * 32 * DATASHEET_CLOCK_GHZ * 1e9
+# v_bcnt_u32_b32 issues at 3.2 cycles per instruction per SIMD against 1.92 for v_bitop3_b32
+# (scripts/microbench/valu_clock.hip, profiles/r02_valu_clock_microbench.txt): 5/3 of a full-rate slot
+BCNT_SLOTS = 5.0 / 3.0
 
 
 def issue_slots_per_pair(nk, ss64):
-    """Per (pair, k, 64-bin chunk): 28 v_xor/v_bitop3 + 2 v_bcnt_u32_b32; v_bcnt issues at half
-    rate (scripts/microbench/valu_clock.hip), so it is charged two slots: 32 slots."""
-    return 32 * nk * ss64
-
-
-def n_for_pairs(pairs):
-    n = int(math.ceil((1 + math.sqrt(1 + 8 * pairs)) / 2))
-    while n * (n - 1) // 2 < pairs:
-        n += 1
-    while (n - 1) * (n - 2) // 2 >= pairs:
-        n -= 1
-    return n
+    """Per (pair, k, 64-bin chunk): 28 v_xor/v_bitop3 (one slot each) + 2 v_bcnt_u32_b32 (5/3 slot each,
+    measured) = 31.33 full-rate VALU issue slots; the instruction count is 30 (`valu_instructions_per_pair`)."""
+    return (28 + 2 * BCNT_SLOTS) * nk * ss64
 
 
 def algorithmic_bytes_per_pair(nk, ss64, ncols):
@@ -119,7 +129,8 @@ def verify_against_oracle(torch, bins_dev, out_dev, n, kmers, ss64, n_random, cl
         ci = rng.integers(0, n - cluster_stride - 1, n_random)
         cj = ci + cluster_stride * (1 + rng.integers(0, n, n_random) % ((n - 1 - ci) // cluster_stride))
         ii, jj = np.concatenate([ii, ci]), np.concatenate([jj, cj])
-    edges = [(0, 1), (0, n - 1), (n - 2, n - 1), (15, 16), (16, 127), (16, 128), (127, 128)]
+    # tile and half-tile edges of the 16 x 128 / 32 x 128 raster
+    edges = [(0, 1), (0, n - 1), (n - 2, n - 1), (15, 16), (16, 127), (16, 128), (127, 128), (63, 64), (64, 65), (79, 127)]
     ii = np.concatenate([ii, [e[0] for e in edges]]).astype(np.int64)
     jj = np.concatenate([jj, [e[1] for e in edges]]).astype(np.int64)
     ids = np.unique(np.concatenate([ii, jj]))
@@ -144,63 +155,150 @@ def static_profile(name):
         return {}
 
 
-LIVE_CLOCK = {"enabled": True, "cache": {}}
+def under_profiler():
+    return any(k.startswith("ROCPROF") for k in os.environ)
 
 
-def live_clock(clock_key):
-    """The shader clock the chip holds under this kernel ON THIS BOX, NOW: the diagnostic build of the
-    pair kernel (scripts/microbench/kslice_trace: s_memtime / s_memrealtime stamps in every wave) run as
-    a child process after the timed region, on the workload's shape -- cfg 2 itself after 200
-    back-to-back launches, or an 8 000-genome slice of the large launches with their 32 x 128 tiles.
-    None when the tool is not built or the run is under a profiler."""
-    if not LIVE_CLOCK["enabled"] or any(k.startswith("ROCPROF") for k in os.environ):
-        return None
-    if clock_key in LIVE_CLOCK["cache"]:
-        return LIVE_CLOCK["cache"][clock_key]
-    exe = os.path.join(ROOT, "scripts", "microbench", "_build", "kslice_trace")
-    argv = {"cfg2": [exe, "1000", "165", "rand", "200", "1"], "large_n": [exe, "8000", "325", "rand", "5", "1"]}[clock_key]
-    res = None
-    if os.path.exists(exe):
-        try:
-            import re
-            import subprocess
-            out = subprocess.run(argv, capture_output=True, text=True, timeout=300).stdout
-            m = re.search(r"in-kernel clock while streaming: p10 ([\d.]+) median ([\d.]+) p90 ([\d.]+) GHz", out)
-            if m:
-                res = {"ghz": float(m.group(2)), "p10": float(m.group(1)), "p90": float(m.group(3)),
-                       "source": "live: " + " ".join(["scripts/microbench/_build/kslice_trace"] + argv[1:]) +
-                                 " run after the timed region on this GPU (median over waves of d(s_memtime)/d(s_memrealtime) "
-                                 "while streaming; diagnostic build of the same kernel)"}
-        except Exception:
-            res = None
-    LIVE_CLOCK["cache"][clock_key] = res
-    return res
-
-
-def valu_block(pairs_per_launch, avg_kernel_s, nk, ss64, clock_key):
+def valu_block(pairs_per_launch, avg_kernel_s, nk, ss64, clock):
+    """roofline numbers of one launch shape: lane-operations the pairs need over the launch duration against
+    the chip's VALU issue rate at the datasheet clock; beside it the same fraction at the clock the chip held
+    during THOSE launches (`clock`: the concurrent sampler's reading, or None)."""
     slots = issue_slots_per_pair(nk, ss64)
     achieved = slots * pairs_per_launch / avg_kernel_s if avg_kernel_s > 0 else 0.0
-    clk = static_profile("in_kernel_clock.json").get(clock_key)
-    live = live_clock(clock_key)
     blk = {
         "achieved": achieved / 1e12,
         "peak": VALU_PEAK_LANE_OPS / 1e12,
         "unit": "T lane-op/s",
         "frac": achieved / VALU_PEAK_LANE_OPS,
         "issue_slots_per_pair": slots,
+        "valu_instructions_per_pair": 30 * nk * ss64,
         "peak_pairs_per_s": VALU_PEAK_LANE_OPS / slots,
         "peak_definition": "256 CUs x 4 SIMD-32 x 32 lanes/cycle (one wave64 instruction per 2 cycles) x 2.4 GHz "
-                           "datasheet clock",
+                           "datasheet clock; a pair needs 28 full-rate instructions + 2 v_bcnt at 5/3 slot each per (k, chunk)",
     }
-    if live:
-        blk["in_kernel_clock"] = live
-        blk["frac_at_in_kernel_clock"] = achieved / (VALU_PEAK_LANE_OPS * live["ghz"] / DATASHEET_CLOCK_GHZ)
-    elif clk:
-        f = clk["clock_ghz_median"]
-        blk["in_kernel_clock"] = {"ghz": f, "source": clk["source"] + " (static: s_memtime / s_memrealtime stamps "
-                                                                      "of a diagnostic build, not this run)"}
-        blk["frac_at_in_kernel_clock"] = achieved / (VALU_PEAK_LANE_OPS * f / DATASHEET_CLOCK_GHZ)
+    if clock and clock.get("ghz", 0) > 0:
+        blk["in_kernel_clock"] = clock
+        blk["frac_at_in_kernel_clock"] = achieved / (VALU_PEAK_LANE_OPS * clock["ghz"] / DATASHEET_CLOCK_GHZ)
     return blk
+
+
+def sampled(ctx, run, interval_us, expect_s=1.0, enabled=True):
+    """run() with the one-wave clock sampler next to it (skl_clock_sampler_*): -> the clock reading, or None.
+    run() must leave its work on the context's stream; it is waited for with a STREAM synchronisation (a
+    device-wide one -- hipDeviceSynchronize, hipMalloc, hipFree -- waits for the sampler too, which then ends
+    by itself after ~4x the expected duration `expect_s`: calls that allocate inside are not sampled)."""
+    if not enabled:
+        run()
+        ctx.synchronize()
+        return None
+    max_samples = int(min(1 << 20, max(256, 4.0 * expect_s * 1e6 / interval_us)))
+    ctx.clock_sampler_start(interval_us, max_samples)
+    try:
+        run()
+        ctx.synchronize()
+    finally:
+        clk = ctx.clock_sampler_stop()
+    if clk["intervals"] < 4:
+        return None
+    clk["source"] = ("live: one-wave sampler on a second stream, s_memtime against s_memrealtime every "
+                     f"{interval_us} us DURING these launches (median over {clk['intervals']} intervals; skl_clock_sampler_*)")
+    return clk
+
+
+def roofline_pass(ctx, launch, launches, interval_us, sampler=True, expect_s=1.0):
+    """The fixed kernel-timing pass: `launches` launches, EVERY one bracketed by HIP events on the launch
+    stream (whatever SKL_TIMING_EVERY the timed region ran with) -- or, with the clock sampler beside them,
+    none: an event record is a barrier packet, and with a second queue busy its timestamps come ~10 us late
+    (the launches themselves are not slowed: scripts/sampler_cost.py), so that pass reports wall time only.
+    -> (average kernel seconds, launches bracketed, wall seconds per launch, clock)."""
+    prev = os.environ.get("SKL_TIMING_EVERY")
+    os.environ["SKL_TIMING_EVERY"] = "1000000000" if sampler else "1"
+    ctx.reload_env()
+    ctx.timing_reset()
+    t = [0.0]
+
+    def run():
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            launch()
+        ctx.synchronize()
+        t[0] = (time.perf_counter() - t0) / launches
+
+    clk = sampled(ctx, run, interval_us, expect_s=expect_s, enabled=sampler)
+    kernel_ms, bracketed = ctx.kernel_ms() if not sampler else (0.0, 0)
+    if prev is None:
+        os.environ.pop("SKL_TIMING_EVERY", None)
+    else:
+        os.environ["SKL_TIMING_EVERY"] = prev
+    ctx.reload_env()
+    return (kernel_ms / 1e3) / max(bracketed, 1), bracketed, t[0], clk
+
+
+# ---- HBM traffic of the launch: two rocprofv3 --pmc child passes of this script ----
+
+def traffic_probe(args):
+    """Child mode (`--traffic-probe`): the workload's launch a few times and nothing else, for a rocprofv3
+    --pmc pass of the parent to count."""
+    import numpy as np
+    import torch
+
+    from sketchlib.rust_amd import capi, synth
+
+    dev = torch.device("cuda", 0)
+    n = args.n or CFG2_N
+    ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    bins = (synth.set_u_device(n, len(KMERS), SS64, dev) if args.dataset == "U"
+            else torch.from_numpy(synth.set_r(n, KMERS, SS64).view(np.int64)).to(dev))
+    sk = ctx.sketches(bins, n, KMERS, SS64)
+    out = torch.zeros((n * (n - 1) // 2, 2), dtype=torch.float32, device=dev)
+    p = sk.set_k()
+    for _ in range(12 if n <= 4000 else 3):
+        capi.self_dists_all(ctx, sk, p, out=out)
+    torch.cuda.synchronize()
+    print(json.dumps({"traffic_probe": True, "kernel": ctx.last_kernel()}))
+
+
+def measure_traffic(n, dataset, timeout_s=240):
+    """HBM-side bytes per pair-kernel launch, measured NOW on this box: FETCH_SIZE and WRITE_SIZE in separate
+    rocprofv3 --pmc passes (they do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots") of this script in
+    --traffic-probe mode; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of a wide stream at 64 bytes,
+    same guide).  -> {"bytes", "fetch_bytes", "write_bytes", "launches", "source"} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals, launches = {}, 0
+    tmp = tempfile.mkdtemp(prefix="skl_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-probe", "--samples", str(n), "--dataset", dataset]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not files:
+                return None
+            got = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                   if "pair_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not got:
+                return None
+            got = got[2:] or got             # (the first launches of a process: cold caches)
+            vals[counter] = sum(got) / len(got)
+            launches = len(got)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
+    return {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "launches": launches,
+            "source": "live: two rocprofv3 --pmc child passes of `bench.py --traffic-probe` on this box after the timed "
+                      "region (FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024, mean per pair-kernel launch)"}
 
 
 def main():
@@ -214,23 +312,35 @@ def main():
     ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override the sample count of the workload")
     ap.add_argument("--dataset", choices=["U", "R"], default="U",
                     help="U = random-bin sketches (north-star workload), R = related clusters (n <= 20000)")
+    ap.add_argument("--precondition-s", type=float, default=1.0,
+                    help="seconds of the workload's own launch, back to back, before the warm-up steps (untimed; 0: none)")
+    ap.add_argument("--roofline-launches", type=int, default=0,
+                    help="launches of the fixed kernel-timing pass after the timed region (default: 100 for cfg2, 3 for large n)")
+    ap.add_argument("--no-clock-sampler", action="store_true", help="roofline pass without the concurrent clock sampler")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="N = 1: quote the committed HBM traffic instead of measuring it with two rocprofv3 --pmc child passes")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-gather", action="store_true", help="skip assembling the output on rank 0")
+    ap.add_argument("--gather", choices=["rccl", "host"], default="rccl",
+                    help="N > 1: rccl = send/recv to rank 0 over xGMI (default); host = every rank copies its band "
+                         "device-to-host into its offsets of one shared host buffer")
+    ap.add_argument("--msg-mib", type=int, default=1024, help="N > 1: largest single RCCL message (MiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the Set R and cfg3 legs")
-    ap.add_argument("--no-live-clock", action="store_true",
-                    help="quote the committed in-kernel clock instead of measuring it after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the Set R, cfg3, cfg4 and cfg5 legs")
+    ap.add_argument("--secondary", default="setR,cfg3,cfg4,cfg5", help="N = 1: which secondary legs to run")
     ap.add_argument("--loopback", action="store_true",
                     help="distributed launch: rank 0 also sends its own band to itself over RCCL (lets one rank "
                          "exercise the send/recv gather)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: finish each step's gather before the next step's kernel (default: one step of overlap)")
     args = ap.parse_args()
-    LIVE_CLOCK["enabled"] = not args.no_live_clock
+    if args.traffic_probe:
+        return traffic_probe(args)
 
     # The library brackets pair-kernel launches with HIP events for skl_ctx_kernel_ms(); an event
-    # record is a barrier packet on the queue and two per launch cost a 0.16 ms step ~5 us.  The
-    # roofline needs the AVERAGE launch duration, so every 4th launch of the timed region is
-    # bracketed and the others run as a caller's would.
+    # record is a barrier packet on the queue and two per launch cost a 0.16 ms step ~5 us.  In the
+    # timed region every 4th launch is bracketed (reported as kernel_avg_ms_timed_region); the roofline's
+    # kernel time comes from the fixed pass after it, where every launch is.
     os.environ.setdefault("SKL_TIMING_EVERY", "4")
 
     import numpy as np
@@ -250,7 +360,6 @@ def main():
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
     dist = None
     if distributed:
-        LIVE_CLOCK["enabled"] = False   # the clock probe is a 1-GPU diagnostic: N > 1 lines quote the committed figure
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -283,6 +392,9 @@ def main():
     total_pairs = n * (n - 1) // 2
     slices = multi_gpu.self_band_slices(n, world)
     r0, r1, p0, my_pairs = slices[rank]
+    small_launch = total_pairs <= (1 << 24)
+    roofline_launches = args.roofline_launches or (100 if small_launch else 3)
+    sampler_interval_us = 20 if small_launch else 200
 
     # ---- inputs resident in HBM before the timed region ----
     stream = torch.cuda.current_stream(device)
@@ -293,10 +405,11 @@ def main():
         bins = torch.from_numpy(synth.set_r(n, KMERS, SS64).view(np.int64)).to(device)
     sk = ctx.sketches(bins, n, KMERS, SS64)
     p = sk.set_k()  # core/accessory
+    host_gather = dist is not None and args.gather == "host" and not args.no_gather
     if rank == 0:
         full = torch.zeros((total_pairs, 2), dtype=torch.float32, device=device)
         bands = [full[p0:p0 + my_pairs]]
-        if args.loopback and dist is not None:
+        if (args.loopback and dist is not None) or host_gather:
             bands = [torch.zeros((my_pairs, 2), dtype=torch.float32, device=device) for _ in range(2)]
     else:
         full = None
@@ -304,9 +417,15 @@ def main():
         bands = [torch.zeros((my_pairs, 2), dtype=torch.float32, device=device) for _ in range(2)]
 
     host_staged = dist is not None and dist.get_backend() != "nccl"
+    msg_elems = max(1, args.msg_mib) * (1 << 20) // 8           # (core, acc) records per message
     pipe = None
-    if dist is not None and not host_staged and not args.no_gather and not args.no_overlap:
-        pipe = multi_gpu.PipelinedGather(full, slices, rank, world, dist, depth=2, loopback=args.loopback)
+    hostbuf = None
+    if host_gather:
+        hostbuf = multi_gpu.HostGather(total_pairs, 2, slices, rank, world, dist, tag=os.environ.get("MASTER_PORT", "0"),
+                                       device=device)
+    elif dist is not None and not host_staged and not args.no_gather and not args.no_overlap:
+        pipe = multi_gpu.PipelinedGather(full, slices, rank, world, dist, depth=2, loopback=args.loopback,
+                                         max_elems=msg_elems)
     step_no = [0]
 
     def step():
@@ -314,28 +433,48 @@ def main():
         step_no[0] += 1
         capi.self_dists_rows(ctx, sk, p, r0, r1, out=local)
         if dist is not None and not args.no_gather:
-            if pipe is not None:
+            if hostbuf is not None:
+                hostbuf.submit(local)
+            elif pipe is not None:
                 pipe.submit(local)
             elif host_staged:  # gloo debugging path
                 torch.cuda.synchronize(device)
                 if rank == 0:
                     full_h = torch.empty((total_pairs, 2), dtype=torch.float32)
-                    multi_gpu.gather_to_root(full_h, None, slices, rank, world, dist)
+                    multi_gpu.gather_to_root(full_h, None, slices, rank, world, dist, max_elems=msg_elems)
                     for w in range(1, world):
                         a, cnt = slices[w][2], slices[w][3]
                         full[a:a + cnt].copy_(full_h[a:a + cnt])
                 else:
-                    multi_gpu.gather_to_root(None, local.cpu(), slices, rank, world, dist)
+                    multi_gpu.gather_to_root(None, local.cpu(), slices, rank, world, dist, max_elems=msg_elems)
             else:
-                multi_gpu.gather_to_root(full, local, slices, rank, world, dist)
+                multi_gpu.gather_to_root(full, local, slices, rank, world, dist, max_elems=msg_elems)
 
     def fence():
         if pipe is not None:
             pipe.drain()
+        if hostbuf is not None:
+            hostbuf.drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def local_launch():
+        capi.self_dists_rows(ctx, sk, p, r0, r1, out=bands[0])
+
+    # ---- 1. preconditioning: this rank's launch back to back for the stated time (no gather) ----
+    precond_s, precond_launches = 0.0, 0
+    if args.precondition_s > 0:
+        batch = 50 if small_launch else 1
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.precondition_s:
+            for _ in range(batch):
+                local_launch()
+            ctx.synchronize()
+            precond_launches += batch
+        precond_s = time.perf_counter() - t0
+
+    # ---- 2. warm-up, then the timed region ----
     for _ in range(warmup):
         step()
     fence()
@@ -345,7 +484,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = ctx.kernel_ms()
+    kernel_ms_timed, launches_timed = ctx.kernel_ms()
     kernel_name = ctx.last_kernel()
 
     if dist is not None:
@@ -353,20 +492,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- untimed: what was timed is what the reference computes ----
+    # ---- 3. the roofline pass: fixed size, every launch bracketed; then once more with the clock sampler beside it ----
+    # (bands[0] is rank 0's slice of `full` when nothing is gathered: the passes rewrite it with the same values)
+    avg_kernel_s, launches, pass_wall_s, _none = roofline_pass(ctx, local_launch, roofline_launches, sampler_interval_us, sampler=False)
+    clock = None
+    if not args.no_clock_sampler and not under_profiler():
+        _k2, _l2, w2, clock = roofline_pass(ctx, local_launch, roofline_launches, sampler_interval_us, sampler=True,
+                                            expect_s=pass_wall_s * roofline_launches)
+        if clock is not None:
+            clock["ms_per_launch_wall_with_sampler"] = w2 * 1e3
+            clock["ms_per_launch_wall_without"] = pass_wall_s * 1e3
+            clock["note"] = ("read in a second pass of the same launches (wall time per launch beside it: the sampler does not slow "
+                             "them); frac_at_in_kernel_clock = frac x 2.4 / this clock")
+
+    # ---- 4. untimed: what was timed is what the reference computes ----
     checksum = None
     verified = None
     if rank == 0:
+        if hostbuf is not None:   # the assembled matrix lives in host memory: bring it to the device for the checks
+            full.copy_(hostbuf.assembled(), non_blocking=False)
         checksum = float(full[:10 ** 8].double().sum().item())
         finite = all(bool(torch.isfinite(full[a:a + (1 << 28)]).all()) for a in range(0, total_pairs, 1 << 28))
         assert finite, "non-finite distances"
         if dist is not None and not args.no_gather:
-            # the assembled matrix must equal the one rank 0 computes alone
-            whole = torch.empty_like(full)
-            capi.self_dists_all(ctx, sk, p, out=whole)
-            torch.cuda.synchronize(device)
-            assert torch.equal(whole, full), "gathered matrix differs from the single-rank result"
-            del whole
+            # the assembled matrix must equal what rank 0 computes alone -- recomputed band by band (row
+            # bands of at most ~1 GiB), never a second whole matrix
+            n_chk = max(1, (total_pairs * 8 + (1 << 30) - 1) >> 30)
+            scratch = None
+            for c0, c1, q0, cnt in multi_gpu.self_band_slices(n, n_chk):
+                if cnt == 0:
+                    continue
+                if scratch is None or scratch.shape[0] < cnt:
+                    scratch = torch.empty((cnt, 2), dtype=torch.float32, device=device)
+                capi.self_dists_rows(ctx, sk, p, c0, c1, out=scratch[:cnt])
+                torch.cuda.synchronize(device)
+                assert torch.equal(scratch[:cnt], full[q0:q0 + cnt]), f"gathered matrix differs from the single-rank result in rows [{c0}, {c1})"
+            del scratch
         cnt, worst, fitted = verify_against_oracle(torch, bins, full, n, KMERS, SS64, 1000 if args.dataset == "R" else 2000,
                                                    cluster_stride=100 if args.dataset == "R" else None)
         assert worst <= 1e-6, f"sampled pairs differ from the oracle by {worst}"
@@ -376,16 +537,19 @@ def main():
     if rank == 0:
         ncols = 2
         b_pair = algorithmic_bytes_per_pair(nk, SS64, ncols)
-        avg_kernel_s = (kernel_ms / 1e3) / max(launches, 1)
         achieved_gbs = (b_pair * my_pairs / avg_kernel_s) / 1e9 if avg_kernel_s > 0 else 0.0
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
-        # WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE): profiles/pmc_traffic.json
-        tbytes = static_profile("pmc_traffic.json").get(f"n{n}_set{args.dataset}_world{world}")
-        traffic = None if tbytes is None else {"bytes": tbytes, "source": "profiles/pmc_traffic.json (static: rocprofv3 "
-                                               "--pmc passes of an earlier run of this command, not measured in this run)"}
-        valu = valu_block(my_pairs, avg_kernel_s, nk, SS64, "cfg2" if n <= 2000 else "large_n")
+        valu = valu_block(my_pairs, avg_kernel_s, nk, SS64, clock)
         names = {"cfg2": "BASELINE configs[1]: 1k synthetic genomes all-vs-all",
                  "cfg3": "BASELINE configs[2]: 100k synthetic genomes all-vs-all (~5e9 pairs)"}
+        gather_txt = ""
+        if dist is not None and not args.no_gather:
+            if hostbuf is not None:
+                gather_txt = ", every rank copies its band device-to-host into its offsets of one shared, pinned host buffer"
+            elif host_staged:
+                gather_txt = ", gather to rank 0 staged through host memory (gloo: debugging backend)"
+            else:
+                gather_txt = (f", grouped send/recv gather to rank 0 (RCCL) in messages of <= {args.msg_mib} MiB"
+                              + (" overlapped with the next step's kernel" if pipe is not None else ""))
         out = {
             "metric": "sketch-pair distances/sec (whole node); achieved HBM GB/s vs roofline",
             "value": total_pairs * steps / elapsed,
@@ -408,10 +572,11 @@ def main():
                 "sketchsize64": SS64,
                 "kmers": KMERS,
                 "dataset": "Set U (uniform random bins)" if args.dataset == "U" else "Set R (related clusters)",
-                "partition": f"{world} row band(s) of equal pair count"
-                             + ("" if dist is None or args.no_gather else (", grouped send/recv gather to rank 0 (RCCL)" if not host_staged else
-                                                                         ", gather to rank 0 staged through host memory (gloo: debugging backend)")
-                                + (" overlapped with the next step's kernel" if pipe is not None else "")),
+                "partition": f"{world} row band(s) of equal pair count" + gather_txt,
+                "preconditioning_s": round(precond_s, 3),
+                "preconditioning": (f"{precond_launches} back-to-back launches of this workload before the warm-up steps, untimed "
+                                    "(the clock needs tens of ms of sustained load to settle; the driver's 25 steps last 4 ms)"
+                                    if precond_launches else "none"),
                 "output_checksum_first_1e8_pairs": checksum,
                 **(verified or {}),
             },
@@ -420,12 +585,15 @@ def main():
                 # hbm_no_reuse below.
                 "bound": "valu",
                 **valu,
-                "traffic": traffic,
+                "traffic": None,
                 "kernel": kernel_name,
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "kernel_launches_timed": launches,
-                "kernel_timing": "HIP events on the launch stream around every "
-                                 f"{os.environ.get('SKL_TIMING_EVERY', '1')}th pair-kernel launch of the timed region",
+                "kernel_timing": f"fixed pass of {launches} launches right after the timed region (independent of --steps / "
+                                 "--warmup), HIP events on the launch stream around EVERY pair-kernel launch",
+                "roofline_pass_ms_per_launch_wall": pass_wall_s * 1e3,
+                "kernel_avg_ms_timed_region": (kernel_ms_timed / max(launches_timed, 1)),
+                "kernel_launches_bracketed_in_timed_region": launches_timed,
                 "pairs_per_launch": my_pairs,
                 # SURVEY 8(d)'s named bound, kept as the measure of on-chip reuse it is: both operands
                 # streamed from HBM once per pair.  A tiled kernel is far above it by construction.
@@ -439,65 +607,180 @@ def main():
         }
         print(f"[bench] primary: {out['value']:.4g} pairs/s, kernel {avg_kernel_s * 1e3:.4f} ms", file=sys.stderr)
 
-    # ---- N = 1 secondary legs (untimed by the driver's metric; each reports its own rate) ----
-    if rank == 0 and world == 1 and dist is None and workload == "cfg2" and not args.no_secondary:
+    # ---- 5. N = 1 secondary legs (untimed by the driver's metric; each reports its own rate) ----
+    single = rank == 0 and world == 1 and dist is None
+    if single and workload == "cfg2" and not args.no_secondary:
         sk.close()
         del full, bands, bins
         torch.cuda.empty_cache()
+        out["config"]["secondary"] = secondary_legs(torch, np, capi, synth, ctx, device, args.secondary.split(","),
+                                                    sampler=not args.no_clock_sampler and not under_profiler())
+        torch.cuda.empty_cache()
 
-        def timed_run(sk2, out2, w, s):
-            p2 = sk2.set_k()
-            for _ in range(w):
-                capi.self_dists_all(ctx, sk2, p2, out=out2)
-            torch.cuda.synchronize(device)
-            ctx.timing_reset()
+    if rank == 0:
+        # HBM traffic of the launch (N = 1): measured now by two rocprofv3 --pmc child passes, else the committed figure
+        traffic = None
+        if single and not args.no_traffic and not under_profiler():
+            traffic = measure_traffic(n, args.dataset)
+        if traffic is None:
+            tbytes = static_profile("pmc_traffic.json").get(f"n{n}_set{args.dataset}_world{world}")
+            traffic = None if tbytes is None else {"bytes": tbytes, "source": "profiles/pmc_traffic.json (static: rocprofv3 "
+                                                   "--pmc passes of an earlier run of this command, not measured in this run)"}
+        out["roofline"]["traffic"] = traffic
+        if single and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, KMERS, SS64, args.dataset)
+        print(json.dumps(out))
+    if hostbuf is not None:
+        hostbuf.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True):
+    """cfg 2 on Set R, and BASELINE configs[2..4] at FULL size on this one GPU, each with its own kernel
+    time (every launch bracketed), clock reading and VALU fraction."""
+    from oracle import oracle as O
+
+    nk = len(KMERS)
+    os.environ["SKL_TIMING_EVERY"] = "1"
+    ctx.reload_env()
+    sec = {}
+
+    def set_timing_every(v):
+        os.environ["SKL_TIMING_EVERY"] = str(v)
+        ctx.reload_env()
+
+    def timed(launch, w, s, interval_us, separate_clock_pass=False, clock=True):
+        """-> wall per step, PAIR-kernel seconds per step (every launch bracketed), launches, clock.  The clock sampler
+        runs beside the bracketed launches -- or, for launches short enough that the late event timestamps of a
+        two-queue device matter (~10 us each), in a second pass of its own without brackets, which then also gives the
+        wall time per step."""
+        t1 = time.perf_counter()
+        for _ in range(w):
+            launch()
+        ctx.synchronize()
+        est = (time.perf_counter() - t1) / max(w, 1) * s if w else 60.0
+        set_timing_every(1)
+        ctx.timing_reset()
+        wall = [0.0]
+
+        def run():
             t1 = time.perf_counter()
             for _ in range(s):
-                capi.self_dists_all(ctx, sk2, p2, out=out2)
-            torch.cuda.synchronize(device)
-            wall = (time.perf_counter() - t1) / s
-            kms, nl = ctx.kernel_ms()
-            return wall, (kms / 1e3) / max(nl, 1)
+                launch()
+            ctx.synchronize()
+            wall[0] = (time.perf_counter() - t1) / s
 
+        clk = sampled(ctx, run, interval_us, expect_s=est, enabled=sampler and clock and not separate_clock_pass)
+        kms, nl = ctx.kernel_ms()
+        if sampler and clock and separate_clock_pass:
+            set_timing_every(1000000000)
+            clk = sampled(ctx, run, interval_us, expect_s=est)
+            set_timing_every(1)
+        return wall[0], kms / 1e3 / s, nl, clk
+
+    if "setR" in which:
         # Set R: the same workload on related genomes (Set U returns (1, 1) for ~99 % of the pairs)
         bins_r = torch.from_numpy(synth.set_r(CFG2_N, KMERS, SS64).view(np.int64)).to(device)
         sk_r = ctx.sketches(bins_r, CFG2_N, KMERS, SS64)
         pairs_r = CFG2_N * (CFG2_N - 1) // 2
         out_r = torch.zeros((pairs_r, 2), dtype=torch.float32, device=device)
-        wall, _k = timed_run(sk_r, out_r, 20, 100)
+        p_r = sk_r.set_k()
+        wall, ksec, _nl, clk = timed(lambda: capi.self_dists_all(ctx, sk_r, p_r, out=out_r), 20, 100, 20, separate_clock_pass=True)
         cnt, worst, fitted = verify_against_oracle(torch, bins_r, out_r, CFG2_N, KMERS, SS64, 1000, cluster_stride=100)
         assert worst <= 1e-6, f"Set R: sampled pairs differ from the oracle by {worst}"
-        secondary = {"cfg2_set_R": {"pairs_per_s": pairs_r / wall, "ms_per_step": wall * 1e3, "verified_pairs": cnt,
-                                    "max_abs_err": worst, "regression_fitted": fitted}}
+        v = valu_block(pairs_r, ksec, nk, SS64, clk)
+        sec["cfg2_set_R"] = {"pairs_per_s": pairs_r / wall, "ms_per_step": wall * 1e3, "kernel_avg_ms": ksec * 1e3,
+                             "valu_frac": v["frac"], "in_kernel_clock": clk, "verified_pairs": cnt, "max_abs_err": worst,
+                             "regression_fitted": fitted}
         sk_r.close()
         del bins_r, out_r
-        # cfg3 at full size on this one GPU
+
+    if "cfg3" in which:
         bins3 = synth.set_u_device(CFG3_N, nk, SS64, device)
         sk3 = ctx.sketches(bins3, CFG3_N, KMERS, SS64)
         pairs3 = CFG3_N * (CFG3_N - 1) // 2
         out3 = torch.zeros((pairs3, 2), dtype=torch.float32, device=device)
-        wall, ksec = timed_run(sk3, out3, 1, 3)
+        p3 = sk3.set_k()
+        wall, ksec, _nl, clk = timed(lambda: capi.self_dists_all(ctx, sk3, p3, out=out3), 1, 3, 200)
         cnt, worst, _f = verify_against_oracle(torch, bins3, out3, CFG3_N, KMERS, SS64, 500)
         assert worst <= 1e-6, f"cfg3: sampled pairs differ from the oracle by {worst}"
-        v3 = valu_block(pairs3, ksec, nk, SS64, "large_n")
-        secondary["cfg3"] = {"workload": "BASELINE configs[2]: 100k genomes all-vs-all on ONE GPU, Set U",
-                             "pairs": pairs3, "pairs_per_s": pairs3 / wall, "s_per_step": wall,
-                             "kernel": ctx.last_kernel(), "kernel_avg_ms": ksec * 1e3, "valu_frac": v3["frac"],
-                             "valu_frac_at_in_kernel_clock": v3.get("frac_at_in_kernel_clock"),
-                             "in_kernel_clock": v3.get("in_kernel_clock"),
-                             "verified_pairs": cnt, "max_abs_err": worst}
-        out["config"]["secondary"] = secondary
+        v3 = valu_block(pairs3, ksec, nk, SS64, clk)
+        sec["cfg3"] = {"workload": "BASELINE configs[2]: 100k genomes all-vs-all on ONE GPU, Set U",
+                       "pairs": pairs3, "pairs_per_s": pairs3 / wall, "s_per_step": wall,
+                       "kernel": ctx.last_kernel(), "kernel_avg_ms": ksec * 1e3, "valu_frac": v3["frac"],
+                       "valu_frac_at_in_kernel_clock": v3.get("frac_at_in_kernel_clock"),
+                       "in_kernel_clock": clk, "verified_pairs": cnt, "max_abs_err": worst}
         sk3.close()
         del bins3, out3
         torch.cuda.empty_cache()
 
-    if rank == 0:
-        if world == 1 and dist is None and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, KMERS, SS64, args.dataset)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if "cfg4" in which or "cfg5" in which:
+        # the 1 M-sketch database of configs[3] and [4]: clustered synthetic sketches (200 relatives per genome)
+        keep = [0.97, 0.955, 0.94, 0.925, 0.91]
+        nr, nq, ss = 1_000_000, 10_000, SS64_CFG45
+        rbins = synth.set_clustered_device(nr, 5, ss, device, cluster_size=200, keep=keep)
+        g_r = ctx.sketches(rbins, nr, K4, ss)
+        if "cfg4" in which:
+            qbins = synth.set_clustered_device(nq, 5, ss, device, keep=keep, first_sample=10_000_000, n_clusters=nr // 200)
+            g_q = ctx.sketches(qbins, nq, K4, ss)
+            p4 = g_r.set_k()
+            out4 = torch.zeros((nr, nq, 2), dtype=torch.float32, device=device)
+            wall, ksec, _nl, clk = timed(lambda: capi.cross_dists_all(ctx, g_r, g_q, p4, out=out4), 1, 2, 200)
+            # spot check: 300 (ref, query) pairs, half of them inside a cluster
+            rng = np.random.default_rng(4)
+            qj = rng.integers(0, nq, 300)
+            ri = np.where(np.arange(300) % 2 == 0, rng.integers(0, nr, 300),
+                          (qj % (nr // 200)) + (nr // 200) * rng.integers(0, 200, 300))
+            rid, qid = np.unique(ri), np.unique(qj)
+            o_r = O.Sketches(rbins[torch.from_numpy(rid).to(device)].cpu().numpy().view(np.uint64), len(rid), K4, ss)
+            o_q = O.Sketches(qbins[torch.from_numpy(qid).to(device)].cpu().numpy().view(np.uint64), len(qid), K4, ss)
+            rp, qp = {int(s): i for i, s in enumerate(rid)}, {int(s): i for i, s in enumerate(qid)}
+            got = out4[torch.from_numpy(ri).to(device), torch.from_numpy(qj).to(device)].cpu().numpy()
+            worst = max(max(abs(float(got[t, c]) - O.core_acc_pair(o_r, o_q, rp[int(ri[t])], qp[int(qj[t])])[c]) for c in (0, 1))
+                        for t in range(300))
+            assert worst <= 1e-6, f"cfg4: sampled pairs differ from the oracle by {worst}"
+            v4 = valu_block(nr * nq, ksec, len(K4), ss, clk)
+            sec["cfg4"] = {"workload": "BASELINE configs[3]: 1M refs x 10k queries, sketchsize64=32, k={13..29}, dense core/accessory "
+                                       "(80 GB of output) on ONE GPU, clustered synthetic sketches",
+                           "pairs": nr * nq, "pairs_per_s": nr * nq / wall, "s_per_step": wall, "kernel": ctx.last_kernel(),
+                           "kernel_avg_ms": ksec * 1e3, "valu_frac": v4["frac"],
+                           "valu_frac_at_in_kernel_clock": v4.get("frac_at_in_kernel_clock"), "in_kernel_clock": clk,
+                           "verified_pairs": 300, "max_abs_err": worst}
+            g_q.close()
+            del qbins, out4
+            torch.cuda.empty_cache()
+        if "cfg5" in which:
+            knn = 50
+            p5 = g_r.set_k(K4[2])
+            res = [None]
+
+            def knn_call():
+                res[0] = capi.self_dists_knn(ctx, g_r, p5, knn)
+
+            # (not sampled: the kNN driver allocates and frees band buffers inside the call -- device-wide synchronisations
+            # that would wait for the sampler)
+            wall, ksec, n_launch, clk = timed(knn_call, 0, 1, 500, clock=False)
+            idx, d0, _d1 = res[0]
+            assert idx.shape == (nr, knn) and bool(np.all(np.diff(d0, axis=1) >= 0)) and not np.any(idx == np.arange(nr, dtype=np.uint64)[:, None])
+            for i in (0, 77_777, nr - 1):     # three rows against the dense path, top-50 by (key, id)
+                dense = capi.cross_dists_rows(ctx, g_r, g_r, p5, i, i + 1)[0, :, 0]
+                dense[i] = np.inf
+                order = np.lexsort((np.arange(nr), dense))[:knn]
+                assert np.array_equal(idx[i], order.astype(np.uint64)) and np.array_equal(d0[i], dense[order]), i
+            evaluated = nr * (nr - 1) // 2            # every pair once (symmetric driver)
+            v5 = valu_block(evaluated, ksec, 1, ss, clk)
+            sec["cfg5"] = {"workload": "BASELINE configs[4]: self kNN-50 over 1M x 1M, single-k Jaccard (k=21), sketchsize64=32, on ONE "
+                                       "GPU, clustered synthetic sketches; every pair evaluated once + running top-k",
+                           "pair_distances_defined": nr * (nr - 1), "pairs_evaluated": evaluated, "s_per_call": wall,
+                           "pair_distances_per_s": nr * (nr - 1) / wall, "kernel": ctx.last_kernel(),
+                           "pair_kernel_s": ksec, "pair_kernel_launches": n_launch, "other_s (top-k merge, copies)": wall - ksec,
+                           "valu_frac": v5["frac"], "valu_frac_at_in_kernel_clock": v5.get("frac_at_in_kernel_clock"),
+                           "in_kernel_clock": clk, "rows_checked_against_dense": 3}
+        g_r.close()
+        del rbins
+    return sec
 
 
 if __name__ == "__main__":

@@ -95,6 +95,16 @@ int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches);
  * "pair_kernel_ksplit<R=4>" -- for benchmark reports.  Valid until the next call. */
 const char *skl_ctx_last_kernel(skl_ctx *ctx);
 
+/* Diagnostic (no reference counterpart): the shader clock the chip holds while the context's kernels
+ * run.  start() launches a one-wave sampler on a stream of its own (it stamps the shader-clock counter
+ * against the constant 100 MHz counter every interval_us, at most max_samples times, then ends by
+ * itself); run the work to be measured, wait for it with skl_ctx_synchronize() -- NOT a device-wide
+ * synchronisation, which would wait for the sampler -- and call stop(): clock readings in GHz, one
+ * per interval (median, 10th / 90th percentile, and the mean over the whole window). */
+int skl_clock_sampler_start(skl_ctx *ctx, uint32_t interval_us, uint32_t max_samples);
+int skl_clock_sampler_stop(skl_ctx *ctx, double *ghz_median, double *ghz_p10, double *ghz_p90, double *ghz_mean,
+                           int *n_intervals);
+
 /* The reference takes ln J with Rust's f64::ln = the platform libm's log() (jaccard.rs:51,88), and
  * the core/accessory regression amplifies its last bit without bound on flat fits, so the
  * device evaluates a restatement of glibc's log() (csrc/glibc_log.hpp) whenever the argument is
@@ -104,6 +114,13 @@ const char *skl_ctx_last_kernel(skl_ctx *ctx);
  * CPU run on this host).  skl_device_log(): y[i] = that logarithm of x[i], evaluated on the
  * device (host pointers) -- for tests. */
 int skl_log_variant(void);
+/* Conditions a caller may want to tell its user about (a null context is accepted: so far every flag is a
+ * property of the host process).  SKL_CTX_FLAG_LOG_UNMATCHED: skl_log_variant() == -1 -- this host's libm
+ * log() is neither form the device can reproduce, so completeness-corrected core distances of FLAT fits
+ * (jaccard.rs:120-133: the same bin-match count at every k-mer length) may come out 0 where a CPU run of
+ * the reference on this host gives 1, or the reverse.  Everything else is unaffected. */
+#define SKL_CTX_FLAG_LOG_UNMATCHED 1u
+unsigned skl_ctx_flags(const skl_ctx *ctx);
 int skl_device_log(skl_ctx *ctx, const double *x_host, size_t n, double *out_host);
 
 /* ---- sketch slabs: MultiSketch::read_sketch_data / get_sketch_slice

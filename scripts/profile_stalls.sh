@@ -9,8 +9,8 @@ cd "$R"
 TAG=$1; shift
 OUT=$R/gpurun_out/stalls_$TAG
 mkdir -p "$OUT"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/a" -- python3 bench.py --no-cpu-baseline --no-live-clock "$@" > "$OUT/bench_a.log" 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/b" -- python3 bench.py --no-cpu-baseline --no-live-clock "$@" > "$OUT/bench_b.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/a" -- python3 bench.py --no-cpu-baseline --no-secondary --no-traffic "$@" > "$OUT/bench_a.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/b" -- python3 bench.py --no-cpu-baseline --no-secondary --no-traffic "$@" > "$OUT/bench_b.log" 2>&1
 python3 - "$OUT" <<'PY' > "$OUT/summary.md"
 import csv, glob, sys, collections
 out = sys.argv[1]

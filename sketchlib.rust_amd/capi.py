@@ -58,6 +58,10 @@ _SIG = [
     ("skl_ctx_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     ("skl_ctx_last_kernel", C.c_char_p, [_P]),
     ("skl_log_variant", C.c_int, []),
+    ("skl_ctx_flags", C.c_uint, [_P]),
+    ("skl_clock_sampler_start", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("skl_clock_sampler_stop", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("skl_device_log", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("skl_sketches_create", C.c_int, [_P, _P, C.c_int, C.c_size_t, C.c_size_t, _P, C.c_size_t,
                                       C.POINTER(_P)]),
@@ -166,6 +170,14 @@ def _ptr(buf):
     raise TypeError(f"unsupported buffer type {type(buf)}")
 
 
+LOG_UNMATCHED = 1
+
+
+def ctx_flags(ctx=None):
+    """skl_ctx_flags(): conditions worth telling the user about (LOG_UNMATCHED: see the header)."""
+    return int(load().skl_ctx_flags(ctx._h if ctx is not None else None))
+
+
 def log_variant():
     """Which restated form of glibc's log() reproduces this host's libm: 0 FMA, 1 SSE2, -1 neither."""
     return int(load().skl_log_variant())
@@ -219,6 +231,16 @@ class Context:
         n = C.c_int()
         _check(load().skl_ctx_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def clock_sampler_start(self, interval_us=20, max_samples=1 << 16):
+        """One-wave shader-clock sampler next to the context's kernels (diagnostic; see the header)."""
+        _check(load().skl_clock_sampler_start(self._h, interval_us, max_samples))
+
+    def clock_sampler_stop(self):
+        """-> {"ghz": median, "p10", "p90", "mean", "intervals"}; call after synchronize(), never after a device-wide sync."""
+        med, p10, p90, mean, n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        _check(load().skl_clock_sampler_stop(self._h, C.byref(med), C.byref(p10), C.byref(p90), C.byref(mean), C.byref(n)))
+        return {"ghz": med.value, "p10": p10.value, "p90": p90.value, "mean": mean.value, "intervals": n.value}
 
     def last_kernel(self):
         return load().skl_ctx_last_kernel(self._h).decode()

@@ -173,6 +173,14 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     for (void *buf : ctx->scratch) {
         if (buf) (void)hipFree(buf);
     }
+    if (ctx->sampler_stop) {
+        *(volatile uint32_t *)ctx->sampler_stop = 1u;   // a sampler still running ends at its next poll
+        if (ctx->sampler_stream) (void)hipStreamSynchronize(ctx->sampler_stream);
+        (void)hipHostFree(ctx->sampler_stop);
+    }
+    if (ctx->sampler_buf) (void)hipFree(ctx->sampler_buf);
+    if (ctx->sampler_count) (void)hipFree(ctx->sampler_count);
+    if (ctx->sampler_stream) (void)hipStreamDestroy(ctx->sampler_stream);
     if (ctx->work_counter) (void)hipFree(ctx->work_counter);
     if (ctx->tile_scratch.d_prefix) (void)hipFree(ctx->tile_scratch.d_prefix);
     if (ctx->tile_scratch.h_staging) (void)hipHostFree(ctx->tile_scratch.h_staging);
@@ -214,6 +222,63 @@ extern "C" int skl_ctx_reload_env(skl_ctx *ctx)
 {
     SKL_TRY(ctx_bind(ctx));
     ctx->knobs = read_knobs();
+    return SKL_OK;
+}
+
+// Shader clock under load.  start(): launches the one-wave sampler (kernels.hip) on a stream of its own;
+// the caller then runs whatever it wants measured and, once THAT work is complete (skl_ctx_synchronize:
+// a device-wide synchronisation would wait for the sampler itself), calls stop(), which raises the flag,
+// waits for the sampler and reduces its (shader counter, 100 MHz counter) pairs to clock readings, one
+// per sampling interval.  The sampler also ends by itself after max_samples intervals.
+extern "C" int skl_clock_sampler_start(skl_ctx *ctx, uint32_t interval_us, uint32_t max_samples)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (ctx->sampler_running) return fail(SKL_ERR_INVALID_ARG, "the clock sampler is already running");
+    if (max_samples < 2 || max_samples > (1u << 22)) return fail(SKL_ERR_INVALID_ARG, "max_samples out of range");
+    if (!ctx->sampler_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->sampler_stream, hipStreamNonBlocking));
+    if (!ctx->sampler_stop) HIP_TRY(hipHostMalloc((void **)&ctx->sampler_stop, sizeof(uint32_t), hipHostMallocMapped));
+    if (!ctx->sampler_count) HIP_TRY(hipMalloc((void **)&ctx->sampler_count, sizeof(uint32_t)));
+    if (ctx->sampler_max < max_samples) {
+        if (ctx->sampler_buf) HIP_TRY(hipFree(ctx->sampler_buf));
+        ctx->sampler_buf = nullptr;
+        ctx->sampler_max = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->sampler_buf, (size_t)max_samples * 2 * sizeof(uint64_t)));
+        ctx->sampler_max = max_samples;
+    }
+    *(volatile uint32_t *)ctx->sampler_stop = 0u;
+    uint32_t *stop_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&stop_dev, ctx->sampler_stop, 0));
+    HIP_TRY(hipMemsetAsync(ctx->sampler_count, 0, sizeof(uint32_t), ctx->sampler_stream));
+    const uint32_t sleeps = std::max(1u, interval_us / 4u);   // s_sleep 127 = 8 128 cycles ~ 4 us
+    HIP_TRY(launch_clock_sampler(stop_dev, ctx->sampler_buf, max_samples, sleeps, ctx->sampler_count, ctx->sampler_stream));
+    ctx->sampler_running = true;
+    return SKL_OK;
+}
+
+extern "C" int skl_clock_sampler_stop(skl_ctx *ctx, double *ghz_median, double *ghz_p10, double *ghz_p90, double *ghz_mean,
+                                      int *n_intervals)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!ctx->sampler_running) return fail(SKL_ERR_INVALID_ARG, "the clock sampler is not running");
+    *(volatile uint32_t *)ctx->sampler_stop = 1u;
+    ctx->sampler_running = false;
+    HIP_TRY(hipStreamSynchronize(ctx->sampler_stream));
+    uint32_t count = 0;
+    HIP_TRY(hipMemcpy(&count, ctx->sampler_count, sizeof count, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> s((size_t)count * 2);
+    if (count) HIP_TRY(hipMemcpy(s.data(), ctx->sampler_buf, s.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (uint32_t i = 1; i < count; ++i) {
+        const uint64_t dt = s[2 * i] - s[2 * i - 2], dr = s[2 * i + 1] - s[2 * i - 1];
+        if (dr > 0) ghz.push_back((double)dt / (double)dr * 0.1);   // shader cycles per 10 ns tick
+    }
+    std::sort(ghz.begin(), ghz.end());
+    const auto at = [&](double q) { return ghz.empty() ? 0.0 : ghz[std::min(ghz.size() - 1, (size_t)(q * (double)ghz.size()))]; };
+    if (ghz_median) *ghz_median = at(0.5);
+    if (ghz_p10) *ghz_p10 = at(0.1);
+    if (ghz_p90) *ghz_p90 = at(0.9);
+    if (ghz_mean) *ghz_mean = count >= 2 && s[2 * count - 1] > s[1] ? (double)(s[2 * count - 2] - s[0]) / (double)(s[2 * count - 1] - s[1]) * 0.1 : 0.0;
+    if (n_intervals) *n_intervals = (int)ghz.size();
     return SKL_OK;
 }
 
@@ -283,6 +348,10 @@ Knobs read_knobs()
 #endif
     return k;
 }
+
+#ifdef SKL_AB
+int ab_forced_log_variant() { return (int)std::max(-2ll, std::min(1ll, env_int("SKL_FORCE_LOG_VARIANT", -2))); }   // -2: not forced
+#endif
 
 int forced_kernel(const skl_ctx *ctx)
 {
@@ -451,6 +520,11 @@ static double probe_uniform(uint64_t &state)
 int host_log_variant()
 {
     static const int variant = [] {
+#ifdef SKL_AB
+        // A/B build only: SKL_FORCE_LOG_VARIANT=-1 | 0 | 1 takes the place of the probe (tests of the "neither form" branch)
+        const int forced = ab_forced_log_variant();
+        if (forced >= -1) return forced;
+#endif
         // arguments of the kind the path takes logarithms of: Jaccard values in (0, 1], the
         // |x - 1| < 1/16 branch, and the values every k-mer length of a sketch size can give
         uint64_t st = 0x5EED0001ull;
@@ -467,17 +541,20 @@ int host_log_variant()
         for (uint32_t b = 1; b <= 4096; ++b) check((double)b / 4096.0);
         if (bad[SKL_LOG_FMA] == 0) return (int)SKL_LOG_FMA;
         if (bad[SKL_LOG_SSE2] == 0) return (int)SKL_LOG_SSE2;
-        fprintf(stderr,
-                "sketchlib_dist: this host's libm log() is neither form of glibc 2.35's x86-64 log that "
-                "glibc_log.hpp restates (%zu / %zu of 304096 probe values differ); completeness-corrected "
-                "core distances of flat fits may differ from a CPU run on this host in the last bit of ln J\n",
-                bad[0], bad[1]);
-        return -1;
+        return -1;   // reported through skl_ctx_flags() / skl_log_variant(); the caller decides what to print
     }();
     return variant;
 }
 
 extern "C" int skl_log_variant(void) { return host_log_variant(); }
+
+extern "C" unsigned skl_ctx_flags(const skl_ctx *ctx)
+{
+    (void)ctx;   // (every flag so far is a property of the host process; a null context is accepted)
+    unsigned flags = 0;
+    if (host_log_variant() < 0) flags |= SKL_CTX_FLAG_LOG_UNMATCHED;
+    return flags;
+}
 
 extern "C" int skl_device_log(skl_ctx *ctx, const double *x_host, size_t n, double *out_host)
 {

@@ -92,6 +92,13 @@ struct skl_ctx {
     // this (pointer, bytes) until anything else writes the scratch.
     const void *clean_plane1 = nullptr;
     size_t clean_plane1_bytes = 0;
+    // skl_clock_sampler_start/stop: one-wave shader-clock sampler on its own stream (diagnostic)
+    hipStream_t sampler_stream = nullptr;
+    uint32_t *sampler_stop = nullptr;   // pinned host flag the kernel polls
+    uint64_t *sampler_buf = nullptr;    // [max][2] (s_memtime, s_memrealtime)
+    uint32_t *sampler_count = nullptr;
+    uint32_t sampler_max = 0;
+    bool sampler_running = false;
     uint32_t *work_counter = nullptr;   // 8 x 32 u32 queue counters of pair_kpersist.hip (zero between launches)
     Knobs knobs;                        // environment switches as of skl_ctx_create
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration

@@ -185,6 +185,12 @@ DistArgs parse_dist(int argc, char **argv, int first)
     return a;
 }
 
+// skl_ctx_flags() & SKL_CTX_FLAG_LOG_UNMATCHED, printed once when a completeness correction is asked for
+const char *const LOG_UNMATCHED_WARNING =
+    "this host's libm log() is neither form of glibc's x86-64 log the GPU reproduces bit for bit: with a completeness "
+    "correction, core distances of flat fits (the same bin-match count at every k-mer length) may be 0 where a CPU run "
+    "of sketchlib on this host prints 1, or the reverse; all other values agree to 1e-6";
+
 struct Logger {
     bool info_on, warn_on;
     void info(const std::string &m) const { if (info_on) std::cerr << "INFO  [sketchlib] " << m << "\n"; }
@@ -291,6 +297,7 @@ int run_dist(const DistArgs &a)
     DeviceSet dev(a.devices);
     t_device = since_start();
     if (a.devices.size() > 1) log.info("Using " + std::to_string(a.devices.size()) + " GPU contexts (row-band partition)");
+    if ((ref_comp || query_comp) && (skl_ctx_flags(dev[0].ctx()) & SKL_CTX_FLAG_LOG_UNMATCHED)) log.warn(LOG_UNMATCHED_WARNING);
     const std::vector<double> *rc = ref_comp ? &*ref_comp : nullptr;
     const std::vector<double> *qc = query_comp ? &*query_comp : nullptr;
     if (!queries) {
@@ -675,6 +682,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     const double t_loaded = since_start();
     Device dev(device);
     const double t_device = since_start();
+    if (comp && (skl_ctx_flags(dev.ctx()) & SKL_CTX_FLAG_LOG_UNMATCHED)) log.warn(LOG_UNMATCHED_WARNING);
     const SparseDistanceMatrix d = distances::self_dists_knn_precluster(
         dev, references, inv, skq_bins, inv.sketch_size(), n, knn, dist_type, comp ? &*comp : nullptr, cutoff,
         retain_mode, threads);

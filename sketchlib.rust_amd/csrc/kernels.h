@@ -188,6 +188,9 @@ struct EpilogueArgs {
     const float *dtab;          // [64*ss64 + 1] f32 output per bin-match count (no completeness correction)
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
+// one-wave shader-clock sampler (kernels.hip): (s_memtime, s_memrealtime) pairs until *stop != 0 or max_samples
+hipError_t launch_clock_sampler(const uint32_t *stop, uint64_t *samples, uint32_t max_samples, uint32_t sleeps,
+                                uint32_t *count, hipStream_t stream);
 // y[i] = glibc_log(x[i], variant) on the device (glibc_log.hpp)
 hipError_t launch_device_log(const double *x, double *y, uint64_t n, int variant, hipStream_t stream);
 

@@ -265,6 +265,35 @@ hipError_t launch_device_log(const double *x, double *y, uint64_t n, int variant
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// shader clock under load (diagnostic): ONE wave that stamps the shader-clock counter (s_memtime)
+// and the constant 100 MHz counter (s_memrealtime) every `sleeps` x s_sleep 127 (~4 us each) until
+// the host raises *stop (pinned host memory) or max_samples are taken.  Launched on its own stream
+// next to the pair kernels, it reads the clock the chip holds WHILE they run; the ratio of the two
+// counters' increments is the clock in units of 100 MHz.  It occupies one wave slot of one CU.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void clock_sampler_kernel(const uint32_t *stop, uint64_t *samples, uint32_t max_samples,
+                                                           uint32_t sleeps, uint32_t *count)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t i = 0;
+    while (i < max_samples) {
+        samples[2 * i] = __builtin_amdgcn_s_memtime();
+        samples[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+        ++i;
+        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+        for (uint32_t s = 0; s < sleeps; ++s) __builtin_amdgcn_s_sleep(127);
+    }
+    *count = i;
+}
+
+hipError_t launch_clock_sampler(const uint32_t *stop, uint64_t *samples, uint32_t max_samples, uint32_t sleeps,
+                                uint32_t *count, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_sampler_kernel, dim3(1), dim3(64), 0, stream, stop, samples, max_samples, sleeps, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream)
 {
     if (args.n_pairs == 0) return hipSuccess;

@@ -185,8 +185,16 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     // three cases and chosen per workgroup (uniform branch); the skipped block's column registers are
     // never loaded and its count fields stay 0 (its pairs are invalid and never stored).
     constexpr bool HALF_TILES = R == 16 && JL == 2 && TIGHT && ABL == 0;
-    const bool skip0 = HALF_TILES && !g.no_half_tiles && g.self_mode && a0 + 1u >= (jb0 + 1u) * 64u;
-    const bool skip1 = HALF_TILES && !g.no_half_tiles && jb0 + 1u >= g.n_jblocks;
+#ifdef SKL_AB
+    // (A/B build only: SKL_HALF_TILES=0 walks every block.  The run-time condition costs the 16-row k-sliced
+    // form 11 registers spilled outside its loops -- 44 B of scratch per lane, 26 MB of HBM traffic per
+    // 1 000-genome launch -- so the product library does not carry it.)
+    const bool half_ok = HALF_TILES && g.no_half_tiles == 0u;
+#else
+    constexpr bool half_ok = HALF_TILES;
+#endif
+    const bool skip0 = half_ok && g.self_mode && a0 + 1u >= (jb0 + 1u) * 64u;
+    const bool skip1 = half_ok && jb0 + 1u >= g.n_jblocks;
     // The walk is TEXTUALLY included once per case (pair_kslice_walk.inc; SKL_J0 / SKL_J1 = the column blocks
     // [J0, J1) it walks), not a lambda or a function template: wrapping it in either changes hipcc's register
     // allocation of the 32-row form (168 VGPRs + 144 B of spills per lane instead of 144 VGPRs).  No value of

@@ -16,6 +16,8 @@ exception: a pair's key is a candidate of BOTH rows, which belong to different r
 rank keeps partial top-k states for all rows and the ranks exchange row shards of them with
 one all-to-all before the final merge (knn_band_deal / exchange_knn_states / self_knn_once).
 """
+import os
+
 import numpy as np
 
 
@@ -60,13 +62,27 @@ def self_band_slices(n, world):
     return out
 
 
-def gather_to_root(full, local, slices, rank, world, dist, root=0):
+MAX_MESSAGE_ELEMS = 1 << 27   # rows ((core, acc) records: 8 B) per message: 1 GiB
+
+
+def message_chunks(cnt, max_elems=MAX_MESSAGE_ELEMS):
+    """[(first row, rows)] of a band of `cnt` rows cut into messages of at most `max_elems` rows.  Sender and
+    receiver cut the same band the same way, so the messages pair up in order.  (A band of cfg 3 is 5 GB per
+    rank at N = 8 and 20 GB at N = 2: as ONE message that is a 2.5e9-element send, past anything the transport's
+    32-bit counts have been exercised with; 1 GiB pieces also let the root's receives from different peers
+    interleave.)"""
+    max_elems = max(1, int(max_elems))
+    return [(a, min(max_elems, cnt - a)) for a in range(0, cnt, max_elems)]
+
+
+def gather_to_root(full, local, slices, rank, world, dist, root=0, max_elems=MAX_MESSAGE_ELEMS):
     """Assemble per-rank slices on `root`.
 
     full:   root's [total_pairs, ncols] tensor (ignored elsewhere); root's own band is
             expected to be computed directly into its slice of `full`.
     local:  this rank's [n_pairs_rank, ncols] tensor (non-root ranks).
     slices: self_band_slices()/cross equivalents: (.., .., first_pair, n_pairs) per rank.
+    Bands travel in messages of at most max_elems rows (message_chunks).
     """
     if world == 1:
         return
@@ -76,9 +92,11 @@ def gather_to_root(full, local, slices, rank, world, dist, root=0):
             if w == root or slices[w][3] == 0:
                 continue
             p0, cnt = slices[w][2], slices[w][3]
-            ops.append(dist.P2POp(dist.irecv, full[p0:p0 + cnt], w))
+            for a, m in message_chunks(cnt, max_elems):
+                ops.append(dist.P2POp(dist.irecv, full[p0 + a:p0 + a + m], w))
     elif slices[rank][3] > 0:
-        ops.append(dist.P2POp(dist.isend, local, root))
+        for a, m in message_chunks(slices[rank][3], max_elems):
+            ops.append(dist.P2POp(dist.isend, local[a:a + m], root))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -96,7 +114,7 @@ class PipelinedGather:
     receives of consecutive steps are ordered by the communicator.
     """
 
-    def __init__(self, full, slices, rank, world, dist, root=0, depth=2, loopback=False):
+    def __init__(self, full, slices, rank, world, dist, root=0, depth=2, loopback=False, max_elems=MAX_MESSAGE_ELEMS):
         """loopback: the root also SENDS its own band to itself (a separate `local` buffer received
         into its slice of `full`) -- with one rank that is the whole exchange, which lets a 1-GPU box
         run the RCCL send/recv path of the N > 1 gather (tests/test_bench_gpu.py)."""
@@ -106,23 +124,28 @@ class PipelinedGather:
         self.depth = max(1, depth)
         self.pending = collections.deque()
         self.loopback = loopback
+        self.max_elems = max_elems
 
     def submit(self, local):
         if self.world == 1 and not self.loopback:
             return
         ops = []
+        P2P, isend, irecv = self.dist.P2POp, self.dist.isend, self.dist.irecv
         if self.rank == self.root and self.loopback and self.slices[self.root][3] > 0:
             p0, cnt = self.slices[self.root][2], self.slices[self.root][3]
-            ops.append(self.dist.P2POp(self.dist.isend, local, self.root))
-            ops.append(self.dist.P2POp(self.dist.irecv, self.full[p0:p0 + cnt], self.root))
+            for a, m in message_chunks(cnt, self.max_elems):
+                ops.append(P2P(isend, local[a:a + m], self.root))
+                ops.append(P2P(irecv, self.full[p0 + a:p0 + a + m], self.root))
         if self.rank == self.root:
             for w in range(self.world):
                 if w == self.root or self.slices[w][3] == 0:
                     continue
                 p0, cnt = self.slices[w][2], self.slices[w][3]
-                ops.append(self.dist.P2POp(self.dist.irecv, self.full[p0:p0 + cnt], w))
+                for a, m in message_chunks(cnt, self.max_elems):
+                    ops.append(P2P(irecv, self.full[p0 + a:p0 + a + m], w))
         elif self.slices[self.rank][3] > 0:
-            ops.append(self.dist.P2POp(self.dist.isend, local, self.root))
+            for a, m in message_chunks(self.slices[self.rank][3], self.max_elems):
+                ops.append(P2P(isend, local[a:a + m], self.root))
         self.pending.append(self.dist.batch_isend_irecv(ops) if ops else [])
         while len(self.pending) >= self.depth:
             for req in self.pending.popleft():
@@ -132,6 +155,85 @@ class PipelinedGather:
         while self.pending:
             for req in self.pending.popleft():
                 req.wait()
+
+
+class HostGather:
+    """The alternative SURVEY 8(e) names for when the host needs the matrix anyway: no transfer between
+    GPUs at all -- every rank copies its band device-to-host straight into ITS offsets of one host buffer
+    shared by the ranks of the node (a file in /dev/shm mapped by every rank, the rank's own slice
+    registered as pinned memory so the copy is one DMA).  The copy of step i runs on a side stream while
+    the kernel of step i + 1 runs; the caller rotates two band buffers, and submit() waits for the copy
+    that last read the buffer it is handed.  Root ingress over xGMI (35 GB per step into one GPU at cfg 3,
+    N = 8) is replaced by 8 independent PCIe streams of 5 GB."""
+
+    def __init__(self, total_rows, ncols, slices, rank, world, dist, tag="0", device=None, directory="/dev/shm"):
+        import torch
+
+        self.torch, self.rank, self.world, self.dist = torch, rank, world, dist
+        self.path = f"{directory}/skl_bench_gather_{tag}.f32"
+        self.shape = (total_rows, ncols)
+        nbytes = total_rows * ncols * 4
+        if rank == 0:
+            with open(self.path, "wb") as f:
+                f.truncate(max(nbytes, 4))
+        if dist is not None:
+            dist.barrier()
+        self.map = np.memmap(self.path, dtype=np.float32, mode="r+", shape=self.shape)
+        p0, cnt = slices[rank][2], slices[rank][3]
+        self.mine = torch.from_numpy(self.map[p0:p0 + cnt])
+        self.pinned = False
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        if self.on_gpu and cnt:
+            # page-locked for the lifetime of the object: the D2H copy is then one asynchronous DMA
+            rc = torch.cuda.cudart().cudaHostRegister(self.mine.data_ptr(), self.mine.numel() * 4, 0)
+            self.pinned = int(rc) == 0
+            self.stream = torch.cuda.Stream(device=device)
+        self.last = None     # event of the newest copy; self.before: the one before it
+
+    def submit(self, local):
+        """Start the copy of `local` (just filled on the current stream) into this rank's slice.  The caller
+        rotates TWO band buffers: the next kernel writes the buffer of the previous submit, so the current
+        stream is made to wait for THAT copy; the copy started here overlaps the next kernel."""
+        torch = self.torch
+        if local.shape[0] == 0:
+            return
+        if not self.on_gpu:
+            self.mine.copy_(local)
+            return
+        cur = torch.cuda.current_stream(local.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                         # the kernel that filled `local`
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            self.mine.copy_(local, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        if self.last is not None:
+            cur.wait_event(self.last)             # the other buffer's copy, before the next kernel overwrites it
+        self.last = ev
+
+    def drain(self):
+        if self.on_gpu and self.last is not None:
+            self.last.synchronize()               # (copies are ordered on one stream)
+
+    def assembled(self):
+        """The whole matrix as a host tensor (after drain() + a barrier every rank's band is in it)."""
+        return self.torch.from_numpy(self.map)
+
+    def close(self):
+        self.drain()
+        if self.pinned:
+            self.torch.cuda.cudart().cudaHostUnregister(self.mine.data_ptr())
+            self.pinned = False
+        if self.dist is not None:
+            self.dist.barrier()
+        del self.mine
+        del self.map
+        if self.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
 
 
 # ---------------------------------------------------------------------------

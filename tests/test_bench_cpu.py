@@ -18,12 +18,26 @@ def test_roofline_constants():
     b = _bench()
     assert b.algorithmic_bytes_per_pair(5, 64, 2) == 71688          # SURVEY 8(d), cfg 2/3 core/acc
     assert b.algorithmic_bytes_per_pair(5, 32, 2) == 35848          # cfg 4/5
-    assert b.issue_slots_per_pair(5, 64) == 10240
+    # per (k, chunk): 28 full-rate instructions + 2 v_bcnt at the measured 3.2 / 1.92 = 5/3 slot each
+    slots = (28 + 2 * 5 / 3) * 5 * 64
+    assert abs(b.issue_slots_per_pair(5, 64) - slots) < 1e-9 and abs(slots - 10026.67) < 0.01
     assert abs(b.VALU_PEAK_LANE_OPS - 7.8643e13) < 1e10             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-    blk = b.valu_block(499500, 0.16e-3, 5, 64, "cfg2")
-    assert abs(blk["frac"] - (10240 * 499500 / 0.16e-3) / b.VALU_PEAK_LANE_OPS) < 1e-12
-    assert abs(blk["peak_pairs_per_s"] - 7.68e9) < 1e7
-    assert b.n_for_pairs(499500) == 1000
+    blk = b.valu_block(499500, 0.16e-3, 5, 64, None)
+    assert abs(blk["frac"] - (slots * 499500 / 0.16e-3) / b.VALU_PEAK_LANE_OPS) < 1e-12
+    assert abs(blk["peak_pairs_per_s"] - 7.8434e9) < 1e6
+    assert blk["valu_instructions_per_pair"] == 9600 and "in_kernel_clock" not in blk
+    clk = {"ghz": 2.0, "p10": 1.9, "p90": 2.1, "mean": 2.0, "intervals": 100, "source": "test"}
+    blk = b.valu_block(499500, 0.16e-3, 5, 64, clk)
+    assert abs(blk["frac_at_in_kernel_clock"] - blk["frac"] * 2.4 / 2.0) < 1e-12
+
+
+def test_the_hidden_child_mode_and_the_driver_arguments_parse():
+    """`bench.py --gpus 1 --steps 20 --warmup 5` is what the driver runs; --traffic-probe is the child mode of the
+    rocprofv3 --pmc passes.  (Parsing only: no GPU here.)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--precondition-s", "--roofline-launches", "--traffic-probe", "--gather", "--msg-mib", "--no-traffic"):
+        assert flag in src, flag
+    assert "preconditioning_s" in src and "kernel_launches_timed" in src
 
 
 def test_condensed_index_matches_the_reference_formula():

@@ -3,6 +3,7 @@ public header declares, and refuses to compute without a GPU (no CPU fallback)."
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -99,3 +100,81 @@ def test_product_never_imports_oracle():
                 if re.search(r"(from|import)\s+oracle|oracle/|sketchlib_oracle|sko_", text):
                     offenders.append(os.path.join(root, f))
     assert not offenders, offenders
+
+
+def test_unmatched_host_log_is_reported_through_ctx_flags():
+    """skl_log_variant() == -1 (this host's libm log() is neither form the device restates) must reach the
+    caller: skl_ctx_flags() carries SKL_CTX_FLAG_LOG_UNMATCHED and the library prints nothing itself.  The
+    branch is forced through the A/B build's SKL_FORCE_LOG_VARIANT (the probe is cached per process, so each
+    case runs in its own)."""
+    import sketchlib.rust_amd as pkg
+
+    lib = pkg.build_ab_library()
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.skl_ctx_flags.restype = ctypes.c_uint; "
+            "L.skl_ctx_flags.argtypes = [ctypes.c_void_p]; print(L.skl_log_variant(), L.skl_ctx_flags(None))")
+    for forced, want in (("-1", "-1 1"), ("0", "0 0"), ("1", "1 0"), (None, None)):
+        env = dict(os.environ)
+        env.pop("SKL_FORCE_LOG_VARIANT", None)
+        if forced is not None:
+            env["SKL_FORCE_LOG_VARIANT"] = forced
+        res = subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        assert res.stderr.strip() == "", "the library itself prints nothing: " + res.stderr
+        if want is not None:
+            assert res.stdout.split() == want.split(), (forced, res.stdout)
+        else:       # unforced: this image's glibc 2.35 matches one of the two forms
+            v, f = res.stdout.split()
+            assert v in ("0", "1") and f == "0"
+    # the product library has no such switch
+    assert b"SKL_FORCE_LOG_VARIANT" not in open(pkg.library_path(), "rb").read()
+    # and the CLI warns once when a completeness correction meets the flag
+    cli = open(os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "host", "cli_main.cpp")).read()
+    assert cli.count("SKL_CTX_FLAG_LOG_UNMATCHED)) log.warn(LOG_UNMATCHED_WARNING)") == 2
+
+
+def _kernel_metadata(lib_path):
+    """{demangled kernel name: (vgprs, scratch bytes per lane, LDS bytes)} from the gfx950 code object in the library."""
+    import tempfile
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    notes = ""
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat])
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"          # one bundle per object file linked into the library
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        for n, a in enumerate(starts):
+            piece, dev = os.path.join(tmp, f"bundle{n}.bin"), os.path.join(tmp, f"dev{n}.o")
+            open(piece, "wb").write(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+            subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={piece}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={dev}"])
+            notes += subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", dev], text=True)
+    out = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        def field(name):
+            return re.search(r"\." + name + r":\s+(\S+)", blk).group(1)
+        name = subprocess.check_output(["c++filt", field("name")], text=True).strip()
+        out[name] = (int(field("vgpr_count")), int(field("private_segment_fixed_size")), int(field("group_segment_fixed_size")))
+    return out
+
+
+def test_register_budget_of_the_shipped_pair_kernels():
+    """The pair kernels are built for a fixed occupancy, and hipcc's register allocation of them has proved fragile
+    (one more run-time condition on the half-tile flags spilled 11 registers of the 16-row k-sliced form; wrapping the
+    tile walk in a lambda spilled the 32-row one).  What ships: the k-sliced forms hold 4 waves per SIMD (<= 128
+    VGPRs, <= 40 KB of LDS) -- the 16-row ones without a byte of scratch, the 32-row ones with a handful of values
+    spilled OUTSIDE their loops -- and the all-k forms keep their per-k totals in private memory by design."""
+    import sketchlib.rust_amd as pkg
+
+    pkg.build_library()
+    meta = {k: v for k, v in _kernel_metadata(pkg.library_path()).items() if "pair_kernel_kslice" in k}
+    assert len(meta) == 10, sorted(meta)
+    for name, (vgpr, scratch, lds) in meta.items():
+        r, _jl, _mode, ksl = re.search(r"pair_kernel_kslice<(\d+), (\d+), (\d+), (true|false)", name).groups()
+        if ksl == "true":
+            assert vgpr <= 128 and lds <= 40 * 1024, (name, vgpr, lds)
+            assert scratch == 0 if r == "16" else scratch <= 32, (name, scratch)
+        else:
+            assert (vgpr <= 128 and lds <= 40 * 1024) if r == "16" else (vgpr <= 168 and lds <= 53 * 1024), (name, vgpr, lds)
+            assert scratch <= 256, (name, scratch)

@@ -75,6 +75,39 @@ pipe.drain()
 if rank == 0:
     assert torch.equal(full, ref + (steps - 1)), "pipelined gather: last step's matrix differs"
     print("PIPELINE_OK")
+# bands cut into messages: a band travels as several sends that pair up with the receives in order
+for max_elems in (1, 7, 100, 10 ** 9):
+    if rank == 0:
+        full.fill_(-1.0)
+        full[p0:p0 + cnt] = mine
+    multi_gpu.gather_to_root(full, mine, slices, rank, world, dist, max_elems=max_elems)
+    if rank == 0:
+        assert torch.equal(full, ref), max_elems
+    pipe = multi_gpu.PipelinedGather(full, slices, rank, world, dist, depth=2, max_elems=max_elems)
+    for it in range(3):
+        b = bufs[it %% 2]
+        b.copy_(ref[p0:p0 + cnt] + 10 * it)
+        if rank == 0:
+            full[p0:p0 + cnt] = b
+        pipe.submit(b)
+    pipe.drain()
+    if rank == 0:
+        assert torch.equal(full, ref + 20), max_elems
+if rank == 0:
+    print("CHUNKS_OK")
+# --gather host: every rank writes its band into its offsets of one shared host buffer
+hg = multi_gpu.HostGather(ref.shape[0], ref.shape[1], slices, rank, world, dist, tag="test%%d" %% os.getpid() if world == 1 else "test_w%%d" %% world)
+for it in range(4):
+    b = bufs[it %% 2]
+    b.copy_(ref[p0:p0 + cnt] + it)
+    hg.submit(b)
+hg.drain()
+dist.barrier()
+if rank == 0:
+    assert torch.equal(hg.assembled(), ref + 3), "host gather: assembled matrix differs"
+    print("HOST_GATHER_OK")
+hg.close()
+assert rank != 0 or not os.path.exists(hg.path)
 dist.barrier()
 dist.destroy_process_group()
 """ % ROOT
@@ -90,6 +123,16 @@ def test_gloo_world2_gather(oracle, tmp_path):
         env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "GATHER_OK" in res.stdout and "PIPELINE_OK" in res.stdout
+    assert "CHUNKS_OK" in res.stdout and "HOST_GATHER_OK" in res.stdout
+
+
+def test_message_chunks():
+    assert multi_gpu.message_chunks(0) == []
+    assert multi_gpu.message_chunks(5, 2) == [(0, 2), (2, 2), (4, 1)]
+    assert multi_gpu.message_chunks(4, 2) == [(0, 2), (2, 2)]
+    # cfg 3 at N = 2: a 2.5e9-row band goes as 19 messages of at most 1 GiB
+    c = multi_gpu.message_chunks(2_499_975_000)
+    assert len(c) == 19 and sum(m for _, m in c) == 2_499_975_000 and max(m for _, m in c) * 8 <= 1 << 30
 
 
 @pytest.mark.parametrize("n_bands,world", [(1, 1), (5, 2), (16, 8), (489, 8), (7, 3)])
