@@ -162,10 +162,24 @@ int skl_cross_dists_rows(skl_ctx *ctx, const skl_sketches *ref, const skl_sketch
                          int out_on_device);
 
 /* ---- sparse k-nearest-neighbour distances ----
- * Output rows hold `knn` items sorted ascending by (key, neighbour index) where
- * key = d0 for Jaccard / core for CoreAcc, or 1-ANI for ANI (mod.rs:173-176);
- * ties resolve to the lowest neighbour index.  out_d1 is written for CoreAcc only
- * and may be NULL otherwise. */
+ * Output rows hold `knn` items sorted ascending by key, where key = d0 for Jaccard / core for
+ * CoreAcc, or 1-ANI for ANI (mod.rs:173-176).  out_d1 is written for CoreAcc only and may be NULL
+ * otherwise.  knn is bounded only by the number of candidates (lib.rs:379-382, mod.rs:325): up to
+ * 2 048 neighbours the running lists live in LDS, longer ones go through global memory.
+ *
+ * Equal keys (common: every genome without knn relatives ties at 1.0, and single-k Jaccard values are
+ * quantised) -- skl_ctx_set_knn_ties() chooses between two rules for the dense kNN calls:
+ *   SKL_KNN_TIES_CANONICAL (default)  smallest (key, neighbour index) first: a property of the data alone.
+ *                                     The distance multiset of every row equals the reference's.
+ *   SKL_KNN_TIES_REFERENCE            the list the reference BINARY prints: candidates j ascending through
+ *                                     push_heap (mod.rs:41-48: strict `<` against the heap's maximum) into
+ *                                     std::collections::BinaryHeap, then into_sorted_vec (mod.rs:156-191,
+ *                                     :335-391) -- which of several equal keys survive, and their order, follow
+ *                                     from the heap's history.  Replayed on the device row by row, so the
+ *                                     self kNN evaluates every pair twice as the reference does. */
+#define SKL_KNN_TIES_CANONICAL 0
+#define SKL_KNN_TIES_REFERENCE 1
+int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);
 
 /* self_dists_knn (src/distances/mod.rs:133-224); requires 1 <= knn < n. */
 int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,

@@ -39,6 +39,8 @@ def main():
     print(json.dumps({"mode": "skl_sketch_signs (bases in host memory)", "samples": n, "bases_per_sample": length,
                       "kmers": kmers, "num_bins": 4096, "kernel_ms": kms, "kernel_Gwindows_per_s": windows / kms / 1e6,
                       "call_wall_s": wall, "call_Gbases_per_s": n * length / wall / 1e9}), flush=True)
+    if os.environ.get("BENCH_KERNEL_ONLY"):   # (profiling runs: the kernel call alone, no child processes)
+        return
     # end to end through the CLI on plain FASTA files
     with tempfile.TemporaryDirectory() as tmp:
         lut = np.frombuffer(b"ACTG", dtype=np.uint8)     # code -> base ((b >> 1) & 3)

@@ -33,4 +33,8 @@ for P in ${PASSES//,/ }; do
   echo "pass $P rc=$?"
 done
 KERNELS="$KERNELS" python3 scripts/summarize_profile.py "$OUT" > "$OUT/summary.md"
+# keep the summary, the kernel stats table and the logs; the raw traces / counter dumps run to hundreds of MB
+# (gpurun copies at most 64 MiB back)
+cp "$(ls "$OUT"/stats/*/*kernel_stats.csv 2>/dev/null | tail -1)" "$OUT/kernel_stats.csv" 2>/dev/null
+for P in ${PASSES//,/ }; do rm -rf "$OUT/$P"; done
 cat "$OUT/summary.md"

@@ -59,6 +59,7 @@ _SIG = [
     ("skl_ctx_last_kernel", C.c_char_p, [_P]),
     ("skl_log_variant", C.c_int, []),
     ("skl_ctx_flags", C.c_uint, [_P]),
+    ("skl_ctx_set_knn_ties", C.c_int, [_P, C.c_int]),
     ("skl_clock_sampler_start", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("skl_clock_sampler_stop", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -171,6 +172,7 @@ def _ptr(buf):
 
 
 LOG_UNMATCHED = 1
+TIES_CANONICAL, TIES_REFERENCE = 0, 1
 
 
 def ctx_flags(ctx=None):
@@ -231,6 +233,10 @@ class Context:
         n = C.c_int()
         _check(load().skl_ctx_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_knn_ties(self, mode):
+        """TIES_CANONICAL (default) or TIES_REFERENCE: see the header."""
+        _check(load().skl_ctx_set_knn_ties(self._h, int(mode)))
 
     def clock_sampler_start(self, interval_us=20, max_samples=1 << 16):
         """One-wave shader-clock sampler next to the context's kernels (diagnostic; see the header)."""

@@ -191,7 +191,23 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     t.out_d1 = nullptr;
     t.row_offsets = d_off;
     t.col_ids = d_cand;
-    HIP_TRY(launch_topk(t, ctx->stream));
+    if (knn <= (size_t)TOPK_LDS_MAX) {
+        HIP_TRY(launch_topk(t, ctx->stream));
+    } else {
+        // more neighbours than the LDS array holds: the selected items of a row are collected and sorted in
+        // global memory, rows in batches of at most 1 GiB of it
+        DevBuf items;
+        t.items_pitch = topk_items_pitch(knn);
+        const size_t batch = std::max<size_t>(1, std::min<size_t>(n, (1ull << 30) / (t.items_pitch * sizeof(uint64_t))));
+        HIP_TRY(hipMalloc(&items.p, batch * t.items_pitch * sizeof(uint64_t)));
+        t.items_scratch = (uint64_t *)items.p;
+        for (size_t r = 0; r < n; r += batch) {
+            t.first_row = (uint32_t)r;
+            t.rows = (uint32_t)std::min(batch, n - r);
+            HIP_TRY(launch_topk(t, ctx->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));   // `items` is freed on scope exit
+    }
     HIP_TRY(hipMemcpyAsync(out_idx, d_idx.p, n * knn * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out_d0, d_d0.p, n * knn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -205,7 +221,7 @@ static int check_candidate_call(skl_ctx *ctx, const skl_sketches *s, const skl_d
     if (p->dist_type != SKL_DIST_JACCARD) {
         return fail(SKL_ERR_INVALID_ARG, "Prefilter only available for single k-mer distances");  // mod.rs:549-551
     }
-    if (knn == 0 || knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, 2048]", knn);
+    if (knn == 0) return fail(SKL_ERR_INVALID_ARG, "knn must be positive");
     return SKL_OK;
 }
 

@@ -100,6 +100,7 @@ struct skl_ctx {
     uint32_t sampler_max = 0;
     bool sampler_running = false;
     uint32_t *work_counter = nullptr;   // 8 x 32 u32 queue counters of pair_kpersist.hip (zero between launches)
+    int knn_ties = 0;                   // SKL_KNN_TIES_CANONICAL / _REFERENCE (skl_ctx_set_knn_ties)
     Knobs knobs;                        // environment switches as of skl_ctx_create
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration
     std::set<skl_sketches *> sketches;  // slabs created on this context

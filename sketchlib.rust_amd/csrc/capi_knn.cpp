@@ -223,8 +223,22 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
     band[1] = band[0];
     if (overlap) SKL_TRY(ctx_scratch(ctx, band_rows * n_cand * rec, &band[1], 3));
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
+    // Three ways from a band of records to neighbour lists:
+    //   * the streaming running top-k (topk_merge_kernel) + finalize: canonical ties, knn <= TOPK_LDS_MAX;
+    //   * the radix select with its items in global memory (topk_kernel, dense form): canonical ties, any knn;
+    //   * the BinaryHeap replay (topk_refheap_kernel): the reference binary's tie order, any knn.
+    const bool ref_ties = ctx->knn_ties == SKL_KNN_TIES_REFERENCE;
+    const bool big = knn > (size_t)TOPK_LDS_MAX;
+    const bool streaming_state = !ref_ties && !big;
     KnnState st;
-    SKL_TRY(knn_state_init(st, r1 - r0, knn, coreacc, ctx->stream));
+    DevBuf big_scratch;
+    if (streaming_state) {
+        SKL_TRY(knn_state_init(st, r1 - r0, knn, coreacc, ctx->stream));
+    } else if (ref_ties && knn > (size_t)REFHEAP_LDS_MAX) {
+        HIP_TRY(hipMalloc(&big_scratch.p, band_rows * 3 * (knn + 1) * sizeof(float)));
+    } else if (!ref_ties && big) {
+        HIP_TRY(hipMalloc(&big_scratch.p, band_rows * topk_items_pitch(knn) * sizeof(uint64_t)));
+    }
     if (overlap) {   // the states are cleared on the context's stream, the merges run on the other one
         HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
         HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[0], 0));
@@ -241,26 +255,65 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
             HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
         }
-        TopkMergeArgs m;
-        memset(&m, 0, sizeof m);
-        m.knn = (uint32_t)knn;
-        m.stride2 = coreacc ? 2 : 1;
-        m.run_key = st.key;
-        m.run_idx = st.idx;
-        m.run_d1 = st.d1;
-        m.streaming = ctx->knobs.topk_stream;
-        m.key_stride = (uint64_t)n_cand * m.stride2;
-        m.rows = (uint32_t)(b1 - b0);
-        m.self_id_base = self_mode ? (uint32_t)b0 : 0xFFFFFFFFu;
-        m.state_row_base = (uint32_t)(b0 - r0);
-        m.keys = (const float *)band[buf];
-        m.cols = (uint32_t)n_cand;
-        m.id_base = 0;
-        HIP_TRY(launch_topk_merge(m, topk_stream));
+        const size_t o = (b0 - r0) * knn;   // first output item of the band
+        const int ani_undo = (!coreacc && p->ani) ? 1 : 0;
+        if (streaming_state) {
+            TopkMergeArgs m;
+            memset(&m, 0, sizeof m);
+            m.knn = (uint32_t)knn;
+            m.stride2 = coreacc ? 2 : 1;
+            m.run_key = st.key;
+            m.run_idx = st.idx;
+            m.run_d1 = st.d1;
+            m.streaming = ctx->knobs.topk_stream;
+            m.key_stride = (uint64_t)n_cand * m.stride2;
+            m.rows = (uint32_t)(b1 - b0);
+            m.self_id_base = self_mode ? (uint32_t)b0 : 0xFFFFFFFFu;
+            m.state_row_base = (uint32_t)(b0 - r0);
+            m.keys = (const float *)band[buf];
+            m.cols = (uint32_t)n_cand;
+            m.id_base = 0;
+            HIP_TRY(launch_topk_merge(m, topk_stream));
+        } else if (ref_ties) {
+            RefHeapArgs h;
+            memset(&h, 0, sizeof h);
+            h.keys = (const float *)band[buf];
+            h.stride2 = coreacc ? 2 : 1;
+            h.key_stride = (uint64_t)n_cand * h.stride2;
+            h.rows = (uint32_t)(b1 - b0);
+            h.cols = (uint32_t)n_cand;
+            h.self_id_base = self_mode ? (uint32_t)b0 : 0xFFFFFFFFu;
+            h.knn = (uint32_t)knn;
+            h.ani_undo = ani_undo;
+            h.out_idx = d_idx + o;
+            h.out_d0 = d_d0 + o;
+            h.out_d1 = coreacc ? d_d1 + o : nullptr;
+            h.heap_scratch = (float *)big_scratch.p;
+            HIP_TRY(launch_topk_refheap(h, topk_stream));
+        } else {
+            TopkArgs t;
+            memset(&t, 0, sizeof t);
+            t.keys = (const float *)band[buf];
+            t.rows = (uint32_t)(b1 - b0);
+            t.cols = (uint32_t)n_cand;
+            t.stride2 = coreacc ? 2 : 1;
+            t.knn = (uint32_t)knn;
+            t.self_mode = self_mode;
+            t.row_begin = (uint32_t)b0;
+            t.ani_undo = ani_undo;
+            t.out_idx = d_idx + o;
+            t.out_d0 = d_d0 + o;
+            t.out_d1 = coreacc ? d_d1 + o : nullptr;
+            t.items_scratch = (uint64_t *)big_scratch.p;
+            t.items_pitch = topk_items_pitch(knn);
+            HIP_TRY(launch_topk(t, topk_stream));
+        }
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
     }
-    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, (r1 - r0) * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0,
-                                 d_d1, topk_stream));
+    if (streaming_state) {
+        HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, (r1 - r0) * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0,
+                                     d_d1, topk_stream));
+    }
     if (overlap) {   // results (and the band buffers) belong to the context's stream again
         HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
@@ -283,8 +336,11 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     if (knn == 0 || knn > max_knn) {
         return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, max_knn);
     }
-    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
     if (r1 == r0) return SKL_OK;
+    // (no upper bound on knn beyond the candidates there are, as in the reference, lib.rs:379-382 / mod.rs:325: up to
+    // TOPK_LDS_MAX neighbours the lists live in LDS; more go through global memory, row by row)
+    const bool ref_ties = ctx->knn_ties == SKL_KNN_TIES_REFERENCE;
+    const bool big_knn = knn > (size_t)TOPK_LDS_MAX;
 
     const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
     // the key band lives only on the device: take up to a quarter of the free HBM (<= 8 GiB)
@@ -301,7 +357,9 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     // The whole self matrix: evaluate each pair once (knn_self_symmetric) when that leaves bands
     // worth launching -- about 8 of them (7/16 of the pair evaluations saved), each at least 32 M
     // pairs, within four band buffers of up to half the free HBM (<= 32 GiB) together.
-    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p) &&
+    // (the reference's tie order depends on the ORDER candidates arrive in, ascending j for every row: row by row;
+    // so do lists too long for the LDS-resident running state)
+    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p) && !ref_ties && !big_knn &&
                      ctx->knobs.knn_symmetric;   // (SKL_KNN_SYMMETRIC=0: A/B against the row-by-row form)
     if (symmetric) {
         size_t budget = band_bytes;
@@ -309,6 +367,11 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         const size_t want = forced_band_rows ? forced_band_rows : symmetric_band_rows(n_cand, rec, budget, 1);
         if (want >= n_cand) symmetric = false;
         else band_rows = want;
+    }
+    if (!symmetric && (big_knn || ref_ties)) {
+        // per-row working arrays in global memory (knn beyond the LDS forms): keep them within 1 GiB
+        const size_t per_row = big_knn ? std::max<size_t>((size_t)topk_items_pitch(knn) * sizeof(uint64_t), 3 * (knn + 1) * sizeof(float)) : 0;
+        if (per_row) band_rows = std::max<size_t>(1, std::min<size_t>(band_rows, (size_t)(1ull << 30) / per_row));
     }
     const bool overlap = ctx->knobs.knn_overlap && band_rows < r1 - r0;
 
@@ -339,6 +402,14 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (mode != SKL_KNN_TIES_CANONICAL && mode != SKL_KNN_TIES_REFERENCE) return fail(SKL_ERR_INVALID_ARG, "unknown kNN tie mode %d", mode);
+    ctx->knn_ties = mode;
     return SKL_OK;
 }
 
@@ -381,7 +452,11 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     if (!state_key || !state_idx || (coreacc && !state_d1)) return fail(SKL_ERR_INVALID_ARG, "state pointers are null");
     const size_t n = s->n;
     if (n < 2 || knn == 0 || knn > n - 1) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, n ? n - 1 : 0);
-    if (knn > 2048) return fail(SKL_ERR_INVALID_ARG, "knn=%zu exceeds the device limit of 2048", knn);
+    if (knn > (size_t)TOPK_LDS_MAX) return fail(SKL_ERR_INVALID_ARG, "the one-evaluation kNN keeps its running lists in LDS: knn=%zu exceeds %u; shard rows with skl_self_dists_knn_rows", knn, TOPK_LDS_MAX);
+    if (ctx->knn_ties == SKL_KNN_TIES_REFERENCE) {
+        return fail(SKL_ERR_INVALID_ARG, "the reference's tie order follows from the order candidates arrive in: no one-evaluation form; "
+                                         "shard rows with skl_self_dists_knn_rows");
+    }
     if (band_rows == 0) return fail(SKL_ERR_INVALID_ARG, "band_rows is zero");
     if (n_bands && !bands) return fail(SKL_ERR_INVALID_ARG, "bands is null");
     if (!knn_symmetric_ok(s, p)) {

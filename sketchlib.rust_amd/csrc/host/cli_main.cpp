@@ -36,6 +36,7 @@ struct DistArgs {
     std::string ref_db;
     std::optional<std::string> query_db, output, subset, ref_completeness_file, query_completeness_file;
     std::optional<size_t> knn, kmer;
+    int knn_ties = SKL_KNN_TIES_CANONICAL;
     bool ani = false;
     size_t threads = 1;
     double completeness_cutoff = 0.64;
@@ -72,9 +73,10 @@ void print_help()
         "Options:\n"
         "  -o <OUTPUT>                     Output filename (omit to output to stdout)\n"
         "      --knn <KNN>                 Calculate sparse distances with k nearest-neighbours (ref-vs-ref or ref-vs-query)\n"
-        "                                  [neighbours at EQUAL distance are kept lowest index first; the reference's\n"
-        "                                  BinaryHeap keeps an unspecified subset of them, so tied rows can list other\n"
-        "                                  ids in another order -- the distances per row are the same]\n"
+        "      --knn-ties <RULE>           Neighbours at EQUAL distance: canonical = lowest index first (default; the\n"
+        "                                  distances per row are the reference's, tied rows may list other ids);\n"
+        "                                  reference = exactly the ids and order the reference binary prints (its\n"
+        "                                  BinaryHeap replayed on the GPU; every pair is then evaluated twice, as there)\n"
         "      --subset <SUBSET>           Sample names to analyse\n"
         "  -k <KMER>                       K-mer length (if provided only calculate Jaccard distance)\n"
         "      --ani                       Calculate ANI rather than Jaccard dists, using Poisson model\n"
@@ -126,6 +128,12 @@ DistArgs parse_dist(int argc, char **argv, int first)
         else if (arg == "--quiet") a.quiet = true;
         else if (arg == "-o") a.output = value("-o <OUTPUT>");
         else if (arg == "--knn") a.knn = parse_usize("--knn <KNN>", value("--knn <KNN>"));
+        else if (arg == "--knn-ties") {
+            const std::string v = value("--knn-ties <RULE>");
+            if (v == "canonical") a.knn_ties = SKL_KNN_TIES_CANONICAL;
+            else if (v == "reference") a.knn_ties = SKL_KNN_TIES_REFERENCE;
+            else usage_error("invalid value '" + v + "' for '--knn-ties <RULE>': possible values: canonical, reference");
+        }
         else if (arg == "--subset") a.subset = value("--subset <SUBSET>");
         else if (arg == "-k") a.kmer = parse_usize("-k <KMER>", value("-k <KMER>"));
         else if (arg == "--ani") a.ani = true;
@@ -297,6 +305,9 @@ int run_dist(const DistArgs &a)
     DeviceSet dev(a.devices);
     t_device = since_start();
     if (a.devices.size() > 1) log.info("Using " + std::to_string(a.devices.size()) + " GPU contexts (row-band partition)");
+    for (size_t d = 0; d < dev.size(); ++d) {
+        if (skl_ctx_set_knn_ties(dev[d].ctx(), a.knn_ties) != SKL_OK) throw std::runtime_error(skl_last_error());
+    }
     if ((ref_comp || query_comp) && (skl_ctx_flags(dev[0].ctx()) & SKL_CTX_FLAG_LOG_UNMATCHED)) log.warn(LOG_UNMATCHED_WARNING);
     const std::vector<double> *rc = ref_comp ? &*ref_comp : nullptr;
     const std::vector<double> *qc = query_comp ? &*query_comp : nullptr;

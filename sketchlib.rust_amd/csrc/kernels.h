@@ -263,8 +263,40 @@ struct TopkArgs {
     // candidates are padded with (row id, 1.0f) as mod.rs:535-546 does.  Null = dense form.
     const uint64_t *row_offsets;
     const uint32_t *col_ids;
+    // knn > TOPK_LDS_MAX: the selected items of row r are collected and sorted in
+    // items_scratch[r * items_pitch ...) (global memory; items_pitch >= topk_items_pitch(knn)) instead of LDS
+    uint64_t *items_scratch;
+    uint64_t items_pitch;
+    uint32_t first_row;      // this launch handles rows first_row .. first_row + rows - 1 (scratch slices are per launch)
 };
+constexpr uint32_t TOPK_LDS_MAX = 2048;   // neighbours per row the LDS-resident top-k kernels hold
+inline uint64_t topk_items_pitch(uint64_t knn)   // next power of two >= knn (the bitonic sort's array)
+{
+    uint64_t m = 1;
+    while (m < knn) m <<= 1;
+    return m;
+}
 hipError_t launch_topk(const TopkArgs &args, hipStream_t stream);
+
+// Reference tie order (opt-in): the neighbour list the reference binary prints -- std::collections::BinaryHeap
+// driven by push_heap (mod.rs:41-48: push when not full or STRICTLY below the maximum, then pop the maximum) over
+// the candidates in ascending index order (mod.rs:156-181, :335-369), then into_sorted_vec.  Which of several
+// equal keys survive, and in what order equal keys are listed, is decided by the heap's history; the kernel
+// replays it (topk.hip: topk_refheap_kernel).  One workgroup per row of a dense [rows][cols] band.
+struct RefHeapArgs {
+    const float *keys;       // row r's records at keys + r * key_stride (floats), ascending candidate id
+    uint64_t key_stride;
+    uint32_t stride2;        // 1: plain keys; 2: (core, acc) records, key = core
+    uint32_t rows, cols;
+    uint32_t self_id_base;   // row r is candidate self_id_base + r and skipped; 0xFFFFFFFF = off
+    uint32_t knn;
+    int32_t ani_undo;        // write 1.0f - key (mod.rs:183-189)
+    uint64_t *out_idx;       // [rows][knn]
+    float *out_d0, *out_d1;
+    float *heap_scratch;     // knn > REFHEAP_LDS_MAX: [rows][3 * (knn + 1)] floats in global memory, else null
+};
+constexpr uint32_t REFHEAP_LDS_MAX = 2048;
+hipError_t launch_topk_refheap(const RefHeapArgs &args, hipStream_t stream);
 
 // Running per-row top-k: merges a row's new keys into its sorted state of knn (sortable key,
 // sample id[, second value]) entries.  New ids must all be larger than the ids already in the

@@ -38,8 +38,9 @@ struct TopkShared {
     uint64_t items[TOPK_MAX];  // (sortable key << 32) | position
 };
 
-// Bitonic sort of sh.items[0, m) (m a power of two), ascending.
-__device__ __forceinline__ void sort_items(TopkShared &sh, uint32_t m)
+// Bitonic sort of items[0, m) (m a power of two), ascending.  `items` is the workgroup's own array: LDS, or --
+// for more neighbours than fit there -- global memory (a barrier orders a workgroup's global accesses too).
+__device__ __forceinline__ void sort_items(uint64_t *items, uint32_t m)
 {
     const uint32_t tid = threadIdx.x;
     for (uint32_t size = 2; size <= m; size <<= 1) {
@@ -48,10 +49,10 @@ __device__ __forceinline__ void sort_items(TopkShared &sh, uint32_t m)
                 const uint32_t lo = 2 * x - (x & (stride - 1));
                 const uint32_t hi = lo + stride;
                 const bool up = (lo & size) == 0;
-                const uint64_t a = sh.items[lo], b = sh.items[hi];
+                const uint64_t a = items[lo], b = items[hi];
                 if ((a > b) == up) {
-                    sh.items[lo] = b;
-                    sh.items[hi] = a;
+                    items[lo] = b;
+                    items[hi] = a;
                 }
             }
             __syncthreads();
@@ -60,10 +61,12 @@ __device__ __forceinline__ void sort_items(TopkShared &sh, uint32_t m)
 }
 
 // The knn_eff smallest (key, position) of positions [0, n_items) for which item(c, u) is true
-// (u = sortable key bits), left sorted in sh.items[0, knn_eff).  At least knn_eff positions
-// must be valid.  Called by the whole workgroup.
+// (u = sortable key bits), left sorted in items[0, knn_eff); `items` holds the next power of two
+// >= knn_eff entries (sh.items, or a global array of the workgroup's own when knn_eff > TOPK_MAX).
+// At least knn_eff positions must be valid.  Called by the whole workgroup.
 template <class Item>
-__device__ __forceinline__ void select_smallest(const Item &item, uint32_t n_items, uint32_t knn_eff, TopkShared &sh)
+__device__ __forceinline__ void select_smallest(const Item &item, uint32_t n_items, uint32_t knn_eff, TopkShared &sh,
+                                                uint64_t *items)
 {
     const uint32_t tid = threadIdx.x;
     // ---- radix select: key value of the knn-th smallest ----
@@ -121,7 +124,7 @@ __device__ __forceinline__ void select_smallest(const Item &item, uint32_t n_ite
         if (!item(c, u)) continue;
         if (u < thresh) {
             const uint32_t pos = atomicAdd(&sh.count, 1u);
-            sh.items[pos] = ((uint64_t)u << 32) | c;
+            items[pos] = ((uint64_t)u << 32) | c;
         }
     }
     __syncthreads();
@@ -143,7 +146,7 @@ __device__ __forceinline__ void select_smallest(const Item &item, uint32_t n_ite
         for (uint32_t w = 0; w < wave; ++w) before += sh.wave_cnt[w];
         const uint32_t taken = sh.taken;
         if (eq && taken + before < take_eq) {
-            sh.items[n_less + taken + before] = ((uint64_t)thresh << 32) | c;
+            items[n_less + taken + before] = ((uint64_t)thresh << 32) | c;
         }
         __syncthreads();
         if (tid == 0) {
@@ -157,16 +160,16 @@ __device__ __forceinline__ void select_smallest(const Item &item, uint32_t n_ite
     // ---- bitonic sort of the knn items by (key, position) ----
     uint32_t m = 1;
     while (m < knn_eff) m <<= 1;
-    for (uint32_t x = knn_eff + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
+    for (uint32_t x = knn_eff + tid; x < m; x += TOPK_THREADS) items[x] = ~0ull;
     __syncthreads();
-    sort_items(sh, m);
+    sort_items(items, m);
 }
 
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
 {
     __shared__ TopkShared sh;
 
-    const uint32_t row = blockIdx.x;
+    const uint32_t row = blockIdx.x + g.first_row;
     const uint32_t tid = threadIdx.x;
     const bool ragged = g.row_offsets != nullptr;
     const uint64_t row_base = ragged ? g.row_offsets[row] : (uint64_t)row * g.cols;
@@ -184,15 +187,17 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
         if (knn_eff == 0) return;
     }
     const uint32_t stride2 = g.stride2;
+    // more neighbours than the LDS array holds: the row's own slice of a global scratch array
+    uint64_t *items = g.items_scratch ? g.items_scratch + (size_t)blockIdx.x * g.items_pitch : sh.items;
     select_smallest(
         [&](uint32_t c, uint32_t &u) {
             if (c == self_col) return false;
             u = sortable_bits(keys[(size_t)c * stride2]);
             return true;
         },
-        n_cols, knn_eff, sh);
+        n_cols, knn_eff, sh, items);
     for (uint32_t x = tid; x < knn_eff; x += TOPK_THREADS) {
-        const uint32_t col = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
+        const uint32_t col = (uint32_t)(items[x] & 0xFFFFFFFFu);
         const size_t o = (size_t)row * g.knn + x;
         const float key = keys[(size_t)col * g.stride2];
         g.out_idx[o] = g.col_ids ? g.col_ids[row_base + col] : col;
@@ -204,7 +209,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const TopkArgs g)
 hipError_t launch_topk(const TopkArgs &args, hipStream_t stream)
 {
     if (args.rows == 0) return hipSuccess;
-    if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
+    if (args.knn == 0) return hipErrorInvalidValue;
+    if (args.knn > TOPK_MAX && (args.items_scratch == nullptr || args.items_pitch < topk_items_pitch(args.knn))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
     return hipGetLastError();
 }
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
                 while (m < total) m <<= 1;
                 for (uint32_t x = total + tid; x < m; x += TOPK_THREADS) sh.items[x] = ~0ull;
                 __syncthreads();
-                sort_items(sh, m);
+                sort_items(sh.items, m);
                 worst = sh.items[knn - 1];
                 changed = true;
             }
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
             }
             return fresh(begin + (c - knn), u);
         },
-        knn + rest, knn, sh);
+        knn + rest, knn, sh, sh.items);
     for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
         const uint32_t pos = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
         const uint32_t id = pos < knn ? si[pos] : g.id_base + begin + (pos - knn);
@@ -445,6 +451,227 @@ hipError_t launch_merge_states(const MergeStatesArgs &args, hipStream_t stream)
         return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(merge_states_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Reference tie order (RefHeapArgs, kernels.h): std::collections::BinaryHeap replayed.
+//
+// The reference keeps a row's neighbours in a max-heap of at most knn items: candidate j (ascending) is pushed
+// when the heap is not full or its key is STRICTLY below the heap's maximum, and the maximum is then popped
+// (mod.rs:41-48); the row is printed in into_sorted_vec order.  Among equal keys, which candidates survive and in
+// what order they are listed is therefore a function of the heap's history.  Rust's std is not part of the
+// reference tree: the routines below restate the published algorithm of alloc::collections::binary_heap (push =
+// sift_up; pop = move the last element to the root, sift_down_to_bottom, sift_up; into_sorted_vec = repeated
+// swap(0, end) + sift_down_range); the test suite checks it against an independent CPU restatement.  Keys compare as f32
+// (SparseJaccard / SparseCoreAcc order on the distance alone, distance_matrix.rs:214-262).
+//
+// One workgroup per row.  All threads scan the row's records in candidate order and compact, IN ORDER, the ones
+// that could enter the heap as it stood at the last drain (not full, or key below its maximum: the maximum only
+// falls, so this is a superset of what the heap accepts) into an LDS buffer; thread 0 drains the buffer through
+// the exact push / pop sequence, which rejects the rest.  The heap lives in LDS (global memory beyond
+// REFHEAP_LDS_MAX neighbours).
+// ---------------------------------------------------------------------------
+namespace {
+struct RefHeap {
+    float *key;       // [knn + 1]
+    float *d1;        // [knn + 1] second values (or unused)
+    uint32_t *id;     // [knn + 1]
+    uint32_t len;
+    bool two;
+
+    struct Elt { float k, d; uint32_t i; };
+    __device__ __forceinline__ Elt get(uint32_t p) const { return Elt{key[p], two ? d1[p] : 0.0f, id[p]}; }
+    __device__ __forceinline__ void set(uint32_t p, const Elt &e) { key[p] = e.k; id[p] = e.i; if (two) d1[p] = e.d; }
+    __device__ __forceinline__ void move(uint32_t dst, uint32_t src) { key[dst] = key[src]; id[dst] = id[src]; if (two) d1[dst] = d1[src]; }
+
+    __device__ void sift_up(uint32_t start, uint32_t pos)
+    {
+        const Elt elt = get(pos);
+        while (pos > start) {
+            const uint32_t parent = (pos - 1u) / 2u;
+            if (elt.k <= key[parent]) break;
+            move(pos, parent);
+            pos = parent;
+        }
+        set(pos, elt);
+    }
+    __device__ void sift_down_range(uint32_t pos, uint32_t end)
+    {
+        const Elt elt = get(pos);
+        uint32_t child = 2u * pos + 1u;
+        while (child <= (end >= 2u ? end - 2u : 0u)) {   // end.saturating_sub(2)
+            child += key[child] <= key[child + 1u] ? 1u : 0u;
+            if (elt.k >= key[child]) {
+                set(pos, elt);
+                return;
+            }
+            move(pos, child);
+            pos = child;
+            child = 2u * pos + 1u;
+        }
+        if (child == end - 1u && elt.k < key[child]) {
+            move(pos, child);
+            pos = child;
+        }
+        set(pos, elt);
+    }
+    __device__ void sift_down_to_bottom(uint32_t pos)
+    {
+        const uint32_t end = len, start = pos;
+        const Elt elt = get(pos);
+        uint32_t child = 2u * pos + 1u;
+        while (child <= (end >= 2u ? end - 2u : 0u)) {
+            child += key[child] <= key[child + 1u] ? 1u : 0u;
+            move(pos, child);
+            pos = child;
+            child = 2u * pos + 1u;
+        }
+        if (child == end - 1u) {
+            move(pos, child);
+            pos = child;
+        }
+        set(pos, elt);
+        sift_up(start, pos);
+    }
+    // mod.rs:41-48
+    __device__ void push_heap(const Elt &item, uint32_t knn)
+    {
+        if (len < knn || item.k < key[0]) {
+            set(len, item);
+            ++len;
+            sift_up(0u, len - 1u);
+            if (len > knn) {   // pop the maximum
+                --len;
+                if (len > 0u) {
+                    move(0u, len);
+                    sift_down_to_bottom(0u);
+                }
+            }
+        }
+    }
+    __device__ void into_sorted()
+    {
+        uint32_t end = len;
+        while (end > 1u) {
+            --end;
+            const Elt a = get(0u), b = get(end);
+            set(0u, b);
+            set(end, a);
+            sift_down_range(0u, end);
+        }
+    }
+};
+}  // namespace
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_refheap_kernel(const RefHeapArgs g)
+{
+    constexpr uint32_t CAP = 2048, UNROLL = 4;
+    __shared__ float lds_heap[3 * (REFHEAP_LDS_MAX + 1)];
+    __shared__ float cand_key[CAP], cand_d1[CAP];
+    __shared__ uint32_t cand_id[CAP];
+    __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
+    __shared__ uint32_t sh_len, sh_ncand;
+    __shared__ float sh_thr;
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t knn = g.knn, cols = g.cols, stride2 = g.stride2;
+    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
+    const float *keys = g.keys + (size_t)row * g.key_stride;
+    float *base = g.heap_scratch ? g.heap_scratch + (size_t)row * 3u * (knn + 1u) : lds_heap;
+    RefHeap h{base, base + (knn + 1u), reinterpret_cast<uint32_t *>(base + 2u * (knn + 1u)), 0u, stride2 == 2u};
+    if (tid == 0) {
+        sh_len = 0;
+        sh_ncand = 0;
+        sh_thr = __builtin_inff();
+    }
+    __syncthreads();
+
+    auto drain = [&]() {   // thread 0: the buffered candidates through the exact push / pop sequence, in order
+        if (tid == 0) {
+            h.len = sh_len;
+            const uint32_t m = sh_ncand;
+            for (uint32_t c = 0; c < m; ++c) h.push_heap(RefHeap::Elt{cand_key[c], cand_d1[c], cand_id[c]}, knn);
+            sh_len = h.len;
+            sh_ncand = 0;
+            sh_thr = h.len < knn ? __builtin_inff() : h.key[0];
+        }
+        __syncthreads();
+    };
+
+    for (uint32_t q0 = 0; q0 < cols; q0 += TOPK_THREADS * UNROLL) {
+        float k[UNROLL], d[UNROLL];
+#pragma unroll
+        for (uint32_t j = 0; j < UNROLL; ++j) {   // unconditional (clamped) loads, all in flight together
+            const uint32_t q = min(q0 + j * TOPK_THREADS + tid, cols - 1u);
+            k[j] = __builtin_nontemporal_load(&keys[(size_t)q * stride2]);
+            d[j] = stride2 == 2u ? __builtin_nontemporal_load(&keys[(size_t)q * 2u + 1u]) : 0.0f;
+        }
+        const float thr = sh_thr;
+        const bool open = sh_len < knn;   // not full: everything is pushed
+        bool take[UNROLL];
+        int any = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < UNROLL; ++j) {
+            const uint32_t q = q0 + j * TOPK_THREADS + tid;
+            take[j] = q < cols && q != self_id && (open || k[j] < thr);
+            any |= take[j] ? 1 : 0;
+        }
+        if (!__syncthreads_or(any)) continue;   // (the common case once the heap has settled)
+#pragma unroll
+        for (uint32_t j = 0; j < UNROLL; ++j) {
+            // ordered compaction: position order = candidate order
+            const uint64_t votes = __ballot(take[j]);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(votes);
+            __syncthreads();
+            uint32_t before = sh_ncand + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < TOPK_THREADS / 64; ++w) {
+                if (w < wave) before += wave_cnt[w];
+                total += wave_cnt[w];
+            }
+            if (take[j]) {
+                cand_key[before] = k[j];
+                cand_d1[before] = d[j];
+                cand_id[before] = q0 + j * TOPK_THREADS + tid;
+            }
+            __syncthreads();
+            if (tid == 0) sh_ncand += total;
+            __syncthreads();
+            if (sh_ncand + TOPK_THREADS > CAP || open) {
+                // (while the heap fills, drain after every round: the threshold must exist before more is buffered)
+                drain();
+                if (open) {   // the threshold may have appeared: re-test what this thread still holds
+                    const float t2 = sh_thr;
+                    const bool open2 = sh_len < knn;
+#pragma unroll
+                    for (uint32_t jj = 0; jj < UNROLL; ++jj) {
+                        if (jj > j) take[jj] = take[jj] && (open2 || k[jj] < t2);
+                    }
+                }
+            }
+        }
+    }
+    drain();
+    if (tid == 0) {
+        h.len = sh_len;
+        h.into_sorted();
+    }
+    __syncthreads();
+    const uint32_t len = sh_len;
+    for (uint32_t x = tid; x < len; x += TOPK_THREADS) {
+        const size_t o = (size_t)row * knn + x;
+        g.out_idx[o] = h.id[x];
+        g.out_d0[o] = g.ani_undo ? 1.0f - h.key[x] : h.key[x];
+        if (stride2 == 2u && g.out_d1) g.out_d1[o] = h.d1[x];
+    }
+}
+
+hipError_t launch_topk_refheap(const RefHeapArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0 || args.cols == 0) return hipSuccess;
+    if (args.knn == 0 || (args.knn > REFHEAP_LDS_MAX && args.heap_scratch == nullptr)) return hipErrorInvalidValue;
+    if (args.stride2 != 1 && args.stride2 != 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_refheap_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -316,3 +316,34 @@ def test_inverted_precluster_reordered_index_and_retain(gpu_ctx, precluster_wd):
     for i in lonely:                                                       # tests/inverted.rs:751-802
         rows = sorted(l for l in brute.splitlines() if l.startswith(three[i] + "\t"))
         assert rows and rows == sorted(l for l in full.splitlines() if l.startswith(three[i] + "\t"))
+
+
+def _sparse_text(names, exp, suppress_padding):
+    """SparseDistanceMatrix's Display (distance_matrix.rs:362-401): `row\tneighbour\tdist`; Jaccard rows with
+    dist >= 1.0 pointing at themselves (padding) are not printed (:379-381)."""
+    lines = []
+    for r in range(exp.shape[0]):
+        for item in exp[r]:
+            if suppress_padding and item["d0"] >= 1.0 and int(item["idx"]) == r:
+                continue
+            lines.append(f"{names[r]}\t{names[int(item['idx'])]}\t{rust_f32(item['d0'])}")
+    return "\n".join(lines) + "\n"
+
+
+def test_knn_3000_and_reference_tie_order_through_the_cli(gpu_ctx, oracle, tmp_path):
+    """`dist --knn 3000` on a 5 000-sample database: the reference only clamps knn to n - 1 (lib.rs:379-382); and
+    `--knn-ties reference` prints the ids the reference binary prints (its BinaryHeap replayed, mod.rs:41-48)."""
+    from sketchlib.rust_amd import synth
+
+    kmers, ss64, n = [21], 2, 5000
+    bins = synth.set_r(n, kmers, ss64, n_clusters=9)
+    prefix, names = _write_db(tmp_path, "big", bins, kmers, ss64)
+    o = oracle.Sketches(bins, n, kmers, ss64)
+    for knn in (3000, 40):
+        canon = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+        heap = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+        assert not np.array_equal(canon["idx"], heap["idx"])          # the two rules differ on this database
+        assert run(prefix, "-k", "21", "--knn", str(knn)) == _sparse_text(names, canon, True)
+        assert run(prefix, "-k", "21", "--knn", str(knn), "--knn-ties", "reference") == _sparse_text(names, heap, True)
+    res = subprocess.run([CLI, "dist", prefix, "--knn", "5", "--knn-ties", "fifo"], capture_output=True, text=True)
+    assert res.returncode == 2 and "possible values: canonical, reference" in res.stderr

@@ -1,0 +1,176 @@
+"""kNN output against the reference BINARY's tie order, and neighbour lists longer than the LDS forms hold.
+
+The reference keeps a row's neighbours in std::collections::BinaryHeap through push_heap (strict `<` against
+the heap's maximum, src/distances/mod.rs:41-48), candidates j ascending (mod.rs:156-181, :335-369), and prints
+into_sorted_vec: with equal keys -- every genome with fewer than knn relatives ties at 1.0, single-k Jaccard
+values are quantised -- which ids survive and in what order is decided by the heap's history.  The oracle
+replays that heap (ties=TIES_RUST_HEAP); `skl_ctx_set_knn_ties(SKL_KNN_TIES_REFERENCE)` must reproduce ids,
+order and distances exactly.  The default (canonical) mode must be unchanged.
+
+knn is bounded only by the candidates there are (src/lib.rs:379-382, mod.rs:325): > 2048 goes through global
+memory."""
+import numpy as np
+import pytest
+
+from sketchlib.rust_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ref_ties(skl, gpu_ctx):
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
+    yield
+    gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+
+
+def _check_self(oracle, skl, ctx, bins, n, kmers, ss64, knn, dist, ties):
+    o, g = oracle.Sketches(bins, n, kmers, ss64), ctx.sketches(bins, n, kmers, ss64)
+    if dist == "coreacc":
+        p, oargs = g.set_k(), (oracle.COREACC, 0, False)
+    else:
+        p, oargs = g.set_k(kmers[1 if len(kmers) > 1 else 0], dist == "ani"), (oracle.JACCARD, 1 if len(kmers) > 1 else 0, dist == "ani")
+    idx, d0, d1 = skl.self_dists_knn(ctx, g, p, knn)
+    exp = oracle.self_dists_knn(o, knn, *oargs, ties=ties, threads=8)
+    assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
+    assert np.array_equal(d0, exp["d0"])
+    if dist == "coreacc":
+        assert np.array_equal(d1, exp["d1"])
+    g.close()
+    return idx
+
+
+@pytest.mark.parametrize("knn", [1, 7, 50])
+@pytest.mark.parametrize("dist", ["jaccard", "ani", "coreacc"])
+def test_reference_order_on_related_genomes(oracle, skl, gpu_ctx, ref_ties, knn, dist):
+    """Clusters smaller than knn: every row's tail ties at 1.0 (or at (1, 1)), and inside a cluster the quantised
+    single-k distances repeat."""
+    kmers, ss64, n = [17, 21, 25, 29], 4, 600
+    bins = synth.set_r(n, kmers, ss64, n_clusters=40)
+    _check_self(oracle, skl, gpu_ctx, bins, n, kmers, ss64, knn, dist, oracle.TIES_RUST_HEAP)
+
+
+@pytest.mark.parametrize("knn", [1, 7, 50, 199])
+def test_reference_order_when_every_key_ties(oracle, skl, gpu_ctx, ref_ties, knn):
+    """n copies of one sketch: the neighbour lists are the heap's history and nothing else -- and they are NOT
+    the canonical lists (lowest index first), which is why the mode exists."""
+    kmers, ss64, n = [21], 4, 200
+    bins = np.tile(synth.set_u(1, 1, ss64), (n, 1))
+    idx = _check_self(oracle, skl, gpu_ctx, bins, n, kmers, ss64, knn, "jaccard", oracle.TIES_RUST_HEAP)
+    if 1 < knn < n - 1:
+        canon = np.array([[j for j in range(n) if j != r][:knn] for r in range(n)], dtype=np.uint64)
+        assert not np.array_equal(idx, canon)
+
+
+def test_reference_order_on_random_sketches(oracle, skl, gpu_ctx, ref_ties):
+    """Set U at BASELINE configs[4]'s sketch shape (sketchsize64 = 32, one of k = {13..29}): nearly every key is 1.0,
+    a few pairs match a bin by chance -- long runs of rejected candidates between accepted ones."""
+    kmers, ss64, n, knn = [13, 17, 21, 25, 29], 32, 3000, 50
+    bins = synth.set_u(n, len(kmers), ss64)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), knn)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 2, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"])
+    g.close()
+
+
+@pytest.mark.parametrize("dist", ["jaccard", "coreacc"])
+def test_reference_order_cross(oracle, skl, gpu_ctx, ref_ties, dist):
+    kmers, ss64, nr, nq, knn = [17, 21, 25, 29], 4, 700, 90, 20
+    rb = synth.set_r(nr, kmers, ss64, n_clusters=30)
+    qb = synth.set_r(nq, kmers, ss64, n_clusters=30, first_sample=5000)
+    o_r, o_q = oracle.Sketches(rb, nr, kmers, ss64), oracle.Sketches(qb, nq, kmers, ss64)
+    g_r, g_q = gpu_ctx.sketches(rb, nr, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
+    p, oargs = (g_r.set_k(), (oracle.COREACC, 0, False)) if dist == "coreacc" else (g_r.set_k(21), (oracle.JACCARD, 1, False))
+    idx, d0, d1 = skl.cross_dists_knn(gpu_ctx, g_r, g_q, p, knn)
+    exp = oracle.cross_dists_knn(o_r, o_q, knn, *oargs, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"])
+    if dist == "coreacc":
+        assert np.array_equal(d1, exp["d1"])
+
+
+def test_several_bands_and_row_ranges(oracle, skl, gpu_ctx, ref_ties, set_switch):
+    """The reference order does not depend on how the rows are cut into bands or calls."""
+    kmers, ss64, n, knn = [21], 4, 500, 9
+    bins = synth.set_r(n, kmers, ss64, n_clusters=50)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+    set_switch("SKL_KNN_BAND_ROWS", 37)
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)      # (reload_env keeps the mode; set again to be explicit)
+    idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), knn)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"])
+    idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), knn, 123, 301)
+    assert np.array_equal(idx, exp["idx"][123:301]) and np.array_equal(d0, exp["d0"][123:301])
+    g.close()
+
+
+def test_default_mode_is_unchanged(oracle, skl, gpu_ctx):
+    kmers, ss64, n, knn = [21], 4, 200, 7
+    bins = np.tile(synth.set_u(1, 1, ss64), (n, 1))
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    idx, _d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), knn)
+    for row in range(n):
+        assert idx[row].tolist() == [j for j in range(n) if j != row][:knn]
+    with pytest.raises(skl.SklError):
+        gpu_ctx.set_knn_ties(7)
+    g.close()
+
+
+# ---- more neighbours than the LDS forms hold ----
+
+@pytest.mark.parametrize("knn", [2049, 3000, 4999])
+@pytest.mark.parametrize("mode", ["canonical", "reference"])
+def test_knn_beyond_2048(oracle, skl, gpu_ctx, knn, mode):
+    """`dist --knn 3000` on a 5 000-sample database works in the reference (only clamped to n - 1)."""
+    kmers, ss64, n = [21], 2, 5000
+    bins = synth.set_r(n, kmers, ss64, n_clusters=7)
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE if mode == "reference" else skl.TIES_CANONICAL)
+    try:
+        _check_self(oracle, skl, gpu_ctx, bins, n, kmers, ss64, knn, "jaccard",
+                    oracle.TIES_RUST_HEAP if mode == "reference" else oracle.TIES_CANONICAL)
+    finally:
+        gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+
+
+def test_knn_beyond_2048_core_accessory_and_cross(oracle, skl, gpu_ctx):
+    kmers, ss64, nr, nq, knn = [17, 21, 25], 2, 2600, 40, 2500
+    rb = synth.set_r(nr, kmers, ss64, n_clusters=5)
+    qb = synth.set_r(nq, kmers, ss64, n_clusters=5, first_sample=9000)
+    o_r, o_q = oracle.Sketches(rb, nr, kmers, ss64), oracle.Sketches(qb, nq, kmers, ss64)
+    g_r, g_q = gpu_ctx.sketches(rb, nr, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
+    idx, d0, d1 = skl.cross_dists_knn(gpu_ctx, g_r, g_q, g_r.set_k(), knn)
+    exp = oracle.cross_dists_knn(o_r, o_q, knn, oracle.COREACC, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"]) and np.array_equal(d1, exp["d1"])
+    idx, d0, d1 = skl.self_dists_knn(gpu_ctx, g_r, g_r.set_k(), knn)
+    exp = oracle.self_dists_knn(o_r, knn, oracle.COREACC, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"]) and np.array_equal(d1, exp["d1"])
+
+
+def test_candidate_lists_with_knn_beyond_2048(oracle, skl, gpu_ctx):
+    """The precluster path (ragged candidate rows): rows with more than 2 048 candidates keep them all."""
+    kmers, ss64, n, knn = [21], 2, 3000, 2400
+    bins = synth.set_r(n, kmers, ss64, n_clusters=4)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    rng = np.random.default_rng(5)
+    lists = [np.sort(rng.choice(np.delete(np.arange(n), r), size=int(rng.integers(0, n - 1)), replace=False)).astype(np.uint32)
+             if r % 3 else np.delete(np.arange(n, dtype=np.uint32), r) for r in range(0, n, 50)]
+    rows = list(range(0, n, 50))
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    for r, l in zip(rows, lists):
+        offs[r + 1] = len(l)
+    offs = np.cumsum(offs).astype(np.uint64)
+    cand = np.concatenate(lists) if lists else np.zeros(0, dtype=np.uint32)
+    idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21), knn, offs, cand)
+    dense = oracle.self_dists_all(o, oracle.JACCARD, 0, False, threads=8)[:, 0]
+
+    def dist(i, j):
+        a, b = (i, j) if i < j else (j, i)
+        return dense[n * a - a * (a + 1) // 2 + b - 1 - a]
+
+    for r, l in zip(rows, lists):
+        keys = np.array([dist(r, int(j)) for j in l], dtype=np.float32)
+        order = np.lexsort((l, keys))[:knn]
+        m = len(order)
+        assert np.array_equal(idx[r, :m], l[order].astype(np.uint64)), r
+        assert np.array_equal(d0[r, :m], keys[order]), r
+        assert np.all(idx[r, m:] == r) and np.all(d0[r, m:] == 1.0)      # padding (mod.rs:535-546)
