@@ -165,6 +165,14 @@ def set_clustered_device(n, nk, ss64, device, cluster_size=200, keep=0.9, seed=S
         coin = ((own >> 14) & 0xFFFF).view(s1 - s0, nk, ss64, 64)
         vals = torch.where(coin < thresh, (par & 0x3FFF).view(s1 - s0, nk, ss64, 64),
                            (own & 0x3FFF).view(s1 - s0, nk, ss64, 64))
-        planes = [(((vals >> p) & 1) << bit).sum(dim=-1) for p in range(BBITS)]   # disjoint bits: sum == or
+        # 64 disjoint bits -> one word: an OR tree of element-wise kernels (not .sum(): torch's reduce kernels
+        # crash rocprofv3's counter collection, and the profiling recipes generate their data with this)
+        def fold(x):
+            while x.shape[-1] > 1:
+                h = x.shape[-1] // 2
+                x = x[..., :h] | x[..., h:]
+            return x[..., 0]
+
+        planes = [fold(((vals >> p) & 1) << bit) for p in range(BBITS)]
         out[s0:s1] = torch.stack(planes, dim=-1).view(s1 - s0, words)
     return out
