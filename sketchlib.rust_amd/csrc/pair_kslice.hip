@@ -98,9 +98,17 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     // buffers of a wave are free -- the 32-row form then needs no overflow region: 32 KB instead of 48 KB of
     // LDS per workgroup, i.e. room for 4 workgroups per CU)
     constexpr uint32_t RED_BUFS = KSL ? 2u : 1u;
-    constexpr int XIN = (RED_BUFS * BUF_U4 * 4 / LANES) < (uint32_t)PX ? (int)(RED_BUFS * BUF_U4 * 4 / LANES) : PX;
-    constexpr int XOV = PX - XIN;
-    constexpr uint32_t RED_U4 = (uint32_t)(W * XOV * LANES) / 4u;
+    // RED2 (the all-k 32-row form held to 4 waves per SIMD): the words that do not fit the one free buffer go
+    // through it in a second phase (two more barriers per k-mer length) instead of an overflow region -- 32 KB
+    // of LDS (36 KB with core/accessory's turned tile) instead of 48 KB, i.e. room for 4 workgroups per CU
+    constexpr bool RED2 = TIGHT && !KSL && R == 32 && OCC == 4;
+    constexpr int RED_PHASES = RED2 ? 2 : 1;
+    constexpr int XIN_FIT = (RED_BUFS * BUF_U4 * 4 / LANES) < (uint32_t)PX ? (int)(RED_BUFS * BUF_U4 * 4 / LANES) : PX;
+    constexpr int XIN = RED2 ? PX / RED_PHASES : XIN_FIT;
+    static_assert(!RED2 || (XIN <= XIN_FIT && SLOTS % RED_PHASES == 0), "a phase's words fit the free row buffer");
+    constexpr int XOV = RED2 ? 0 : PX - XIN;
+    constexpr uint32_t TURNED_U4 = (MODE == MODE_COREACC) ? (uint32_t)(JL * 64 * (R + 4) * 8 + 15) / 16u : 0u;   // see the turned tile below
+    constexpr uint32_t RED_U4 = RED2 ? (TURNED_U4 > ROWS_U4 ? TURNED_U4 - ROWS_U4 : 0u) : (uint32_t)(W * XOV * LANES) / 4u;
     __shared__ uint4 lds_all[ROWS_U4 + RED_U4];
     uint4 (*lds_rows)[2][BUF_U4] = reinterpret_cast<uint4 (*)[2][BUF_U4]>(&lds_all[0]);
 
@@ -339,6 +347,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
             return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
 #ifdef SKL_AB
+        case 3255:   // experiment: the all-k forms held to 4 waves per SIMD too (two-phase reduction, 32-36 KB of LDS)
+            return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
+                            : launch_rjk<32, 2, false, true, 2, 4>(args, mode, grid, stream);
         case 3254:   // the k-sliced 32 x 128 form of round 2: blocks of 4 rows, 143 registers, 3 waves per SIMD
             return k_sliced ? launch_rjk<32, 2, true, true, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
