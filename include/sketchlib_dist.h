@@ -114,12 +114,16 @@ int skl_clock_sampler_stop(skl_ctx *ctx, double *ghz_median, double *ghz_p10, do
  * CPU run on this host).  skl_device_log(): y[i] = that logarithm of x[i], evaluated on the
  * device (host pointers) -- for tests. */
 int skl_log_variant(void);
-/* Conditions a caller may want to tell its user about (a null context is accepted: so far every flag is a
- * property of the host process).  SKL_CTX_FLAG_LOG_UNMATCHED: skl_log_variant() == -1 -- this host's libm
+/* Conditions a caller may want to tell its user about (a null context is accepted and reports the flags that are
+ * properties of the host process).  SKL_CTX_FLAG_LOG_UNMATCHED: skl_log_variant() == -1 -- this host's libm
  * log() is neither form the device can reproduce, so completeness-corrected core distances of FLAT fits
  * (jaccard.rs:120-133: the same bin-match count at every k-mer length) may come out 0 where a CPU run of
  * the reference on this host gives 1, or the reverse.  Everything else is unaffected. */
 #define SKL_CTX_FLAG_LOG_UNMATCHED 1u
+/* SKL_CTX_FLAG_NOT_SPX (needs a context): the device does not report the 256 compute units of an unpartitioned (SPX)
+ * MI355X.  Results do not depend on it; the launch heuristics (tile order across 8 XCDs, the launch sizes at which
+ * tile shapes and chunk slicing switch) were tuned on SPX only (DESIGN.md "Topology assumptions"). */
+#define SKL_CTX_FLAG_NOT_SPX 2u
 unsigned skl_ctx_flags(const skl_ctx *ctx);
 int skl_device_log(skl_ctx *ctx, const double *x_host, size_t n, double *out_host);
 

@@ -550,9 +550,9 @@ extern "C" int skl_log_variant(void) { return host_log_variant(); }
 
 extern "C" unsigned skl_ctx_flags(const skl_ctx *ctx)
 {
-    (void)ctx;   // (every flag so far is a property of the host process; a null context is accepted)
     unsigned flags = 0;
     if (host_log_variant() < 0) flags |= SKL_CTX_FLAG_LOG_UNMATCHED;
+    if (ctx && ctx->n_cu != 256) flags |= SKL_CTX_FLAG_NOT_SPX;
     return flags;
 }
 

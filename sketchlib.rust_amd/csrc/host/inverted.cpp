@@ -181,7 +181,17 @@ void Inverted::save(const std::string &file_prefix) const
     root.arr.push_back(CborValue::uint(kmer_size));
     root.arr.push_back(CborValue::text(sketch_version));
     root.arr.push_back(CborValue::boolean(rc));
-    root.arr.push_back(CborValue::text(hash_type));                       // unit variant HashType::DNA -> "DNA"
+    {   // HashType as rmp-serde writes it: a unit variant (DNA, PDB) is its name; the newtype variant AA(level),
+        // held here as "AA(LevelN)", is the one-entry map {"AA": "LevelN"}
+        const size_t open = hash_type.find('(');
+        if (open == std::string::npos || hash_type.empty() || hash_type.back() != ')') {
+            root.arr.push_back(CborValue::text(hash_type));
+        } else {
+            CborValue o = CborValue::object();
+            o.put(hash_type.substr(0, open), CborValue::text(hash_type.substr(open + 1, hash_type.size() - open - 2)));
+            root.arr.push_back(o);
+        }
+    }
     const std::vector<uint8_t> framed = snappy_frame_encode(msgpack_encode(root));
     std::ofstream f(file_prefix + ".ski", std::ios::binary);
     if (!f) throw std::runtime_error("Couldn't write to " + file_prefix + ".ski");

@@ -127,6 +127,10 @@ int main(int argc, char **argv)
             std::cout.flush();
             return 0;
         }
+        if (argc >= 4 && std::string(argv[1]) == "reski") {   // <in prefix> <out prefix>: load a .ski and write it again
+            Inverted::load(strip_sketch_extension(argv[2])).save(argv[3]);
+            return 0;
+        }
         if (argc >= 6 && std::string(argv[1]) == "make-ski") {
             const std::string prefix = argv[2];
             const size_t k = strtoull(argv[3], nullptr, 10), sketch_size = strtoull(argv[4], nullptr, 10);

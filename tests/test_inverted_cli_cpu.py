@@ -312,6 +312,16 @@ def test_rmp_serde_byte_layout_is_read(tmp_path):
             assert res.stdout == "Identified 3 prefilter pairs from a max of 3\n", name
         else:
             assert res.returncode == 1 and "hash_type" in res.stderr
+    # load -> save keeps the variant's encoding: {"AA": "Level2"} stays a one-entry map (rmp-serde's newtype variant),
+    # "DNA" stays a string -- a flattened "AA(Level2)" string would be a file the reference cannot deserialize
+    dbtool = os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build", "skl_dbtool")
+    for name, want in (("aa", {"AA": "Level2"}), ("dna", "DNA")):
+        subprocess.check_call([dbtool, "reski", str(tmp_path / name), str(tmp_path / (name + "_again"))])
+        payload = subprocess.check_output([dbtool, "unframe", str(tmp_path / (name + "_again.ski")), "/dev/stdout"])
+        again = msgpack.unpackb(payload, raw=False, strict_map_key=False)
+        first = msgpack.unpackb(b"\x99" + body(b"\x81" + fixstr("AA") + fixstr("Level2") if name == "aa" else fixstr("DNA")),
+                                raw=False, strict_map_key=False)
+        assert again[8] == want and again[:8] == first[:8], name
     # with_struct_map: the same nine values keyed by field name
     vals = msgpack.unpackb(b"\x99" + body(fixstr("DNA")), raw=False, strict_map_key=False)
     (tmp_path / "map.ski").write_bytes(_py_frame(msgpack.packb(dict(zip(FIELDS, vals)), use_bin_type=True)))
