@@ -326,7 +326,7 @@ Knobs read_knobs()
     k.tail_max_pct = env_int("SKL_TAIL_MAX_PCT", 90);
     k.round_priority = env_int("SKL_ROUND_PRIORITY", 1) != 0;
     k.half_tiles = env_int("SKL_HALF_TILES", 1) != 0;
-    k.tile32_min = env_int("SKL_TILE32_MIN", 16ll << 20);
+    k.tile32_min = env_int("SKL_TILE32_MIN", 8ll << 20);
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;

@@ -24,7 +24,7 @@
 //     coreacc_epilogue_kernel (kernels.hip) -- 28 bytes per pair of extra traffic.
 //
 // Two tile heights in the product library: R = 16 in 128 registers (4 waves per SIMD) for
-// launches below 16 M pair x k evaluations, R = 32 above (one chunk per wave and stage; every column
+// launches below 8 M pair x k evaluations, R = 32 above (one chunk per wave and stage; every column
 // register then meets 32 rows, which halves the lane-slab bytes per pair): k-sliced in 128 registers
 // and 32 KB of LDS (4 waves, chunks walked in plane-major blocks of MB = 2 rows), all k + fused
 // regression in 168 registers (3 waves, MB = 4).

@@ -224,13 +224,9 @@ hipError_t launch_topk(const TopkArgs &args, hipStream_t stream)
 // scanned again) when the buffer overflows.  Data that keeps overflowing -- keys arriving in
 // descending order -- falls back to the radix select over state ++ remaining records, which
 // needs the drivers' guarantee that new ids are larger than the ids already in the state.
-__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMergeArgs g)
+__device__ __forceinline__ void topk_merge_row(const TopkMergeArgs &g, const uint32_t row, TopkShared &sh, float *second)
 {
-    __shared__ TopkShared sh;
-    __shared__ float second[TOPK_MAX];   // second values of the new state (stride2 == 2)
-    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
-    // the pair kernel flagged the rows that received a record below their knn-th best: nothing to do for the others
-    if (g.flag != nullptr && g.flag[row] != g.flag_value) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
     const uint32_t knn = g.knn;
     const size_t srow = (size_t)(g.state_row_base + row) * knn;
@@ -384,6 +380,19 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMerg
         si[x] = (uint32_t)(sh.items[x] & 0xFFFFFFFFu);
         if (stride2 == 2) g.run_d1[srow + x] = second[x];
     }
+}
+
+// One workgroup per row.  (Round 3 also built "one workgroup per 64 rows that merges the flagged ones in turn", so that
+// the ~1 M workgroups per band of cfg 5 that only read their flag and exit are never dispatched: wall time and pair-kernel
+// time of cfg 5 did not move -- 12.009 against 12.006 s, interleaved in one process, profiles/r03_ab_merge_block.jsonl --
+// because these merges run beside the pair kernel on a second stream and are hidden already.  Not kept.)
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkMergeArgs g)
+{
+    __shared__ TopkShared sh;
+    __shared__ float second[TOPK_MAX];   // second values of the new state (stride2 == 2)
+    // the pair kernel flagged the rows that received a record below their knn-th best: nothing to do for the others
+    if (g.flag != nullptr && g.flag[blockIdx.x] != g.flag_value) return;
+    topk_merge_row(g, blockIdx.x, sh, second);
 }
 
 hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream)
