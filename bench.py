@@ -510,7 +510,12 @@ def main():
     verified = None
     if rank == 0:
         if hostbuf is not None:   # the assembled matrix lives in host memory: bring it to the device for the checks
-            full.copy_(hostbuf.assembled(), non_blocking=False)
+            # (rank by rank: a copy may not span this rank's page-locked slice AND pageable memory)
+            whole = hostbuf.assembled()
+            for _r0, _r1, q0, cnt in slices:
+                if cnt:
+                    full[q0:q0 + cnt].copy_(whole[q0:q0 + cnt], non_blocking=False)
+            del whole
         checksum = float(full[:10 ** 8].double().sum().item())
         finite = all(bool(torch.isfinite(full[a:a + (1 << 28)]).all()) for a in range(0, total_pairs, 1 << 28))
         assert finite, "non-finite distances"

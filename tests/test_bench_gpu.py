@@ -29,6 +29,31 @@ def _torchrun(script_args, port):
     return _last_json(res.stdout)
 
 
+def _torchrun_world(world, script_args, port):
+    """`world` ranks sharing the ONE GPU of the box over gloo (SKL_BENCH_BACKEND=gloo: RCCL refuses two ranks on a
+    device): everything of the N > 1 path except the RCCL transport -- the band partition, every rank's `*_rows` call on
+    real device buffers, the gather, max-over-ranks timing and the band-by-band self-check on rank 0."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SKL_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+    return _last_json(res.stdout)
+
+
+@pytest.mark.parametrize("world,gather,port", [(2, "rccl", 29621), (3, "host", 29623)])
+def test_bench_with_several_ranks_on_the_one_gpu(gpu_ctx, world, gather, port):
+    """(`--gather rccl` under the gloo debugging backend is the host-staged send/recv gather.)"""
+    line = _torchrun_world(world, ["bench.py", "--gpus", str(world), "--samples", "4000", "--steps", "3", "--warmup", "1",
+                                   "--gather", gather, "--no-cpu-baseline", "--precondition-s", "0.05", "--msg-mib", "8"], port)
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["n_samples"] == 4000
+    assert f"{world} row band(s)" in line["config"]["partition"]
+    assert ("shared, pinned host buffer" if gather == "host" else "gather to rank 0") in line["config"]["partition"]
+    # rank 0 compared the assembled matrix band by band with what it computes alone, then 2 010 pairs with the oracle
+    assert line["config"]["verified_pairs"] >= 2000 and line["config"]["max_abs_err"] <= 1e-6
+    assert line["value"] > 0 and line["roofline"]["pairs_per_launch"] < 4000 * 3999 // 2
+
+
 def test_bench_line_on_the_drivers_arguments(gpu_ctx):
     """`--steps 20 --warmup 5` is what the driver passes: the roofline's kernel time must not depend on it."""
     res = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
