@@ -174,3 +174,57 @@ def test_candidate_lists_with_knn_beyond_2048(oracle, skl, gpu_ctx):
         assert np.array_equal(idx[r, :m], l[order].astype(np.uint64)), r
         assert np.array_equal(d0[r, :m], keys[order]), r
         assert np.all(idx[r, m:] == r) and np.all(d0[r, m:] == 1.0)      # padding (mod.rs:535-546)
+
+
+FUZZ_SEEDS = int(__import__("os").environ.get("SKL_FUZZ_SEEDS", "12"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
+def test_random_reference_tie_configuration(oracle, skl, gpu_ctx, seed):
+    """Seeded fuzz of the heap replay: random sizes, knn, sketch sizes (small sketches quantise the distances into few
+    levels: long runs of equal keys), cluster structure, self / cross, all three key types, several row bands."""
+    rng = np.random.default_rng(1000 + seed)
+    ss64 = int(rng.choice([1, 2, 4, 16]))
+    kmers = [[21], [17, 21, 25], [15, 19, 23, 27, 31]][int(rng.integers(0, 3))]
+    n = int(rng.integers(40, 900))
+    knn = int(rng.integers(1, min(n - 1, 130)))
+    bins = synth.set_r(n, kmers, ss64, n_clusters=int(rng.integers(1, 40)))
+    if rng.random() < 0.3:          # exact duplicates: keys of 0 that tie with each other
+        src = rng.integers(0, n, n // 4)
+        dst = rng.integers(0, n, n // 4)
+        bins = bins.reshape(n, -1).copy()
+        bins[dst] = bins[src]
+    dist = ["jaccard", "ani", "coreacc"][int(rng.integers(0, 3))]
+    if dist == "coreacc" and len(kmers) < 2:
+        dist = "jaccard"
+    k_idx = int(rng.integers(0, len(kmers)))
+    os_env = __import__("os").environ
+    old = os_env.get("SKL_KNN_BAND_ROWS")
+    os_env["SKL_KNN_BAND_ROWS"] = str(int(rng.integers(5, 400)))
+    gpu_ctx.reload_env()
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
+    try:
+        o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+        p, oargs = ((g.set_k(), (oracle.COREACC, 0, False)) if dist == "coreacc"
+                    else (g.set_k(kmers[k_idx], dist == "ani"), (oracle.JACCARD, k_idx, dist == "ani")))
+        if rng.random() < 0.5:
+            idx, d0, d1 = skl.self_dists_knn(gpu_ctx, g, p, knn)
+            exp = oracle.self_dists_knn(o, knn, *oargs, ties=oracle.TIES_RUST_HEAP, threads=8)
+        else:
+            nq = int(rng.integers(1, 120))
+            qb = synth.set_r(nq, kmers, ss64, n_clusters=int(rng.integers(1, 40)), first_sample=int(rng.integers(0, n)))
+            oq, gq = oracle.Sketches(qb, nq, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
+            knn = min(knn, n)
+            idx, d0, d1 = skl.cross_dists_knn(gpu_ctx, g, gq, p, knn)
+            exp = oracle.cross_dists_knn(o, oq, knn, *oargs, ties=oracle.TIES_RUST_HEAP, threads=8)
+        assert np.array_equal(idx, exp["idx"]), (seed, n, knn, dist, ss64)
+        assert np.array_equal(d0, exp["d0"])
+        if dist == "coreacc":
+            assert np.array_equal(d1, exp["d1"])
+    finally:
+        gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+        if old is None:
+            os_env.pop("SKL_KNN_BAND_ROWS", None)
+        else:
+            os_env["SKL_KNN_BAND_ROWS"] = old
+        gpu_ctx.reload_env()
