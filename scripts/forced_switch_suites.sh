@@ -6,7 +6,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
-for e in "SKL_TILE32_MIN=0" "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=2" "SKL_GROUP_SPAN=5" \
+for e in "SKL_TILE32_MIN=0" "SKL_TILE32_MIN=-1" "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=2" "SKL_GROUP_SPAN=5" \
          "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=8 SKL_TILE32_MIN=0 SKL_GROUP_SPAN=3" \
          "SKL_ROUND_PRIORITY=0 SKL_KNN_ROW_FLAGS=0"; do
   echo "== $e"
