@@ -327,6 +327,7 @@ Knobs read_knobs()
     k.round_priority = env_int("SKL_ROUND_PRIORITY", 1) != 0;
     k.half_tiles = env_int("SKL_HALF_TILES", 1) != 0;
     k.tile32_min = env_int("SKL_TILE32_MIN", 8ll << 20);
+    k.mid_band = env_int("SKL_MID_BAND", 1) != 0;
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
@@ -392,6 +393,7 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     {
         const uint64_t k_walked = mode == MODE_JACCARD ? 1u : args.k_count;
         if (ctx->knobs.tile32_min >= 0 && pairs * k_walked >= (uint64_t)ctx->knobs.tile32_min) shape = 325;
+        if (args.mid_band) shape = 325;   // dense_band's mid-band rule: 32-row tiles with the last round cut in 2
     }
 #ifdef SKL_AB
     const Knobs &kn = ctx->knobs;
@@ -939,8 +941,22 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
 #endif
         // (launches of less than 1/16 round -- ~200 genomes -- are cut twice as fine when the sketch allows it)
         const uint32_t tail_slices = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 % 64 == 0 ? 8u : (uint32_t)ctx->knobs.tail_slices;
-        const bool tail = sliced && !persistent && k_slices == 1u && tail_slices > 1u && rows->ss64 % (8u * tail_slices) == 0 &&
-                          forced_kernel(ctx) == 0 && est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
+        bool tail = sliced && !persistent && k_slices == 1u && tail_slices > 1u && rows->ss64 % (8u * tail_slices) == 0 &&
+                    forced_kernel(ctx) == 0 && est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
+        // MID BAND (round 3): from half the 32-row threshold up to it (4-8 Mi pair x k evaluations: 1 300-1 790 genomes at
+        // 5 k-mer lengths) the launch is a handful of rounds of workgroups whichever tile it takes, and its last, partial
+        // round decides: 32 x 128 tiles with THAT round cut into 2 chunk slices are 0.7-4.6 % ahead of 16 x 128 tiles
+        // there (profiles/r03_ab_mid_sizes.jsonl, r03_ab_mid_band.jsonl); plain 32-row tiles are not (+-4 %).  Above the
+        // band plain 32-row tiles, below it 16-row tiles (cfg 2: 0.156 against 0.162 ms).
+        const uint64_t evals = pairs * rows->nk;
+        const long long t32 = ctx->knobs.tile32_min;
+        const bool mid_band = ctx->knobs.mid_band && !tail && sliced && !persistent && k_slices == 1u && t32 > 0 && tail_slices > 1u &&
+                              forced_kernel(ctx) == 0 && rows->ss64 % 16 == 0 && evals * 2 >= (uint64_t)t32 && evals < (uint64_t)t32;
+        uint32_t tail_slices_eff = tail_slices;
+        if (mid_band) {
+            tail = true;
+            tail_slices_eff = 2;
+        }
         const bool two_planes = persistent || tail;
         const size_t plane_bytes = pairs * rows->nk * sizeof(uint32_t);
         SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(two_planes ? 2u : 1u, k_slices), &counts, 1));
@@ -951,7 +967,8 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             g.k_slices = persistent ? 2u : k_slices;
             g.persistent_ok = persistent ? 1u : 0u;
             g.work_counter = ctx->work_counter;
-            g.tail_slices = tail ? tail_slices : 0u;
+            g.tail_slices = tail ? tail_slices_eff : 0u;
+            g.mid_band = mid_band ? 1u : 0u;
         }
         if (two_planes) {
             void *plane1 = (char *)counts + plane_bytes;

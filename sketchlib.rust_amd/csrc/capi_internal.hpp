@@ -48,6 +48,7 @@ struct Knobs {
     int k_slices = 0;                 // SKL_K_SLICES: chunk slices per k of k-sliced core/acc launches (0: chosen per launch)
     int group_span = 2;                 // SKL_GROUP_SPAN: column groups whose tiles are numbered side by side (device_common.hpp lookup_tile_at)
     long long tile32_min = 8ll << 20;   // SKL_TILE32_MIN: pair x k evaluations from which launches use 32 x 128 tiles (-1: never, 0: always); 8 Mi since the k-sliced 32-row form holds 4 waves per SIMD (profiles/r03_ab_tile32_threshold.jsonl)
+    bool mid_band = true;               // SKL_MID_BAND=0: no mid-band rule (32-row tiles + 2 slices of the last round at 0.5-1 x tile32_min evaluations; A/B only, results are identical)
     int tail_slices = 4;                // SKL_TAIL_SLICES: chunk slices per unit in the last, partial round of a k-sliced core/acc launch (0/1: off)
     bool half_tiles = true;             // SKL_HALF_TILES=0: 64-column blocks of a tile without a pair of the launch are walked anyway (A/B only, results are identical)
     bool round_priority = true;         // SKL_ROUND_PRIORITY=0: k-sliced workgroups of later rounds keep the default wave priority (A/B only, results are identical)

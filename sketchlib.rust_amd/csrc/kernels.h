@@ -70,6 +70,7 @@ struct PairArgs {
     // pair_kslice.hip: workgroups of round r of an XCD (index / round_size) run at wave priority min(r, 3),
     // so that a later round is not served after every older wave on its SIMD (0: off)
     uint32_t round_size;
+    uint32_t mid_band;            // host-side request (dense_band): 32 x 128 tiles whatever the launch size
     uint32_t no_half_tiles;       // 1: walk both 64-column blocks of every tile (A/B timing of the half tiles; results identical)
     uint32_t persistent_ok;       // the caller prepared two planes with plane 1 zeroed: pair_kpersist.hip may run
     uint32_t *work_counter;       // pair_kpersist.hip: 8 x 32 u32, entry [xcd * 32] = stages of that XCD handed out; zero on entry
