@@ -417,9 +417,9 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     const int ablate = 0;
 #endif
     args.no_half_tiles = ctx->knobs.half_tiles ? 0u : 1u;
-    // workgroups resident per CU: 4, except the all-k 32-row form (168 registers, 48 KB of LDS): 3
+    // workgroups resident per CU: 4 for every shipped form (the A/B build's 3-wave all-k 32-row form: 3)
     const bool sliced_launch = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
-    const uint32_t wg_per_cu = (shape == 325 && !sliced_launch) ? 3u : 4u;
+    const uint32_t wg_per_cu = (shape == 3255 && !sliced_launch) ? 3u : 4u;
     args.round_size = ctx->knobs.round_priority ? wg_per_cu * (uint32_t)ctx->n_cu / 8u : 0u;
     ctx->last_count_planes = std::max(1u, args.k_slices);
     ctx->last_persistent = false;

@@ -55,6 +55,27 @@ __device__ __forceinline__ void skl_dma16(const void *src, uint32_t lds_byte_add
 #endif
 }
 
+// The same with the address split into a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset:
+// the lane offsets of a wave's row pieces never change, so they are computed once (one register per DMA
+// instruction) and a stage only supplies the base.
+__device__ __forceinline__ void skl_dma16_saddr(const void *uniform_base, uint32_t lane_byte_offset, uint32_t lds_byte_addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t b = (uint64_t)uniform_base;
+    // (the builtin returns int: widen as unsigned, or a low half with bit 31 set smears into the high one)
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_byte_offset), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr))
+                 : "memory");
+#else
+    (void)uniform_base;
+    (void)lane_byte_offset;
+    (void)lds_byte_addr;
+#endif
+}
+
 __device__ __forceinline__ uint32_t skl_lds_addr(const void *p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

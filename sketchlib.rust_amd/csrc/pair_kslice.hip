@@ -25,9 +25,9 @@
 //
 // Two tile heights in the product library: R = 16 in 128 registers (4 waves per SIMD) for
 // launches below 8 M pair x k evaluations, R = 32 above (one chunk per wave and stage; every column
-// register then meets 32 rows, which halves the lane-slab bytes per pair): k-sliced in 128 registers
-// and 32 KB of LDS (4 waves, chunks walked in plane-major blocks of MB = 2 rows), all k + fused
-// regression in 168 registers (3 waves, MB = 4).
+// register then meets 32 rows, which halves the lane-slab bytes per pair), in 128 registers = 4 waves per
+// SIMD (chunks walked in plane-major blocks of MB = 2 rows): k-sliced with 32 KB of LDS, all k + fused
+// regression with 32-36 KB (per-k reduction in two phases).
 // Launches smaller than the chip (k-sliced counts): the units of the last, partial round of
 // workgroups are cut into chunk slices, slice 0 storing and the others adding into a second counts
 // plane (PairArgs::tail_slices).
@@ -103,6 +103,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     // of LDS (36 KB with core/accessory's turned tile) instead of 48 KB, i.e. room for 4 workgroups per CU
     constexpr bool RED2 = TIGHT && !KSL && R == 32 && OCC == 4;
     constexpr int RED_PHASES = RED2 ? 2 : 1;
+    // Row DMA addressed as scalar base + 32-bit per-lane offset (pair_kslice_walk.inc): the lane part of the address -- which
+    // row, chunk of the stage and plane pair a lane fetches -- never changes.  Kept as 64-bit per-lane pointers it was what the 4-wave all-k form spilled
+    // at every stage (a scratch reload waits for the column prefetch too): 5-6 % slower than 3 waves with them, 6 % FASTER without.
+    constexpr bool SADDR_DMA = TIGHT && ABL == 0;
     constexpr int XIN_FIT = (RED_BUFS * BUF_U4 * 4 / LANES) < (uint32_t)PX ? (int)(RED_BUFS * BUF_U4 * 4 / LANES) : PX;
     constexpr int XIN = RED2 ? PX / RED_PHASES : XIN_FIT;
     static_assert(!RED2 || (XIN <= XIN_FIT && SLOTS % RED_PHASES == 0), "a phase's words fit the free row buffer");
@@ -341,15 +345,16 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         case 165:   // the product shape: 16 x 128 tiles, 128 VGPRs
             return k_sliced ? launch_rjk<16, 2, true, true>(args, mode, grid, stream)
                             : launch_rjk<16, 2, false, true>(args, mode, grid, stream);
-        case 325:   // large launches: 32 x 128 tiles, packed counts, half the column traffic per pair.  k-sliced: blocks of 2
-                    // rows in 128 registers and 32 KB of LDS = 4 waves per SIMD (-3 ... -5 % against blocks of 4 rows at 3
-                    // waves, n = 8 000 ... 32 000 single-k, profiles/r03_ab_occ4.jsonl); all k: blocks of 4 rows, 3 waves
-            return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
-                            : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
-#ifdef SKL_AB
-        case 3255:   // experiment: the all-k forms held to 4 waves per SIMD too (two-phase reduction, 32-36 KB of LDS)
+        case 325:   // large launches: 32 x 128 tiles, packed counts, half the column traffic per pair, blocks of 2 rows, 128
+                    // registers = 4 waves per SIMD.  k-sliced: 32 KB of LDS (-3 ... -5 % against round 2's 3-wave form,
+                    // profiles/r03_ab_occ4.jsonl); all k: per-k reduction in two phases, 32-36 KB of LDS, row DMA with a scalar
+                    // base (-6 % against the 3-wave form, profiles/r03_ab_allk_occ4.jsonl)
             return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 2, 4>(args, mode, grid, stream);
+#ifdef SKL_AB
+        case 3255:   // the all-k 32 x 128 form of rounds 2-3a: blocks of 4 rows, 168 registers, 48 KB of LDS, 3 waves per SIMD
+            return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
+                            : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
         case 3254:   // the k-sliced 32 x 128 form of round 2: blocks of 4 rows, 143 registers, 3 waves per SIMD
             return k_sliced ? launch_rjk<32, 2, true, true, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);

@@ -43,10 +43,10 @@ def test_product_library_has_no_ab_kernels_or_switches():
     kernels = sorted(set(re.findall(r"skl::(pair_kernel\w*<[^>]*>)", demangled)))
     assert kernels, "no pair kernel exported?"
     for k in kernels:
-        # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only (32 x 128: k-sliced in blocks of 2 rows
-        # held to 4 waves per SIMD, all k in blocks of 4 rows), ablation parameter 0; ksplit fallback: 8-row tiles
+        # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only (32 x 128: blocks of 2 rows, held to
+        # 4 waves per SIMD), ablation parameter 0; ksplit fallback: 8-row tiles
         assert re.fullmatch(r"pair_kernel_kslice<16, 2, [012], (true|false), 0, true, 1, 0>|pair_kernel_kslice<32, 2, [01], true, 0, true, 2, 4>|"
-                            r"pair_kernel_kslice<32, 2, [012], false, 0, true, 4, 0>|pair_kernel_ksplit<8, [012], 8, false>", k), k
+                            r"pair_kernel_kslice<32, 2, [012], false, 0, true, 2, 4>|pair_kernel_ksplit<8, [012], 8, false>", k), k
     assert "pair_kernel_kpersist" not in demangled      # the persistent form of the k-sliced launch: A/B build only
     blob = open(pkg.library_path(), "rb").read()
     for needle in (b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
@@ -162,9 +162,10 @@ def _kernel_metadata(lib_path):
 def test_register_budget_of_the_shipped_pair_kernels():
     """The pair kernels are built for a fixed occupancy, and hipcc's register allocation of them has proved fragile
     (one more run-time condition on the half-tile flags spilled 11 registers of the 16-row k-sliced form; wrapping the
-    tile walk in a lambda spilled the 32-row one).  What ships: the k-sliced forms hold 4 waves per SIMD (<= 128
-    VGPRs, <= 40 KB of LDS) -- the 16-row ones without a byte of scratch, the 32-row ones with a handful of values
-    spilled OUTSIDE their loops -- and the all-k forms keep their per-k totals in private memory by design."""
+    tile walk in a lambda spilled the 32-row one; 64-bit per-lane DMA pointers made the 4-wave all-k form reload
+    registers at every stage).  What ships: EVERY form holds 4 waves per SIMD (<= 128 VGPRs, <= 40 KB of LDS) -- the
+    16-row k-sliced ones without a byte of scratch, the 32-row ones with a handful of values spilled OUTSIDE their stage
+    loops -- and the all-k forms keep their per-k totals (<= 192 B per lane) in private memory by design."""
     import sketchlib.rust_amd as pkg
 
     pkg.build_library()
@@ -176,5 +177,5 @@ def test_register_budget_of_the_shipped_pair_kernels():
             assert vgpr <= 128 and lds <= 40 * 1024, (name, vgpr, lds)
             assert scratch == 0 if r == "16" else scratch <= 32, (name, scratch)
         else:
-            assert (vgpr <= 128 and lds <= 40 * 1024) if r == "16" else (vgpr <= 168 and lds <= 53 * 1024), (name, vgpr, lds)
+            assert vgpr <= 128 and lds <= 40 * 1024, (name, vgpr, lds)
             assert scratch <= 256, (name, scratch)

@@ -90,8 +90,7 @@ VARIANTS = [
     ({**AB, "SKL_KSLICE_SHAPE": "162"}, "R=16, JL=2, COUNTS, k-sliced>"),   # the 141-register form
     ({**AB, "SKL_KSLICE_SHAPE": "162", "SKL_SLICED_MAX_PAIRS": "0"}, "R=16, JL=2, COREACC, all k>"),
     ({**AB, "SKL_KSLICE_SHAPE": "3254"}, "R=32, JL=2, COUNTS, k-sliced"),    # round 2's k-sliced 32-row form (3 waves per SIMD)
-    ({**AB, "SKL_KSLICE_SHAPE": "3255", "SKL_SLICED_MAX_PAIRS": "0"}, "R=32, JL=2, COREACC, all k"),   # all k at 4 waves: two-phase reduction
-    ({**AB, "SKL_KSLICE_SHAPE": "3255"}, "R=32, JL=2, COUNTS, k-sliced"),
+    ({**AB, "SKL_KSLICE_SHAPE": "3255", "SKL_SLICED_MAX_PAIRS": "0"}, "R=32, JL=2, COREACC, all k"),   # the all-k 32-row form of round 2 (3 waves per SIMD)
     ({**AB, "SKL_KSLICE_SHAPE": "82"}, "R=8, JL=2"),
     ({**AB, "SKL_KSLICE_SHAPE": "81", "SKL_SLICED_MAX_PAIRS": "0"}, "R=8, JL=1"),
     ({**AB, "SKL_KSLICE_SHAPE": "161"}, "R=16, JL=1"),
