@@ -342,8 +342,10 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         return k_sliced ? launch_rjk<RR, JJ, true>(args, mode, grid, stream)                   \
                         : launch_rjk<RR, JJ, false>(args, mode, grid, stream);
     switch (shape) {
-        case 165:   // the product shape: 16 x 128 tiles, 128 VGPRs
-            return k_sliced ? launch_rjk<16, 2, true, true>(args, mode, grid, stream)
+        case 165:   // the product shape for launches below 8 Mi evaluations: 16 x 128 tiles, 4 waves per SIMD; k-sliced: walked in
+                    // plane-major blocks of 4 rows (121-123 registers; the 14 the scalar-base DMA freed: -1.6 % at cfg 2,
+                    // profiles/r03_ab_mb16.jsonl)
+            return k_sliced ? launch_rjk<16, 2, true, true, 4>(args, mode, grid, stream)
                             : launch_rjk<16, 2, false, true>(args, mode, grid, stream);
         case 325:   // large launches: 32 x 128 tiles, packed counts, half the column traffic per pair, blocks of 2 rows, 128
                     // registers = 4 waves per SIMD.  k-sliced: 32 KB of LDS (-3 ... -5 % against round 2's 3-wave form,
@@ -352,6 +354,12 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
             return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 2, 4>(args, mode, grid, stream);
 #ifdef SKL_AB
+        case 1651:   // the 16-row tight form walked row by row (what shipped until the scalar-base DMA freed registers) / in blocks of 2
+            return k_sliced ? launch_rjk<16, 2, true, true, 1>(args, mode, grid, stream)
+                            : launch_rjk<16, 2, false, true, 1>(args, mode, grid, stream);
+        case 1652:
+            return k_sliced ? launch_rjk<16, 2, true, true, 2>(args, mode, grid, stream)
+                            : launch_rjk<16, 2, false, true, 2>(args, mode, grid, stream);
         case 3255:   // the all-k 32 x 128 form of rounds 2-3a: blocks of 4 rows, 168 registers, 48 KB of LDS, 3 waves per SIMD
             return k_sliced ? launch_rjk<32, 2, true, true, 2, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);

@@ -45,7 +45,7 @@ def test_product_library_has_no_ab_kernels_or_switches():
     for k in kernels:
         # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only (32 x 128: blocks of 2 rows, held to
         # 4 waves per SIMD), ablation parameter 0; ksplit fallback: 8-row tiles
-        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [012], (true|false), 0, true, 1, 0>|pair_kernel_kslice<32, 2, [01], true, 0, true, 2, 4>|"
+        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [01], true, 0, true, 4, 0>|pair_kernel_kslice<16, 2, [012], false, 0, true, 1, 0>|pair_kernel_kslice<32, 2, [01], true, 0, true, 2, 4>|"
                             r"pair_kernel_kslice<32, 2, [012], false, 0, true, 2, 4>|pair_kernel_ksplit<8, [012], 8, false>", k), k
     assert "pair_kernel_kpersist" not in demangled      # the persistent form of the k-sliced launch: A/B build only
     blob = open(pkg.library_path(), "rb").read()
