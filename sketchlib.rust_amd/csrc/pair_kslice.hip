@@ -266,6 +266,8 @@ static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStrea
 bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
 {
     if (args.ss64 > 1023u || args.k_count < 1u) return false;   // u16 count fields
+    // the row DMA's per-lane byte offsets (up to 31 rows + 1 chunk from the tile's first row) are 32-bit
+    if ((uint64_t)32u * args.nk * args.ss64 * BBITS * sizeof(uint64_t) >= (1ull << 32)) return false;
     if (mode == MODE_COREACC) return !k_sliced && args.k_count <= (uint32_t)MAX_FUSED_K;
     return mode == MODE_COUNTS || mode == MODE_JACCARD;
 }
