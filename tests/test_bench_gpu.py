@@ -41,11 +41,14 @@ def _torchrun_world(world, script_args, port):
     return _last_json(res.stdout)
 
 
-@pytest.mark.parametrize("world,gather,port", [(2, "rccl", 29621), (3, "host", 29623)])
+@pytest.mark.parametrize("world,gather,port", [(2, "rccl", 29621), (3, "host", 29623), (8, "rccl", 29625)])
 def test_bench_with_several_ranks_on_the_one_gpu(gpu_ctx, world, gather, port):
-    """(`--gather rccl` under the gloo debugging backend is the host-staged send/recv gather.)"""
+    """(`--gather rccl` under the gloo debugging backend is the host-staged send/recv gather.  World 8 = the north star's
+    partition; its ranks run without the clock sampler: eight spinning one-wave kernels of eight processes on ONE GPU
+    time-slice each other for minutes.)"""
+    extra = ["--no-clock-sampler"] if world > 3 else []
     line = _torchrun_world(world, ["bench.py", "--gpus", str(world), "--samples", "4000", "--steps", "3", "--warmup", "1",
-                                   "--gather", gather, "--no-cpu-baseline", "--precondition-s", "0.05", "--msg-mib", "8"], port)
+                                   "--gather", gather, "--no-cpu-baseline", "--precondition-s", "0.05", "--msg-mib", "8"] + extra, port)
     assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["n_samples"] == 4000
     assert f"{world} row band(s)" in line["config"]["partition"]
     assert ("shared, pinned host buffer" if gather == "host" else "gather to rank 0") in line["config"]["partition"]
