@@ -49,6 +49,7 @@ KMERS = [15, 19, 23, 27, 31]
 SS64 = 64
 CFG2_N = 1000
 CFG3_N = 100_000
+CPU_SAMPLE_MAX_N = 20_000      # cpu_baseline: largest triangle the CPU leg times ("a 20k-sample slice of cfg3")
 K4, SS64_CFG45 = [13, 17, 21, 25, 29], 32          # BASELINE configs[3], [4]
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # Vector-ALU peak of the chip (the resource that binds this kernel: 32-bit integer bitwise work, no
@@ -87,6 +88,8 @@ def cpu_baseline(n, kmers, ss64, dataset):
     from sketchlib.rust_amd import synth
 
     cores = os.cpu_count() or 1
+    n_workload = n
+    n = min(n, CPU_SAMPLE_MAX_N)       # a BOUNDED sample: the first 20 000 genomes of a larger workload (2e8 pairs, ~10 s on 256 threads)
     bins = synth.set_u(n, len(kmers), ss64) if dataset == "U" else synth.set_r(n, kmers, ss64)
     s = O.Sketches(bins, n, kmers, ss64)
     pairs = n * (n - 1) // 2
@@ -97,18 +100,22 @@ def cpu_baseline(n, kmers, ss64, dataset):
     single = (time.perf_counter() - t0) * pairs / (m * (m - 1) // 2)   # one pass of the workload, one thread
     repeat = max(1, int(round(15.0 / single)))
     best = float("inf")
-    for _ in range(3):
+    tries = 3 if n == n_workload else 2
+    for _ in range(tries):
         t0 = time.perf_counter()
         O.self_dists_all_repeat(s, repeat, O.COREACC, threads=cores)
         best = min(best, time.perf_counter() - t0)
+    what = (f"the workload itself (n={n} Set {dataset}, {pairs} pairs)" if n == n_workload else
+            f"the all-vs-all triangle of the first {n} of the workload's {n_workload} genomes (Set {dataset}, {pairs} pairs; "
+            "the rate is per pair, the full workload on the CPU would take minutes)")
     return {
         "value": pairs * repeat / best,
         "unit": "pairs/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"the N=1 workload itself (n={n} Set {dataset}, {pairs} pairs) x {repeat} passes in one "
+        "sample": f"{what} x {repeat} pass(es) in one "
                   f"thread pool = {pairs * repeat} pairs, self_dists_all core/acc, 1000-pair chunks over "
-                  f"{cores} threads, best of 3 ({best:.3f} s wall, {single * repeat:.1f} core-s of work; "
+                  f"{cores} threads, best of {tries} ({best:.3f} s wall, {single * repeat:.1f} core-s of work; "
                   f"single thread {pairs / single:.3g} pairs/s)",
     }
 
@@ -301,6 +308,44 @@ def measure_traffic(n, dataset, timeout_s=120):
                       "region (FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024, mean per pair-kernel launch)"}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` typed as is (no launcher, WORLD_SIZE unset): start the N ranks ourselves, the way
+    the contract's launcher line does -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py <same arguments>` -- as a FRESH CHILD PROCESS, relay its one JSON line and
+    exit with its code.  This parent never imports torch and never touches the GPU (a process that has initialised
+    the GPU must not be replaced by, or fork into, another program on this pool); it only builds the library first
+    (make + hipcc: no GPU), so that the ranks do not race for it."""
+    import socket
+    import subprocess
+
+    import sketchlib.rust_amd as pkg
+
+    pkg.build_library()
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    exe = os.path.realpath(sys.executable)
+    cmd = [exe, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] --gpus {n_gpus} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out_line in proc.stdout:            # rank 0 prints the one JSON line; anything else on stdout is passed on to stderr
+        t = out_line.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("[bench] the ranks exited with code 0 but printed no JSON line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,6 +381,8 @@ def main():
     args = ap.parse_args()
     if args.traffic_probe:
         return traffic_probe(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args.gpus)      # (before torch is imported or the GPU touched)
 
     # The library brackets pair-kernel launches with HIP events for skl_ctx_kernel_ms(); an event
     # record is a barrier packet on the queue and two per launch cost a 0.16 ms step ~5 us.  In the
@@ -352,9 +399,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs", file=sys.stderr)
+    # no CPU path: stop here, with the reason, before any torch.cuda call that would only say "no HIP GPUs"
+    if rank == 0:
+        pkg.build_library()
+    if torch.cuda.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # a 1-rank torch.distributed.run launch initialises RCCL too, so that the N > 1 code path
     # (process group, pipelined gather, self-check) runs on a 1-GPU box: tests/test_bench_gpu.py
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
@@ -374,8 +425,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if rank == 0:
-        pkg.build_library()
     if dist is not None:
         dist.barrier()
     capi.load()
@@ -462,6 +511,23 @@ def main():
     def local_launch():
         capi.self_dists_rows(ctx, sk, p, r0, r1, out=bands[0])
 
+    # ---- 0. COLD figure (N = 1, small launches): the driver's own W + K steps as the first launches after the slab
+    # upload, before any preconditioning -- what a one-off `sketchlib dist` on 1 000 genomes sees.  Reported beside
+    # `value` (config.cold_pairs_per_s); never `value` itself.
+    cold = None
+    if dist is None and small_launch and args.precondition_s > 0:
+        for _ in range(warmup):
+            local_launch()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            local_launch()
+        ctx.synchronize()
+        cold_s = time.perf_counter() - t0
+        cold = {"pairs_per_s": total_pairs * steps / cold_s, "ms_per_step": cold_s / steps * 1e3,
+                "what": f"the same {warmup} untimed + {steps} timed steps run as the FIRST launches after the slab upload, "
+                        "before the preconditioning (chip clock not yet settled)"}
+
     # ---- 1. preconditioning: this rank's launch back to back for the stated time (no gather) ----
     precond_s, precond_launches = 0.0, 0
     if args.precondition_s > 0:
@@ -508,6 +574,7 @@ def main():
     # ---- 4. untimed: what was timed is what the reference computes ----
     checksum = None
     verified = None
+    n1_same = None
     if rank == 0:
         if hostbuf is not None:   # the assembled matrix lives in host memory: bring it to the device for the checks
             # (rank by rank: a copy may not span this rank's page-locked slice AND pageable memory)
@@ -533,6 +600,19 @@ def main():
                 torch.cuda.synchronize(device)
                 assert torch.equal(scratch[:cnt], full[q0:q0 + cnt]), f"gathered matrix differs from the single-rank result in rows [{c0}, {c1})"
             del scratch
+        if dist is not None and world > 1:
+            # The N = 1 point of THIS workload, measured now on rank 0's GPU while the other ranks wait: the whole triangle
+            # by one rank into `full` (same values), 1 untimed + 2 timed launches.
+            capi.self_dists_all(ctx, sk, p, out=full)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                capi.self_dists_all(ctx, sk, p, out=full)
+            ctx.synchronize()
+            one = (time.perf_counter() - t1) / 2
+            n1_same = {"pairs_per_s": total_pairs / one, "s_per_step": one, "n_gpus": 1,
+                       "what": "the same workload (whole triangle) computed by rank 0 alone on its GPU, in this run, after the "
+                               "timed region: 1 untimed + 2 timed launches, no gather (the output is already on rank 0)"}
         cnt, worst, fitted = verify_against_oracle(torch, bins, full, n, KMERS, SS64, 1000 if args.dataset == "R" else 2000,
                                                    cluster_stride=100 if args.dataset == "R" else None)
         assert worst <= 1e-6, f"sampled pairs differ from the oracle by {worst}"
@@ -564,7 +644,10 @@ def main():
             "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong",
+            # N > 1 cuts ONE fixed job (cfg 3) over the ranks: strong scaling.  The N = 1 line is BASELINE's single-GPU
+            # configuration (cfg 2); the N = 1 point of the strong-scaled job is config.n1_same_workload (N > 1 lines)
+            # = config.secondary.cfg3 (N = 1 line).
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
@@ -584,6 +667,9 @@ def main():
                                     if precond_launches else "none"),
                 "output_checksum_first_1e8_pairs": checksum,
                 **(verified or {}),
+                **({"cold_pairs_per_s": cold["pairs_per_s"], "cold": cold} if cold else {}),
+                **({"n1_same_workload": n1_same} if n1_same else {}),
+                **({"host_gather_pinned": bool(hostbuf.pinned)} if hostbuf is not None else {}),
             },
             "roofline": {
                 # The resource that binds: the vector ALU.  HBM does not: see
@@ -632,14 +718,17 @@ def main():
             traffic = None if tbytes is None else {"bytes": tbytes, "source": "profiles/pmc_traffic.json (static: rocprofv3 "
                                                    "--pmc passes of an earlier run of this command, not measured in this run)"}
         out["roofline"]["traffic"] = traffic
-        if single and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, KMERS, SS64, args.dataset)
-        print(json.dumps(out))
     if hostbuf is not None:
         hostbuf.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # (after the process group is gone: the other ranks have exited and their host threads are not in the way)
+        if not args.no_cpu_baseline:
+            sk = bins = full = bands = None        # (device memory is not needed any more)
+            out["cpu_baseline"] = cpu_baseline(n, KMERS, SS64, args.dataset)
+        print(json.dumps(out), flush=True)
 
 
 def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True):

@@ -170,14 +170,29 @@ class HostGather:
         import torch
 
         self.torch, self.rank, self.world, self.dist = torch, rank, world, dist
-        self.path = f"{directory}/skl_bench_gather_{tag}.f32"
-        self.shape = (total_rows, ncols)
-        nbytes = total_rows * ncols * 4
+        if total_rows <= 0:
+            raise ValueError("HostGather: nothing to gather (total_rows == 0)")
+        # One file per run, under a random name chosen by rank 0 and created there with O_EXCL | O_NOFOLLOW (never an
+        # existing file or a symlink somebody left at a guessable path), mode 0600; the name travels to the other ranks
+        # by broadcast.  The ranks must share the node: a /dev/shm file exists on rank 0's node only.
+        name = [None]
         if rank == 0:
-            with open(self.path, "wb") as f:
-                f.truncate(max(nbytes, 4))
+            import secrets
+
+            name[0] = f"{directory}/skl_bench_gather_{tag}_{secrets.token_hex(8)}.f32"
+            fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW | os.O_RDWR, 0o600)
+            try:
+                os.ftruncate(fd, max(total_rows * ncols * 4, 4))
+            finally:
+                os.close(fd)
+        if dist is not None and world > 1:
+            dist.broadcast_object_list(name, src=0)
+        self.path = name[0]
+        self.shape = (total_rows, ncols)
         if dist is not None:
             dist.barrier()
+        if not os.path.exists(self.path):
+            raise RuntimeError(f"HostGather: rank {rank} does not see {self.path}: the ranks of a host gather must share one node")
         self.map = np.memmap(self.path, dtype=np.float32, mode="r+", shape=self.shape)
         p0, cnt = slices[rank][2], slices[rank][3]
         self.mine = torch.from_numpy(self.map[p0:p0 + cnt])
@@ -187,6 +202,11 @@ class HostGather:
             # page-locked for the lifetime of the object: the D2H copy is then one asynchronous DMA
             rc = torch.cuda.cudart().cudaHostRegister(self.mine.data_ptr(), self.mine.numel() * 4, 0)
             self.pinned = int(rc) == 0
+            if not self.pinned:   # the copy still works (staged, synchronous) but the advertised overlap is gone: say so
+                import sys
+
+                print(f"[HostGather] rank {rank}: cudaHostRegister failed (rc {int(rc)}): device-to-host copies will be staged, "
+                      "not overlapped", file=sys.stderr)
             self.stream = torch.cuda.Stream(device=device)
         self.last = None     # event of the newest copy; self.before: the one before it
 

@@ -40,6 +40,29 @@ def test_the_hidden_child_mode_and_the_driver_arguments_parse():
     assert "preconditioning_s" in src and "kernel_launches_timed" in src
 
 
+def test_plain_gpus_2_starts_its_own_ranks_and_fails_only_for_want_of_a_gpu():
+    """`python bench.py --gpus 2` typed as is (no torch.distributed.run, WORLD_SIZE unset) must get past the launcher:
+    the parent starts the ranks as a child process; here, without a GPU, every rank stops at "needs an MI355X"."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SKL_BENCH_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert "must be launched with torch.distributed.run" not in res.stderr
+    assert "torch.distributed.run --nnodes=1 --nproc-per-node=2" in res.stderr, res.stderr[-2000:]
+    assert "needs an MI355X" in res.stderr, res.stderr[-3000:]
+    assert res.returncode != 0 and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+def test_cpu_baseline_sample_is_bounded():
+    b = _bench()
+    assert b.CPU_SAMPLE_MAX_N == 20_000      # cfg 3's CPU leg: 2e8 pairs, not 5e9
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "n1_same_workload" in src and "cold_pairs_per_s" in src
+
+
 def test_condensed_index_matches_the_reference_formula():
     b = _bench()
     n = 37

@@ -57,6 +57,24 @@ def test_bench_with_several_ranks_on_the_one_gpu(gpu_ctx, world, gather, port):
     assert line["value"] > 0 and line["roofline"]["pairs_per_launch"] < 4000 * 3999 // 2
 
 
+def test_plain_bench_gpus_2_launches_itself(gpu_ctx):
+    """`python bench.py --gpus 2 ...` as typed -- no torch.distributed.run in front, WORLD_SIZE unset: bench.py starts the
+    two ranks itself as a fresh child process (here over gloo, both on the one GPU) and relays rank 0's JSON line, which
+    carries the CPU baseline and the N = 1 figure of the same workload."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    env["SKL_BENCH_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--samples", "4000", "--steps", "3", "--warmup", "1",
+                          "--precondition-s", "0.05", "--msg-mib", "8"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+    line = _last_json(res.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["n_samples"] == 4000
+    assert line["config"]["verified_pairs"] >= 2000 and line["config"]["max_abs_err"] <= 1e-6
+    n1 = line["config"]["n1_same_workload"]
+    assert n1["n_gpus"] == 1 and n1["pairs_per_s"] > 0
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+
+
 def test_bench_line_on_the_drivers_arguments(gpu_ctx):
     """`--steps 20 --warmup 5` is what the driver passes: the roofline's kernel time must not depend on it."""
     res = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
@@ -66,6 +84,9 @@ def test_bench_line_on_the_drivers_arguments(gpu_ctx):
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["unit"] == "pairs/s"
     assert "configs[1]" in line["config"]["workload"] and line["config"]["pairs"] == 499500
     assert 0.5 <= line["config"]["preconditioning_s"] <= 3.0
+    # the cold figure (the same 5 + 20 steps as the first launches of the process) rides beside the preconditioned value
+    assert 0.5 * line["value"] < line["config"]["cold_pairs_per_s"] < 1.1 * line["value"], line["config"]["cold"]
+    assert line["scaling"] == "strong"
     rf = line["roofline"]
     assert rf["bound"] == "valu" and 0.05 < rf["frac"] <= 1.0
     assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-9
