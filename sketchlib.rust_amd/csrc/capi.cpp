@@ -134,9 +134,7 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
         return fail(SKL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
-    e = hipMalloc((void **)&ctx->work_counter, 8 * 32 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 8 * 32 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     for (int x = 0; x < 2 && e == hipSuccess; ++x) {
         e = hipEventCreateWithFlags(&ctx->knn_pair_done[x], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->knn_topk_done[x], hipEventDisableTiming);
@@ -181,7 +179,6 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     if (ctx->sampler_buf) (void)hipFree(ctx->sampler_buf);
     if (ctx->sampler_count) (void)hipFree(ctx->sampler_count);
     if (ctx->sampler_stream) (void)hipStreamDestroy(ctx->sampler_stream);
-    if (ctx->work_counter) (void)hipFree(ctx->work_counter);
     if (ctx->tile_scratch.d_prefix) (void)hipFree(ctx->tile_scratch.d_prefix);
     if (ctx->tile_scratch.h_staging) (void)hipHostFree(ctx->tile_scratch.h_staging);
     if (ctx->tile_scratch.staged) (void)hipEventDestroy(ctx->tile_scratch.staged);
@@ -337,12 +334,8 @@ Knobs read_knobs()
     const char *sk = getenv("SKL_SKETCH_KERNEL");
     k.sketch_global = sk && strcmp(sk, "global") == 0;
 #ifdef SKL_AB
-    k.persist = (int)env_int("SKL_PERSIST", 0);   // 2: the persistent form (pair_kpersist.hip) whenever it is supported
-    // SKL_KERNEL = smem | lds | ksplit | kslice forces one implementation (0: dispatcher's choice)
-    if (const char *e = getenv("SKL_KERNEL")) {
-        k.kernel = strcmp(e, "smem") == 0 ? 1 : strcmp(e, "lds") == 0 ? 2 : strcmp(e, "ksplit") == 0 ? 3
-                   : strcmp(e, "kslice") == 0 ? 4 : 0;
-    }
+    // SKL_KERNEL = ksplit | kslice forces one implementation (0: dispatcher's choice)
+    if (const char *e = getenv("SKL_KERNEL")) k.kernel = strcmp(e, "ksplit") == 0 ? 3 : strcmp(e, "kslice") == 0 ? 4 : 0;
     k.kslice_shape = (int)env_int("SKL_KSLICE_SHAPE", 0);
     k.ksplit_rows = (int)env_int("SKL_KSPLIT_ROWS", 0);
     k.kslice_ablate = (int)env_int("SKL_KSLICE_ABLATE", 0);
@@ -357,7 +350,7 @@ int ab_forced_log_variant() { return (int)std::max(-2ll, std::min(1ll, env_int("
 int forced_kernel(const skl_ctx *ctx)
 {
 #ifdef SKL_AB
-    // a forced tile shape or ablation counts as a forced kernel for the persistent form (it has one shape)
+    // a forced tile shape or ablation counts as a forced kernel (no chunk slices, no mid-band rule)
     if (ctx->knobs.kernel == 0 && (ctx->knobs.kslice_shape || ctx->knobs.kslice_ablate)) return 4;
     return ctx->knobs.kernel;
 #else
@@ -369,8 +362,8 @@ int forced_kernel(const skl_ctx *ctx)
 // One tile computation.  Product library: the chunk-split kernel (pair_kslice.hip: 16 x 128 tiles,
 // chunks split over the 4 waves, rows by LDS DMA; one workgroup per (tile, k) for small launches
 // and for single-k Jaccard, all k + fused regression otherwise) and, for the shapes it does not
-// take (sketches beyond 65 535 bins), pair_ksplit.hip.  The A/B build adds the earlier kernels
-// (pair_lds.hip, pair_smem.hip) and the other tile shapes behind SKL_KERNEL / SKL_KSLICE_SHAPE.
+// take, pair_ksplit.hip.  The A/B build adds the round-2/3 forms of the two tile shapes behind
+// SKL_KSLICE_SHAPE and SKL_KERNEL=ksplit.
 static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, int mode, hipStream_t stream)
 {
     PairArgs args = args_in;
@@ -399,17 +392,6 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     const Knobs &kn = ctx->knobs;
     if (kn.kslice_shape) shape = kn.kslice_shape;
     if (kn.ksplit_rows) ksplit_rows = kn.ksplit_rows;
-    if (kn.kernel == 1) {
-        const int na = choose_na(rows, args.nB, args.self_mode, mode);
-        *name = "skl::pair_kernel<NA=" + std::to_string(na) + ", " + m + "> (scalar-cache rows)";
-        return launch_pair_kernel(args, mode, na, stream);
-    }
-    if (kn.kernel == 2) {
-        const int ls = choose_lds_shape(rows, args.nB, args.self_mode, mode);
-        *name = "skl::pair_kernel_lds<R=" + std::to_string(ls / 10) + ", JL=" + std::to_string(ls % 10) + ", " + m +
-                "> (" + std::to_string(ls / 10) + "x" + std::to_string((ls % 10) * 256) + " tiles)";
-        return launch_pair_kernel_lds(args, mode, ls, tiles, stream);
-    }
     const bool try_kslice = kn.kernel != 3;
     const int ablate = kn.kslice_ablate;
 #else
@@ -419,10 +401,9 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     args.no_half_tiles = ctx->knobs.half_tiles ? 0u : 1u;
     // workgroups resident per CU: 4 for every shipped form (the A/B build's 3-wave all-k 32-row form: 3)
     const bool sliced_launch = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
-    const uint32_t wg_per_cu = (shape == 3255 && !sliced_launch) ? 3u : 4u;
+    const uint32_t wg_per_cu = ((shape == 3255 && !sliced_launch) || (shape == 3254 && sliced_launch)) ? 3u : 4u;
     args.round_size = ctx->knobs.round_priority ? wg_per_cu * (uint32_t)ctx->n_cu / 8u : 0u;
     ctx->last_count_planes = std::max(1u, args.k_slices);
-    ctx->last_persistent = false;
     ctx->last_tail = false;
     if (args.tail_slices > 1u) {
         // tail-sliced one-workgroup-per-unit launch: two planes whatever kernel ends up running (a
@@ -431,22 +412,6 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
         ctx->last_count_planes = 2;
         ctx->last_tail = true;
     }
-#ifdef SKL_AB
-    if (try_kslice && args.k_slices == 2u && args.persistent_ok && kpersist_supported(args, mode, 4u * (uint32_t)ctx->n_cu)) {
-        // k-sliced core/acc (counts + epilogue) with fewer (tile, k) units than resident workgroup
-        // slots: the persistent form, the workgroups share the stages of all units
-        bool used = false;
-        const hipError_t e = launch_pair_kernel_kpersist(args, 4u * (uint32_t)ctx->n_cu, tiles, stream, &used);
-        if (e != hipSuccess) return e;
-        if (used) {
-            ctx->last_count_planes = 2;
-            ctx->last_persistent = true;
-            *name = "skl::pair_kernel_kpersist (16x128 tiles, chunks split over 4 waves; persistent: " +
-                    std::to_string(4 * ctx->n_cu) + " workgroups share the (tile, k, stage) sequence, " + m + ")";
-            return hipSuccess;
-        }
-    }
-#endif
     if (try_kslice) {
         // single-k Jaccard: the sliced and the all-k form are the same work, the sliced one
         // compiles to fewer registers; core/acc arrives here as MODE_COUNTS from dense_band when sliced
@@ -933,15 +898,9 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // plane that is zero on entry and re-zeroed by the epilogue.
         const uint64_t est_units = pairs * rows->nk / 2048;
         const uint64_t slots = 4ull * (uint64_t)ctx->n_cu;
-#ifdef SKL_AB
-        // the persistent form of the k-sliced launch (pair_kpersist.hip, A/B build): same two planes
-        const bool persistent = sliced && ctx->knobs.persist >= 2 && k_slices == 1u && rows->ss64 % 8 == 0 && forced_kernel(ctx) == 0;
-#else
-        const bool persistent = false;
-#endif
         // (launches of less than 1/16 round -- ~200 genomes -- are cut twice as fine when the sketch allows it)
         const uint32_t tail_slices = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 % 64 == 0 ? 8u : (uint32_t)ctx->knobs.tail_slices;
-        bool tail = sliced && !persistent && k_slices == 1u && tail_slices > 1u && rows->ss64 % (8u * tail_slices) == 0 &&
+        bool tail = sliced && k_slices == 1u && tail_slices > 1u && rows->ss64 % (8u * tail_slices) == 0 &&
                     forced_kernel(ctx) == 0 && est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
         // MID BAND (round 3): from half the 32-row threshold up to it (4-8 Mi pair x k evaluations: 1 300-1 790 genomes at
         // 5 k-mer lengths) the launch is a handful of rounds of workgroups whichever tile it takes, and its last, partial
@@ -950,23 +909,21 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // band plain 32-row tiles, below it 16-row tiles (cfg 2: 0.156 against 0.162 ms).
         const uint64_t evals = pairs * rows->nk;
         const long long t32 = ctx->knobs.tile32_min;
-        const bool mid_band = ctx->knobs.mid_band && !tail && sliced && !persistent && k_slices == 1u && t32 > 0 && tail_slices > 1u &&
+        const bool mid_band = ctx->knobs.mid_band && !tail && sliced && k_slices == 1u && t32 > 0 && tail_slices > 1u &&
                               forced_kernel(ctx) == 0 && rows->ss64 % 16 == 0 && evals * 2 >= (uint64_t)t32 && evals < (uint64_t)t32;
         uint32_t tail_slices_eff = tail_slices;
         if (mid_band) {
             tail = true;
             tail_slices_eff = 2;
         }
-        const bool two_planes = persistent || tail;
+        const bool two_planes = tail;
         const size_t plane_bytes = pairs * rows->nk * sizeof(uint32_t);
         SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(two_planes ? 2u : 1u, k_slices), &counts, 1));
         if (sliced) {   // k-major scratch: coalesced stores from the (tile, k[, chunk slice]) workgroups
             g.cnt_pair_stride = 1;
             g.cnt_k_stride = pairs;
             g.k_sliced = 1;
-            g.k_slices = persistent ? 2u : k_slices;
-            g.persistent_ok = persistent ? 1u : 0u;
-            g.work_counter = ctx->work_counter;
+            g.k_slices = k_slices;
             g.tail_slices = tail ? tail_slices_eff : 0u;
             g.mid_band = mid_band ? 1u : 0u;
         }
@@ -1000,8 +957,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.nk = (uint32_t)rows->nk;
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
-        e.rezero_plane1 = sliced && (ctx->last_persistent || ctx->last_tail) ? 1u : 0u;
-        e.work_counter = sliced && ctx->last_persistent ? ctx->work_counter : nullptr;
+        e.rezero_plane1 = sliced && ctx->last_tail ? 1u : 0u;
         e.nA_rows = (uint32_t)rows->n;
         e.nB_cols = (uint32_t)cols->n;
         e.row_begin = (uint32_t)r0;
@@ -1019,7 +975,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.out = (float *)dst_dev;
         HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));
         // (an empty launch, or one another kernel took, leaves plane 1 not known to be zero)
-        if (two_planes && (ctx->last_persistent || ctx->last_tail)) ctx->clean_plane1 = plane1_clean;
+        if (two_planes && ctx->last_tail) ctx->clean_plane1 = plane1_clean;
         return SKL_OK;
     }
     PairArgs g;

@@ -60,9 +60,8 @@ struct Knobs {
     bool cand_symmetric = true;       // SKL_CAND_SYMMETRIC=0: evaluate symmetric candidate lists in full
     bool sketch_global = false;       // SKL_SKETCH_KERNEL=global: the unstaged sketching kernel
 #ifdef SKL_AB
-    int kernel = 0;                   // SKL_KERNEL: 0 none, 1 smem, 2 lds, 3 ksplit, 4 kslice
-    int persist = 0;                  // SKL_PERSIST=2: k-sliced core/acc launches take the persistent form (pair_kpersist.hip)
-    int kslice_shape = 0;             // SKL_KSLICE_SHAPE: R*10 + JL
+    int kernel = 0;                   // SKL_KERNEL: 0 none, 3 ksplit, 4 kslice
+    int kslice_shape = 0;             // SKL_KSLICE_SHAPE: 165 / 325 (shipped), 1651 / 1652 / 3254 / 3255 (their round-2/3 forms)
     int ksplit_rows = 0;              // SKL_KSPLIT_ROWS: 4 or 8
     int kslice_ablate = 0;            // SKL_KSLICE_ABLATE: timing only, outputs wrong by construction
 #endif
@@ -88,8 +87,7 @@ struct skl_ctx {
     std::string last_kernel;
     uint32_t last_count_planes = 1;     // planes the last MODE_COUNTS k-sliced launch wrote (epilogue: n_slices)
     bool last_tail = false;             // ... or the tail-sliced one-workgroup-per-unit launch (plane 1 added to as well)
-    bool last_persistent = false;       // ... and whether it was the persistent form (plane 1 added to, re-zeroed by the epilogue)
-    // plane 1 of the counts scratch as the persistent form needs it: all zero.  Valid for exactly
+    // plane 1 of the counts scratch as the tail slices need it: all zero.  Valid for exactly
     // this (pointer, bytes) until anything else writes the scratch.
     const void *clean_plane1 = nullptr;
     size_t clean_plane1_bytes = 0;
@@ -100,7 +98,6 @@ struct skl_ctx {
     uint32_t *sampler_count = nullptr;
     uint32_t sampler_max = 0;
     bool sampler_running = false;
-    uint32_t *work_counter = nullptr;   // 8 x 32 u32 queue counters of pair_kpersist.hip (zero between launches)
     int knn_ties = 0;                   // SKL_KNN_TIES_CANONICAL / _REFERENCE (skl_ctx_set_knn_ties)
     Knobs knobs;                        // environment switches as of skl_ctx_create
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration

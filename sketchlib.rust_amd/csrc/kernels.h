@@ -43,8 +43,7 @@ struct PairArgs {
     uint32_t self_mode;           // 1: A == B sample set, only i < j
     uint32_t a_tiles;             // workgroup tiles along rows
     uint32_t n_jblocks;           // 64-wide column blocks
-    uint32_t share_rows;          // 1: waves of a workgroup share rows, differ in column block
-    // balanced tile enumeration (pair_lds / pair_ksplit): active tiles are numbered column
+    // balanced tile enumeration: active tiles are numbered column
     // group by column group and each XCD takes one contiguous eighth of the numbering
     uint32_t n_active_tiles;
     uint32_t tiles_per_xcd;       // ceil(n_active_tiles / 8)
@@ -64,7 +63,7 @@ struct PairArgs {
     // Tail slicing of a k-sliced MODE_COUNTS launch (pair_kslice.hip): on every XCD the workgroups from
     // index tail_first on are chunk slices of units (tail_slices per unit, adjacent) instead of whole
     // units; slice 0 stores its counts to plane 0, the others ADD theirs to plane 1 (k index
-    // k_count + kk: zero on entry, summed and re-zeroed by the epilogue, as for pair_kpersist.hip).
+    // k_count + kk: zero on entry, summed and re-zeroed by the epilogue).
     // tail_slices <= 1: off.  The launcher sets tail_first from tail_resident = workgroups resident per XCD.
     uint32_t tail_slices, tail_first, tail_resident;
     // pair_kslice.hip: workgroups of round r of an XCD (index / round_size) run at wave priority min(r, 3),
@@ -72,8 +71,6 @@ struct PairArgs {
     uint32_t round_size;
     uint32_t mid_band;            // host-side request (dense_band): 32 x 128 tiles whatever the launch size
     uint32_t no_half_tiles;       // 1: walk both 64-column blocks of every tile (A/B timing of the half tiles; results identical)
-    uint32_t persistent_ok;       // the caller prepared two planes with plane 1 zeroed: pair_kpersist.hip may run
-    uint32_t *work_counter;       // pair_kpersist.hip: 8 x 32 u32, entry [xcd * 32] = stages of that XCD handed out; zero on entry
     // Symmetric self kNN (pair_kslice.hip: k-sliced MODE_JACCARD and all-k MODE_COREACC): besides
     // out, the record of (row i, column j >= t_col_begin) also goes to record
     // (j - t_col_begin) * t_stride + (i - row_begin) of out_t, i.e. as a candidate of row j.
@@ -108,12 +105,6 @@ struct PairArgs {
     double kf[MAX_FUSED_K];       // k-mer lengths as f64
 };
 
-#ifdef SKL_AB
-// pair_smem.hip (A/B build only): rows-per-wave for a launch, and the scalar-cache kernel.
-int choose_na(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
-hipError_t launch_pair_kernel(const PairArgs &args, int mode, int na, hipStream_t stream);
-#endif
-
 // Device buffer the launchers may use for the tile-prefix table (owned by the context).
 struct TileScratch {
     uint32_t *d_prefix = nullptr;
@@ -129,32 +120,18 @@ struct TileScratch {
 hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_group,
                       TileScratch &scratch, hipStream_t stream, uint64_t *grid_out);
 
-#ifdef SKL_AB
-// LDS-staged variant (pair_lds.hip, A/B build only).  shape = R*10 + JL: R rows per workgroup tile,
-// JL 64-column blocks per lane; valid shapes: 41, 81, 82, 162.
-hipError_t launch_pair_kernel_lds(const PairArgs &args, int mode, int shape, TileScratch &scratch,
-                                  hipStream_t stream);
-int choose_lds_shape(uint64_t n_rows, uint64_t n_cols, int self_mode, int mode);
-#endif
 // K-split variant for small launches (pair_ksplit.hip): rows_per_tile in {4, 8}.
 hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_per_tile,
                                      TileScratch &scratch, hipStream_t stream);
 // Chunk-split kernel (pair_kslice.hip): R x 64*JL tiles, the 4 waves of a workgroup split the
 // chunks.  k_sliced = one workgroup per (tile, k-mer length), MODE_COUNTS / MODE_JACCARD only;
 // otherwise one workgroup walks all k-mer lengths and runs the fused epilogue.
-// shape: 165 (16 x 128 tiles, the 128-register form) in the product library; the A/B build also has
-// R*10 + JL = 81, 82, 84, 161, 162, 163, 164 and the timing-only ablations (ablate != 0: outputs wrong
+// shape: 165 / 325 (16 x 128 and 32 x 128 tiles in 128 registers) in the product library; the A/B build also has
+// their round-2/3 forms (1651, 1652, 3254, 3255) and two timing-only ablations (ablate = 4, 8: outputs wrong
 // by construction).
 hipError_t launch_pair_kernel_kslice(const PairArgs &args, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream);
 bool kslice_supported(const PairArgs &args, int mode, bool k_sliced);
-// Persistent form of the k-sliced MODE_COUNTS launch (pair_kpersist.hip): grid = `slots` resident
-// workgroups, each walking an equal share of its XCD's stages; counts land in TWO planes ("k index"
-// plane * k_count + kk) that the epilogue sums.  *used = false when the launch was not taken
-// (fewer units than slots): the caller then launches the one-workgroup-per-unit form.
-bool kpersist_supported(const PairArgs &args, int mode, uint32_t slots);
-hipError_t launch_pair_kernel_kpersist(const PairArgs &args, uint32_t slots, TileScratch &scratch,
-                                       hipStream_t stream, bool *used);
 
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
 hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint32_t n,
@@ -167,8 +144,7 @@ struct EpilogueArgs {
     uint64_t n_pairs;
     uint32_t nk, ss64;
     uint32_t n_slices;          // counts come in this many chunk slices per k (k index s * nk + t): summed here
-    uint32_t rezero_plane1;     // 1: after reading, write 0 to the slice-1 records (pair_kpersist.hip adds into them)
-    uint32_t *work_counter;     // ... and reset these 8 x 32 queue counters (or null)
+    uint32_t rezero_plane1;     // 1: after reading, write 0 to the slice-1 records (the tail slices add into them)
     uint32_t nA_rows, nB_cols;  // to recover (i, j) for completeness lookups
     uint32_t row_begin;
     uint32_t self_mode;

@@ -152,7 +152,6 @@ hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint3
 __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArgs g)
 {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g.work_counter && p < 8u) g.work_counter[p * 32u] = 0u;   // the persistent pair kernel's queues, for its next launch
     if (p >= g.n_pairs) return;
     double c1 = 0.0, c2 = 0.0;
     if (g.has_comp) {
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
             if (t < g.nk) {
                 same[u] = cnt[t * g.k_stride];
                 for (uint32_t sl = 1; sl < g.n_slices; ++sl) same[u] += cnt[((uint64_t)sl * g.nk + t) * g.k_stride];
-                // plane 1 goes back to zero for the persistent pair kernel's next launch, whether or not k index t is used
+                // plane 1 goes back to zero for the next tail-sliced launch, whether or not k index t is used
                 if (g.rezero_plane1) cnt[((uint64_t)g.nk + t) * g.k_stride] = 0u;
             }
         }

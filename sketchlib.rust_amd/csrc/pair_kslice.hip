@@ -64,8 +64,8 @@ constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk 
 #define SKL_TRACE_MARK(SLOT) do { } while (0)
 #endif
 
-// (3 columns per lane: the register allocator is held to 3 waves per SIMD, 168 VGPRs.  TIGHT: the
-// 2-column form squeezed into 128 VGPRs -- packed counts, 4-deep row ring -- for 4 waves per SIMD.)
+// (TIGHT: the 2-column form squeezed into 128 VGPRs -- packed counts, 4-deep row ring -- for 4 waves per SIMD;
+// the only form left, the parameter is kept for the kernels' names.)
 // MB: rows walked plane by plane together (1: row by row).  A chunk is walked in blocks of MB rows, and
 // inside a block plane pair q of all MB rows comes before plane pair q + 1 of any.  Column register
 // b[.][q] is then free -- and re-loaded with the next chunk's data -- 6/7 of a BLOCK before its first
@@ -272,16 +272,16 @@ bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
     return mode == MODE_COUNTS || mode == MODE_JACCARD;
 }
 
-// shape = R*10 + JL, or 165 / 325 = the tight forms of 16 x 128 and 32 x 128 (the product library's shapes); the A/B
-// build (-DSKL_AB) has the others and the ablations
+// shape = 165 / 325: 16 x 128 and 32 x 128 tiles (the product library's shapes); the A/B build (-DSKL_AB) also has their
+// round-2/3 forms (1651, 1652, 3254, 3255) and two timing-only ablations
 hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream)
 {
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     if (!kslice_supported(args, mode, k_sliced)) return hipErrorInvalidValue;
-    const int R = shape > 1000 ? shape / 100 : shape / 10;   // 165 / 325 (and 1652, 325x in the A/B build): the tight forms of 16 x 128 and 32 x 128
-    const int JL = (shape == 165 || shape == 325 || shape > 1000) ? 2 : shape % 10;
+    const int R = shape > 1000 ? shape / 100 : shape / 10;   // 165 / 325 (and 165x, 325x in the A/B build): 16 x 128 and 32 x 128 tiles
+    const int JL = 2;
     uint64_t n_wg = 0;
     const hipError_t pe = plan_tiles(args, (uint32_t)R, (uint32_t)JL * 64u, scratch, stream, &n_wg);
     if (pe != hipSuccess) return pe;
@@ -315,7 +315,8 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
 #ifdef SKL_AB
     // timing-only: rows read as if the row slab were tile-major ([row tile][k][chunk][row][plane]: a wave's
     // stage is one contiguous 3.5 KB run instead of 16-32 runs of 112 B, one per sample)
-    if (ablate == 8 && shape == 165 && k_sliced && mode == MODE_COUNTS) {   // timing only: all workgroups on one hot tile
+    // timing-only ablations (outputs wrong by construction): SKL_KSLICE_ABLATE = 8 all workgroups on one hot tile, 4 a tile-major row slab
+    if (ablate == 8 && shape == 165 && k_sliced && mode == MODE_COUNTS) {
         hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 8, true, 1>), grid, dim3(LANES * WAVES_PER_WG), 0, stream, args);
         return hipGetLastError();
     }
@@ -327,22 +328,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    // timing-only ablations of the sliced COUNTS kernel (outputs wrong by construction):
-    // SKL_KSLICE_ABLATE = 1 no row re-reads from LDS, 2 no column reloads, 3 both
-    if (ablate && (shape == 162 || shape == 165) && k_sliced && mode == MODE_COUNTS) {
-        const dim3 block(LANES * WAVES_PER_WG);
-        if (ablate == 1) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 1>), grid, block, 0, stream, args);
-        else if (ablate == 2) hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 2>), grid, block, 0, stream, args);
-        else hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 3>), grid, block, 0, stream, args);
-        return hipGetLastError();
-    }
 #else
     (void)ablate;
 #endif
-#define SKL_SHAPE(SH, RR, JJ)                                                                  \
-    case SH:                                                                                   \
-        return k_sliced ? launch_rjk<RR, JJ, true>(args, mode, grid, stream)                   \
-                        : launch_rjk<RR, JJ, false>(args, mode, grid, stream);
     switch (shape) {
         case 165:   // the product shape for launches below 8 Mi evaluations: 16 x 128 tiles, 4 waves per SIMD; k-sliced: walked in
                     // plane-major blocks of 4 rows (121-123 registers; the 14 the scalar-base DMA freed: -1.6 % at cfg 2,
@@ -368,20 +356,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
         case 3254:   // the k-sliced 32 x 128 form of round 2: blocks of 4 rows, 143 registers, 3 waves per SIMD
             return k_sliced ? launch_rjk<32, 2, true, true, 4>(args, mode, grid, stream)
                             : launch_rjk<32, 2, false, true, 4>(args, mode, grid, stream);
-        case 3251:   // ... walked row by row
-            return k_sliced ? launch_rjk<32, 2, true, true, 1>(args, mode, grid, stream)
-                            : launch_rjk<32, 2, false, true, 1>(args, mode, grid, stream);
-        SKL_SHAPE(162, 16, 2)
-        SKL_SHAPE(81, 8, 1)
-        SKL_SHAPE(82, 8, 2)
-        SKL_SHAPE(84, 8, 4)
-        SKL_SHAPE(161, 16, 1)
-        SKL_SHAPE(163, 16, 3)
-        SKL_SHAPE(164, 16, 4)
 #endif
         default: return hipErrorInvalidValue;
     }
-#undef SKL_SHAPE
 }
 
 }  // namespace skl

@@ -1,14 +1,10 @@
-"""The two-plane forms of the k-sliced core/accessory launch against the plain one and the oracle, over
-sequences of launches in ONE context:
+"""The two-plane form of the k-sliced core/accessory launch against the plain one and the oracle, over
+sequences of launches in ONE context: chunk slices (default for launches of less than one round of
+workgroups, forced onto the last round of longer ones here) -- slice 0 of a unit stores its counts, the
+others add into a second plane.
 
-* chunk slices (product library; default for launches of less than one round of workgroups, forced onto
-  the last round of longer ones here): slice 0 of a unit stores its counts, the others add into a second
-  plane;
-* the persistent form (pair_kpersist.hip, A/B library): parts of units add into the same second plane.
-
-Plane 1 must be found zero by every such launch whatever ran before (another size, the other form, a
-single-k launch or raw counts through the same scratch), and the persistent form's queue counters must
-be back at zero."""
+Plane 1 must be found zero by every such launch whatever ran before (another size, a single-k launch or
+raw counts through the same scratch)."""
 import os
 
 import numpy as np
@@ -83,23 +79,6 @@ def test_chunk_slices_in_sequences_of_launches(oracle, skl, gpu_ctx, monkeypatch
     took = _sequence(oracle, skl, gpu_ctx, switch, seed * 3 + slices, on, {"SKL_TAIL_SLICES": "0", "SKL_TAIL_MAX_PCT": "90"},
                      "chunk slices")
     assert took >= 1, took     # (sketch sizes that are not a multiple of 8 x slices run plain)
-
-
-@pytest.mark.parametrize("seed", range(max(3, SOAK // 40)))
-def test_persistent_form_in_sequences_of_launches(oracle, skl, monkeypatch, seed):
-    import sketchlib.rust_amd as pkg
-
-    with skl.using_library(pkg.build_ab_library()):
-        ctx = skl.Context(0)
-
-        def switch(env):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)   # (the A/B library re-reads its switches on every launch)
-            ctx.reload_env()
-
-        took = _sequence(oracle, skl, ctx, switch, seed, {"SKL_PERSIST": "2"}, {"SKL_PERSIST": "0", "SKL_TAIL_SLICES": "0"}, "kpersist")
-        assert took >= 5, took
-        ctx.close()
 
 
 def test_default_rule_slices_launches_of_less_than_a_round(oracle, skl, gpu_ctx):
