@@ -198,7 +198,8 @@ def sampled(ctx, run, interval_us, expect_s=1.0, enabled=True):
         run()
         ctx.synchronize()
         return None
-    max_samples = int(min(1 << 20, max(256, 4.0 * expect_s * 1e6 / interval_us)))
+    # (the library caps interval x samples at 10 s: a sampler that outlives its launches stalls device-wide synchronisations)
+    max_samples = int(min(1 << 20, 9.5e6 / interval_us, max(256, 4.0 * expect_s * 1e6 / interval_us)))
     ctx.clock_sampler_start(interval_us, max_samples)
     try:
         run()

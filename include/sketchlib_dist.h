@@ -21,6 +21,20 @@
  * panics (jaccard.rs:70-72, mod.rs:318-323) the ABI returns the matching code
  * and the same message text.  There is no CPU fallback: without a usable GPU
  * every compute entry point fails with SKL_ERR_NO_DEVICE.
+ *
+ * LIMITS (one place; each is checked and reported with SKL_ERR_INVALID_ARG / SKL_ERR_OOM, never silently):
+ *   - samples per slab: < 2^31; the library keeps TWO copies of every slab in HBM (row layout + lane layout,
+ *     2 x n x nk x sketchsize64 x 112 B): ~7 M genomes per 288 GB GPU at sketchsize64 = 32, nk = 5.
+ *   - sketchsize64: < 2^25.  Up to 1 023 (65 472 bins) a k-mer length's counts live in u16 fields; larger sketches
+ *     (the reference's "100000-1000000 for SNP level resolution", lib.rs:41-42) take the same kernel, walked in
+ *     segments of 1 016 chunks; their core/accessory distances go through a bin-match count scratch of at most
+ *     4 GiB per launch (bands of rows).  nk x sketchsize64 < 1 198 372 for the fast kernel (32-bit row offsets).
+ *   - k-mer lengths: < 2^16; the fused core/accessory kernel takes up to 6, more go counts + epilogue.
+ *   - knn: 1 <= knn <= candidates.  Up to 2 048 neighbours the running lists live in LDS (one-evaluation self kNN,
+ *     skl_self_dists_knn_partial, skl_knn_merge_states); longer lists go row by row through global memory.
+ *   - skl_self_dists_knn_shared_bins: at most skl_shared_bins_max_samples() = 1 294 336 samples per call.
+ *   - timing: at most 4 096 bracketed pair-kernel launches between two skl_ctx_timing_reset();
+ *     skl_clock_sampler_start: interval_us x max_samples <= 10 s.
  */
 #ifndef SKETCHLIB_DIST_H
 #define SKETCHLIB_DIST_H
@@ -202,8 +216,9 @@ int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_
  * row shards of these states (an all-to-all: the one data-path collective of this library) and
  * skl_knn_merge_states turns the n_states partial states of a row shard -- stacked
  * [n_states][rows][knn] -- into the rows of skl_self_dists_knn's output.
- * Returns SKL_ERR_INVALID_ARG when the configuration has no one-evaluation form (more than 6
- * k-mer lengths for CoreAcc, sketchsize64 > 1023): shard rows with skl_self_dists_knn_rows then. */
+ * Returns SKL_ERR_INVALID_ARG when the configuration has no one-evaluation form (CoreAcc with more than 6
+ * k-mer lengths or sketchsize64 > 1023; knn > 2 048; the reference tie order): shard rows with
+ * skl_self_dists_knn_rows then. */
 size_t skl_knn_band_rows(const skl_sketches *s, const skl_dist_params *p, size_t n_participants);
 int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
                                size_t band_rows, const uint32_t *bands, size_t n_bands,

@@ -10,10 +10,7 @@
 #define launch_pair_kernel_kslice launch_pair_kernel_kslice_traced
 #define kslice_supported kslice_supported_traced
 #include "../../sketchlib.rust_amd/csrc/pair_kslice.hip"
-#define pair_kernel_kpersist pair_kernel_kpersist_traced
-#define launch_pair_kernel_kpersist launch_pair_kernel_kpersist_traced
-#define kpersist_supported kpersist_supported_traced
-#include "../../sketchlib.rust_amd/csrc/pair_kpersist.hip"
+// (the persistent form this tool also traced in round 2 is archived: experiments/dropped_kernels/pair_kpersist.hip)
 
 #include <algorithm>
 #include <cstdio>
@@ -29,7 +26,7 @@ using namespace skl;
 int main(int argc, char **argv)
 {
     const uint32_t n = argc > 1 ? atoi(argv[1]) : 1000;
-    int shape = argc > 2 ? atoi(argv[2]) : 162;
+    int shape = argc > 2 ? atoi(argv[2]) : 165;
     const uint32_t nk = 5, ss64 = 64;
     constexpr size_t TW = 8;   // words per trace record (SKL_TRACE_WORDS)
     const size_t sample_words = (size_t)nk * ss64 * BBITS;
@@ -69,9 +66,7 @@ int main(int argc, char **argv)
     const int ablate = getenv("SKL_KSLICE_ABLATE") ? atoi(getenv("SKL_KSLICE_ABLATE")) : 0;
     // argv[5]: chunk slices per k-mer length (k_slices of the k-sliced COUNTS launch)
     const uint32_t slices = argc > 5 ? (uint32_t)atoi(argv[5]) : 1u;
-    int pflags = 1;
-    if (shape >= 980 && shape <= 999) { pflags = shape == 999 ? 1 : shape - 980; shape = 999; }   // 991 queue, 993 +priority rotation, 995 equal split, 997 both
-    const bool persistent = shape == 999;
+    const bool persistent = false;
     if (getenv("KT_ROUND")) g.round_size = (uint32_t)atoi(getenv("KT_ROUND"));   // wave priority by round of workgroups (PairArgs::round_size)
     // KT_TAIL=S: tail slicing of the one-workgroup-per-unit launch (pair_kslice.hip, PairArgs::tail_slices)
     if (getenv("KT_TAIL") && !persistent) {
@@ -79,27 +74,17 @@ int main(int argc, char **argv)
         g.tail_resident = (shape == 325 ? 3u : 4u) * 256u / 8u;
         CK(hipMemset(dOut, 0, pairs * nk * 4 * 2));
     }
-    uint32_t *dCtr = nullptr;
-    CK(hipMalloc(&dCtr, 8 * 32 * 4));
-    CK(hipMemset(dCtr, 0, 8 * 32 * 4));
-    if (persistent) { g.k_sliced = 1; g.k_slices = 2; g.persistent_ok = (uint32_t)pflags; g.work_counter = dCtr; CK(hipMemset(dOut, 0, pairs * nk * 4 * 2)); }
-    bool used = false;
-    for (int i = 0; i < warm; ++i) {
-        if (persistent) { CK(hipMemsetAsync(dCtr, 0, 8 * 32 * 4, 0)); CK(launch_pair_kernel_kpersist(g, 1024, ts, 0, &used)); }
-        else CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
-    }
-    if (persistent) { CK(hipMemsetAsync(dCtr, 0, 8 * 32 * 4, 0)); CK(hipMemsetAsync(dTrace, 0, trace_words * 8, 0)); }
+    for (int i = 0; i < warm; ++i) CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
     CK(hipDeviceSynchronize());
     fprintf(stderr, "warm done\n");
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    if (persistent) CK(launch_pair_kernel_kpersist(g, 1024, ts, 0, &used));
-    else CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
+    CK(launch_pair_kernel_kslice(g, MODE_COUNTS, shape, true, ablate, ts, 0));
     hipEventRecord(e1);
     CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const int R = shape == 999 ? 16 : shape / 10, JL = (shape == 165 || shape == 325 || shape == 999) ? 2 : shape % 10;
+    const int R = shape > 1000 ? shape / 100 : shape / 10, JL = 2;
     PairArgs gp = g; uint64_t n_wg = 0;
     CK(plan_tiles(gp, R, JL * 64, ts, 0, &n_wg));
     n_wg = 8ull * gp.tiles_per_xcd * nk * slices;   // as launch_pair_kernel_kslice sizes it

@@ -232,6 +232,12 @@ extern "C" int skl_clock_sampler_start(skl_ctx *ctx, uint32_t interval_us, uint3
     SKL_TRY(ctx_bind(ctx));
     if (ctx->sampler_running) return fail(SKL_ERR_INVALID_ARG, "the clock sampler is already running");
     if (max_samples < 2 || max_samples > (1u << 22)) return fail(SKL_ERR_INVALID_ARG, "max_samples out of range");
+    // The sampler ends by itself after interval_us x max_samples: anything that synchronises the whole device while it runs
+    // (hipMalloc / hipFree inside a sampled call) waits that long at worst, so the product is capped at 10 s.
+    if ((uint64_t)std::max(4u, interval_us) * max_samples > 10000000ull) {
+        return fail(SKL_ERR_INVALID_ARG, "clock sampler: interval_us x max_samples = %llu us exceeds the 10 s cap",
+                    (unsigned long long)std::max(4u, interval_us) * max_samples);
+    }
     if (!ctx->sampler_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->sampler_stream, hipStreamNonBlocking));
     if (!ctx->sampler_stop) HIP_TRY(hipHostMalloc((void **)&ctx->sampler_stop, sizeof(uint32_t), hipHostMallocMapped));
     if (!ctx->sampler_count) HIP_TRY(hipMalloc((void **)&ctx->sampler_count, sizeof(uint32_t)));
@@ -400,7 +406,9 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
 #endif
     args.no_half_tiles = ctx->knobs.half_tiles ? 0u : 1u;
     // workgroups resident per CU: 4 for every shipped form (the A/B build's 3-wave all-k 32-row form: 3)
-    const bool sliced_launch = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced));
+    // (sketches beyond 65 535 bins: the k-sliced forms only -- they walk a k-mer length in segments, pair_kslice_walk.inc)
+    const bool big_sketch = args.ss64 > (uint32_t)KSLICE_MAX_U16_CHUNKS;
+    const bool sliced_launch = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced || big_sketch));
     const uint32_t wg_per_cu = ((shape == 3255 && !sliced_launch) || (shape == 3254 && sliced_launch)) ? 3u : 4u;
     args.round_size = ctx->knobs.round_priority ? wg_per_cu * (uint32_t)ctx->n_cu / 8u : 0u;
     ctx->last_count_planes = std::max(1u, args.k_slices);
@@ -422,6 +430,7 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
             *name = "skl::pair_kernel_kslice<R=" + std::to_string(rr) + ", JL=" + std::to_string(jl) +
                     ", " + m + (sliced ? ", k-sliced" : ", all k") + ((shape == 165 || shape == 325 || shape > 1000) ? ", tight" : "") + "> (" +
                     std::to_string(rr) + "x" + std::to_string(jl * 64) + " tiles, chunks split over 4 waves" +
+                    (big_sketch ? "; segments of " + std::to_string(KSLICE_SEG_CHUNKS) + " chunks" : "") +
                     (sliced && mode == MODE_COUNTS && args.tail_slices > 1u
                          ? "; " + std::to_string(args.tail_slices) + " chunk slices per unit in the last round of workgroups" : "") + ")";
             return launch_pair_kernel_kslice(args, mode, shape, sliced, ablate, tiles, stream);
@@ -829,10 +838,12 @@ int fill_args(const skl_sketches *rows, const skl_sketches *cols, const skl_dist
 // Launch-size rule shared with dispatch_pair_kernel: core/acc launches below this many pairs
 // run k-sliced (counts + epilogue kernel), larger ones as one fused kernel.
 constexpr long long SLICED_MAX_PAIRS = 32ll << 20;   // n ~ 8000 all-vs-all: equal there (scripts/ab_sweep.py)
+constexpr size_t COUNTS_SCRATCH_MAX = 4ull << 30;    // bytes of bin-match counts one unfused core/accessory launch may park in HBM
 static bool coreacc_runs_sliced(const skl_ctx *ctx, const skl_sketches *s, uint64_t pairs)
 {
     const int forced = forced_kernel(ctx);
-    if (s->ss64 > 1023 || (forced != 0 && forced != 4)) return false;   // another kernel forced: never slice
+    if (forced != 0 && forced != 4) return false;   // another kernel forced: never slice
+    if (s->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS) return true;   // beyond 65 535 bins the fused form's u16 fields do not hold a count: always counts + epilogue
     const long long limit = ctx->knobs.sliced_max_pairs >= 0 ? ctx->knobs.sliced_max_pairs : SLICED_MAX_PAIRS;
     return pairs < (uint64_t)limit;
 }
@@ -884,6 +895,23 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
     const bool sliced = coreacc && coreacc_runs_sliced(ctx, rows, pairs);
     if (coreacc && (sliced || !fused_coreacc_ok(rows))) {
         // unfused: counts -> scratch2 -> epilogue kernel
+        // (the counts scratch is bounded: a band whose counts would not fit COUNTS_SCRATCH_MAX is computed in two halves
+        // of equal pair count, each into its slice of the destination -- only sketches beyond 65 535 bins or more than 6
+        // k-mer lengths come here with that many pairs)
+        if (pairs * rows->nk * sizeof(uint32_t) > COUNTS_SCRATCH_MAX && r1 - r0 > 1) {
+            uint64_t mid = r0 + (r1 - r0) / 2;
+            if (self_mode) {   // the row that splits the pairs evenly
+                uint64_t lo = r0 + 1, hi = r1 - 1;
+                while (lo < hi) {
+                    const uint64_t m = (lo + hi) / 2;
+                    if (self_rows_pairs(r0, m, n_cols) * 2 < pairs) lo = m + 1; else hi = m;
+                }
+                mid = lo;
+            }
+            SKL_TRY(dense_band(ctx, rows, cols, p, mode, jout, self_mode, r0, mid, dst_dev));
+            const uint64_t base_mid = self_mode ? cond_index(mid, mid + 1, n_cols) : mid * n_cols;
+            return dense_band(ctx, rows, cols, p, mode, jout, self_mode, mid, r1, (char *)dst_dev + (base_mid - base) * 2 * sizeof(float));
+        }
         PairArgs g;
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
         void *counts = nullptr;

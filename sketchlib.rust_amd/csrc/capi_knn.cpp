@@ -56,7 +56,8 @@ static int knn_state_init(KnnState &st, size_t rows, size_t knn, bool coreacc, h
 // symmetric).  Same neighbours, same order as the row-by-row form.
 static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
 {
-    if (s->ss64 > 1023) return false;
+    // (beyond 65 535 bins: single-k only -- the k-sliced form walks the k-mer length in segments, the fused
+    // core/accessory form has no such walk)
     if (p->dist_type == SKL_DIST_COREACC && !fused_coreacc_ok(s)) return false;
     const int forced = forced_kernel(s->ctx);
     if (forced != 0 && forced != 4) return false;          // the turned store lives in pair_kslice.hip

@@ -16,6 +16,10 @@ constexpr int LANES = 64;          // wavefront width on gfx950
 constexpr int WAVES_PER_WG = 4;    // 256-thread workgroups
 constexpr int MAX_FUSED_K = 6;     // k-mer lengths the fused core/acc epilogue packs (3 x 2 x u16)
 constexpr int A_PAD_ROWS = 64;     // rows the scalar-operand slab is over-allocated by
+// pair_kslice.hip keeps a k-mer length's mismatch counts in u16 fields: whole sketches up to 1 023 chunks (65 472 bins);
+// larger ones are walked in segments of 1 016 chunks (a multiple of 8 = the chunks per stage of both tile heights)
+constexpr int KSLICE_MAX_U16_CHUNKS = 1023;
+constexpr int KSLICE_SEG_CHUNKS = 1016;
 
 // What the pair kernel does with the per-(pair,k) mismatch counts.
 enum PairMode : int {
@@ -58,6 +62,7 @@ struct PairArgs {
     // ([pair][k] for the public bin-match calls, k-major for the internal counts scratch)
     uint64_t cnt_pair_stride, cnt_k_stride;
     uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
+    uint32_t seg_chunks;          // pair_kslice.hip, set by its launcher: chunks per segment of the segmented walk (0: whole k-mer lengths)
     uint32_t k_slices;            // k-sliced MODE_COUNTS: chunk slices per k-mer length (0/1: none); slice s of k index kk
                                   // stores the matches of ITS bins at "k index" s * k_count + kk
     // Tail slicing of a k-sliced MODE_COUNTS launch (pair_kslice.hip): on every XCD the workgroups from

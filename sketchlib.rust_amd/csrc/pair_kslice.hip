@@ -76,7 +76,9 @@ constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk 
 // mostly the LDS reads of a kernel that runs at the LDS's rate, not the column loads.
 // OCC: waves per SIMD the register allocator is held to (0: 4 for the tight 16-row form, 3 for the tight
 // 32-row form and for 3 columns per lane, 1 otherwise).
-template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1, int OCC = 0>
+// BIG: sketches beyond 65 535 bins (k-sliced counts / single-k forms only): the k-mer length is walked in segments
+// whose totals fit the u16 fields and are added up in 32 bits (pair_kslice_walk.inc).
+template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1, int OCC = 0, bool BIG = false>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R > 16 ? 3 : 4) : (JL == 3 ? 3 : 1))) void pair_kernel_kslice(const PairArgs g)
 {
     constexpr int W = WAVES_PER_WG;
@@ -97,11 +99,12 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     // (a k-sliced workgroup walks ONE k-mer length: no next stage is in flight when it reduces, so both row
     // buffers of a wave are free -- the 32-row form then needs no overflow region: 32 KB instead of 48 KB of
     // LDS per workgroup, i.e. room for 4 workgroups per CU)
-    constexpr uint32_t RED_BUFS = KSL ? 2u : 1u;
+    // (not with segments: the next segment's first stage IS in flight at the end of a segment)
+    constexpr uint32_t RED_BUFS = (KSL && !BIG) ? 2u : 1u;
     // RED2 (the all-k 32-row form held to 4 waves per SIMD): the words that do not fit the one free buffer go
     // through it in a second phase (two more barriers per k-mer length) instead of an overflow region -- 32 KB
     // of LDS (36 KB with core/accessory's turned tile) instead of 48 KB, i.e. room for 4 workgroups per CU
-    constexpr bool RED2 = TIGHT && !KSL && R == 32 && OCC == 4;
+    constexpr bool RED2 = TIGHT && (!KSL || BIG) && R == 32 && OCC == 4;
     constexpr int RED_PHASES = RED2 ? 2 : 1;
     // Row DMA addressed as scalar base + 32-bit per-lane offset (pair_kslice_walk.inc): the lane part of the address -- which
     // row, chunk of the stage and plane pair a lane fetches -- never changes.  Kept as 64-bit per-lane pointers it was what the 4-wave all-k form spilled
@@ -245,6 +248,15 @@ template <int R, int JL, bool KSL, bool TIGHT = false, int MB = 1, int OCC = 0>
 static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
 {
     const dim3 block(LANES * WAVES_PER_WG);
+    if constexpr (KSL && OCC == (R == 32 ? 4 : 0)) {   // (the shipped k-sliced forms only)
+        if (args.seg_chunks != 0u) {   // sketches beyond 65 535 bins: the segmented walk
+            if (mode == MODE_COUNTS) hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, true, 0, TIGHT, MB, OCC, true>), grid, block, 0, stream, args);
+            else if (mode == MODE_JACCARD) hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, true, 0, TIGHT, MB, OCC, true>), grid, block, 0, stream, args);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
+    if (args.seg_chunks != 0u) return hipErrorInvalidValue;
     switch (mode) {
         case MODE_COUNTS:
             hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, KSL, 0, TIGHT, MB, OCC>), grid, block, 0, stream, args);
@@ -265,7 +277,9 @@ static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStrea
 
 bool kslice_supported(const PairArgs &args, int mode, bool k_sliced)
 {
-    if (args.ss64 > 1023u || args.k_count < 1u) return false;   // u16 count fields
+    if (args.k_count < 1u) return false;
+    // u16 count fields: beyond 65 535 bins only the k-sliced counts / single-k forms, walked in segments
+    if (args.ss64 > (uint32_t)KSLICE_MAX_U16_CHUNKS && !(k_sliced && (mode == MODE_COUNTS || mode == MODE_JACCARD))) return false;
     // the row DMA's per-lane byte offsets (up to 31 rows + 1 chunk from the tile's first row) are 32-bit
     if ((uint64_t)32u * args.nk * args.ss64 * BBITS * sizeof(uint64_t) >= (1ull << 32)) return false;
     if (mode == MODE_COREACC) return !k_sliced && args.k_count <= (uint32_t)MAX_FUSED_K;
@@ -280,6 +294,9 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     PairArgs args = args_in;
     if (args.row_end <= args.row_begin || args.nB == 0) return hipSuccess;
     if (!kslice_supported(args, mode, k_sliced)) return hipErrorInvalidValue;
+    // beyond 65 535 bins: segments of KSLICE_SEG_CHUNKS chunks (a multiple of every form's chunks per stage)
+    args.seg_chunks = args.ss64 > (uint32_t)KSLICE_MAX_U16_CHUNKS ? (uint32_t)KSLICE_SEG_CHUNKS : 0u;
+    if (args.seg_chunks != 0u && shape != 165 && shape != 325) return hipErrorInvalidValue;
     const int R = shape > 1000 ? shape / 100 : shape / 10;   // 165 / 325 (and 165x, 325x in the A/B build): 16 x 128 and 32 x 128 tiles
     const int JL = 2;
     uint64_t n_wg = 0;
