@@ -176,6 +176,42 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
         if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
     }
     ctx->last_kernel = "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)";
+    if (ctx->knn_ties == SKL_KNN_TIES_REFERENCE) {
+        // The reference's tie order: its BinaryHeap replayed over each row's candidates IN THE ORDER THEY ARE LISTED
+        // (mod.rs:459-487 pushes in the order Inverted::any_shared_bins returns them: ascending .ski index -- the
+        // caller lists them that way; lists built on the device are ascending in the slab's sample order).
+        RefHeapArgs h;
+        memset(&h, 0, sizeof h);
+        h.keys = (const float *)d_keys.p;
+        h.stride2 = 1;
+        h.rows = (uint32_t)n;
+        h.self_id_base = 0xFFFFFFFFu;
+        h.knn = (uint32_t)knn;
+        h.ani_undo = p->ani ? 1 : 0;
+        h.out_idx = (uint64_t *)d_idx.p;
+        h.out_d0 = (float *)d_d0.p;
+        h.row_offsets = d_off;
+        h.col_ids = d_cand;
+        if (knn <= (size_t)REFHEAP_LDS_MAX) {
+            HIP_TRY(launch_topk_refheap(h, ctx->stream));
+        } else {   // heaps in global memory, rows in batches of at most 1 GiB of it
+            DevBuf heaps;
+            const size_t per_row = 3 * (knn + 1) * sizeof(float);
+            const size_t batch = std::max<size_t>(1, std::min<size_t>(n, (1ull << 30) / per_row));
+            HIP_TRY(hipMalloc(&heaps.p, batch * per_row));
+            h.heap_scratch = (float *)heaps.p;
+            for (size_t r = 0; r < n; r += batch) {
+                h.first_row = (uint32_t)r;
+                h.rows = (uint32_t)std::min(batch, n - r);
+                HIP_TRY(launch_topk_refheap(h, ctx->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(ctx->stream));   // `heaps` is freed on scope exit
+        }
+        HIP_TRY(hipMemcpyAsync(out_idx, d_idx.p, n * knn * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out_d0, d_d0.p, n * knn * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return SKL_OK;
+    }
     TopkArgs t;
     memset(&t, 0, sizeof t);
     t.keys = (const float *)d_keys.p;

@@ -18,11 +18,16 @@ namespace {
 struct KnnState {
     uint32_t *key = nullptr, *idx = nullptr;
     float *d1 = nullptr;
+    // Reference tie order (skl_ctx_set_knn_ties): the state of a row is the reference's BinaryHeap itself -- heap-ordered
+    // (key, id[, second value]) arrays of h_len items -- and thr its maximum once full, in sortable bits
+    // (refheap_merge_kernel, topk.hip).  Null in the canonical mode.
+    float *h_key = nullptr, *h_d1 = nullptr;
+    uint32_t *h_id = nullptr, *h_len = nullptr, *thr = nullptr;
     ~KnnState()
     {
-        if (key) (void)hipFree(key);
-        if (idx) (void)hipFree(idx);
-        if (d1) (void)hipFree(d1);
+        for (void *p : {(void *)key, (void *)idx, (void *)d1, (void *)h_key, (void *)h_d1, (void *)h_id, (void *)h_len, (void *)thr}) {
+            if (p) (void)hipFree(p);
+        }
     }
 };
 }  // namespace
@@ -37,9 +42,19 @@ static size_t symmetric_band_rows(size_t n, size_t rec, size_t budget, size_t pa
     return std::min(budget_rows, std::max(up16((n + 8 * parts - 1) / (8 * parts)), up16((32ull << 20) / n + 1)));
 }
 
-static int knn_state_init(KnnState &st, size_t rows, size_t knn, bool coreacc, hipStream_t stream)
+static int knn_state_init(KnnState &st, size_t rows, size_t knn, bool coreacc, hipStream_t stream, bool ref_heap = false)
 {
     const size_t items = rows * knn;
+    if (ref_heap) {
+        HIP_TRY(hipMalloc((void **)&st.h_key, items * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&st.h_id, items * sizeof(uint32_t)));
+        if (coreacc) HIP_TRY(hipMalloc((void **)&st.h_d1, items * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&st.h_len, rows * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&st.thr, rows * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(st.h_len, 0, rows * sizeof(uint32_t), stream));     // empty heaps
+        HIP_TRY(hipMemsetAsync(st.thr, 0xFF, rows * sizeof(uint32_t), stream));    // not full: everything may enter
+        return SKL_OK;
+    }
     HIP_TRY(hipMalloc((void **)&st.key, items * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&st.idx, items * sizeof(uint32_t)));
     if (coreacc) HIP_TRY(hipMalloc((void **)&st.d1, items * sizeof(float)));
@@ -71,6 +86,8 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
 {
     const size_t n = s->n;
     const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    const bool ref = st.h_key != nullptr;   // the reference's tie order: heaps replayed (a row's candidates arrive in ascending id
+                                            // over the bands -- turned from the bands above its own, then its own band's columns)
     const int mode = coreacc ? MODE_COREACC : MODE_JACCARD;
     const int jout = coreacc ? 0 : (p->ani ? JOUT_ANI_KEY : JOUT_DIST);
     const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
@@ -134,19 +151,57 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             HIP_TRY(hipMemsetAsync(row_bits[buf], 0, band_rows * bit_words * sizeof(uint32_t), ctx->stream));
             g.r_bits = row_bits[buf];
             g.r_bits_stride = (uint32_t)bit_words;
-            g.r_thr = st.key + b0 * knn + (knn - 1);        // knn-th best of sample b0 + r
-            g.r_thr_stride = (uint32_t)knn;
+            g.r_thr = ref ? st.thr + b0 : st.key + b0 * knn + (knn - 1);        // knn-th best of sample b0 + r
+            g.r_thr_stride = ref ? 1u : (uint32_t)knn;
         }
         if (g.out_t && ctx->knobs.knn_row_flags) {
             g.t_flag = flags[buf] + col0;                   // indexed by the view's column number, like t_col_begin
             g.t_flag_value = flag_value;
-            g.t_thr = st.key + col0 * knn + (knn - 1);      // knn-th best of sample col0 + c
-            g.t_thr_stride = (uint32_t)knn;
+            g.t_thr = ref ? st.thr + col0 : st.key + col0 * knn + (knn - 1);      // knn-th best of sample col0 + c
+            g.t_thr_stride = ref ? 1u : (uint32_t)knn;
         }
         SKL_TRY(timed_pair_launch(ctx, g, mode));
         if (overlap) {
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
             HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
+        }
+        if (ref) {
+            RefHeapMergeArgs m;
+            memset(&m, 0, sizeof m);
+            m.knn = (uint32_t)knn;
+            m.stride2 = coreacc ? 2 : 1;
+            m.h_key = st.h_key;
+            m.h_id = st.h_id;
+            m.h_d1 = st.h_d1;
+            m.h_len = st.h_len;
+            m.thr = st.thr;
+            // rows below the band FIRST: for them the band's samples are the next candidates in ascending id, and their
+            // own band comes later; then the band's own rows (columns [b0, n) minus themselves: everything below b0 reached
+            // them turned, from the bands above).  Either way a row is fed ascending ids over the sequence of launches.
+            m.keys = (const float *)tband[buf];
+            m.key_stride = (uint64_t)t_stride * m.stride2;
+            m.rows = (uint32_t)(n - b1);
+            m.cols = (uint32_t)(b1 - b0);
+            m.id_base = (uint32_t)b0;
+            m.skip_below = 0;
+            m.self_id_base = m.state_row_base = (uint32_t)b1;
+            m.flag = ctx->knobs.knn_row_flags ? flags[buf] + b1 : nullptr;
+            m.flag_value = flag_value;
+            HIP_TRY(launch_refheap_merge(m, topk_stream));
+            m.flag = nullptr;
+            m.keys = (const float *)kband[buf];
+            m.key_stride = (uint64_t)g.nB * m.stride2;
+            m.rows = (uint32_t)(b1 - b0);
+            m.cols = g.nB;
+            m.id_base = (uint32_t)col0;
+            m.skip_below = (uint32_t)b0;
+            m.self_id_base = m.state_row_base = (uint32_t)b0;
+            m.seg_bits = ctx->knobs.knn_row_flags ? row_bits[buf] : nullptr;
+            m.seg_bits_stride = (uint32_t)bit_words;
+            HIP_TRY(launch_refheap_merge(m, topk_stream));
+            if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
+            ++it;
+            continue;
         }
         TopkMergeArgs m;
         memset(&m, 0, sizeof m);
@@ -195,13 +250,19 @@ static int knn_self_symmetric(skl_ctx *ctx, const skl_sketches *s, const skl_dis
 {
     const size_t n = s->n;
     const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    const bool ref = ctx->knn_ties == SKL_KNN_TIES_REFERENCE;
     KnnState st;
-    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
+    SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream, ref));
     std::vector<uint32_t> bands((n + band_rows - 1) / band_rows);
     for (size_t b = 0; b < bands.size(); ++b) bands[b] = (uint32_t)b;
     SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, bands, overlap, st));
-    HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, n * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0, d_d1,
-                                 ctx->stream));
+    if (ref) {
+        HIP_TRY(launch_refheap_finalize(st.h_key, st.h_id, st.h_d1, st.h_len, (uint32_t)n, (uint32_t)knn, (!coreacc && p->ani) ? 1 : 0,
+                                        d_idx, d_d0, d_d1, ctx->stream));
+    } else {
+        HIP_TRY(launch_topk_finalize(st.key, st.idx, st.d1, n * knn, (!coreacc && p->ani) ? 1 : 0, d_idx, d_d0, d_d1,
+                                     ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
     return SKL_OK;
 }
@@ -358,9 +419,10 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     // The whole self matrix: evaluate each pair once (knn_self_symmetric) when that leaves bands
     // worth launching -- about 8 of them (7/16 of the pair evaluations saved), each at least 32 M
     // pairs, within four band buffers of up to half the free HBM (<= 32 GiB) together.
-    // (the reference's tie order depends on the ORDER candidates arrive in, ascending j for every row: row by row;
-    // so do lists too long for the LDS-resident running state)
-    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p) && !ref_ties && !big_knn &&
+    // (the reference's tie order depends on the ORDER candidates arrive in, ascending j for every row: the symmetric driver
+    // delivers exactly that order, band by band, to a heap that lives in global memory between the bands; lists too long for
+    // the LDS-resident running state go row by row)
+    bool symmetric = self_mode && r0 == 0 && r1 == n_cand && knn_symmetric_ok(rows, p) && !big_knn &&
                      ctx->knobs.knn_symmetric;   // (SKL_KNN_SYMMETRIC=0: A/B against the row-by-row form)
     if (symmetric) {
         size_t budget = band_bytes;

@@ -36,7 +36,7 @@ struct DistArgs {
     std::string ref_db;
     std::optional<std::string> query_db, output, subset, ref_completeness_file, query_completeness_file;
     std::optional<size_t> knn, kmer;
-    int knn_ties = SKL_KNN_TIES_CANONICAL;
+    int knn_ties = SKL_KNN_TIES_REFERENCE;
     bool ani = false;
     size_t threads = 1;
     double completeness_cutoff = 0.64;
@@ -73,10 +73,12 @@ void print_help()
         "Options:\n"
         "  -o <OUTPUT>                     Output filename (omit to output to stdout)\n"
         "      --knn <KNN>                 Calculate sparse distances with k nearest-neighbours (ref-vs-ref or ref-vs-query)\n"
-        "      --knn-ties <RULE>           Neighbours at EQUAL distance: canonical = lowest index first (default; the\n"
-        "                                  distances per row are the reference's, tied rows may list other ids);\n"
-        "                                  reference = exactly the ids and order the reference binary prints (its\n"
-        "                                  BinaryHeap replayed on the GPU; every pair is then evaluated twice, as there)\n"
+        "      --knn-ties <RULE>           Neighbours at EQUAL distance: reference (default) = exactly the ids and order\n"
+        "                                  the reference binary prints (its BinaryHeap replayed on the GPU);\n"
+        "                                  canonical = lowest index first (a property of the data alone; the distances\n"
+        "                                  per row are the reference's, tied rows may list other ids).  With --gpus N > 1\n"
+        "                                  the reference rule shards rows (every pair evaluated twice, as the reference\n"
+        "                                  does); canonical evaluates every pair once on any number of GPUs\n"
         "      --subset <SUBSET>           Sample names to analyse\n"
         "  -k <KMER>                       K-mer length (if provided only calculate Jaccard distance)\n"
         "      --ani                       Calculate ANI rather than Jaccard dists, using Poisson model\n"
@@ -589,6 +591,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     g_usage = "sketchlib inverted precluster [OPTIONS] <SKI> <--skd <SKD>|--count>";
     std::optional<std::string> ski, skd, output, completeness_file, retain;
     bool count = false, ani = false, host_candidates = false;
+    int knn_ties = SKL_KNN_TIES_REFERENCE;
     size_t knn = 50, threads = 1;   // DEFAULT_KNN, cli.rs
     double cutoff = 0.64;
     int device = 0;
@@ -607,6 +610,12 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
         else if (arg == "--retain-unmatched") retain = next_value(i, arg);
         else if (arg == "--device") device = (int)parse_usize("--device <D>", next_value(i, arg));
         else if (arg == "--host-candidates") host_candidates = true;   // candidate lists from the .ski on host threads
+        else if (arg == "--knn-ties") {   // as `dist --knn-ties`: reference (default) | canonical
+            const std::string v = next_value(i, "--knn-ties <RULE>");
+            if (v == "canonical") knn_ties = SKL_KNN_TIES_CANONICAL;
+            else if (v == "reference") knn_ties = SKL_KNN_TIES_REFERENCE;
+            else usage_error("invalid value '" + v + "' for '--knn-ties <RULE>': possible values: canonical, reference");
+        }
         else if (arg.size() > 1 && arg[0] == '-') usage_error("unexpected argument '" + arg + "' found");
         else if (!ski) ski = arg;
         else usage_error("unexpected argument '" + arg + "' found");
@@ -670,6 +679,13 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     log.info("Loading sketch data from " + ref_db_name + ".skd");
     references.read_sketch_data(ref_db_name);
     const size_t n = references.number_samples_loaded();
+    if (knn_ties == SKL_KNN_TIES_REFERENCE && !inv.has_index() && !distances::ski_order_is_skd_order(references, inv)) {
+        // the reference pushes a row's candidates in ascending .ski index (mod.rs:459-487); lists built on the device are
+        // ascending in .skd order, so with a .ski that orders the samples differently they come from the index, on the host
+        log.info("The .ski orders the samples differently from the .skd: candidate lists from the index on the host "
+                 "(--knn-ties canonical keeps them on the device)");
+        inv = Inverted::load(input_prefix, true);
+    }
     if (knn >= n) {   // lib.rs:737-740
         log.warn("knn=" + std::to_string(knn) + " is higher than number of samples=" + std::to_string(n));
         knn = n - 1;
@@ -696,7 +712,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     if (comp && (skl_ctx_flags(dev.ctx()) & SKL_CTX_FLAG_LOG_UNMATCHED)) log.warn(LOG_UNMATCHED_WARNING);
     const SparseDistanceMatrix d = distances::self_dists_knn_precluster(
         dev, references, inv, skq_bins, inv.sketch_size(), n, knn, dist_type, comp ? &*comp : nullptr, cutoff,
-        retain_mode, threads);
+        retain_mode, threads, knn_ties);
     const double t_dist = since_start();
     log.info("Writing out in sparse matrix form");
     d.write(*sink, threads);

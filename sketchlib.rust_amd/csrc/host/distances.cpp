@@ -199,7 +199,7 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
                                                const std::vector<uint16_t> &skq_bins, size_t skq_stride, size_t n,
                                                size_t knn, const DistType &dist_type,
                                                const std::vector<double> *completeness_vec,
-                                               double completeness_cutoff, RetainUnmatched retain, size_t threads)
+                                               double completeness_cutoff, RetainUnmatched retain, size_t threads, int knn_ties)
 {
     // sample sets of .ski and .skm must agree; i <-> j lookups (mod.rs:412-440)
     std::unordered_map<std::string, size_t> skq_lookup;
@@ -223,6 +223,14 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
     const bool timing = std::getenv("SKL_CLI_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    const bool reference_order = knn_ties == SKL_KNN_TIES_REFERENCE;
+    check(skl_ctx_set_knn_ties(dev.ctx(), knn_ties));
+    bool monotone = true;   // does ascending .skd id mean ascending .ski index?
+    for (size_t i = 1; i < ski_of_skd.size(); ++i) monotone = monotone && ski_of_skd[i - 1] < ski_of_skd[i];
+    if (reference_order && !monotone && !inv.has_index()) {
+        throw std::runtime_error("the reference's tie order pushes a row's candidates in ascending .ski index, and this .ski orders the "
+                                 "samples differently from the .skd: load the index (host candidate lists)");
+    }
     Slab s(dev, sketches, completeness_vec);
     const skl_dist_params p = to_params(dist_type, completeness_cutoff);
     std::vector<uint64_t> idx(n * knn);
@@ -277,10 +285,12 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
                         }
                         inv.any_shared_bins(skq_bins.data() + ski_i * skq_stride, stamp, epoch, hits);
                         const size_t begin = buf.size();
-                        for (uint32_t j : hits) {
+                        for (uint32_t j : hits) {   // (ascending .ski index)
                             if (j != ski_i) buf.push_back((uint32_t)skd_of_ski[j]);   // mod.rs:458-461
                         }
-                        std::sort(buf.begin() + begin, buf.end());
+                        // canonical ties: ascending .skd id (the lists are a set); the reference's tie order: the order the
+                        // reference pushes them in, i.e. as any_shared_bins returned them
+                        if (!reference_order) std::sort(buf.begin() + begin, buf.end());
                         rows[i].worker = (uint32_t)wid;
                         rows[i].begin = begin;
                         rows[i].len = (uint32_t)(buf.size() - begin);
@@ -353,6 +363,20 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
     SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
     out.ref_names = sketch_names(sketches);
     return out;
+}
+
+bool ski_order_is_skd_order(const MultiSketch &sketches, const Inverted &inv)
+{
+    std::unordered_map<std::string, size_t> pos;
+    for (size_t i = 0; i < inv.sample_names.size(); ++i) pos.emplace(inv.sample_names[i], i);
+    size_t last = 0;
+    for (size_t i = 0; i < sketches.number_samples_loaded(); ++i) {
+        const auto it = pos.find(sketches.sketch_name(i));
+        if (it == pos.end()) return true;   // (reported by self_dists_knn_precluster itself)
+        if (i && it->second <= last) return false;
+        last = it->second;
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------

@@ -98,13 +98,20 @@ std::string npy_header(size_t rows, size_t cols);
 // (skl_self_dists_knn_candidates); rows without candidates follow --retain-unmatched.  If the
 // index was loaded without its bitmaps (Inverted::load(prefix, false)) the candidate lists are
 // built on the device too, from the .skq alone (skl_self_dists_knn_shared_bins).
+// knn_ties = SKL_KNN_TIES_REFERENCE: ids and order of equal keys as the reference binary prints them -- its BinaryHeap
+// replayed over each row's candidates in ascending .ski index (mod.rs:459-487).  Lists built on the device are ascending
+// in .skd order: with a .ski that orders the samples differently the caller must load the index (host lists), or this
+// throws.
 enum class RetainUnmatched { None, Singleton, Bruteforce };
 SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &sketches, const Inverted &inverted_index,
                                                const std::vector<uint16_t> &skq_bins, size_t skq_stride, size_t n,
                                                size_t knn, const DistType &dist_type,
                                                const std::vector<double> *completeness_vec,
                                                double completeness_cutoff, RetainUnmatched retain_unmatched,
-                                               size_t threads);
+                                               size_t threads, int knn_ties = 0 /* SKL_KNN_TIES_CANONICAL */);
+// Whether the .ski lists the .skd's samples in the .skd's own order (then "ascending .ski index", the order the
+// reference pushes a row's candidates in, is "ascending sample id", the order lists built on the device have).
+bool ski_order_is_skd_order(const MultiSketch &sketches, const Inverted &inverted_index);
 
 // mod.rs:25-37.  Throws std::runtime_error("K-mer size {k} not found in file").
 DistType set_k(const MultiSketch &sketches, std::optional<size_t> kmer, bool ani);

@@ -275,10 +275,39 @@ struct RefHeapArgs {
     int32_t ani_undo;        // write 1.0f - key (mod.rs:183-189)
     uint64_t *out_idx;       // [rows][knn]
     float *out_d0, *out_d1;
-    float *heap_scratch;     // knn > REFHEAP_LDS_MAX: [rows][3 * (knn + 1)] floats in global memory, else null
+    float *heap_scratch;     // knn > REFHEAP_LDS_MAX: [rows of this launch][3 * (knn + 1)] floats in global memory, else null
+    // Ragged form (candidate lists, precluster): row r owns keys[row_offsets[r] .. row_offsets[r+1]) and col_ids maps a
+    // position to the sample id; the candidates are pushed in the order they are LISTED; rows with fewer than knn
+    // candidates are padded with (row id, 1.0f) (mod.rs:535-546).  Null = dense form.  stride2 == 1 only.
+    const uint64_t *row_offsets;
+    const uint32_t *col_ids;
+    uint32_t first_row;      // this launch handles rows first_row .. first_row + rows - 1 (heap_scratch slices are per launch)
 };
 constexpr uint32_t REFHEAP_LDS_MAX = 2048;
 hipError_t launch_topk_refheap(const RefHeapArgs &args, hipStream_t stream);
+// The same replay, resumable: the heap of row r (RefHeap layout: h_key / h_id / h_d1 [.][knn], h_len [.]) is read from and
+// written back to global memory, and thr[.] keeps the sortable key bits of its maximum once it is full (0xFFFFFFFF before),
+// which is what the pair kernel's row / block flags compare with.  One launch feeds rows [state_row_base, + rows) the
+// records keys[r * key_stride ...] as candidates id_base + position; the caller guarantees ascending ids per row over the
+// sequence of launches (topk.hip: refheap_merge_kernel).  knn <= REFHEAP_LDS_MAX.
+struct RefHeapMergeArgs {
+    const float *keys;
+    uint64_t key_stride;
+    uint32_t stride2;
+    uint32_t rows, cols;
+    uint32_t id_base, skip_below, self_id_base, state_row_base, knn;
+    float *h_key;
+    uint32_t *h_id;
+    float *h_d1;              // stride2 == 2, else null
+    uint32_t *h_len, *thr;
+    const uint32_t *flag;     // row r is fed only if flag[r] == flag_value (null: every row)
+    uint32_t flag_value;
+    const uint32_t *seg_bits; // as TopkMergeArgs::seg_bits
+    uint32_t seg_bits_stride;
+};
+hipError_t launch_refheap_merge(const RefHeapMergeArgs &args, hipStream_t stream);
+hipError_t launch_refheap_finalize(const float *h_key, const uint32_t *h_id, const float *h_d1, const uint32_t *h_len, uint32_t rows,
+                                   uint32_t knn, int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1, hipStream_t stream);
 
 // Running per-row top-k: merges a row's new keys into its sorted state of knn (sortable key,
 // sample id[, second value]) entries.  New ids must all be larger than the ids already in the

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     // Row DMA addressed as scalar base + 32-bit per-lane offset (pair_kslice_walk.inc): the lane part of the address -- which
     // row, chunk of the stage and plane pair a lane fetches -- never changes.  Kept as 64-bit per-lane pointers it was what the 4-wave all-k form spilled
     // at every stage (a scratch reload waits for the column prefetch too): 5-6 % slower than 3 waves with them, 6 % FASTER without.
-    constexpr bool SADDR_DMA = TIGHT && ABL == 0;
+    constexpr bool SADDR_DMA = TIGHT && (ABL & 4) == 0;
     constexpr int XIN_FIT = (RED_BUFS * BUF_U4 * 4 / LANES) < (uint32_t)PX ? (int)(RED_BUFS * BUF_U4 * 4 / LANES) : PX;
     constexpr int XIN = RED2 ? PX / RED_PHASES : XIN_FIT;
     static_assert(!RED2 || (XIN <= XIN_FIT && SLOTS % RED_PHASES == 0), "a phase's words fit the free row buffer");
@@ -332,9 +332,14 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
 #ifdef SKL_AB
     // timing-only: rows read as if the row slab were tile-major ([row tile][k][chunk][row][plane]: a wave's
     // stage is one contiguous 3.5 KB run instead of 16-32 runs of 112 B, one per sample)
-    // timing-only ablations (outputs wrong by construction): SKL_KSLICE_ABLATE = 8 all workgroups on one hot tile, 4 a tile-major row slab
+    // timing-only ablations (outputs wrong by construction): SKL_KSLICE_ABLATE = 8 all workgroups on one hot tile, 4 a tile-major
+    // row slab, 16 the all-k form without its per-k totals in private memory
     if (ablate == 8 && shape == 165 && k_sliced && mode == MODE_COUNTS) {
         hipLaunchKernelGGL((pair_kernel_kslice<16, 2, MODE_COUNTS, true, 8, true, 1>), grid, dim3(LANES * WAVES_PER_WG), 0, stream, args);
+        return hipGetLastError();
+    }
+    if (ablate == 16 && shape == 325 && !k_sliced && mode == MODE_COREACC) {   // timing only: per-k totals not parked
+        hipLaunchKernelGGL((pair_kernel_kslice<32, 2, MODE_COREACC, false, 16, true, 2, 4>), grid, dim3(LANES * WAVES_PER_WG), 0, stream, args);
         return hipGetLastError();
     }
     if (ablate == 4 && (shape == 165 || shape == 325)) {

@@ -573,41 +573,49 @@ struct RefHeap {
 };
 }  // namespace
 
-__global__ __launch_bounds__(TOPK_THREADS) void topk_refheap_kernel(const RefHeapArgs g)
-{
-    constexpr uint32_t CAP = 2048, UNROLL = 4;
-    __shared__ float lds_heap[3 * (REFHEAP_LDS_MAX + 1)];
-    __shared__ float cand_key[CAP], cand_d1[CAP];
-    __shared__ uint32_t cand_id[CAP];
-    __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
-    __shared__ uint32_t sh_len, sh_ncand;
-    __shared__ float sh_thr;
-    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t knn = g.knn, cols = g.cols, stride2 = g.stride2;
-    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
-    const float *keys = g.keys + (size_t)row * g.key_stride;
-    float *base = g.heap_scratch ? g.heap_scratch + (size_t)row * 3u * (knn + 1u) : lds_heap;
-    RefHeap h{base, base + (knn + 1u), reinterpret_cast<uint32_t *>(base + 2u * (knn + 1u)), 0u, stride2 == 2u};
-    if (tid == 0) {
-        sh_len = 0;
-        sh_ncand = 0;
-        sh_thr = __builtin_inff();
-    }
-    __syncthreads();
+// Shared scratch of the replay kernels: the candidates that passed the pre-filter since the last drain, in order.
+constexpr uint32_t REFHEAP_CAP = 2048;
+struct RefHeapShared {
+    float cand_key[REFHEAP_CAP], cand_d1[REFHEAP_CAP];
+    uint32_t cand_id[REFHEAP_CAP];
+    uint32_t wave_cnt[TOPK_THREADS / 64];
+    uint32_t len, ncand;
+    float thr;
+};
 
+// The records keys[0, cols) of one row (stride2 floats apiece) fed to the heap in position order.  id_of(q, id): is
+// position q a candidate, and under which sample id.  `bits` (nullable): bit b clear = positions [64 b, 64 b + 64) hold
+// nothing below the heap's maximum (set by the pair kernel against a maximum that may be stale, i.e. too high: never too
+// few bits), such stretches are not read.  sh.len / sh.thr describe the heap on entry and on return (whole workgroup).
+template <class IdOf>
+__device__ __forceinline__ void refheap_feed(RefHeap &h, RefHeapShared &sh, const float *keys, uint32_t stride2, uint32_t cols,
+                                             uint32_t knn, const IdOf &id_of, const uint32_t *bits)
+{
+    constexpr uint32_t UNROLL = 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     auto drain = [&]() {   // thread 0: the buffered candidates through the exact push / pop sequence, in order
         if (tid == 0) {
-            h.len = sh_len;
-            const uint32_t m = sh_ncand;
-            for (uint32_t c = 0; c < m; ++c) h.push_heap(RefHeap::Elt{cand_key[c], cand_d1[c], cand_id[c]}, knn);
-            sh_len = h.len;
-            sh_ncand = 0;
-            sh_thr = h.len < knn ? __builtin_inff() : h.key[0];
+            h.len = sh.len;
+            const uint32_t m = sh.ncand;
+            for (uint32_t c = 0; c < m; ++c) h.push_heap(RefHeap::Elt{sh.cand_key[c], sh.cand_d1[c], sh.cand_id[c]}, knn);
+            sh.len = h.len;
+            sh.ncand = 0;
+            sh.thr = h.len < knn ? __builtin_inff() : h.key[0];
         }
         __syncthreads();
     };
-
     for (uint32_t q0 = 0; q0 < cols; q0 += TOPK_THREADS * UNROLL) {
+        if (bits != nullptr) {
+            const uint32_t b_lo = q0 >> 6, b_hi = (min(q0 + TOPK_THREADS * UNROLL, cols) - 1u) >> 6;
+            bool marked = false;
+            for (uint32_t w = b_lo >> 5; w <= (b_hi >> 5); ++w) {
+                uint32_t word = bits[w];
+                if (w == (b_lo >> 5)) word &= ~0u << (b_lo & 31u);
+                if (w == (b_hi >> 5) && (b_hi & 31u) != 31u) word &= (2u << (b_hi & 31u)) - 1u;
+                marked |= word != 0u;
+            }
+            if (!marked) continue;   // (workgroup-uniform)
+        }
         float k[UNROLL], d[UNROLL];
 #pragma unroll
         for (uint32_t j = 0; j < UNROLL; ++j) {   // unconditional (clamped) loads, all in flight together
@@ -615,14 +623,16 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_refheap_kernel(const RefHea
             k[j] = __builtin_nontemporal_load(&keys[(size_t)q * stride2]);
             d[j] = stride2 == 2u ? __builtin_nontemporal_load(&keys[(size_t)q * 2u + 1u]) : 0.0f;
         }
-        const float thr = sh_thr;
-        const bool open = sh_len < knn;   // not full: everything is pushed
+        const float thr = sh.thr;
+        const bool open = sh.len < knn;   // not full: everything is pushed
         bool take[UNROLL];
+        uint32_t id[UNROLL];
         int any = 0;
 #pragma unroll
         for (uint32_t j = 0; j < UNROLL; ++j) {
             const uint32_t q = q0 + j * TOPK_THREADS + tid;
-            take[j] = q < cols && q != self_id && (open || k[j] < thr);
+            id[j] = 0u;
+            take[j] = q < cols && id_of(q, id[j]) && (open || k[j] < thr);
             any |= take[j] ? 1 : 0;
         }
         if (!__syncthreads_or(any)) continue;   // (the common case once the heap has settled)
@@ -630,28 +640,28 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_refheap_kernel(const RefHea
         for (uint32_t j = 0; j < UNROLL; ++j) {
             // ordered compaction: position order = candidate order
             const uint64_t votes = __ballot(take[j]);
-            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(votes);
+            if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(votes);
             __syncthreads();
-            uint32_t before = sh_ncand + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+            uint32_t before = sh.ncand + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
             uint32_t total = 0;
             for (uint32_t w = 0; w < TOPK_THREADS / 64; ++w) {
-                if (w < wave) before += wave_cnt[w];
-                total += wave_cnt[w];
+                if (w < wave) before += sh.wave_cnt[w];
+                total += sh.wave_cnt[w];
             }
             if (take[j]) {
-                cand_key[before] = k[j];
-                cand_d1[before] = d[j];
-                cand_id[before] = q0 + j * TOPK_THREADS + tid;
+                sh.cand_key[before] = k[j];
+                sh.cand_d1[before] = d[j];
+                sh.cand_id[before] = id[j];
             }
             __syncthreads();
-            if (tid == 0) sh_ncand += total;
+            if (tid == 0) sh.ncand += total;
             __syncthreads();
-            if (sh_ncand + TOPK_THREADS > CAP || open) {
+            if (sh.ncand + TOPK_THREADS > REFHEAP_CAP || open) {
                 // (while the heap fills, drain after every round: the threshold must exist before more is buffered)
                 drain();
                 if (open) {   // the threshold may have appeared: re-test what this thread still holds
-                    const float t2 = sh_thr;
-                    const bool open2 = sh_len < knn;
+                    const float t2 = sh.thr;
+                    const bool open2 = sh.len < knn;
 #pragma unroll
                     for (uint32_t jj = 0; jj < UNROLL; ++jj) {
                         if (jj > j) take[jj] = take[jj] && (open2 || k[jj] < t2);
@@ -661,26 +671,158 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_refheap_kernel(const RefHea
         }
     }
     drain();
+}
+
+// One-shot form: a whole row of a dense band, or (row_offsets != null) a ragged candidate row whose position p stands for
+// sample col_ids[row_offsets[row] + p] -- the candidates in the order they are LISTED (the reference pushes in the order
+// Inverted::any_shared_bins returns them, mod.rs:459-487) -- padded with (row, 1.0) behind fewer than knn candidates
+// (mod.rs:535-546).
+__global__ __launch_bounds__(TOPK_THREADS) void topk_refheap_kernel(const RefHeapArgs g)
+{
+    __shared__ float lds_heap[3 * (REFHEAP_LDS_MAX + 1)];
+    __shared__ RefHeapShared sh;
+    const uint32_t row = blockIdx.x + g.first_row, tid = threadIdx.x;
+    const uint32_t knn = g.knn, stride2 = g.stride2;
+    const bool ragged = g.row_offsets != nullptr;
+    const uint64_t row_base = ragged ? g.row_offsets[row] : 0ull;
+    const uint32_t cols = ragged ? (uint32_t)(g.row_offsets[row + 1] - row_base) : g.cols;
+    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
+    const float *keys = ragged ? g.keys + row_base * stride2 : g.keys + (size_t)row * g.key_stride;
+    const uint32_t *ids = ragged ? g.col_ids + row_base : nullptr;
+    float *base = g.heap_scratch ? g.heap_scratch + (size_t)blockIdx.x * 3u * (knn + 1u) : lds_heap;
+    RefHeap h{base, base + (knn + 1u), reinterpret_cast<uint32_t *>(base + 2u * (knn + 1u)), 0u, stride2 == 2u};
     if (tid == 0) {
-        h.len = sh_len;
+        sh.len = 0;
+        sh.ncand = 0;
+        sh.thr = __builtin_inff();
+    }
+    __syncthreads();
+    if (cols != 0u) {
+        refheap_feed(h, sh, keys, stride2, cols, knn,
+                     [&](uint32_t q, uint32_t &id) {
+                         id = ids ? ids[q] : q;
+                         return q != self_id || ids != nullptr;
+                     },
+                     nullptr);
+    }
+    if (tid == 0) {
+        h.len = sh.len;
         h.into_sorted();
     }
     __syncthreads();
-    const uint32_t len = sh_len;
-    for (uint32_t x = tid; x < len; x += TOPK_THREADS) {
+    const uint32_t len = sh.len;
+    for (uint32_t x = tid; x < knn; x += TOPK_THREADS) {
         const size_t o = (size_t)row * knn + x;
-        g.out_idx[o] = h.id[x];
-        g.out_d0[o] = g.ani_undo ? 1.0f - h.key[x] : h.key[x];
-        if (stride2 == 2u && g.out_d1) g.out_d1[o] = h.d1[x];
+        if (x < len) {
+            g.out_idx[o] = h.id[x];
+            g.out_d0[o] = g.ani_undo ? 1.0f - h.key[x] : h.key[x];
+            if (stride2 == 2u && g.out_d1) g.out_d1[o] = h.d1[x];
+        } else if (ragged) {
+            g.out_idx[o] = row;
+            g.out_d0[o] = 1.0f;
+        }
     }
 }
 
 hipError_t launch_topk_refheap(const RefHeapArgs &args, hipStream_t stream)
 {
-    if (args.rows == 0 || args.cols == 0) return hipSuccess;
+    if (args.rows == 0 || (args.cols == 0 && args.row_offsets == nullptr)) return hipSuccess;
     if (args.knn == 0 || (args.knn > REFHEAP_LDS_MAX && args.heap_scratch == nullptr)) return hipErrorInvalidValue;
     if (args.stride2 != 1 && args.stride2 != 2) return hipErrorInvalidValue;
+    if (args.row_offsets != nullptr && (args.col_ids == nullptr || args.stride2 != 1)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_refheap_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+// Resumable form (the one-evaluation self kNN in the reference's tie order): a row's heap lives in global memory
+// between launches -- RefHeapMergeArgs -- and each launch continues the replay with the row's next batch of candidates.
+// The drivers feed a row its candidates in ascending sample id over the sequence of launches, which is the order the
+// reference pushes them in (mod.rs:156-181), so the heap goes through the same states.
+__global__ __launch_bounds__(TOPK_THREADS) void refheap_merge_kernel(const RefHeapMergeArgs g)
+{
+    __shared__ float lds_heap[3 * (REFHEAP_LDS_MAX + 1)];
+    __shared__ RefHeapShared sh;
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    if (g.flag != nullptr && g.flag[row] != g.flag_value) return;
+    const uint32_t knn = g.knn, stride2 = g.stride2;
+    const size_t srow = (size_t)(g.state_row_base + row);
+    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
+    RefHeap h{lds_heap, lds_heap + (knn + 1u), reinterpret_cast<uint32_t *>(lds_heap + 2u * (knn + 1u)), 0u, stride2 == 2u};
+    const uint32_t len0 = g.h_len[srow];
+    for (uint32_t x = tid; x < len0; x += TOPK_THREADS) {
+        h.key[x] = g.h_key[srow * knn + x];
+        h.id[x] = g.h_id[srow * knn + x];
+        if (stride2 == 2u) h.d1[x] = g.h_d1[srow * knn + x];
+    }
+    if (tid == 0) {
+        sh.len = len0;
+        sh.ncand = 0;
+    }
+    __syncthreads();
+    if (tid == 0) sh.thr = len0 < knn ? __builtin_inff() : h.key[0];
+    __syncthreads();
+    refheap_feed(h, sh, g.keys + (size_t)row * g.key_stride, stride2, g.cols, knn,
+                 [&](uint32_t q, uint32_t &id) {
+                     id = g.id_base + q;
+                     return id >= g.skip_below && id != self_id;
+                 },
+                 g.seg_bits ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr);
+    const uint32_t len = sh.len;
+    for (uint32_t x = tid; x < len; x += TOPK_THREADS) {
+        g.h_key[srow * knn + x] = h.key[x];
+        g.h_id[srow * knn + x] = h.id[x];
+        if (stride2 == 2u) g.h_d1[srow * knn + x] = h.d1[x];
+    }
+    if (tid == 0) {
+        g.h_len[srow] = len;
+        g.thr[srow] = len < knn ? 0xFFFFFFFFu : sortable_bits(h.key[0]);
+    }
+}
+
+hipError_t launch_refheap_merge(const RefHeapMergeArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0 || args.cols == 0) return hipSuccess;
+    if (args.knn == 0 || args.knn > REFHEAP_LDS_MAX) return hipErrorInvalidValue;
+    if (args.stride2 != 1 && !(args.stride2 == 2 && args.h_d1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(refheap_merge_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ... and its last step: into_sorted_vec of every row's heap -> the public output form.
+__global__ __launch_bounds__(64) void refheap_finalize_kernel(const float *h_key, const uint32_t *h_id, const float *h_d1, const uint32_t *h_len,
+                                                              uint32_t rows, uint32_t knn, int ani_undo, uint64_t *out_idx, float *out_d0,
+                                                              float *out_d1)
+{
+    __shared__ float lds_heap[3 * (REFHEAP_LDS_MAX + 1)];
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    RefHeap h{lds_heap, lds_heap + (knn + 1u), reinterpret_cast<uint32_t *>(lds_heap + 2u * (knn + 1u)), 0u, h_d1 != nullptr};
+    const uint32_t len = h_len[row];
+    for (uint32_t x = tid; x < len; x += 64u) {
+        h.key[x] = h_key[(size_t)row * knn + x];
+        h.id[x] = h_id[(size_t)row * knn + x];
+        if (h_d1) h.d1[x] = h_d1[(size_t)row * knn + x];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        h.len = len;
+        h.into_sorted();
+    }
+    __syncthreads();
+    for (uint32_t x = tid; x < len; x += 64u) {
+        const size_t o = (size_t)row * knn + x;
+        out_idx[o] = h.id[x];
+        out_d0[o] = ani_undo ? 1.0f - h.key[x] : h.key[x];
+        if (h_d1 && out_d1) out_d1[o] = h.d1[x];
+    }
+}
+
+hipError_t launch_refheap_finalize(const float *h_key, const uint32_t *h_id, const float *h_d1, const uint32_t *h_len, uint32_t rows,
+                                   uint32_t knn, int ani_undo, uint64_t *out_idx, float *out_d0, float *out_d1, hipStream_t stream)
+{
+    if (rows == 0) return hipSuccess;
+    if (knn == 0 || knn > REFHEAP_LDS_MAX || (h_d1 && !out_d1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(refheap_finalize_kernel, dim3(rows), dim3(64), 0, stream, h_key, h_id, h_d1, h_len, rows, knn, ani_undo,
+                       out_idx, out_d0, out_d1);
     return hipGetLastError();
 }
 

@@ -104,6 +104,49 @@ def test_several_bands_and_row_ranges(oracle, skl, gpu_ctx, ref_ties, set_switch
     g.close()
 
 
+@pytest.mark.parametrize("dist", ["jaccard", "ani", "coreacc"])
+@pytest.mark.parametrize("knn,band,flags", [(1, 48, "1"), (7, 64, "1"), (50, 100, "1"), (7, 37, "0")])
+def test_one_evaluation_driver_in_reference_order(oracle, skl, gpu_ctx, ref_ties, set_switch, dist, knn, band, flags):
+    """The whole self matrix with every pair evaluated ONCE (round 4): the heap of a row lives in global memory between the
+    bands and is fed the row's candidates in ascending id -- turned from the bands above its own, then its own band's
+    columns -- so it goes through the reference's states.  Band heights that are / are not multiples of the tile, with
+    and without the pair kernel's row and block flags."""
+    kmers, ss64, n = [17, 21, 25, 29], 4, 600
+    bins = synth.set_r(n, kmers, ss64, n_clusters=40)
+    set_switch("SKL_KNN_BAND_ROWS", band)
+    set_switch("SKL_KNN_ROW_FLAGS", flags)
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
+    _check_self(oracle, skl, gpu_ctx, bins, n, kmers, ss64, knn, dist, oracle.TIES_RUST_HEAP)
+    assert "k-sliced" in gpu_ctx.last_kernel() or "all k" in gpu_ctx.last_kernel()
+    # the row-by-row form (every pair twice, as the reference does) gives the same lists
+    set_switch("SKL_KNN_SYMMETRIC", "0")
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
+    _check_self(oracle, skl, gpu_ctx, bins, n, kmers, ss64, knn, dist, oracle.TIES_RUST_HEAP)
+
+
+@pytest.mark.parametrize("knn", [1, 7, 50, 199])
+def test_one_evaluation_driver_when_every_key_ties(oracle, skl, gpu_ctx, ref_ties, set_switch, knn):
+    kmers, ss64, n = [21], 4, 200
+    bins = np.tile(synth.set_u(1, 1, ss64), (n, 1))
+    set_switch("SKL_KNN_BAND_ROWS", 32)
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
+    _check_self(oracle, skl, gpu_ctx, bins, n, kmers, ss64, knn, "jaccard", oracle.TIES_RUST_HEAP)
+
+
+def test_one_evaluation_reference_order_on_random_sketches(oracle, skl, gpu_ctx, ref_ties):
+    """Default band rule (no switch): 12 000 random sketches are enough for the one-evaluation driver to be chosen."""
+    kmers, ss64, n, knn = [13, 17, 21], 8, 12000, 20
+    bins = synth.set_u(n, len(kmers), ss64)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    gpu_ctx.timing_reset()
+    idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(17), knn)
+    _ms, launches = gpu_ctx.kernel_ms()
+    assert launches >= 3, launches         # several bands
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"])
+    g.close()
+
+
 def test_default_mode_is_unchanged(oracle, skl, gpu_ctx):
     kmers, ss64, n, knn = [21], 4, 200, 7
     bins = np.tile(synth.set_u(1, 1, ss64), (n, 1))

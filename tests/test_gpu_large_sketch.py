@@ -119,6 +119,7 @@ def test_counts_scratch_is_bounded(oracle, skl, gpu_ctx):
     bins = synth.set_clustered_device(n, len(kmers), ss64, dev, cluster_size=50, keep=[0.97, 0.95, 0.93])
     g = gpu_ctx.sketches(bins, n, kmers, ss64)
     out = torch.zeros((n, n, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()      # (the fill runs on torch's stream, the library on the context's own)
     gpu_ctx.timing_reset()
     skl.cross_dists_all(gpu_ctx, g, g, g.set_k(), out=out)
     torch.cuda.synchronize()

@@ -100,6 +100,62 @@ def test_reordered_index_and_errors(oracle, skl, gpu_ctx):
     assert "single k-mer" in str(e.value)
 
 
+@pytest.fixture()
+def ref_ties(skl, gpu_ctx):
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
+    yield
+    gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+
+
+@pytest.mark.parametrize("ani", [False, True])
+def test_reference_tie_order_over_candidate_lists(oracle, skl, gpu_ctx, ref_ties, ani):
+    """skl_ctx_set_knn_ties(REFERENCE) on the candidate-list path: the reference's BinaryHeap replayed over each row's
+    candidates in the order they are listed (mod.rs:459-487: the order any_shared_bins returns them).  A database of
+    near-copies (most keys tie) with ragged lists; host lists and lists built on the device."""
+    kmers, ss64, n = [17, 21, 25], 2, 500
+    bins = synth.set_r(n, kmers, ss64, n_clusters=9)
+    bins[::3] = bins[0]                                          # a third of the database is one sketch: rows of ties
+    rng = np.random.default_rng(5)
+    skq = rng.integers(0, 40, size=(n, 5), dtype=np.uint16)      # small alphabet: ~60 candidates per row
+    skq[7] = 60000 + np.arange(5, dtype=np.uint16)               # no candidate at all
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    offs, cols = candidates(skq)
+    differs = False
+    for knn in (1, 4, 30):
+        idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21, ani), knn, offs, cols)
+        exp = oracle.self_dists_knn_precluster(o, skq, knn, 1, ani, ties=oracle.TIES_RUST_HEAP, threads=8)
+        assert as_pairs(idx, d0) == oracle_pairs(exp), knn
+        idx2, d02, _total = skl.self_dists_knn_shared_bins(gpu_ctx, g, g.set_k(21, ani), knn, skq)
+        assert np.array_equal(idx2, idx) and np.array_equal(d02, d0)
+        canon = oracle.self_dists_knn_precluster(o, skq, knn, 1, ani, ties=oracle.TIES_CANONICAL, threads=8)
+        differs = differs or oracle_pairs(canon) != oracle_pairs(exp)
+    assert differs, "the data set is meant to make the two tie rules disagree"
+    g.close()
+
+
+def test_reference_tie_order_with_a_reordered_index(oracle, skl, gpu_ctx, ref_ties):
+    """A .ski that orders the samples differently from the .skd: the reference pushes in ascending .ski index, so the
+    caller lists each row's candidates in that order (what the host driver does from the index)."""
+    kmers, ss64, n = [21], 2, 160
+    bins = synth.set_r(n, kmers, ss64, n_clusters=4)
+    bins[::2] = bins[1]
+    rng = np.random.default_rng(8)
+    skq = rng.integers(0, 30, size=(n, 4), dtype=np.uint16)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    perm = rng.permutation(n)                                    # ski position of skd sample i
+    skq_ski = np.empty_like(skq)
+    skq_ski[perm] = skq
+    offs, cols = candidates(skq)
+    cols_ski = cols.copy()
+    for i in range(n):                                           # each row in ascending .ski index
+        a, b = int(offs[i]), int(offs[i + 1])
+        cols_ski[a:b] = cols[a:b][np.argsort(perm[cols[a:b]], kind="stable")]
+    idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21), 12, offs, cols_ski)
+    exp = oracle.self_dists_knn_precluster(o, skq_ski, 12, 0, ski_of_skd=perm, ties=oracle.TIES_RUST_HEAP, threads=4)
+    assert as_pairs(idx, d0) == oracle_pairs(exp)
+    g.close()
+
+
 def test_device_candidate_lists_many_bins_and_samples(oracle, skl, gpu_ctx):
     """cand_gen.hip on its own terms: 5 000 samples (157 bitmap words per row, 20 per thread),
     300 bins (more bins than waves), values that collide in one bin only, a value shared by
