@@ -117,9 +117,10 @@ def test_counts_scratch_is_bounded(oracle, skl, gpu_ctx):
     kmers, ss64, n = [17, 21, 25], 1024, 20000
     dev = torch.device("cuda", 0)
     bins = synth.set_clustered_device(n, len(kmers), ss64, dev, cluster_size=50, keep=[0.97, 0.95, 0.93])
+    torch.cuda.synchronize()      # (torch fills on ITS stream; the session's context runs on a stream of its own)
     g = gpu_ctx.sketches(bins, n, kmers, ss64)
     out = torch.zeros((n, n, 2), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()      # (the fill runs on torch's stream, the library on the context's own)
+    torch.cuda.synchronize()
     gpu_ctx.timing_reset()
     skl.cross_dists_all(gpu_ctx, g, g, g.set_k(), out=out)
     torch.cuda.synchronize()
