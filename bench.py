@@ -287,7 +287,7 @@ def measure_traffic(n, dataset, timeout_s=120):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                   sys.executable, os.path.abspath(__file__), "--traffic-probe", "--samples", str(n), "--dataset", dataset]
+                   os.path.realpath(sys.executable), os.path.abspath(__file__), "--traffic-probe", "--samples", str(n), "--dataset", dataset]
             res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if res.returncode != 0 or not files:

@@ -9,8 +9,30 @@ set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
+if [ $# -lt 4 ]; then
+  echo "usage: $0 <tag> '<kernel regex>' <passes> -- python3 <script> [args...]" >&2
+  exit 2
+fi
 TAG=$1; KERNELS=$2; PASSES=$3; shift 3
-[ "$1" = "--" ] && shift
+[ "${1:-}" = "--" ] && shift
+if [ $# -lt 1 ]; then
+  echo "$0: no command after --" >&2
+  exit 2
+fi
+# The profiler's preloaded library initialises the GPU before the program starts (with --pmc it does), and on this
+# pool a process that has initialised the GPU must not exec another program: what follows `--` has to be the
+# interpreter BINARY itself (an ELF file), never env / bash -c / taskset / numactl or a `#!/usr/bin/env` script.
+PROG=$(command -v -- "$1" || true)
+PROG=$(readlink -f -- "${PROG:-$1}")
+case "$(basename -- "$PROG")" in
+  env|bash|sh|dash|taskset|numactl|nice|timeout|stdbuf) echo "$0: '$1' would exec the real program after the GPU is initialised: name the interpreter itself" >&2; exit 2;;
+esac
+if [ ! -x "$PROG" ] || [ "$(head -c 4 -- "$PROG" | od -An -c | tr -d ' ')" != "177ELF" ]; then
+  echo "$0: '$1' ($PROG) is not an ELF executable (a script's #! line is an exec hop too)" >&2
+  exit 2
+fi
+shift
+set -- "$PROG" "$@"
 [ "$PASSES" = "all" ] && PASSES=stats,fetch,write,sq,tcc,stall_a,stall_b
 [ "$PASSES" = "traffic" ] && PASSES=stats,fetch,write
 OUT=$R/gpurun_out/prof_$TAG

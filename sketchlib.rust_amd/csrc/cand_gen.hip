@@ -69,48 +69,112 @@ __global__ __launch_bounds__(CG_THREADS) void bin_scatter_kernel(const CandGenAr
 }
 
 // After the scatter cursor[b][v] is the END of the group that starts at starts[b][v].
+//
+// Round 4.  Round 3's form walked a row's bins one after the other, each a chain of three dependent loads (the row's
+// value -> the group's bounds -> its members, 64 four-byte loads per wave and trip): 82-86 % of the wave-cycles on
+// s_waitcnt, 0.18 of HBM's rate for the 78 KB of member lists a row of the benchmark reads.  Now:
+//   A. every bin's group bounds are looked up at once, one THREAD per bin (two dependent loads for the whole row), and
+//      parked in LDS;
+//   B. a wave takes U_BINS bins per trip and reads each group with ONE 16-byte load per lane (256 members per wave
+//      and load, aligned down to 16 bytes and masked by the group's bounds; longer groups loop) -- U_BINS independent
+//      loads in flight per lane before the first bitmap update of the trip;
+//   C. the per-thread counts are scanned with wave shuffles instead of a serial loop of thread 0.
+constexpr int CG_U_BINS = 4;
+constexpr uint32_t CG_BIN_BLOCK = 192;   // bins whose bounds are parked at a time (1.5 KB of LDS beside a bitmap of up to 158 KB)
+
 template <bool FILL>
 __global__ __launch_bounds__(CG_THREADS) void cand_rows_kernel(const CandGenArgs g)
 {
-    extern __shared__ uint32_t bitmap[];   // ceil(n / 32) words
-    __shared__ uint32_t part[CG_THREADS];
+    extern __shared__ uint32_t cg_lds[];   // [2 * CG_BIN_BLOCK] group bounds (later the waves' totals), then the bitmap: ceil(n / 32) words
     const uint32_t i = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t S = g.sketch_size;
+    uint32_t *gb = cg_lds, *ge = cg_lds + CG_BIN_BLOCK;
+    uint32_t *wave_tot = cg_lds;
+    uint32_t *bitmap = cg_lds + 2u * CG_BIN_BLOCK;
     const uint32_t n_words = (g.n + 31u) / 32u;
-    for (uint32_t w = tid; w < n_words; w += CG_THREADS) bitmap[w] = 0;
+    const uint32_t n_quads = (n_words + 3u) / 4u;
+    for (uint32_t q = tid; q < n_quads; q += CG_THREADS) reinterpret_cast<uint4 *>(bitmap)[q] = make_uint4(0u, 0u, 0u, 0u);
+    const uint16_t *sig = g.skq + (uint64_t)i * S;
+    constexpr uint32_t W = CG_THREADS / 64, U = CG_U_BINS;
+    for (uint32_t blk = 0; blk < S; blk += CG_BIN_BLOCK) {
+    const uint32_t SB = min(CG_BIN_BLOCK, S - blk);   // bins of this block
+    if (blk) __syncthreads();                          // the previous block's bounds have been used
+    // A: the bounds of this row's group in every bin of the block
+    for (uint32_t b = tid; b < SB; b += CG_THREADS) {
+        const uint64_t slot = (uint64_t)(blk + b) * 65536u + sig[blk + b];
+        gb[b] = g.starts[slot];
+        ge[b] = g.cursor[slot];
+    }
     __syncthreads();
-    const uint16_t *sig = g.skq + (uint64_t)i * g.sketch_size;
-    for (uint32_t b = wave; b < g.sketch_size; b += CG_THREADS / 64) {   // one wave per bin
-        const uint64_t slot = (uint64_t)b * 65536u + sig[b];
-        const uint32_t begin = g.starts[slot], end = g.cursor[slot];
-        const uint32_t *mem = g.members + (uint64_t)b * g.n;
-        for (uint32_t m = begin + lane; m < end; m += 64) {
-            const uint32_t j = mem[m];
-            atomicOr(&bitmap[j >> 5], 1u << (j & 31u));
+    // B: OR the members of every group into the bitmap
+    for (uint32_t b0 = wave; b0 < SB; b0 += W * U) {
+        uint4 v[U];
+        uint64_t e0[U];
+        uint32_t lo[U], hi[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t b = b0 + u * W;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            lo[u] = hi[u] = 0u;
+            e0[u] = 0ull;
+            if (b < SB) {   // (wave-uniform)
+                const uint64_t base = (uint64_t)(blk + b) * g.n;
+                const uint64_t first = (base + gb[b]) & ~3ull;     // element index of the 16-byte block the group starts in
+                e0[u] = first + 4ull * lane;                        // this lane's four elements
+                lo[u] = gb[b];
+                hi[u] = ge[b];
+                if (e0[u] < base + hi[u]) v[u] = *reinterpret_cast<const uint4 *>(g.members + e0[u]);
+            }
         }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t b = b0 + u * W;
+            if (b >= SB) continue;
+            const uint64_t base = (uint64_t)(blk + b) * g.n;
+            const uint64_t begin = base + lo[u], end = base + hi[u];
+            uint64_t e = e0[u];
+            uint4 x = v[u];
+            for (;;) {
+                const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    if (e + c >= begin && e + c < end) atomicOr(&bitmap[xs[c] >> 5], 1u << (xs[c] & 31u));
+                }
+                e += 256u;   // (groups of more than ~256 members: further trips of this wave)
+                if (e - 4ull * lane >= end) break;   // (wave-uniform: the trip's first element)
+                x = e < end ? *reinterpret_cast<const uint4 *>(g.members + e) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
     }
     __syncthreads();
     if (tid == 0) bitmap[i >> 5] &= ~(1u << (i & 31u));   // a sample is not its own candidate (mod.rs:458-461)
     __syncthreads();
-    // contiguous word range per thread, so that the output is ascending
+    // C: contiguous word range per thread, so that the output is ascending; exclusive scan of the per-thread counts
     const uint32_t per = (n_words + CG_THREADS - 1) / CG_THREADS;
     const uint32_t w0 = tid * per, w1 = (w0 + per < n_words) ? w0 + per : n_words;
     uint32_t cnt = 0;
     for (uint32_t w = w0; w < w1; ++w) cnt += __popc(bitmap[w]);
-    part[tid] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int t = 0; t < CG_THREADS; ++t) {
-            const uint32_t v = part[t];
-            part[t] = acc;
-            acc += v;
-        }
-        if (!FILL) g.counts[i] = acc;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
     }
-    if constexpr (FILL) {
-        __syncthreads();
-        uint32_t *out = g.cand + g.row_offsets[i] + part[tid];
+    if (lane == 63u) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - cnt;
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < W; ++w) {
+        if (w < wave) before += wave_tot[w];
+        total += wave_tot[w];
+    }
+    if constexpr (!FILL) {
+        if (tid == 0) g.counts[i] = total;
+    } else {
+        uint32_t *out = g.cand + g.row_offsets[i] + before;
         for (uint32_t w = w0; w < w1; ++w) {
             uint32_t bits = bitmap[w];
             while (bits) {
@@ -157,8 +221,9 @@ hipError_t launch_first_greater(const uint64_t *row_offsets, const uint32_t *can
 hipError_t launch_cand_rows(const CandGenArgs &g, bool fill, hipStream_t stream)
 {
     if (g.n == 0) return hipSuccess;
-    const size_t lds = (size_t)((g.n + 31u) / 32u) * sizeof(uint32_t);
-    if (lds > 158 * 1024) return hipErrorInvalidValue;
+    // the group bounds of a block of bins + the bitmap rounded up to whole 16-byte blocks
+    const size_t lds = ((size_t)2u * CG_BIN_BLOCK + (size_t)(((g.n + 31u) / 32u + 3u) & ~3u)) * sizeof(uint32_t);
+    if (lds > 158 * 1024 + 2 * CG_BIN_BLOCK * sizeof(uint32_t)) return hipErrorInvalidValue;
     if (fill) {
         (void)hipFuncSetAttribute((const void *)cand_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(cand_rows_kernel<true>, dim3(g.n), dim3(CG_THREADS), lds, stream, g);

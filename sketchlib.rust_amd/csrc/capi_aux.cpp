@@ -310,7 +310,7 @@ extern "C" int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *
     HIP_TRY(hipMalloc(&d_skq.p, n * sketch_size * sizeof(uint16_t)));
     HIP_TRY(hipMalloc(&d_starts.p, table));
     HIP_TRY(hipMalloc(&d_cursor.p, table));
-    HIP_TRY(hipMalloc(&d_members.p, n * sketch_size * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_members.p, n * sketch_size * sizeof(uint32_t) + 16));   // (+16: cand_rows_kernel reads whole 16-byte blocks)
     HIP_TRY(hipMalloc(&d_counts.p, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d_off.p, (n + 1) * sizeof(uint64_t)));
     HIP_TRY(hipMemcpyAsync(d_skq.p, skq, n * sketch_size * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
