@@ -60,7 +60,7 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
             return fail(SKL_ERR_INVALID_ARG, "sample ranges must not decrease");
         }
         uint64_t spans = (code_begin[s + 1] - code_begin[s] + span - 1) / span;
-        if (lds_form) spans = (spans + 255) / 256 * 256;   // whole workgroups per sample
+        if (lds_form) spans = (spans + (uint64_t)sketch_wg_lds() - 1) / (uint64_t)sketch_wg_lds() * (uint64_t)sketch_wg_lds();   // whole workgroups per sample
         span_begin[s + 1] = span_begin[s] + spans;
     }
     DevBuf d_codes, d_cb, d_offs, d_ob, d_sb, d_k, d_tf, d_tr, d_signs;
@@ -108,8 +108,8 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
         HIP_TRY(launch_sketch_signs(a, ctx->stream));
         if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
     }
-    ctx->last_kernel = lds_form ? "skl::nthash_binmin_lds_kernel (bases staged in LDS, 128 window starts per thread, rolling canonical "
-                                  "ntHash, bin minima in LDS)"
+    ctx->last_kernel = lds_form ? "skl::nthash_binmin_lds_kernel (bases staged in LDS as 2-bit codes, 128 window starts per thread, rolling "
+                                  "canonical ntHash through a fused 16-entry step table, bin minima in LDS)"
                                 : "skl::nthash_binmin_kernel (256 window starts per thread, rolling canonical ntHash, atomicMin per bin)";
     HIP_TRY(hipMemcpyAsync(out_signs, d_signs.p, sign_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

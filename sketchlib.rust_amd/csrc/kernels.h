@@ -205,13 +205,14 @@ struct SketchArgs {
     int32_t rc;
     uint64_t *signs;               // [n_samples][nk][num_bins], pre-set to UINT64_MAX
     // 1: LDS-staged kernel -- span_begin counts spans of sketch_span_lds() window starts, every
-    // sample's count padded to a multiple of 256 (a workgroup never straddles samples), every
+    // sample's count padded to a multiple of sketch_wg_lds() (a workgroup never straddles samples), every
     // k-mer length <= sketch_span_lds() + 1
     uint32_t lds_form;
 };
 hipError_t launch_sketch_signs(const SketchArgs &args, hipStream_t stream);
 int sketch_span();
 int sketch_span_lds();
+int sketch_wg_lds();   // threads (= spans) per workgroup of the LDS-staged kernel: a sample's span count is padded to a multiple
 
 // Candidate lists on the device (cand_gen.hip): any shared bin between index sketches.
 struct CandGenArgs {

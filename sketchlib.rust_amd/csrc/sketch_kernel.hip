@@ -119,26 +119,44 @@ __global__ __launch_bounds__(256) void nthash_binmin_kernel(const SketchArgs g)
 // ---------------------------------------------------------------------------------------------
 // LDS-staged form (the default).  The form above reads two bytes per window straight from
 // global memory, each lane from its own cache line, and checks the bin in global memory: ~190
-// cache-line requests per wave and window, which is what it runs at.  Here a workgroup owns 256
-// consecutive spans OF ONE SAMPLE (the host pads every sample's span count to a multiple of 256),
-// stages their bases once into LDS (row pitch 132 bytes: lanes that read the same column of
-// consecutive rows hit different banks) and walks them for every k-mer length; the bin minima of
+// cache-line requests per wave and window, which is what it runs at.  Here a workgroup owns
+// WG2 consecutive spans OF ONE SAMPLE (the host pads every sample's span count to a multiple of
+// WG2), stages their bases once into LDS and walks them for every k-mer length; the bin minima of
 // the current k-mer length live in LDS too (64-bit ds_min) and are flushed with one global
 // atomicMin per touched bin.
+//
+// Round 4 (round 3's form: 140 VALU lane-instructions per window, 0.30 of the VALU issue peak, 42 % of the
+// wave-cycles waiting at 2 waves per SIMD):
+//   * the bases are staged PACKED, 16 two-bit codes per dword (row pitch 9 dwords: lanes that read the same
+//     column of consecutive rows hit different banks): 18 KB instead of 34 KB per 256 threads, so a workgroup
+//     of 512 threads + its 32 KB of bin minima fit a CU three times (6 waves per SIMD instead of 2);
+//   * a thread keeps the codes that leave and enter its next 16 windows in two registers (one LDS dword
+//     and one v_alignbit per stream and 16 windows) instead of two byte reads with their address
+//     arithmetic per window;
+//   * srol / sror are linear over XOR, so  fh' = srol(fh ^ top_f[old]) ^ seed_f[new] = srol(fh) ^ Tf[old][new]
+//     and  rh' = sror(rh) ^ Tr[old][new]:  the four 4-way 64-bit selects per window become ONE 16-byte LDS
+//     read from a 16-entry table per k-mer length;
+//   * a window that spans a break (N, record end) is not hashed into a bin, but the hashes roll on through
+//     it -- `codes` holds valid bases only, so the roll stays exact -- and nothing is re-seeded after a break
+//     (one seed of k steps per thread and k-mer length);
+//   * the bin of a sign comes from the reciprocal estimate and ONE 64-bit multiply (the estimate is off by at
+//     most one: the two `while` loops of round 3 evaluated two).
 // ---------------------------------------------------------------------------------------------
 
 constexpr int SPAN2 = 128;                    // window starts per thread
-constexpr int PITCH2 = SPAN2 + 4;             // bytes per staged row
-constexpr int ROWS2 = 256 + 1;                // one more row: a window reaches k - 1 <= SPAN2 bytes past its span
+constexpr int WG2 = 512;                      // threads (= spans) per workgroup
+constexpr int PITCH2_DW = SPAN2 / 16 + 1;     // dwords per staged row (8 of codes + 1 of padding)
+constexpr int ROWS2 = WG2 + 1;                // one more row: a window reaches k - 1 <= SPAN2 codes past its span
 constexpr int LDS_BINS_MAX = 4096;
 
 template <bool LDS_BINS>
-__global__ __launch_bounds__(256) void nthash_binmin_lds_kernel(const SketchArgs g)
+__global__ __launch_bounds__(WG2) void nthash_binmin_lds_kernel(const SketchArgs g)
 {
-    __shared__ uint8_t staged[ROWS2 * PITCH2];
+    __shared__ uint32_t staged[ROWS2 * PITCH2_DW];
+    __shared__ uint4 tabs[16];                 // {Tf.lo, Tf.hi, Tr.lo, Tr.hi} by (old << 2) | new, for the current k-mer length
     __shared__ unsigned long long lbins[LDS_BINS ? LDS_BINS_MAX : 1];
     const uint32_t tid = threadIdx.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * 256u;   // first span of this workgroup
+    const uint64_t t0 = (uint64_t)blockIdx.x * WG2;   // first span of this workgroup
     uint32_t lo = 0, hi = g.n_samples;
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -152,30 +170,54 @@ __global__ __launch_bounds__(256) void nthash_binmin_lds_kernel(const SketchArgs
     const uint64_t wg0 = (t0 - g.span_begin[sample]) * SPAN2;   // first base of the workgroup
     if (wg0 >= n_codes) return;                                // (padding spans of the sample)
     const uint64_t wg1 = wg0 + (uint64_t)ROWS2 * SPAN2 < n_codes ? wg0 + (uint64_t)ROWS2 * SPAN2 : n_codes;
-    for (uint32_t x = tid; x < (uint32_t)(wg1 - wg0); x += 256u) {
-        staged[(x >> 7) * PITCH2 + (x & 127u)] = codes[wg0 + x];
+    const uint32_t n_staged = (uint32_t)(wg1 - wg0);
+    // stage: one packed dword (16 codes) per thread and trip
+    for (uint32_t d = tid; d < (uint32_t)ROWS2 * (SPAN2 / 16); d += WG2) {
+        uint32_t word = 0;
+        const uint32_t x0 = d * 16u;
+        if (x0 < n_staged) {
+            const uint8_t *src = codes + wg0 + x0;
+            const uint32_t m = n_staged - x0 < 16u ? n_staged - x0 : 16u;
+            if (m == 16u && (((uintptr_t)src) & 3u) == 0u) {
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);   // (4-byte aligned)
+                const uint32_t w4[4] = {s32[0], s32[1], s32[2], s32[3]};
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const uint32_t v = w4[c] & 0x03030303u;              // four codes, one per byte
+                    word |= ((v & 3u) | ((v >> 6) & 0xCu) | ((v >> 12) & 0x30u) | ((v >> 18) & 0xC0u)) << (8u * c);
+                }
+            } else {
+                for (uint32_t c = 0; c < m; ++c) word |= (uint32_t)(src[c] & 3u) << (2u * c);
+            }
+        }
+        staged[(d >> 3) * PITCH2_DW + (d & 7u)] = word;
     }
     if (LDS_BINS) {
-        for (uint32_t b = tid; b < (uint32_t)g.num_bins; b += 256u) lbins[b] = ~0ull;
+        for (uint32_t b = tid; b < (uint32_t)g.num_bins; b += WG2) lbins[b] = ~0ull;
     }
-    __syncthreads();
-    auto code_at = [&](uint64_t pos) -> uint32_t {   // base at sample position pos (inside the staged range)
-        const uint32_t x = (uint32_t)(pos - wg0);
-        return staged[(x >> 7) * PITCH2 + (x & 127u)];
-    };
+    // flat dword m of the staged codes (dword m holds codes 16 m .. 16 m + 15 from wg0)
+    auto dword_at = [&](uint32_t m) -> uint32_t { return staged[(m >> 3) * PITCH2_DW + (m & 7u)]; };
+    auto code_at = [&](uint32_t x) -> uint32_t { return (dword_at(x >> 4) >> ((x & 15u) * 2u)) & 3u; };   // code x from wg0
     const uint64_t p0 = wg0 + (uint64_t)tid * SPAN2;
-    const uint64_t p1 = p0 + SPAN2 < n_codes ? p0 + SPAN2 : n_codes;
+    const uint32_t x0 = tid * SPAN2;              // this thread's first code, from wg0
+    const uint32_t last_bin = (uint32_t)(g.num_bins - 1u);
 
     for (uint32_t ki = 0; ki < g.nk; ++ki) {
         const uint32_t k = g.kmers[ki];
-        uint64_t top_f[4], top_r[4];
-#pragma unroll
-        for (uint32_t b = 0; b < 4; ++b) {
-            top_f[b] = g.top_f[ki * 4 + b];
-            top_r[b] = g.top_r[ki * 4 + b];
+        __syncthreads();   // staged / lbins ready (first k); everyone done with the previous k's table
+        if (tid < 16u) {
+            const uint32_t old_b = tid >> 2, new_b = tid & 3u;
+            const uint64_t tf = srol(g.top_f[ki * 4 + old_b]) ^ hash_fwd(new_b);
+            const uint64_t tr = sror(hash_rc(old_b)) ^ g.top_r[ki * 4 + new_b];
+            tabs[tid] = make_uint4((uint32_t)tf, (uint32_t)(tf >> 32), (uint32_t)tr, (uint32_t)(tr >> 32));
         }
+        __syncthreads();
         uint64_t *bins = g.signs + ((uint64_t)sample * g.nk + ki) * g.num_bins;
-        if (p0 < n_codes) {
+        // windows of this thread: starts p0 .. p0 + n_win - 1 (a start needs k codes of the sample)
+        const uint64_t last_start_excl = n_codes >= k ? n_codes - k + 1u : 0u;
+        const uint32_t n_win = p0 < last_start_excl ? (uint32_t)(last_start_excl - p0 < SPAN2 ? last_start_excl - p0 : SPAN2) : 0u;
+        if (n_win != 0u) {
+            // first break strictly after p0; positions from here on are relative to p0 (32-bit)
             uint32_t oi;
             {
                 uint32_t a = 0, b = n_offs;   // first index with offs[idx] > p0
@@ -185,55 +227,73 @@ __global__ __launch_bounds__(256) void nthash_binmin_lds_kernel(const SketchArgs
                 }
                 oi = a;
             }
-            uint64_t next_off = oi < n_offs ? offs[oi] : n_codes;
-            bool have = false;
+            constexpr uint32_t FAR = 0x7FFFFFFFu;
+            auto rel = [&](uint32_t idx) -> uint32_t {
+                if (idx >= n_offs) return FAR;
+                const uint64_t d = offs[idx] - p0;
+                return d < (uint64_t)FAR ? (uint32_t)d : FAR;
+            };
+            uint32_t next_rel = rel(oi);   // first break after window start j (relative): the window is hashed iff j + k <= next_rel
+            // seed: the window at p0 (nthash_iterator.rs: forward fold, reverse-complement fold from the far end)
             uint64_t fh = 0, rh = 0;
-            for (uint64_t s = p0; s < p1; ++s) {
-                if (next_off <= s) {
-                    while (oi < n_offs && offs[oi] <= s) ++oi;
-                    next_off = oi < n_offs ? offs[oi] : n_codes;
-                }
-                if (s + k > next_off) {   // the window would span a break (next_iterator, :325-346)
-                    have = false;
-                    continue;
-                }
-                if (have) {
-                    const uint32_t old_b = code_at(s - 1), new_b = code_at(s + k - 1);
-                    fh = srol(fh ^ top_f[old_b]) ^ hash_fwd(new_b);
-                    if (g.rc) rh = sror(rh ^ hash_rc(old_b)) ^ top_r[new_b];
-                } else {
-                    fh = 0;
-                    rh = 0;
-                    for (uint32_t i = 0; i < k; ++i) fh = srol(fh) ^ hash_fwd(code_at(s + i));
-                    if (g.rc) {
-                        for (uint32_t i = k; i-- > 0;) rh = srol(rh) ^ hash_rc(code_at(s + i));
+            for (uint32_t i = 0; i < k; ++i) fh = srol(fh) ^ hash_fwd(code_at(x0 + i));
+            if (g.rc) {
+                for (uint32_t i = k; i-- > 0;) rh = srol(rh) ^ hash_rc(code_at(x0 + i));
+            }
+            const uint32_t a = k - 1u;                        // lag of the entering code
+            const uint32_t da = a >> 4, pa = (a & 15u) * 2u;
+            uint32_t d_prev = 0u;                             // dword x0/16 + q - 1 of the leaving stream (unused for q = 0)
+            uint32_t e_prev = dword_at((x0 >> 4) + da);       // dword of the entering stream
+            for (uint32_t q = 0; q < SPAN2 / 16 && q * 16u < n_win; ++q) {
+                const uint32_t d_cur = dword_at((x0 >> 4) + q);
+                // (k = 129: the entering stream starts exactly one row on and its last look-ahead dword is not used -- nor staged)
+                const uint32_t e_cur = dword_at(min((x0 >> 4) + q + da + 1u, (uint32_t)(ROWS2 * (SPAN2 / 16)) - 1u));
+                // 16 codes from index 16 q - 1 (leaving) and 16 q + k - 1 (entering) of this thread's row
+                const uint32_t old_reg = __builtin_amdgcn_alignbit(d_cur, d_prev, 30);
+                const uint32_t new_reg = pa ? __builtin_amdgcn_alignbit(e_cur, e_prev, pa) : e_prev;
+                d_prev = d_cur;
+                e_prev = e_cur;
+#pragma unroll
+                for (uint32_t jj = 0; jj < 16u; ++jj) {
+                    const uint32_t j = q * 16u + jj;
+                    if (j >= n_win) break;
+                    if (j != 0u) {   // roll from window j - 1 to window j
+                        const uint32_t idx = (((old_reg >> (2u * jj)) & 3u) << 2) | ((new_reg >> (2u * jj)) & 3u);
+                        const uint4 t = tabs[idx];
+                        fh = srol(fh) ^ (((uint64_t)t.y << 32) | t.x);
+                        if (g.rc) rh = sror(rh) ^ (((uint64_t)t.w << 32) | t.z);
                     }
-                    have = true;
-                }
-                const uint64_t h = g.rc ? (fh < rh ? fh : rh) : fh;      // nthash_iterator.rs:62-68
-                const uint64_t sign = mod_sign(h);
-                // bin = sign / bin_size: reciprocal estimate, then exact fix-up
-                uint64_t bin = (uint64_t)((double)sign * g.inv_bin_size);
-                if (bin >= g.num_bins) bin = g.num_bins - 1;
-                while (bin * g.bin_size > sign) --bin;
-                while ((bin + 1) * g.bin_size <= sign) ++bin;
-                if (LDS_BINS) {
-                    if (sign < lbins[bin]) atomicMin(&lbins[bin], (unsigned long long)sign);
-                } else {
-                    if (sign < bins[bin]) atomicMin((unsigned long long *)&bins[bin], (unsigned long long)sign);
+                    if (next_rel <= j) {   // (breaks are rare: a few per span at most)
+                        while (oi < n_offs && offs[oi] <= p0 + j) ++oi;
+                        next_rel = rel(oi);
+                    }
+                    if (j + k > next_rel) continue;   // the window spans a break (next_iterator, :325-346): not hashed into a bin
+                    const uint64_t h = g.rc ? (fh < rh ? fh : rh) : fh;      // nthash_iterator.rs:62-68
+                    const uint64_t sign = mod_sign(h);
+                    // bin = sign / bin_size: the reciprocal estimate is off by at most one (relative error 2^-52 on a
+                    // quotient below 2^32), one exact product settles it
+                    uint32_t bin = (uint32_t)((double)sign * g.inv_bin_size);
+                    if (bin > last_bin) bin = last_bin;
+                    const uint64_t prod = (uint64_t)bin * g.bin_size;
+                    if (prod > sign) --bin;
+                    else if (sign - prod >= g.bin_size && bin < last_bin) ++bin;
+                    if (LDS_BINS) {
+                        if (sign < lbins[bin]) atomicMin(&lbins[bin], (unsigned long long)sign);
+                    } else {
+                        if (sign < bins[bin]) atomicMin((unsigned long long *)&bins[bin], (unsigned long long)sign);
+                    }
                 }
             }
         }
         if (LDS_BINS) {   // one global atomic per bin this workgroup touched
             __syncthreads();
-            for (uint32_t b = tid; b < (uint32_t)g.num_bins; b += 256u) {
+            for (uint32_t b = tid; b < (uint32_t)g.num_bins; b += WG2) {
                 const unsigned long long v = lbins[b];
                 if (v != ~0ull) {
                     if (v < bins[b]) atomicMin((unsigned long long *)&bins[b], v);
                     lbins[b] = ~0ull;
                 }
             }
-            __syncthreads();
         }
     }
 }
@@ -241,13 +301,14 @@ __global__ __launch_bounds__(256) void nthash_binmin_lds_kernel(const SketchArgs
 hipError_t launch_sketch_signs(const SketchArgs &args, hipStream_t stream)
 {
     if (args.n_spans == 0) return hipSuccess;
-    const uint64_t blocks = (args.n_spans + 255) / 256;
+    const uint64_t wg = args.lds_form ? (uint64_t)WG2 : 256u;
+    const uint64_t blocks = (args.n_spans + wg - 1) / wg;
     if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
     if (args.lds_form) {
         if (args.num_bins <= (uint64_t)LDS_BINS_MAX) {
-            hipLaunchKernelGGL(nthash_binmin_lds_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+            hipLaunchKernelGGL(nthash_binmin_lds_kernel<true>, dim3((unsigned)blocks), dim3(WG2), 0, stream, args);
         } else {
-            hipLaunchKernelGGL(nthash_binmin_lds_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+            hipLaunchKernelGGL(nthash_binmin_lds_kernel<false>, dim3((unsigned)blocks), dim3(WG2), 0, stream, args);
         }
     } else {
         hipLaunchKernelGGL(nthash_binmin_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, args);
@@ -257,5 +318,6 @@ hipError_t launch_sketch_signs(const SketchArgs &args, hipStream_t stream)
 
 int sketch_span() { return SKETCH_SPAN; }
 int sketch_span_lds() { return SPAN2; }
+int sketch_wg_lds() { return WG2; }
 
 }  // namespace skl
