@@ -43,12 +43,13 @@ struct DistArgs {
     bool verbose = false, quiet = false;
     std::vector<int> devices = {0};   // --device D | --devices a,b,.. | --gpus N
     bool npy = false;                  // --npy: dense output as a NumPy .npy array instead of text
-    size_t band_bytes = 256ull << 20;  // --band-mb: host memory per streamed output band
+    size_t band_bytes = 0;             // --band-mb: host memory per streamed output band (0: default)
     size_t band() const
     {
         // finer-than-MB override, for tests that want many bands on a small database
         if (const char *e = std::getenv("SKL_DIST_BAND_BYTES")) return std::max<size_t>(1, std::strtoull(e, nullptr, 10));
-        return band_bytes;
+        // default: 256 MB, and at least 8 MB per output thread (a band is a barrier for the workers that format it)
+        return band_bytes ? band_bytes : std::max<size_t>(256ull << 20, threads * (8ull << 20));
     }
 };
 
@@ -89,7 +90,7 @@ void print_help()
         "      --device <D>                GPU to run on [default: 0]\n"
         "      --npy                       Dense output as a NumPy .npy array (f32, one row per pair in the\n"
         "                                  order of the text lines) instead of text; needs -o\n"
-        "      --band-mb <MB>              Host memory per streamed dense output band [default: 256]\n"
+        "      --band-mb <MB>              Host memory per streamed dense output band [default: 256, and at least 8 per thread]\n"
         "      --gpus <N>                  Split the pair space over GPUs 0..N-1 (row bands)\n"
         "      --devices <LIST>            Same, with an explicit comma separated device list\n"
         "  -v, --verbose                   Show progress messages\n"

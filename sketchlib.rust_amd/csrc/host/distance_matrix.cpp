@@ -5,6 +5,8 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <chrono>
@@ -209,10 +211,99 @@ void FileSink::finish(uint64_t off, const char *p, size_t len)
     }
 }
 
-// Blocks 0..n_blocks-1 formatted by `threads` workers (each into a private reusable buffer)
-// and handed to the sink in block order: threads take blocks from a shared counter, format,
-// then pass through an ordered section (stream: write there; file: reserve the byte range there
-// and pwrite outside it).
+// Output workers that live for the whole process: a streamed listing hands them one band after the other (160 bands of
+// 256 MB at 100 000 genomes), and a worker's text buffer -- a megabyte and more, grown by need() -- is faulted in ONCE
+// instead of once per band (round 3 started `threads` fresh threads with fresh buffers for every band: at 256 threads
+// the page faults and the condition-variable wake-ups of the ordered section were 55 of the 68 s the text listing of
+// BASELINE configs[2] took, profiles/r04_e2e_cfg3.txt).
+namespace {
+class OutputPool {
+  public:
+    static OutputPool &instance()
+    {
+        static OutputPool pool;
+        return pool;
+    }
+    // fn(tid) on workers 0 .. threads-1 (the caller runs as worker 0); returns when all are done.  Not re-entrant.
+    void run(size_t threads, const std::function<void(size_t)> &fn)
+    {
+        threads = std::max<size_t>(1, threads);
+        if (threads == 1) {
+            fn(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (workers_.size() + 1 < threads) {
+                const size_t tid = workers_.size() + 1;
+                workers_.emplace_back([this, tid] { loop(tid); });
+            }
+            job_ = &fn;
+            job_threads_ = threads;
+            pending_ = threads - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    TextBlock &block(size_t tid)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (blocks_.size() <= tid) blocks_.resize(tid + 1);
+        if (!blocks_[tid]) blocks_[tid] = std::make_unique<TextBlock>();
+        return *blocks_[tid];
+    }
+    ~OutputPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+
+  private:
+    void loop(size_t tid)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                if (tid < job_threads_) job = job_;
+            }
+            if (!job) continue;
+            (*job)(tid);
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                last = --pending_ == 0;
+            }
+            if (last) done_cv_.notify_one();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    std::vector<std::unique_ptr<TextBlock>> blocks_;
+    const std::function<void(size_t)> *job_ = nullptr;
+    size_t job_threads_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+}  // namespace
+
+// Blocks 0..n_blocks-1 formatted by `threads` workers (each into its own reusable buffer) and handed to the sink in
+// block order: workers take blocks from a shared counter, format, then pass through an ordered section (stream: write
+// there; file: reserve the byte range there and pwrite outside it).  The order is a ticket the workers poll (yielding):
+// a condition variable woke every waiting worker for every block.
 template <class Format>
 static void write_blocks_in_order(TextSink &sink, size_t n_blocks, size_t threads, Format format)
 {
@@ -220,49 +311,36 @@ static void write_blocks_in_order(TextSink &sink, size_t n_blocks, size_t thread
     threads = std::max<size_t>(1, std::min(threads, n_blocks));
     const double t_begin = now_s();
     std::atomic<size_t> next{0};
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t turn = 0;          // block whose ordered section may run
-    bool failed = false;
+    std::atomic<size_t> turn{0};          // block whose ordered section may run
+    std::atomic<bool> failed{false};
+    std::mutex err_mu;
     std::exception_ptr err;
     std::vector<double> sink_s(threads, 0.0);
-    auto work = [&](size_t tid) {
-        TextBlock block;
+    OutputPool &pool = OutputPool::instance();
+    pool.run(threads, [&](size_t tid) {
+        TextBlock &block = pool.block(tid);
         try {
             for (;;) {
                 const size_t b = next.fetch_add(1);
-                if (b >= n_blocks) break;
+                if (b >= n_blocks || failed.load(std::memory_order_relaxed)) break;
                 block.len = 0;
                 format(b, block);
                 const double t0 = now_s();
-                uint64_t token;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return turn == b || failed; });
-                    if (failed) return;
-                    token = sink.begin(block.p, block.len);
-                    turn = b + 1;
+                for (unsigned spins = 0; turn.load(std::memory_order_acquire) != b; ++spins) {
+                    if (failed.load(std::memory_order_relaxed)) return;
+                    if (spins > 64) std::this_thread::yield();
                 }
-                cv.notify_all();
+                const uint64_t token = sink.begin(block.p, block.len);
+                turn.store(b + 1, std::memory_order_release);
                 sink.finish(token, block.p, block.len);
                 sink_s[tid] += now_s() - t0;
             }
         } catch (...) {
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (!failed) err = std::current_exception();
-                failed = true;
-            }
-            cv.notify_all();
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (!err) err = std::current_exception();
+            failed.store(true);
         }
-    };
-    if (threads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < threads; ++t) pool.emplace_back(work, t);
-        for (auto &t : pool) t.join();
-    }
+    });
     if (err) std::rethrow_exception(err);
     // wall time of this call, split by the share of thread time spent in/waiting for the sink
     const double wall = now_s() - t_begin;
@@ -271,6 +349,39 @@ static void write_blocks_in_order(TextSink &sink, size_t n_blocks, size_t thread
     sink_share = std::min(1.0, sink_share / (wall * (double)threads + 1e-12));
     output_timing().sink_s += wall * sink_share;
     output_timing().format_s += wall * (1.0 - sink_share);
+}
+
+// Raw bytes (a band of a .npy array) to the sink: one reservation, then the workers write 8 MB pieces at their
+// offsets -- a single writer copies into the page cache at ~7 GB/s, which was 5.6 of the 6.9 s `--npy` took at
+// BASELINE configs[2] (profiles/r04_e2e_cfg3.txt).  A stream sink takes the whole range in begin().
+void write_raw(TextSink &sink, const char *bytes, size_t len, size_t threads)
+{
+    if (len == 0) return;
+    const uint64_t token = sink.begin(bytes, len);
+    constexpr size_t PIECE = 8u << 20;
+    const size_t n_pieces = (len + PIECE - 1) / PIECE;
+    threads = std::max<size_t>(1, std::min(threads, n_pieces));
+    if (threads == 1 || !sink.positional()) {
+        sink.finish(token, bytes, len);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::mutex err_mu;
+    std::exception_ptr err;
+    OutputPool::instance().run(threads, [&](size_t) {
+        try {
+            for (;;) {
+                const size_t x = next.fetch_add(1);
+                if (x >= n_pieces) break;
+                const size_t at = x * PIECE;
+                sink.finish(token + at, bytes + at, std::min(PIECE, len - at));
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (!err) err = std::current_exception();
+        }
+    });
+    if (err) std::rethrow_exception(err);
 }
 
 void DistanceMatrix::write(std::ostream &os, size_t threads) const

@@ -52,7 +52,11 @@ class TextSink {
     virtual uint64_t begin(const char *p, size_t len) = 0;
     // Called after begin() for the same block, from any thread, in any order.
     virtual void finish(uint64_t /*token*/, const char * /*p*/, size_t /*len*/) {}
+    // true: the token is a byte offset and finish(token + d, p + d, len - d) may be called piecewise (a regular file)
+    virtual bool positional() const { return false; }
 };
+// `len` raw bytes to the sink (a band of a .npy array), written by up to `threads` workers when the sink is positional.
+void write_raw(TextSink &sink, const char *bytes, size_t len, size_t threads);
 class StreamSink : public TextSink {
   public:
     explicit StreamSink(std::ostream &os) : os_(os) {}
@@ -66,6 +70,7 @@ class FileSink : public TextSink {
     ~FileSink() override;
     uint64_t begin(const char *p, size_t len) override;
     void finish(uint64_t token, const char *p, size_t len) override;
+    bool positional() const override { return true; }
   private:
     int fd_ = -1;
     uint64_t offset_ = 0;
