@@ -130,8 +130,7 @@ static void format_rows(const DistanceMatrix &m, size_t r0, size_t r1, const flo
     const bool coreacc = m.jaccard.kind == DistType::CoreAcc;
     const size_t ncols = coreacc ? 2 : 1;
     const size_t n = m.ref_names.size();
-    out.len = 0;
-    for (size_t i = r0; i < r1; ++i) {
+    for (size_t i = r0; i < r1; ++i) {   // (appends to `out`)
         size_t dist_idx;
         size_t j_begin, j_end;
         if (m.query_names) {
@@ -300,55 +299,79 @@ class OutputPool {
 };
 }  // namespace
 
-// Blocks 0..n_blocks-1 formatted by `threads` workers (each into its own reusable buffer) and handed to the sink in
-// block order: workers take blocks from a shared counter, format, then pass through an ordered section (stream: write
-// there; file: reserve the byte range there and pwrite outside it).  The order is a ticket the workers poll (yielding):
-// a condition variable woke every waiting worker for every block.
+// Blocks 0..n_blocks-1 of text to the sink, in block order, formatted by `threads` workers.  `format(b, out)` APPENDS
+// block b to `out`.  Groups of up to 8 blocks per worker go through two phases with nothing ordered inside either:
+//   1. the workers take blocks from a shared counter and format them one behind the other into their own buffers;
+//   2. the lengths give every block its place: a positional sink (file) reserves the group's byte range once and the
+//      workers pwrite their own blocks there; a stream gets the blocks in order from the calling thread.
+// (Rounds 2-3 passed every block through an ordered section, condition variable or ticket: with 256 workers that
+// section -- 150 000 blocks at 100 000 genomes -- was most of the listing's wall time, profiles/r04_e2e_cfg3.txt.)
 template <class Format>
 static void write_blocks_in_order(TextSink &sink, size_t n_blocks, size_t threads, Format format)
 {
     if (n_blocks == 0) return;
     threads = std::max<size_t>(1, std::min(threads, n_blocks));
-    const double t_begin = now_s();
-    std::atomic<size_t> next{0};
-    std::atomic<size_t> turn{0};          // block whose ordered section may run
-    std::atomic<bool> failed{false};
+    OutputPool &pool = OutputPool::instance();
+    struct Piece {
+        size_t worker, off, len;
+    };
+    constexpr size_t BLOCKS_PER_WORKER = 8;
+    const size_t group = threads * BLOCKS_PER_WORKER;
+    std::vector<Piece> pieces(std::min(group, n_blocks));
+    std::vector<uint64_t> place(pieces.size());
     std::mutex err_mu;
     std::exception_ptr err;
-    std::vector<double> sink_s(threads, 0.0);
-    OutputPool &pool = OutputPool::instance();
-    pool.run(threads, [&](size_t tid) {
-        TextBlock &block = pool.block(tid);
+    auto guarded = [&](auto &&body) {
         try {
-            for (;;) {
-                const size_t b = next.fetch_add(1);
-                if (b >= n_blocks || failed.load(std::memory_order_relaxed)) break;
-                block.len = 0;
-                format(b, block);
-                const double t0 = now_s();
-                for (unsigned spins = 0; turn.load(std::memory_order_acquire) != b; ++spins) {
-                    if (failed.load(std::memory_order_relaxed)) return;
-                    if (spins > 64) std::this_thread::yield();
-                }
-                const uint64_t token = sink.begin(block.p, block.len);
-                turn.store(b + 1, std::memory_order_release);
-                sink.finish(token, block.p, block.len);
-                sink_s[tid] += now_s() - t0;
-            }
+            body();
         } catch (...) {
             std::lock_guard<std::mutex> lk(err_mu);
             if (!err) err = std::current_exception();
-            failed.store(true);
         }
-    });
-    if (err) std::rethrow_exception(err);
-    // wall time of this call, split by the share of thread time spent in/waiting for the sink
-    const double wall = now_s() - t_begin;
-    double sink_share = 0;
-    for (double v : sink_s) sink_share += v;
-    sink_share = std::min(1.0, sink_share / (wall * (double)threads + 1e-12));
-    output_timing().sink_s += wall * sink_share;
-    output_timing().format_s += wall * (1.0 - sink_share);
+    };
+    for (size_t g0 = 0; g0 < n_blocks; g0 += group) {
+        const size_t g1 = std::min(n_blocks, g0 + group);
+        const double t0 = now_s();
+        std::atomic<size_t> next{g0};
+        pool.run(threads, [&](size_t tid) {
+            guarded([&] {
+                TextBlock &buf = pool.block(tid);
+                buf.len = 0;
+                for (;;) {
+                    const size_t b = next.fetch_add(1);
+                    if (b >= g1) break;
+                    const size_t start = buf.len;
+                    format(b, buf);
+                    pieces[b - g0] = Piece{tid, start, buf.len - start};
+                }
+            });
+        });
+        if (err) std::rethrow_exception(err);
+        const double t1 = now_s();
+        output_timing().format_s += t1 - t0;
+        if (sink.positional()) {
+            uint64_t total = 0;
+            for (size_t x = 0; x < g1 - g0; ++x) {
+                place[x] = total;
+                total += pieces[x].len;
+            }
+            const uint64_t token = sink.begin(nullptr, total);
+            pool.run(threads, [&](size_t tid) {
+                guarded([&] {
+                    const TextBlock &buf = pool.block(tid);
+                    for (size_t x = 0; x < g1 - g0; ++x) {
+                        if (pieces[x].worker == tid && pieces[x].len) sink.finish(token + place[x], buf.p + pieces[x].off, pieces[x].len);
+                    }
+                });
+            });
+            if (err) std::rethrow_exception(err);
+        } else {
+            for (size_t x = 0; x < g1 - g0; ++x) {
+                if (pieces[x].len) sink.begin(pool.block(pieces[x].worker).p + pieces[x].off, pieces[x].len);
+            }
+        }
+        output_timing().sink_s += now_s() - t1;
+    }
 }
 
 // Raw bytes (a band of a .npy array) to the sink: one reservation, then the workers write 8 MB pieces at their

@@ -232,10 +232,13 @@ def test_multi_context_synthetic(gpu_ctx, tmp_path):
     assert run(prefix, "--knn", "10", "--devices", "0,0,0") == knn
     # several bands per device: every pair is evaluated once across the devices, the partial
     # top-k states are merged shard by shard (single-k and core/accessory keys)
+    # (--knn-ties canonical: the one-evaluation split over the devices; the default rule shards rows instead -- the
+    # reference's heap cannot be merged from partial states -- and must give the same text whatever the partition)
     for flags in (("--knn", "10"), ("--knn", "7", "-k", "23"), ("--knn", "7", "-k", "23", "--ani")):
-        want = run(prefix, *flags)
-        for devices in ("0,0", "0,0,0,0,0"):
-            assert run(prefix, *flags, "--devices", devices, env={"SKL_KNN_BAND_ROWS": "16"}) == want
+        for ties in ((), ("--knn-ties", "canonical")):
+            want = run(prefix, *flags, *ties)
+            for devices in ("0,0", "0,0,0,0,0"):
+                assert run(prefix, *flags, *ties, "--devices", devices, env={"SKL_KNN_BAND_ROWS": "16"}) == want
 
 
 # ---- `sketchlib inverted precluster`, as tests/inverted.rs drives it ----
@@ -331,8 +334,9 @@ def _sparse_text(names, exp, suppress_padding):
 
 
 def test_knn_3000_and_reference_tie_order_through_the_cli(gpu_ctx, oracle, tmp_path):
-    """`dist --knn 3000` on a 5 000-sample database: the reference only clamps knn to n - 1 (lib.rs:379-382); and
-    `--knn-ties reference` prints the ids the reference binary prints (its BinaryHeap replayed, mod.rs:41-48)."""
+    """`dist --knn 3000` on a 5 000-sample database: the reference only clamps knn to n - 1 (lib.rs:379-382); the default
+    (`--knn-ties reference`) prints the ids the reference binary prints (its BinaryHeap replayed, mod.rs:41-48),
+    `--knn-ties canonical` the lowest-index-first lists."""
     from sketchlib.rust_amd import synth
 
     kmers, ss64, n = [21], 2, 5000
@@ -343,7 +347,9 @@ def test_knn_3000_and_reference_tie_order_through_the_cli(gpu_ctx, oracle, tmp_p
         canon = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
         heap = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_RUST_HEAP, threads=8)
         assert not np.array_equal(canon["idx"], heap["idx"])          # the two rules differ on this database
-        assert run(prefix, "-k", "21", "--knn", str(knn)) == _sparse_text(names, canon, True)
-        assert run(prefix, "-k", "21", "--knn", str(knn), "--knn-ties", "reference") == _sparse_text(names, heap, True)
+        # (bool() around the comparisons: pytest's diff of two multi-megabyte strings takes longer than the test)
+        assert bool(run(prefix, "-k", "21", "--knn", str(knn)) == _sparse_text(names, heap, True)), "default = the reference's tie order"
+        assert bool(run(prefix, "-k", "21", "--knn", str(knn), "--knn-ties", "reference") == _sparse_text(names, heap, True))
+        assert bool(run(prefix, "-k", "21", "--knn", str(knn), "--knn-ties", "canonical") == _sparse_text(names, canon, True))
     res = subprocess.run([CLI, "dist", prefix, "--knn", "5", "--knn-ties", "fifo"], capture_output=True, text=True)
     assert res.returncode == 2 and "possible values: canonical, reference" in res.stderr

@@ -75,3 +75,18 @@ def test_unwritable_output_file_fails(tmp_path):
     res = subprocess.run([DBTOOL, "format", "self", "jaccard", "2", "0", "1", "2", str(raw),
                           str(tmp_path / "no_such_dir" / "x.txt")], capture_output=True, text=True)
     assert res.returncode != 0 and "cannot create output file" in res.stderr
+
+
+def test_text_writer_is_byte_identical_for_any_thread_count_and_band_height(tmp_path):
+    """tests/native/output_writer_check.cpp: the CLI's worker pool / two-phase block writer against its own
+    single-threaded output, through a file sink (positional writes) and a stream sink, no GPU needed."""
+    import subprocess
+
+    host = os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "host")
+    exe = str(tmp_path / "output_writer_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + host, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "output_writer_check.cpp"), os.path.join(host, "distance_matrix.cpp"),
+                           "-lpthread", "-o", exe])
+    res = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "DIFFERENT" not in res.stderr, res.stderr[-2000:]
+    assert res.stderr.count("same") == 12
