@@ -6,6 +6,8 @@
 #include <sstream>
 #include <fstream>
 #include <cstdio>
+#include <cstring>
+#include <vector>
 using namespace skl_host;
 static std::string slurp(const char *p) { std::ifstream f(p, std::ios::binary); std::stringstream ss; ss << f.rdbuf(); return ss.str(); }
 int main(int argc, char **argv) {
@@ -45,6 +47,24 @@ int main(int argc, char **argv) {
         if (rep == 0) ref = got;
         fprintf(stderr, "rep %d threads %zu rows_per %zu bytes %zu %s\n", rep, threads, rows_per, got.size(), got == ref ? "same" : "DIFFERENT");
         if (got != ref) return 1;
+    }
+    // raw bytes (a .npy band) behind a header that is not page aligned: written through a shared mapping by 7 workers
+    {
+        std::vector<char> raw((20u << 20) + 3);
+        for (size_t i = 0; i < raw.size(); ++i) raw[i] = (char)((i * 131u + (i >> 13)) & 0xFF);
+        {
+            FileSink fs(scratch);
+            const std::string header(128, 'h');
+            fs.finish(fs.begin(header.data(), header.size()), header.data(), header.size());
+            write_raw(fs, raw.data(), raw.size(), 7);
+            write_raw(fs, raw.data(), 1000, 7);      // (a short tail: one piece, plain write)
+        }
+        const std::string got = slurp(scratch.c_str());
+        const bool ok = got.size() == 128 + raw.size() + 1000 && got.compare(0, 128, std::string(128, 'h')) == 0 &&
+                        std::memcmp(got.data() + 128, raw.data(), raw.size()) == 0 &&
+                        std::memcmp(got.data() + 128 + raw.size(), raw.data(), 1000) == 0;
+        fprintf(stderr, "raw %s\n", ok ? "same" : "DIFFERENT");
+        if (!ok) return 1;
     }
     return 0;
 }

@@ -89,4 +89,4 @@ def test_text_writer_is_byte_identical_for_any_thread_count_and_band_height(tmp_
                            "-lpthread", "-o", exe])
     res = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "DIFFERENT" not in res.stderr, res.stderr[-2000:]
-    assert res.stderr.count("same") == 12
+    assert res.stderr.count("same") == 13
