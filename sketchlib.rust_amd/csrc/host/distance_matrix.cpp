@@ -15,8 +15,6 @@
 #include <ostream>
 #include <stdexcept>
 #include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
 #include <vector>
@@ -185,8 +183,7 @@ uint64_t StreamSink::begin(const char *p, size_t len)
 
 FileSink::FileSink(const std::string &path)
 {
-    fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);   // (read-write: a shared writable mapping needs it)
-    if (fd_ < 0) fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
     if (fd_ < 0) throw std::runtime_error("cannot create output file " + path);
 }
 
@@ -302,26 +299,6 @@ class OutputPool {
 };
 }  // namespace
 
-char *FileSink::map(uint64_t token, size_t len)
-{
-    if (len == 0) return nullptr;
-    struct stat st;
-    if (::fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) return nullptr;   // pipes, /dev/null, ...: write() it is
-    if ((uint64_t)st.st_size < token + len && ::ftruncate(fd_, (off_t)(token + len)) != 0) return nullptr;
-    const uint64_t page = (uint64_t)::sysconf(_SC_PAGESIZE);
-    const uint64_t lo = token / page * page;
-    void *m = ::mmap(nullptr, (size_t)(token + len - lo), PROT_READ | PROT_WRITE, MAP_SHARED, fd_, (off_t)lo);
-    if (m == MAP_FAILED) return nullptr;
-    return static_cast<char *>(m) + (token - lo);
-}
-
-void FileSink::unmap(char *p, uint64_t token, size_t len)
-{
-    const uint64_t page = (uint64_t)::sysconf(_SC_PAGESIZE);
-    const uint64_t lo = token / page * page;
-    ::munmap(p - (token - lo), (size_t)(token + len - lo));
-}
-
 // Blocks 0..n_blocks-1 of text to the sink, in block order, formatted by `threads` workers.  `format(b, out)` APPENDS
 // block b to `out`.  Groups of up to 8 blocks per worker go through two phases with nothing ordered inside either:
 //   1. the workers take blocks from a shared counter and format them one behind the other into their own buffers;
@@ -397,40 +374,14 @@ static void write_blocks_in_order(TextSink &sink, size_t n_blocks, size_t thread
     }
 }
 
-// Raw bytes (a band of a .npy array) to the sink: one reservation, then the workers write 8 MB pieces at their
-// offsets -- a single writer copies into the page cache at ~7 GB/s, which was 5.6 of the 6.9 s `--npy` took at
-// BASELINE configs[2] (profiles/r04_e2e_cfg3.txt).  A stream sink takes the whole range in begin().
-void write_raw(TextSink &sink, const char *bytes, size_t len, size_t threads)
+// Raw bytes (a band of a .npy array) to the sink: ONE write.  Measured at BASELINE configs[2] (40 GB into a tmpfs file,
+// 2 x EPYC 9575F, profiles/r04_e2e_cfg3.txt): one pwrite per 256 MB band copies into the page cache at 7.1 GB/s; 8 MB
+// pieces pwritten by the worker pool at their offsets 6.0 GB/s (a file's writes queue behind its inode lock however
+// many threads issue them); stores through a shared mapping from 64 / 256 workers 1.4 / 0.7 GB/s (page faults under
+// the mapping's lock).  The copy into the page cache, not the GPU or PCIe, is what `--npy` waits for.
+void write_raw(TextSink &sink, const char *bytes, size_t len)
 {
-    if (len == 0) return;
-    const uint64_t token = sink.begin(bytes, len);
-    constexpr size_t PIECE = 8u << 20;
-    const size_t n_pieces = (len + PIECE - 1) / PIECE;
-    threads = std::max<size_t>(1, std::min(threads, n_pieces));
-    if (threads == 1 || !sink.positional()) {
-        sink.finish(token, bytes, len);
-        return;
-    }
-    std::atomic<size_t> next{0};
-    std::mutex err_mu;
-    std::exception_ptr err;
-    char *const mapped = sink.map(token, len);
-    OutputPool::instance().run(threads, [&](size_t) {
-        try {
-            for (;;) {
-                const size_t x = next.fetch_add(1);
-                if (x >= n_pieces) break;
-                const size_t at = x * PIECE;
-                if (mapped) std::memcpy(mapped + at, bytes + at, std::min(PIECE, len - at));
-                else sink.finish(token + at, bytes + at, std::min(PIECE, len - at));
-            }
-        } catch (...) {
-            std::lock_guard<std::mutex> lk(err_mu);
-            if (!err) err = std::current_exception();
-        }
-    });
-    if (mapped) sink.unmap(mapped, token, len);
-    if (err) std::rethrow_exception(err);
+    if (len) sink.finish(sink.begin(bytes, len), bytes, len);
 }
 
 void DistanceMatrix::write(std::ostream &os, size_t threads) const

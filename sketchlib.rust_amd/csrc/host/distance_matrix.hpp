@@ -54,14 +54,9 @@ class TextSink {
     virtual void finish(uint64_t /*token*/, const char * /*p*/, size_t /*len*/) {}
     // true: the token is a byte offset and finish(token + d, p + d, len - d) may be called piecewise (a regular file)
     virtual bool positional() const { return false; }
-    // A writable mapping of the reserved byte range [token, token + len), or nullptr if the sink has none (then finish()
-    // is the way); unmap() gives it back.  Stores through a shared mapping fault pages in from many threads at once; a
-    // file's write()s queue behind its inode lock one after the other however many threads issue them.
-    virtual char *map(uint64_t /*token*/, size_t /*len*/) { return nullptr; }
-    virtual void unmap(char * /*p*/, uint64_t /*token*/, size_t /*len*/) {}
 };
-// `len` raw bytes to the sink (a band of a .npy array), written by up to `threads` workers when the sink is positional.
-void write_raw(TextSink &sink, const char *bytes, size_t len, size_t threads);
+// `len` raw bytes to the sink (a band of a .npy array).
+void write_raw(TextSink &sink, const char *bytes, size_t len);
 class StreamSink : public TextSink {
   public:
     explicit StreamSink(std::ostream &os) : os_(os) {}
@@ -76,8 +71,6 @@ class FileSink : public TextSink {
     uint64_t begin(const char *p, size_t len) override;
     void finish(uint64_t token, const char *p, size_t len) override;
     bool positional() const override { return true; }
-    char *map(uint64_t token, size_t len) override;
-    void unmap(char *p, uint64_t token, size_t len) override;
   private:
     int fd_ = -1;
     uint64_t offset_ = 0;

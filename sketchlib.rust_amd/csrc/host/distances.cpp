@@ -643,7 +643,7 @@ void stream_bands(const DistanceMatrix &shape, const std::vector<size_t> &b, siz
             const char *bytes = reinterpret_cast<const char *>(buf[i & 1].data());
             const size_t len = band_floats(b[i], b[i + 1]) * sizeof(float);
             const auto t1 = std::chrono::steady_clock::now();
-            write_raw(sink, bytes, len, threads);
+            write_raw(sink, bytes, len);
             output_timing().sink_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         } else {
             shape.write_rows(sink, b[i], b[i + 1], buf[i & 1].data(), threads);

@@ -48,7 +48,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "rep %d threads %zu rows_per %zu bytes %zu %s\n", rep, threads, rows_per, got.size(), got == ref ? "same" : "DIFFERENT");
         if (got != ref) return 1;
     }
-    // raw bytes (a .npy band) behind a header that is not page aligned: written through a shared mapping by 7 workers
+    // raw bytes (a .npy band) behind a header
     {
         std::vector<char> raw((20u << 20) + 3);
         for (size_t i = 0; i < raw.size(); ++i) raw[i] = (char)((i * 131u + (i >> 13)) & 0xFF);
@@ -56,8 +56,8 @@ int main(int argc, char **argv) {
             FileSink fs(scratch);
             const std::string header(128, 'h');
             fs.finish(fs.begin(header.data(), header.size()), header.data(), header.size());
-            write_raw(fs, raw.data(), raw.size(), 7);
-            write_raw(fs, raw.data(), 1000, 7);      // (a short tail: one piece, plain write)
+            write_raw(fs, raw.data(), raw.size());
+            write_raw(fs, raw.data(), 1000);
         }
         const std::string got = slurp(scratch.c_str());
         const bool ok = got.size() == 128 + raw.size() + 1000 && got.compare(0, 128, std::string(128, 'h')) == 0 &&
