@@ -79,6 +79,34 @@ def cond_index(i, j, n):
     return n * i - (i * (i + 1)) // 2 + j - 1 - i
 
 
+def effective_cpus():
+    """Host threads this process can really run at once: os.cpu_count() capped by the cgroup's CPU quota (the GPU boxes
+    of this pool show 256 hardware threads and grant 16 CPUs' worth of time: /sys/fs/cgroup/cpu.max = "1600000 100000";
+    256 runnable threads under such a quota are throttled, not parallel)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if text[0] != "max":
+                    quota = float(text[0]) / float(text[1])
+            else:
+                q = float(text[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def cpu_baseline(n, kmers, ss64, dataset):
     """The oracle (CPU restatement of the reference's rayon path: 1000-pair chunks over the
     condensed triangle, src/distances/mod.rs:20,69-76) on all host cores, on the SAME
@@ -87,7 +115,7 @@ def cpu_baseline(n, kmers, ss64, dataset):
     from oracle import oracle as O
     from sketchlib.rust_amd import synth
 
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     n_workload = n
     n = min(n, CPU_SAMPLE_MAX_N)       # a BOUNDED sample: the first 20 000 genomes of a larger workload (2e8 pairs, ~10 s on 256 threads)
     bins = synth.set_u(n, len(kmers), ss64) if dataset == "U" else synth.set_r(n, kmers, ss64)
@@ -112,6 +140,7 @@ def cpu_baseline(n, kmers, ss64, dataset):
         "value": pairs * repeat / best,
         "unit": "pairs/s",
         "cores": cores,
+        "host_hardware_threads": os.cpu_count() or 1,
         "kind": "port",
         "sample": f"{what} x {repeat} pass(es) in one "
                   f"thread pool = {pairs * repeat} pairs, self_dists_all core/acc, 1000-pair chunks over "

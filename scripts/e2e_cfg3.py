@@ -31,7 +31,7 @@ def mem_available_gb():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=100_000)
-    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--skip-text", action="store_true")
     ap.add_argument("--band-mb", default="")
     args = ap.parse_args()

@@ -119,7 +119,7 @@ def test_precluster_with_completeness(oracle, gpu_ctx, wd):
     assert rows and all(0.0 <= float(r[2]) <= 1.0 for r in rows)
     skq = np.fromfile(wd / "precluster_index.skq", dtype="<u2").reshape(n, 10)
     oc = oracle.Sketches(bins, n, [21], ss64, completeness=np.array([0.8, 0.9, 0.7]))
-    exp = oracle.self_dists_knn_precluster(oc, skq, 2)
+    exp = oracle.self_dists_knn_precluster(oc, skq, 2, ties=oracle.TIES_RUST_HEAP)
     want = sorted(f"{genomes[i]}\t{genomes[int(e['idx'])]}\t{rust_f32(e['d0'])}" for i in range(n) for e in exp[i]
                   if not (int(e["idx"]) == i and e["d0"] >= 1.0))          # padding is not printed (distance_matrix.rs:379-381)
     assert sorted("\t".join(r) for r in rows) == want
@@ -154,9 +154,12 @@ def test_core_accessory_and_cross_query_with_completeness(oracle, gpu_ctx, wd):
                           for i in range(nr) for j in range(nq))
     # self kNN with completeness
     out = cli(wd, "dist", "refs", "--knn", "2", "--ref-completeness-file", "rc.txt").stdout
-    exp = oracle.self_dists_knn(o_r, 2)
+    exp = oracle.self_dists_knn(o_r, 2, ties=oracle.TIES_RUST_HEAP)      # the CLI's default: the reference binary's tie order
     want = "".join(f"{refs[i]}\t{refs[int(e['idx'])]}\t{rust_f32(e['d0'])}\t{rust_f32(e['d1'])}\n" for i in range(nr) for e in exp[i])
     assert out == want
+    out = cli(wd, "dist", "refs", "--knn", "2", "--ref-completeness-file", "rc.txt", "--knn-ties", "canonical").stdout
+    exp = oracle.self_dists_knn(o_r, 2, ties=oracle.TIES_CANONICAL)
+    assert out == "".join(f"{refs[i]}\t{refs[int(e['idx'])]}\t{rust_f32(e['d0'])}\t{rust_f32(e['d1'])}\n" for i in range(nr) for e in exp[i])
 
 
 def test_completeness_file_errors(gpu_ctx, wd):
