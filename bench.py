@@ -893,6 +893,16 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True):
                 dense[i] = np.inf
                 order = np.lexsort((np.arange(nr), dense))[:knn]
                 assert np.array_equal(idx[i], order.astype(np.uint64)) and np.array_equal(d0[i], dense[order]), i
+            # the same call in the reference binary's tie order (the CLI's default: BinaryHeap replayed, every pair still
+            # evaluated once -- the heaps live in global memory between the bands): cost beside the canonical call's
+            ctx.set_knn_ties(capi.TIES_REFERENCE)
+            t_ref = time.perf_counter()
+            idx_r, d0_r, _ = capi.self_dists_knn(ctx, g_r, p5, knn)
+            ref_s = time.perf_counter() - t_ref
+            ctx.set_knn_ties(capi.TIES_CANONICAL)
+            assert np.array_equal(d0_r, d0), "the two tie rules list the same distances per row"
+            ref_rows_differ = int((idx_r != idx).any(axis=1).sum())
+            del idx_r, d0_r
             evaluated = nr * (nr - 1) // 2            # every pair once (symmetric driver)
             v5 = valu_block(evaluated, ksec, 1, ss, clk)
             sec["cfg5"] = {"workload": "BASELINE configs[4]: self kNN-50 over 1M x 1M, single-k Jaccard (k=21), sketchsize64=32, on ONE "
@@ -900,6 +910,9 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True):
                            "pair_distances_defined": nr * (nr - 1), "pairs_evaluated": evaluated, "s_per_call": wall,
                            "s_per_call_note": "the second call of the context (the first also allocates the band buffers: +1-2 s)",
                            "pair_distances_per_s": nr * (nr - 1) / wall, "kernel": ctx.last_kernel(),
+                           "reference_tie_order": {"s_per_call": ref_s, "rows_whose_ids_differ_from_canonical": ref_rows_differ,
+                                                   "what": "skl_ctx_set_knn_ties(REFERENCE), the CLI's default: ids and order of equal keys as the "
+                                                           "reference binary prints them; same distances"},
                            "pair_kernel_s": ksec, "pair_kernel_launches": n_launch, "other_s (top-k merge, copies)": wall - ksec,
                            "valu_frac": v5["frac"], "valu_frac_at_in_kernel_clock": v5.get("frac_at_in_kernel_clock"),
                            "in_kernel_clock": clk, "rows_checked_against_dense": 3}

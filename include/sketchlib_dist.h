@@ -135,8 +135,9 @@ int skl_log_variant(void);
  * the reference on this host gives 1, or the reverse.  Everything else is unaffected. */
 #define SKL_CTX_FLAG_LOG_UNMATCHED 1u
 /* SKL_CTX_FLAG_NOT_SPX (needs a context): the device does not report the 256 compute units of an unpartitioned (SPX)
- * MI355X.  Results do not depend on it; the launch heuristics (tile order across 8 XCDs, the launch sizes at which
- * tile shapes and chunk slicing switch) were tuned on SPX only (DESIGN.md "Topology assumptions"). */
+ * MI355X.  Results do not depend on it.  The tile order follows the device (workgroups are dealt to CUs / 32 XCDs, the
+ * resident-round sizes use the CU count); the launch sizes at which tile shapes and chunk slicing switch were tuned on
+ * SPX only (DESIGN.md "Topology assumptions"). */
 #define SKL_CTX_FLAG_NOT_SPX 2u
 unsigned skl_ctx_flags(const skl_ctx *ctx);
 int skl_device_log(skl_ctx *ctx, const double *x_host, size_t n, double *out_host);

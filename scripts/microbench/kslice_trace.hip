@@ -54,6 +54,7 @@ int main(int argc, char **argv)
     g.k_begin = 0; g.k_count = nk; g.row_begin = 0; g.row_end = n - 1; g.self_mode = 1;
     g.out_base = 0; g.out = dOut; g.cnt_pair_stride = 1; g.cnt_k_stride = pairs;
     g.k_slices = argc > 5 ? (uint32_t)atoi(argv[5]) : 1u;
+    g.xcd_shift = 3;   // an unpartitioned MI355X: 8 XCDs
     uint64_t *dTrace;
     const size_t trace_words = (size_t)TW << 20;   // up to 1 M waves
     CK(hipMalloc(&dTrace, trace_words * 8));

@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--variants", default=",".join(v[0] for v in VARIANTS))
+    ap.add_argument("--shape", choices=["cfg3", "cfg4"], default="cfg3",
+                    help="cfg3: dense self, n genomes, ss64 = 64; cfg4: dense cross 1M refs x 10k queries, ss64 = 32 (k-mer length "
+                         "boundaries twice as often per pair)")
     args = ap.parse_args()
     import torch
 
@@ -64,15 +67,37 @@ def main():
 
     n = args.samples
     want = args.variants.split(",")
+    cfg4 = args.shape == "cfg4"
+    ss = 32 if cfg4 else 64
+    kmers = [13, 17, 21, 25, 29] if cfg4 else KMERS
     with capi.using_library(pkg.build_ab_library()):
         dev = torch.device("cuda", 0)
         ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
-        sk = ctx.sketches(synth.set_u_device(n, len(KMERS), 64, dev), n, KMERS, 64)
-        zeros = torch.zeros((n, len(KMERS) * 64 * 14), dtype=torch.int64, device=dev)
-        sk0 = ctx.sketches(zeros, n, KMERS, 64)
-        del zeros
-        pairs = n * (n - 1) // 2
-        out = torch.zeros((pairs, 2), dtype=torch.float32, device=dev)
+        if cfg4:
+            n, nq = 1_000_000, 10_000
+            sk = ctx.sketches(synth.set_u_device(n, 5, ss, dev), n, kmers, ss)
+            q = ctx.sketches(synth.set_u_device(nq, 5, ss, dev, first_sample=10 ** 7), nq, kmers, ss)
+            zeros = torch.zeros((n, 5 * ss * 14), dtype=torch.int64, device=dev)
+            sk0 = ctx.sketches(zeros, n, kmers, ss)
+            q0 = ctx.sketches(zeros[:nq].contiguous(), nq, kmers, ss)
+            del zeros
+            pairs = n * nq
+            out = torch.zeros((n, nq, 2), dtype=torch.float32, device=dev)
+        else:
+            sk = ctx.sketches(synth.set_u_device(n, len(kmers), ss, dev), n, kmers, ss)
+            zeros = torch.zeros((n, len(kmers) * ss * 14), dtype=torch.int64, device=dev)
+            sk0 = ctx.sketches(zeros, n, kmers, ss)
+            del zeros
+            q = q0 = None
+            pairs = n * (n - 1) // 2
+            out = torch.zeros((pairs, 2), dtype=torch.float32, device=dev)
+
+        def launch(s, p):
+            if cfg4:
+                capi.cross_dists_all(ctx, s, q0 if s is sk0 else q, p, out=out)
+            else:
+                capi.self_dists_all(ctx, s, p, out=out)
+
         torch.cuda.synchronize()
         print(json.dumps({"idle_power_W": smi_power(), "n": n, "pairs": pairs}), flush=True)
         for rnd in range(args.rounds):
@@ -84,7 +109,7 @@ def main():
                 os.environ.update(env)
                 s = sk0 if zero else sk
                 p = s.set_k()
-                capi.self_dists_all(ctx, s, p, out=out)      # warm (and the clock settles)
+                launch(s, p)      # warm (and the clock settles)
                 ctx.synchronize()
                 watts, stop = [], [False]
 
@@ -102,7 +127,7 @@ def main():
                 t0 = time.perf_counter()
                 launches = 0
                 while time.perf_counter() - t0 < args.seconds:
-                    capi.self_dists_all(ctx, s, p, out=out)
+                    launch(s, p)
                     ctx.synchronize()
                     launches += 1
                 wall = time.perf_counter() - t0
@@ -112,7 +137,7 @@ def main():
                 kms, nl = ctx.kernel_ms()
                 ksec = kms / 1e3 / max(nl, 1)
                 w = sum(watts[2:]) / max(1, len(watts[2:])) if len(watts) > 2 else None
-                print(json.dumps({"round": rnd, "variant": name, "switches": env, "kernel": ctx.last_kernel().split(" (")[0],
+                print(json.dumps({"shape": args.shape, "round": rnd, "variant": name, "switches": env, "kernel": ctx.last_kernel().split(" (")[0],
                                   "launches": launches, "kernel_s": ksec, "pairs_per_s": pairs / ksec, "wall_pairs_per_s": pairs * launches / wall,
                                   "clock_ghz": clk["ghz"], "clock_p10": clk["p10"], "clock_p90": clk["p90"],
                                   "package_power_W": w, "power_samples": len(watts),
@@ -120,8 +145,9 @@ def main():
                                   "pair_cycles": ksec * clk["ghz"] * 1e9 / pairs if clk["ghz"] else None}), flush=True)
         for k in SWITCHES:
             os.environ.pop(k, None)
-        sk.close()
-        sk0.close()
+        for h in (sk, sk0, q, q0):
+            if h is not None:
+                h.close()
         ctx.close()
 
 

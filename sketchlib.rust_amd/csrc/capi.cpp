@@ -332,6 +332,7 @@ Knobs read_knobs()
     k.tile32_min = env_int("SKL_TILE32_MIN", 8ll << 20);
     k.mid_band = env_int("SKL_MID_BAND", 1) != 0;
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
+    k.xcds = (int)std::min(8ll, std::max(0ll, env_int("SKL_XCDS", 0)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
@@ -352,6 +353,16 @@ Knobs read_knobs()
 #ifdef SKL_AB
 int ab_forced_log_variant() { return (int)std::max(-2ll, std::min(1ll, env_int("SKL_FORCE_LOG_VARIANT", -2))); }   // -2: not forced
 #endif
+
+// XCDs the device presents as one: an MI355X XCD has 32 CUs, so an unpartitioned (SPX) part shows 256 CUs = 8 XCDs, a CPX
+// partition 32 CUs = 1.  The tile order deals workgroups to XCDs by blockIdx mod that number; SKL_XCDS forces it (tests).
+uint32_t ctx_xcd_shift(const skl_ctx *ctx)
+{
+    int x = ctx->knobs.xcds > 0 ? ctx->knobs.xcds : ctx->n_cu / 32;
+    uint32_t shift = 0;
+    while (shift < 3u && (2 << shift) <= x) ++shift;
+    return shift;
+}
 
 int forced_kernel(const skl_ctx *ctx)
 {
@@ -374,6 +385,8 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
 {
     PairArgs args = args_in;
     args.group_span = (uint32_t)ctx->knobs.group_span;
+    args.xcd_shift = ctx_xcd_shift(ctx);
+    const uint32_t n_xcd = 1u << args.xcd_shift;
     static const char *mode_names[] = {"COUNTS", "JACCARD", "COREACC"};
     const std::string m = mode_names[mode];
     std::string *name = &ctx->last_kernel;
@@ -410,13 +423,13 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     const bool big_sketch = args.ss64 > (uint32_t)KSLICE_MAX_U16_CHUNKS;
     const bool sliced_launch = mode == MODE_JACCARD || (mode == MODE_COUNTS && (small || args.k_sliced || big_sketch));
     const uint32_t wg_per_cu = ((shape == 3255 && !sliced_launch) || (shape == 3254 && sliced_launch)) ? 3u : 4u;
-    args.round_size = ctx->knobs.round_priority ? wg_per_cu * (uint32_t)ctx->n_cu / 8u : 0u;
+    args.round_size = ctx->knobs.round_priority ? wg_per_cu * (uint32_t)ctx->n_cu / n_xcd : 0u;
     ctx->last_count_planes = std::max(1u, args.k_slices);
     ctx->last_tail = false;
     if (args.tail_slices > 1u) {
         // tail-sliced one-workgroup-per-unit launch: two planes whatever kernel ends up running (a
         // kernel without the slices leaves plane 1 as it found it: zero)
-        args.tail_resident = wg_per_cu * (uint32_t)ctx->n_cu / 8u;
+        args.tail_resident = wg_per_cu * (uint32_t)ctx->n_cu / n_xcd;
         ctx->last_count_planes = 2;
         ctx->last_tail = true;
     }

@@ -46,6 +46,7 @@ struct Knobs {
     long long sliced_max_pairs = -1;  // SKL_SLICED_MAX_PAIRS: core/acc launches below this run k-sliced (-1: default)
     long long knn_band_rows = 0;      // SKL_KNN_BAND_ROWS: force the band height of the kNN drivers (tests)
     int k_slices = 0;                 // SKL_K_SLICES: chunk slices per k of k-sliced core/acc launches (0: chosen per launch)
+    int xcds = 0;                       // SKL_XCDS: XCDs the tile order assumes (0: from the device's CU count: 256 CUs = 8, a 32-CU partition = 1)
     int group_span = 2;                 // SKL_GROUP_SPAN: column groups whose tiles are numbered side by side (device_common.hpp lookup_tile_at)
     long long tile32_min = 8ll << 20;   // SKL_TILE32_MIN: pair x k evaluations from which launches use 32 x 128 tiles (-1: never, 0: always); 8 Mi since the k-sliced 32-row form holds 4 waves per SIMD (profiles/r03_ab_tile32_threshold.jsonl)
     bool mid_band = true;               // SKL_MID_BAND=0: no mid-band rule (32-row tiles + 2 slices of the last round at 0.5-1 x tile32_min evaluations; A/B only, results are identical)
@@ -135,6 +136,7 @@ SKL_INTERNAL int ctx_bind(skl_ctx *ctx);
 SKL_INTERNAL int host_log_variant();
 // grow-only scratch slot `which` of the context, at least `bytes` large
 SKL_INTERNAL int ctx_scratch(skl_ctx *ctx, size_t bytes, void **out, int which = 0);
+SKL_INTERNAL uint32_t ctx_xcd_shift(const skl_ctx *ctx);   // log2 of the XCDs the tile order deals workgroups to
 SKL_INTERNAL int forced_kernel(const skl_ctx *ctx);   // A/B build: SKL_KERNEL; product library: always 0
 // the pair kernel bracketed by HIP events on the context's stream (skl_ctx_kernel_ms)
 SKL_INTERNAL int timed_pair_launch(skl_ctx *ctx, const skl::PairArgs &args, int mode);

@@ -203,7 +203,8 @@ __device__ __forceinline__ uint32_t sortable_bits(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// blockIdx % 8 labels the XCD (MI355X_MICROARCH.md); XCD x takes tiles
+// blockIdx % (number of XCDs) labels the XCD (MI355X_MICROARCH.md; 8 on an unpartitioned MI355X, PairArgs::xcd_shift);
+// XCD x takes tiles
 // [x*tiles_per_xcd, (x+1)*tiles_per_xcd) of the super-group-major numbering of the ACTIVE
 // tiles: every XCD gets the same number of (equal-cost) tiles.  The ~100 workgroups resident on an
 // XCD are consecutive tiles = row tiles x group_span column groups, each row tile shared by
@@ -233,7 +234,7 @@ __device__ __forceinline__ bool lookup_tile_at(const PairArgs &g, uint32_t xcd, 
 
 __device__ __forceinline__ bool lookup_tile(const PairArgs &g, uint32_t &group, uint32_t &row_tile)
 {
-    return lookup_tile_at(g, blockIdx.x & 7u, blockIdx.x >> 3, group, row_tile);
+    return lookup_tile_at(g, blockIdx.x & ((1u << g.xcd_shift) - 1u), blockIdx.x >> g.xcd_shift, group, row_tile);
 }
 
 __device__ __forceinline__ bool pair_valid(const PairArgs &g, uint32_t i, uint32_t jcol)

@@ -50,7 +50,9 @@ struct PairArgs {
     // balanced tile enumeration: active tiles are numbered column
     // group by column group and each XCD takes one contiguous eighth of the numbering
     uint32_t n_active_tiles;
-    uint32_t tiles_per_xcd;       // ceil(n_active_tiles / 8)
+    uint32_t tiles_per_xcd;       // ceil(n_active_tiles / XCDs)
+    uint32_t xcd_shift;           // log2 of the XCDs the device shows as one (SPX MI355X: 3; CPX: 0): workgroup b runs on XCD
+                                  // b mod 2^xcd_shift (MI355X_MICROARCH.md), set by the C ABI from the device's CU count
     uint32_t n_groups;            // column groups
     uint32_t group_span;          // column groups per super-group: the tiles of a super-group are numbered row tile by
                                   // row tile, its groups side by side (1: column group by column group)

@@ -95,8 +95,9 @@ hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_
     if (total == 0) return hipSuccess;
     if (total >= (1ull << 31)) return hipErrorInvalidValue;
     args.n_active_tiles = (uint32_t)total;
-    args.tiles_per_xcd = (uint32_t)((total + 7) / 8);
-    *grid_out = 8ull * args.tiles_per_xcd;
+    const uint64_t n_xcd = 1ull << args.xcd_shift;
+    args.tiles_per_xcd = (uint32_t)((total + n_xcd - 1) / n_xcd);
+    *grid_out = n_xcd * args.tiles_per_xcd;
     return hipSuccess;
 }
 

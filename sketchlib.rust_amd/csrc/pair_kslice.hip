@@ -134,7 +134,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
 
     // blockIdx -> (XCD, tile slot on that XCD[, k-mer length]): the k slices of a tile are
     // neighbours in the per-XCD order
-    const uint32_t xcd = blockIdx.x & 7u, s_idx = blockIdx.x >> 3;
+    const uint32_t xcd = blockIdx.x & ((1u << g.xcd_shift) - 1u), s_idx = blockIdx.x >> g.xcd_shift;
     // k-sliced: blocks of KSL_TILE_BLOCK consecutive tiles of an XCD walk one k-mer length together
     // (tile index fastest, then k, then block), so that the workgroups resident on an XCD at one time
     // share a (column group, k) plane of the lane slab in its L2: 2 % at n = 4 000 ... 8 000 against
@@ -320,11 +320,11 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (!k_sliced || (uint64_t)args.tiles_per_xcd * args.k_count * args.k_slices * 4u > 9ull * args.round_size) args.round_size = 0;
     if (k_sliced) {
         const uint64_t units_pad = (uint64_t)args.tiles_per_xcd * args.k_count;   // exact: the last tile block of an XCD is short
-        n_wg = 8ull * units_pad * args.k_slices;
+        n_wg = ((uint64_t)units_pad << args.xcd_shift) * args.k_slices;
         if (args.tail_slices > 1u) {
             const uint64_t first = std::min<uint64_t>(args.tail_first, units_pad);
             args.tail_first = (uint32_t)first;
-            n_wg = 8ull * (first + (units_pad - first) * args.tail_slices);
+            n_wg = (first + (units_pad - first) * args.tail_slices) << args.xcd_shift;
         }
     }
     if (n_wg >= (1ull << 31)) return hipErrorInvalidValue;

@@ -84,6 +84,10 @@ VARIANTS = [
     ({"SKL_K_SLICES": "2"}, "k-sliced"),                           # ... cut into 2 / 4 / 8 chunk slices
     ({"SKL_K_SLICES": "4"}, "k-sliced"),
     ({"SKL_K_SLICES": "8"}, "k-sliced"),
+    # tile order for devices that show fewer than 8 XCDs (partitioned MI355X: the C ABI derives it from the CU count)
+    ({"SKL_XCDS": "1"}, "4 chunk slices"),
+    ({"SKL_XCDS": "2", "SKL_SLICED_MAX_PAIRS": "0"}, "all k"),
+    ({"SKL_XCDS": "4", "SKL_TILE32_MIN": "0"}, "R=32, JL=2, COUNTS, k-sliced"),
     # A/B library
     ({**AB}, "4 chunk slices"),
     ({**AB, "SKL_KSLICE_SHAPE": "1651"}, "R=16, JL=2, COUNTS, k-sliced"),   # the 16-row form walked row by row (round 3a)
