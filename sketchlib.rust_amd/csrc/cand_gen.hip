@@ -218,6 +218,22 @@ hipError_t launch_first_greater(const uint64_t *row_offsets, const uint32_t *can
     return hipGetLastError();
 }
 
+// key[i] = the first candidate of row i (0xFFFFFFFF for an empty row): rows whose lists start with the same sample are,
+// as a rule, members of one cluster with nearly the same list -- the launch order of pair_cand_kernel's work items
+__global__ void first_candidate_kernel(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint32_t *key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = row_offsets[i + 1] > row_offsets[i] ? cand[row_offsets[i]] : 0xFFFFFFFFu;
+}
+
+hipError_t launch_first_candidate(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint32_t *key, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(first_candidate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, row_offsets, cand, n, key);
+    return hipGetLastError();
+}
+
 hipError_t launch_cand_rows(const CandGenArgs &g, bool fill, hipStream_t stream)
 {
     if (g.n == 0) return hipSuccess;

@@ -338,6 +338,7 @@ Knobs read_knobs()
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
     k.cand_symmetric = env_int("SKL_CAND_SYMMETRIC", 1) != 0;
+    k.cand_row_order = env_int("SKL_CAND_ROW_ORDER", 1) != 0;
     const char *sk = getenv("SKL_SKETCH_KERNEL");
     k.sketch_global = sk && strcmp(sk, "global") == 0;
 #ifdef SKL_AB

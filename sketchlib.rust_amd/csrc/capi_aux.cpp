@@ -138,9 +138,29 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
         HIP_TRY(hipMemcpyAsync(first.data(), d_first.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    // Launch order of the rows (round 4).  pair_cand_kernel is bound by the gather of the candidates' sketches, and the rows
+    // of one cluster gather nearly the SAME candidates: dispatched next to each other they find them in the L2 of their XCD;
+    // in sample order -- cluster members scattered over the database -- every pair goes to HBM.  Rows are therefore taken
+    // in the order of their first candidate (the lowest member of the cluster, as a rule): a counting sort, no list is
+    // looked at.  (SKL_CAND_ROW_ORDER=0: sample order, A/B.)
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    if (ctx->knobs.cand_row_order && n > 1) {
+        DevBuf d_key;
+        HIP_TRY(hipMalloc(&d_key.p, n * sizeof(uint32_t)));
+        HIP_TRY(launch_first_candidate(d_off, d_cand, (uint32_t)n, (uint32_t *)d_key.p, ctx->stream));
+        std::vector<uint32_t> key(n);
+        HIP_TRY(hipMemcpyAsync(key.data(), d_key.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> begin(n + 2, 0);   // bucket n: empty rows
+        for (size_t i = 0; i < n; ++i) ++begin[(key[i] < n ? key[i] : n) + 1];
+        for (size_t b = 0; b <= n; ++b) begin[b + 1] += begin[b];
+        for (size_t i = 0; i < n; ++i) order[begin[key[i] < n ? key[i] : n]++] = (uint32_t)i;
+    }
     std::vector<uint32_t> work_row;
     std::vector<uint64_t> work_start;
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t x = 0; x < n; ++x) {
+        const size_t i = order[x];
         for (uint64_t c0 = symmetric ? first[i] : host_offsets[i]; c0 < host_offsets[i + 1]; c0 += 64) {
             work_row.push_back((uint32_t)i);
             work_start.push_back(c0);
@@ -160,6 +180,7 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
 
     PairArgs g;
     SKL_TRY(fill_args(s, s, p, MODE_JACCARD, p->ani ? JOUT_ANI_KEY : JOUT_DIST, &g));
+    g.xcd_shift = ctx->knobs.cand_row_order ? ctx_xcd_shift(ctx) : 0u;
     CandArgs c;
     memset(&c, 0, sizeof c);
     c.row_offsets = d_off;

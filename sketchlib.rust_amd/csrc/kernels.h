@@ -188,6 +188,9 @@ struct CandArgs {
     uint64_t n_work;
     float *keys;                  // [n_candidates] MODE_JACCARD output per candidate
     uint32_t symmetric;           // 1: the lists are symmetric -- evaluate j > i only, store both copies
+    // consecutive work items (rows of one cluster, capi_aux.cpp) stay on ONE XCD, whose L2 then holds the candidates they
+    // share: workgroup b takes the items of block (b mod XCDs) * blocks_per_xcd + b / XCDs (set by the launcher)
+    uint32_t xcd_shift, blocks_per_xcd;
 };
 hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream);
 
@@ -231,6 +234,8 @@ hipError_t launch_cand_rows(const CandGenArgs &g, bool fill, hipStream_t stream)
 // first[i] = position of the first candidate of row i with an id greater than i
 hipError_t launch_first_greater(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint64_t *first,
                                 hipStream_t stream);
+// key[i] = first candidate of row i, 0xFFFFFFFF for an empty row
+hipError_t launch_first_candidate(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint32_t *key, hipStream_t stream);
 constexpr size_t MAX_DEVICE_CANDGEN_SAMPLES = 158ull * 1024 * 8;   // n-bit bitmap in LDS
 
 struct TopkArgs {

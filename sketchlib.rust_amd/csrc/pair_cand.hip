@@ -21,7 +21,9 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const Ca
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_WG + wave;
+    const uint32_t blk = (blockIdx.x & ((1u << c.xcd_shift) - 1u)) * c.blocks_per_xcd + (blockIdx.x >> c.xcd_shift);
+    if ((blockIdx.x >> c.xcd_shift) >= c.blocks_per_xcd) return;
+    const uint64_t w = (uint64_t)blk * WAVES_PER_WG + wave;
     if (w >= c.n_work) return;
     const uint32_t row = c.work_row[w];
     const uint64_t start = c.work_start[w];
@@ -81,12 +83,16 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const Ca
     }
 }
 
-hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream)
+hipError_t launch_pair_cand(const CandArgs &c_in, const PairArgs &g, hipStream_t stream)
 {
+    CandArgs c = c_in;
     if (c.n_work == 0) return hipSuccess;
     const uint64_t blocks = (c.n_work + WAVES_PER_WG - 1) / WAVES_PER_WG;
-    if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pair_cand_kernel, dim3((unsigned)blocks), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
+    c.xcd_shift = g.xcd_shift;
+    c.blocks_per_xcd = (uint32_t)((blocks + (1ull << c.xcd_shift) - 1) >> c.xcd_shift);
+    const uint64_t grid = (uint64_t)c.blocks_per_xcd << c.xcd_shift;
+    if (grid >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pair_cand_kernel, dim3((unsigned)grid), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
     return hipGetLastError();
 }
 
