@@ -8,8 +8,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 for e in "SKL_TILE32_MIN=0" "SKL_TILE32_MIN=-1" "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=2" "SKL_GROUP_SPAN=5" \
          "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=8 SKL_TILE32_MIN=0 SKL_GROUP_SPAN=3" \
-         "SKL_ROUND_PRIORITY=0 SKL_KNN_ROW_FLAGS=0"; do
+         "SKL_ROUND_PRIORITY=0 SKL_KNN_ROW_FLAGS=0" "SKL_XCDS=1 SKL_CAND_ROW_ORDER=0" "SKL_XCDS=4 SKL_TILE32_MIN=0"; do
   echo "== $e"
   env $e python3 -m pytest tests -m gpu -q --deselect tests/test_gpu_fullsize_configs.py --deselect tests/test_bench_gpu.py 2>&1 |
-    grep -E "^FAILED|passed|failed"
+    grep -E "^FAILED|^ERROR|passed|failed"
 done
