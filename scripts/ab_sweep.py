@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 from sketchlib.rust_amd import capi, synth  # noqa: E402
 
-KNOBS = ("SKL_MID_BAND", "SKL_HALF_TILES", "SKL_PERSIST", "SKL_TILE32_MIN", "SKL_ROUND_PRIORITY", "SKL_TAIL_MAX_PCT", "SKL_TAIL_SLICES", "SKL_GROUP_SPAN", "SKL_K_SLICES", "SKL_KSLICE_ABLATE", "SKL_KERNEL", "SKL_KSLICE_SHAPE", "SKL_SLICED_MAX_PAIRS", "SKL_LDS_SHAPE", "SKL_KSPLIT_ROWS",
+KNOBS = ("SKL_INLINE_PREFIX", "SKL_XCDS", "SKL_MID_BAND", "SKL_HALF_TILES", "SKL_TILE32_MIN", "SKL_ROUND_PRIORITY", "SKL_TAIL_MAX_PCT", "SKL_TAIL_SLICES", "SKL_GROUP_SPAN", "SKL_K_SLICES", "SKL_KSLICE_ABLATE", "SKL_KERNEL", "SKL_KSLICE_SHAPE", "SKL_SLICED_MAX_PAIRS", "SKL_LDS_SHAPE", "SKL_KSPLIT_ROWS",
          "SKL_TIMING_EVERY")
 
 

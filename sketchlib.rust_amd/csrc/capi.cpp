@@ -339,6 +339,7 @@ Knobs read_knobs()
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
     k.cand_symmetric = env_int("SKL_CAND_SYMMETRIC", 1) != 0;
     k.cand_row_order = env_int("SKL_CAND_ROW_ORDER", 1) != 0;
+    k.inline_prefix = env_int("SKL_INLINE_PREFIX", 1) != 0;
     const char *sk = getenv("SKL_SKETCH_KERNEL");
     k.sketch_global = sk && strcmp(sk, "global") == 0;
 #ifdef SKL_AB
@@ -387,6 +388,7 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
     PairArgs args = args_in;
     args.group_span = (uint32_t)ctx->knobs.group_span;
     args.xcd_shift = ctx_xcd_shift(ctx);
+    args.inline_prefix_ok = ctx->knobs.inline_prefix ? 1u : 0u;
     const uint32_t n_xcd = 1u << args.xcd_shift;
     static const char *mode_names[] = {"COUNTS", "JACCARD", "COREACC"};
     const std::string m = mode_names[mode];

@@ -223,6 +223,18 @@ __device__ __forceinline__ bool lookup_tile_at(const PairArgs &g, uint32_t xcd, 
         return true;
     }
     const uint32_t n_super = (g.n_groups + g.group_span - 1u) / g.group_span;
+    if (g.n_prefix_inline != 0u) {   // the table rides in the kernel arguments: no global load before the first row DMA
+        uint32_t lo = 0, base = 0;
+#pragma unroll
+        for (int x = 1; x < TILE_PREFIX_INLINE; ++x) {
+            if ((uint32_t)x < n_super && g.tile_prefix_inline[x] <= t) {
+                lo = (uint32_t)x;
+                base = g.tile_prefix_inline[x];
+            }
+        }
+        tile_in_supergroup_self(g, lo, t - base, group, row_tile);
+        return true;
+    }
     uint32_t lo = 0, hi = n_super;  // largest lo with prefix[lo] <= t
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;

@@ -15,6 +15,7 @@ constexpr int BBITS = 14;          // src/sketch/mod.rs:34
 constexpr int LANES = 64;          // wavefront width on gfx950
 constexpr int WAVES_PER_WG = 4;    // 256-thread workgroups
 constexpr int MAX_FUSED_K = 6;     // k-mer lengths the fused core/acc epilogue packs (3 x 2 x u16)
+constexpr int TILE_PREFIX_INLINE = 16;
 constexpr int A_PAD_ROWS = 64;     // rows the scalar-operand slab is over-allocated by
 // pair_kslice.hip keeps a k-mer length's mismatch counts in u16 fields: whole sketches up to 1 023 chunks (65 472 bins);
 // larger ones are walked in segments of 1 016 chunks (a multiple of 8 = the chunks per stage of both tile heights)
@@ -58,6 +59,12 @@ struct PairArgs {
                                   // row tile, its groups side by side (1: column group by column group)
     uint32_t tile_rows, group_cols;   // tile height / columns per group the numbering was planned for
     const uint32_t *tile_prefix;  // [ceil(n_groups / group_span) + 1] first tile number of each super-group (self mode)
+    // ... and a copy of its first entries IN the kernel arguments when it has at most TILE_PREFIX_INLINE of them (launches of
+    // up to ~3 800 genomes): a workgroup's tile lookup is then scalar loads from the kernarg segment (scalar cache) instead of
+    // a binary search of dependent global loads -- the first thing every workgroup of a small launch waits for
+    uint32_t inline_prefix_ok;    // host-side request (SKL_INLINE_PREFIX=0 clears it: A/B)
+    uint32_t n_prefix_inline;     // entries valid in tile_prefix_inline (0: search tile_prefix)
+    uint32_t tile_prefix_inline[16];
     uint64_t out_base;            // flat index of the first pair of this launch
     void *out;
     // MODE_COUNTS record layout: count of (pair p, k index kk) at out[p*cnt_pair_stride + kk*cnt_k_stride]

@@ -91,6 +91,11 @@ hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_
             memcpy(scratch.cached_key, key, sizeof key);
         }
         args.tile_prefix = scratch.d_prefix;
+        args.n_prefix_inline = 0;
+        if (args.inline_prefix_ok && prefix.size() <= (size_t)TILE_PREFIX_INLINE) {
+            args.n_prefix_inline = (uint32_t)prefix.size();
+            for (size_t x = 0; x < prefix.size(); ++x) args.tile_prefix_inline[x] = prefix[x];
+        }
     }
     if (total == 0) return hipSuccess;
     if (total >= (1ull << 31)) return hipErrorInvalidValue;
