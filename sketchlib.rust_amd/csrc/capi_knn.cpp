@@ -175,6 +175,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             m.h_d1 = st.h_d1;
             m.h_len = st.h_len;
             m.thr = st.thr;
+            m.force_workgroup_form = ctx->knobs.refheap_wave ? 0u : 1u;
             // rows below the band FIRST: for them the band's samples are the next candidates in ascending id, and their
             // own band comes later; then the band's own rows (columns [b0, n) minus themselves: everything below b0 reached
             // them turned, from the bands above).  Either way a row is fed ascending ids over the sequence of launches.

@@ -319,6 +319,7 @@ struct RefHeapMergeArgs {
     uint32_t flag_value;
     const uint32_t *seg_bits; // as TopkMergeArgs::seg_bits
     uint32_t seg_bits_stride;
+    uint32_t force_workgroup_form;   // 1: one workgroup per row whatever knn is (default: one WAVE per row up to 256 neighbours; A/B, tests)
 };
 hipError_t launch_refheap_merge(const RefHeapMergeArgs &args, hipStream_t stream);
 hipError_t launch_refheap_finalize(const float *h_key, const uint32_t *h_id, const float *h_d1, const uint32_t *h_len, uint32_t rows,

@@ -779,11 +779,115 @@ __global__ __launch_bounds__(TOPK_THREADS) void refheap_merge_kernel(const RefHe
     }
 }
 
+// The same with ONE WAVE per row (knn <= REFHEAP_WAVE_KNN): what the one-evaluation driver's merges look like at scale is
+// a million rows per band, each fed a few hundred to a few thousand records of which a handful enter the heap -- a
+// 256-thread workgroup per row spends its time in barriers and in the serial drain of one thread while three rows fit
+// a CU.  Here a workgroup is 4 independent rows: no barrier anywhere (a wave's LDS operations execute in order), the heap
+// and the candidate buffer of a row take 4.6 KB of LDS, and 24-32 rows are in flight per CU to hide each other's drains.
+constexpr uint32_t REFHEAP_WAVE_KNN = 256, REFHEAP_WAVE_CAND = 128;
+
+__global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMergeArgs g)
+{
+    __shared__ float heap_mem[4][3 * (REFHEAP_WAVE_KNN + 1)];
+    __shared__ float cand_key[4][REFHEAP_WAVE_CAND], cand_d1[4][REFHEAP_WAVE_CAND];
+    __shared__ uint32_t cand_id[4][REFHEAP_WAVE_CAND];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t row = blockIdx.x * 4u + wave;
+    if (row >= g.rows) return;
+    if (g.flag != nullptr && g.flag[row] != g.flag_value) return;
+    const uint32_t knn = g.knn, stride2 = g.stride2, cols = g.cols;
+    const size_t srow = (size_t)(g.state_row_base + row);
+    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
+    float *hm = heap_mem[wave];
+    RefHeap h{hm, hm + (knn + 1u), reinterpret_cast<uint32_t *>(hm + 2u * (knn + 1u)), 0u, stride2 == 2u};
+    auto wave_sync = [] {   // orders this wave's LDS traffic as the program states it
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    uint32_t len = g.h_len[srow];
+    for (uint32_t x = lane; x < len; x += 64u) {
+        h.key[x] = g.h_key[srow * knn + x];
+        h.id[x] = g.h_id[srow * knn + x];
+        if (stride2 == 2u) h.d1[x] = g.h_d1[srow * knn + x];
+    }
+    wave_sync();
+    float thr = len < knn ? __builtin_inff() : h.key[0];
+    uint32_t ncand = 0;
+    bool dirty = false;
+    auto drain = [&]() {   // lane 0: the buffered candidates through the exact push / pop sequence, in order
+        wave_sync();
+        if (lane == 0u) {
+            h.len = len;
+            for (uint32_t c = 0; c < ncand; ++c) h.push_heap(RefHeap::Elt{cand_key[wave][c], cand_d1[wave][c], cand_id[wave][c]}, knn);
+            len = h.len;
+            thr = h.len < knn ? __builtin_inff() : h.key[0];
+        }
+        wave_sync();
+        len = __shfl(len, 0);
+        thr = __shfl(thr, 0);
+        dirty = dirty || ncand != 0u;
+        ncand = 0;
+    };
+    const float *keys = g.keys + (size_t)row * g.key_stride;
+    const uint32_t *bits = g.seg_bits ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr;
+    constexpr uint32_t UNROLL = 4;
+    for (uint32_t q0 = 0; q0 < cols; q0 += 64u * UNROLL) {
+        uint32_t mask = (1u << UNROLL) - 1u;   // which 64-record blocks of this trip are read
+        if (bits != nullptr) {
+            const uint32_t b = q0 >> 6;          // (64 * UNROLL = 256 records = bits b .. b + 3, inside one word: b is a multiple of 4)
+            mask &= bits[b >> 5] >> (b & 31u);
+            if (mask == 0u) continue;
+        }
+        float k[UNROLL], d[UNROLL];
+#pragma unroll
+        for (uint32_t j = 0; j < UNROLL; ++j) {
+            const uint32_t q = min(q0 + j * 64u + lane, cols - 1u);
+            k[j] = (mask >> j) & 1u ? __builtin_nontemporal_load(&keys[(size_t)q * stride2]) : 0.0f;
+            d[j] = (stride2 == 2u && ((mask >> j) & 1u)) ? __builtin_nontemporal_load(&keys[(size_t)q * 2u + 1u]) : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < UNROLL; ++j) {
+            if (!((mask >> j) & 1u)) continue;
+            const uint32_t q = q0 + j * 64u + lane;
+            const uint32_t id = g.id_base + q;
+            const bool open = len < knn;
+            const bool take = q < cols && id >= g.skip_below && id != self_id && (open || k[j] < thr);
+            const uint64_t votes = __ballot(take);
+            if (votes == 0ull) continue;
+            if (take) {
+                const uint32_t pos = ncand + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+                cand_key[wave][pos] = k[j];
+                cand_d1[wave][pos] = d[j];
+                cand_id[wave][pos] = id;
+            }
+            ncand += (uint32_t)__popcll(votes);
+            // (while the heap fills, drain at once: the threshold must exist before more is buffered)
+            if (open || ncand + 64u > REFHEAP_WAVE_CAND) drain();
+        }
+    }
+    if (ncand != 0u) drain();
+    if (dirty) {
+        for (uint32_t x = lane; x < len; x += 64u) {
+            g.h_key[srow * knn + x] = h.key[x];
+            g.h_id[srow * knn + x] = h.id[x];
+            if (stride2 == 2u) g.h_d1[srow * knn + x] = h.d1[x];
+        }
+        if (lane == 0u) {
+            g.h_len[srow] = len;
+            g.thr[srow] = len < knn ? 0xFFFFFFFFu : sortable_bits(h.key[0]);
+        }
+    }
+}
+
 hipError_t launch_refheap_merge(const RefHeapMergeArgs &args, hipStream_t stream)
 {
     if (args.rows == 0 || args.cols == 0) return hipSuccess;
     if (args.knn == 0 || args.knn > REFHEAP_LDS_MAX) return hipErrorInvalidValue;
     if (args.stride2 != 1 && !(args.stride2 == 2 && args.h_d1)) return hipErrorInvalidValue;
+    if (args.knn <= REFHEAP_WAVE_KNN && !args.force_workgroup_form) {
+        hipLaunchKernelGGL(refheap_merge_wave_kernel, dim3((args.rows + 3u) / 4u), dim3(256), 0, stream, args);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(refheap_merge_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
     return hipGetLastError();
 }

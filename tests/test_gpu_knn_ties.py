@@ -105,8 +105,9 @@ def test_several_bands_and_row_ranges(oracle, skl, gpu_ctx, ref_ties, set_switch
 
 
 @pytest.mark.parametrize("dist", ["jaccard", "ani", "coreacc"])
-@pytest.mark.parametrize("knn,band,flags", [(1, 48, "1"), (7, 64, "1"), (50, 100, "1"), (7, 37, "0")])
-def test_one_evaluation_driver_in_reference_order(oracle, skl, gpu_ctx, ref_ties, set_switch, dist, knn, band, flags):
+@pytest.mark.parametrize("knn,band,flags,wave", [(1, 48, "1", "1"), (7, 64, "1", "1"), (50, 100, "1", "1"), (7, 37, "0", "1"), (50, 64, "1", "0"),
+                                                 (300, 96, "1", "1")])
+def test_one_evaluation_driver_in_reference_order(oracle, skl, gpu_ctx, ref_ties, set_switch, dist, knn, band, flags, wave):
     """The whole self matrix with every pair evaluated ONCE (round 4): the heap of a row lives in global memory between the
     bands and is fed the row's candidates in ascending id -- turned from the bands above its own, then its own band's
     columns -- so it goes through the reference's states.  Band heights that are / are not multiples of the tile, with
@@ -115,6 +116,7 @@ def test_one_evaluation_driver_in_reference_order(oracle, skl, gpu_ctx, ref_ties
     bins = synth.set_r(n, kmers, ss64, n_clusters=40)
     set_switch("SKL_KNN_BAND_ROWS", band)
     set_switch("SKL_KNN_ROW_FLAGS", flags)
+    set_switch("SKL_REFHEAP_WAVE", wave)     # one wave per row (knn <= 256; default) / one workgroup per row (also what knn = 300 takes)
     gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
     _check_self(oracle, skl, gpu_ctx, bins, n, kmers, ss64, knn, dist, oracle.TIES_RUST_HEAP)
     assert "k-sliced" in gpu_ctx.last_kernel() or "all k" in gpu_ctx.last_kernel()
