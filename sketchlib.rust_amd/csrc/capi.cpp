@@ -891,8 +891,9 @@ static uint64_t self_rows_pairs(uint64_t r0, uint64_t r1, uint64_t n)
 // SKL_K_SLICES forces a value (tests keep the sliced form bit-exact; A/B runs).
 static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 {
-    const uint32_t S = ctx->knobs.k_slices > 0 ? (uint32_t)ctx->knobs.k_slices : 1u;
-    return (S == 1 || ((S == 2 || S == 4 || S == 8) && ss64 % (8 * S) == 0)) ? S : 1u;
+    const uint32_t S = ctx->knobs.k_slices > 0 ? std::min(8u, (uint32_t)ctx->knobs.k_slices) : 1u;
+    uint32_t chunks = 0;
+    return slice_plan((uint32_t)ss64, S, &chunks);   // (slices that hold something: a short sketch gets fewer)
 }
 
 // Core of every dense call: rows [r0, r1) of the pair space into `dst` (device).
@@ -944,9 +945,15 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         const uint64_t est_units = pairs * rows->nk / 2048;
         const uint64_t slots = 4ull * (uint64_t)ctx->n_cu;
         // (launches of less than 1/16 round -- ~200 genomes -- are cut twice as fine when the sketch allows it)
-        const uint32_t tail_slices = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 % 64 == 0 ? 8u : (uint32_t)ctx->knobs.tail_slices;
-        bool tail = sliced && k_slices == 1u && tail_slices > 1u && rows->ss64 % (8u * tail_slices) == 0 &&
-                    forced_kernel(ctx) == 0 && est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
+        // (round 4: any sketch size is cut -- slices of whole stages, the last one shorter, slice_plan() -- e.g. the 157
+        // chunks of `-s 10000`; and launches over sketches beyond 65 535 bins slice their last round however many rounds
+        // they have: a unit of 1 563+ chunks dwarfs the fixed cost of a workgroup)
+        const bool big_sketch = rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS;
+        const uint32_t tail_wanted = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 >= 64 ? 8u : (uint32_t)ctx->knobs.tail_slices;
+        uint32_t tail_chunks = 0;
+        const uint32_t tail_slices = slice_plan((uint32_t)rows->ss64, tail_wanted, &tail_chunks);
+        bool tail = sliced && k_slices == 1u && tail_slices > 1u && forced_kernel(ctx) == 0 &&
+                    ((big_sketch && est_units <= 16 * slots) || est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots);
         // MID BAND (round 3): from half the 32-row threshold up to it (4-8 Mi pair x k evaluations: 1 300-1 790 genomes at
         // 5 k-mer lengths) the launch is a handful of rounds of workgroups whichever tile it takes, and its last, partial
         // round decides: 32 x 128 tiles with THAT round cut into 2 chunk slices are 0.7-4.6 % ahead of 16 x 128 tiles
@@ -955,11 +962,11 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         const uint64_t evals = pairs * rows->nk;
         const long long t32 = ctx->knobs.tile32_min;
         const bool mid_band = ctx->knobs.mid_band && !tail && sliced && k_slices == 1u && t32 > 0 && tail_slices > 1u &&
-                              forced_kernel(ctx) == 0 && rows->ss64 % 16 == 0 && evals * 2 >= (uint64_t)t32 && evals < (uint64_t)t32;
-        uint32_t tail_slices_eff = tail_slices;
+                              forced_kernel(ctx) == 0 && rows->ss64 >= 16 && evals * 2 >= (uint64_t)t32 && evals < (uint64_t)t32;
+        uint32_t tail_slices_eff = tail_slices, tail_chunks_eff = tail_chunks;
         if (mid_band) {
             tail = true;
-            tail_slices_eff = 2;
+            tail_slices_eff = slice_plan((uint32_t)rows->ss64, 2u, &tail_chunks_eff);
         }
         const bool two_planes = tail;
         const size_t plane_bytes = pairs * rows->nk * sizeof(uint32_t);
@@ -970,6 +977,8 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             g.k_sliced = 1;
             g.k_slices = k_slices;
             g.tail_slices = tail ? tail_slices_eff : 0u;
+            if (tail) g.slice_chunks = tail_chunks_eff;
+            else if (k_slices > 1u) (void)slice_plan((uint32_t)rows->ss64, std::min(8u, (uint32_t)ctx->knobs.k_slices), &g.slice_chunks);
             g.mid_band = mid_band ? 1u : 0u;
         }
         if (two_planes) {
@@ -1037,9 +1046,12 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // slices per tile + an epilogue launch that turns the summed counts into the f32 output.
         const uint64_t est_units = pairs / 2048;
         const uint64_t slots = 4ull * (uint64_t)ctx->n_cu;
-        const uint32_t tail_slices = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 % 64 == 0 ? 8u : (uint32_t)ctx->knobs.tail_slices;
-        const bool tail = tail_slices > 1u && rows->ss64 <= 1023 && rows->ss64 % (8u * tail_slices) == 0 && forced_kernel(ctx) == 0 &&
-                          est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots;
+        const uint32_t tail_wanted = ctx->knobs.tail_slices == 4 && est_units * 16 <= slots && rows->ss64 >= 64 ? 8u : (uint32_t)ctx->knobs.tail_slices;
+        uint32_t tail_chunks = 0;
+        const uint32_t tail_slices = slice_plan((uint32_t)rows->ss64, tail_wanted, &tail_chunks);
+        const bool tail = tail_slices > 1u && forced_kernel(ctx) == 0 &&
+                          ((rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS && est_units <= 16 * slots) ||
+                           est_units * 100 <= (uint64_t)std::max(0ll, ctx->knobs.tail_max_pct) * slots);
         if (tail) {
             void *counts = nullptr;
             const size_t plane_bytes = pairs * sizeof(uint32_t);
@@ -1055,6 +1067,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             g.k_sliced = 1;
             g.k_slices = 1;
             g.tail_slices = tail_slices;
+            g.slice_chunks = tail_chunks;
             g.out = counts;
             const void *const plane1_clean = ctx->clean_plane1;   // as above: dirty until the epilogue is enqueued
             ctx->clean_plane1 = nullptr;

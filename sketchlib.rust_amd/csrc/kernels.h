@@ -71,6 +71,8 @@ struct PairArgs {
     // ([pair][k] for the public bin-match calls, k-major for the internal counts scratch)
     uint64_t cnt_pair_stride, cnt_k_stride;
     uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
+    uint32_t slice_chunks;        // chunks per chunk slice (k_slices / tail_slices > 1): a multiple of 8; the last slice takes what is
+                                  // left, so any sketch size can be cut (slice_plan(); 0: ss64 / slices, the even split)
     uint32_t seg_chunks;          // pair_kslice.hip, set by its launcher: chunks per segment of the segmented walk (0: whole k-mer lengths)
     uint32_t k_slices;            // k-sliced MODE_COUNTS: chunk slices per k-mer length (0/1: none); slice s of k index kk
                                   // stores the matches of ITS bins at "k index" s * k_count + kk
@@ -146,6 +148,18 @@ hipError_t launch_pair_kernel_ksplit(const PairArgs &args, int mode, int rows_pe
 hipError_t launch_pair_kernel_kslice(const PairArgs &args, int mode, int shape, bool k_sliced, int ablate,
                                      TileScratch &scratch, hipStream_t stream);
 bool kslice_supported(const PairArgs &args, int mode, bool k_sliced);
+// A sketch of ss64 chunks cut into at most `wanted` chunk slices of whole stages: *chunks per slice (a multiple of 8, the
+// last slice shorter) -> number of slices that hold something (1: the sketch is too short to cut)
+inline uint32_t slice_plan(uint32_t ss64, uint32_t wanted, uint32_t *chunks)
+{
+    if (wanted < 2u || ss64 < 16u) {
+        *chunks = 0;
+        return 1u;
+    }
+    const uint32_t per = ((ss64 + wanted - 1u) / wanted + 7u) / 8u * 8u;
+    *chunks = per;
+    return (ss64 + per - 1u) / per;
+}
 
 // reference layout -> lane-interleaved layout (B operand); n_pad = 64*ceil(n/64)
 hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint32_t n,

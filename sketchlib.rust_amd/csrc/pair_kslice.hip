@@ -179,8 +179,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
         else if (round_ == 2u) __builtin_amdgcn_s_setprio(2);
         else if (round_ >= 3u) __builtin_amdgcn_s_setprio(3);
     }
-    const uint32_t c_begin = slice * (g.ss64 / n_slices);       // chunk range of this workgroup
-    const uint32_t c_end = n_slices > 1u ? c_begin + g.ss64 / n_slices : g.ss64;
+    // chunk range of this workgroup: whole stages per slice, the last slice takes what is left (any sketch size)
+    const uint32_t per_slice = g.slice_chunks != 0u ? g.slice_chunks : g.ss64 / n_slices;
+    const uint32_t c_begin = n_slices > 1u ? min(g.ss64, slice * per_slice) : 0u;
+    const uint32_t c_end = n_slices > 1u ? min(g.ss64, c_begin + per_slice) : g.ss64;
     uint32_t jg, at;  // column group (JL blocks of 64), row tile
     if (!lookup_tile_at(g, xcd, slot, jg, at)) return;
     if constexpr ((ABL & 8) != 0) {   // timing only: every workgroup computes tile (0, group 1): all operands cache-hot
@@ -309,12 +311,23 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (args.tail_slices > 1u) {
         // whole units for the XCD's whole rounds of resident workgroups, slices for the rest
         // (counted on the real units: the padding slots of the last tile block exit at once)
-        if (args.ss64 % (args.tail_slices * 8u) != 0 || args.tail_resident == 0) return hipErrorInvalidValue;   // whole stages per slice
+        if (args.tail_resident == 0) return hipErrorInvalidValue;
         const uint32_t units_x = args.tiles_per_xcd * args.k_count;
         args.tail_first = units_x / args.tail_resident * args.tail_resident;
         args.k_slices = 1;
     }
-    if (args.ss64 % (args.k_slices * 8u) != 0 && args.k_slices != 1) return hipErrorInvalidValue;   // whole stages per slice
+    {   // whole stages per slice, every slice holds something
+        const uint32_t S = args.tail_slices > 1u ? args.tail_slices : args.k_slices;
+        if (S > 1u) {
+            if (args.slice_chunks == 0u) {
+                if (args.ss64 % (S * 8u) != 0) return hipErrorInvalidValue;
+            } else if (args.slice_chunks % 8u != 0 || (uint64_t)args.slice_chunks * (S - 1u) >= args.ss64 || (uint64_t)args.slice_chunks * S < args.ss64) {
+                return hipErrorInvalidValue;
+            }
+        } else {
+            args.slice_chunks = 0;
+        }
+    }
     // wave priority by round: for launches of up to 2.25 rounds of workgroups (it costs 2 % at 2.5-2.7 rounds
     // and is neutral beyond; profiles/r02_ab_round_priority.jsonl)
     if (!k_sliced || (uint64_t)args.tiles_per_xcd * args.k_count * args.k_slices * 4u > 9ull * args.round_size) args.round_size = 0;

@@ -93,16 +93,29 @@ def test_default_rule_slices_launches_of_less_than_a_round(oracle, skl, gpu_ctx)
         g.close()
 
 
-def test_unsupported_shapes_run_plain(oracle, skl, gpu_ctx, set_switch):
-    """sketchsize64 not a multiple of 8 x slices: no slices, whatever the switches say."""
-    kmers, ss64, n = [13, 17, 21], 20, 150
+@pytest.mark.parametrize("ss64,expect", [(12, None), (20, "3 chunk slices"), (37, "4 chunk slices"), (157, "4 chunk slices")])
+def test_any_sketch_size_is_cut_into_whole_stages(oracle, skl, gpu_ctx, set_switch, ss64, expect):
+    """Round 4: slices of whole stages (multiples of 8 chunks), the last one shorter -- 20 chunks = 8 + 8 + 4, the 157
+    chunks of `-s 10000` = 40 + 40 + 40 + 37; a sketch of fewer than 16 chunks runs plain.  Self, cross and a row band."""
+    kmers, n, nq = [13, 17, 21], 150, 40
     bins = synth.set_r(n, kmers, ss64, n_clusters=4)
-    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    qb = synth.set_r(nq, kmers, ss64, n_clusters=4, first_sample=900)
+    g, gq = gpu_ctx.sketches(bins, n, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
+    o, oq = oracle.Sketches(bins, n, kmers, ss64), oracle.Sketches(qb, nq, kmers, ss64)
     set_switch("SKL_TAIL_MAX_PCT", "100000000")
     got = skl.self_dists_all(gpu_ctx, g, g.set_k())
-    assert "chunk slices" not in gpu_ctx.last_kernel()
-    assert np.array_equal(got, oracle.self_dists_all(oracle.Sketches(bins, n, kmers, ss64), threads=8))
+    assert (expect in gpu_ctx.last_kernel()) if expect else ("chunk slices" not in gpu_ctx.last_kernel()), gpu_ctx.last_kernel()
+    assert np.array_equal(got, oracle.self_dists_all(o, threads=8))
+    assert np.array_equal(skl.cross_dists_all(gpu_ctx, g, gq, g.set_k()), oracle.cross_dists_all(o, oq, threads=8))
+    assert np.array_equal(skl.self_dists_rows(gpu_ctx, g, g.set_k(), 40, 93), oracle.self_dists_all(o, threads=8)[40 * n - 40 * 41 // 2:93 * n - 93 * 94 // 2])
+    for ani in (False, True):
+        assert np.array_equal(skl.self_dists_all(gpu_ctx, g, g.set_k(17, ani)), oracle.self_dists_all(o, oracle.JACCARD, 1, ani, threads=8))
+    assert np.array_equal(skl.self_binmatch(gpu_ctx, g), oracle.self_binmatch(o, threads=8))
+    set_switch("SKL_K_SLICES", "3")        # ... and uniform slices of every unit (three planes of counts)
+    set_switch("SKL_TAIL_SLICES", "0")
+    assert np.array_equal(skl.self_dists_all(gpu_ctx, g, g.set_k()), oracle.self_dists_all(o, threads=8))
     g.close()
+    gq.close()
 
 
 @pytest.mark.parametrize("ss64,slices", [(64, 4), (32, 4), (32, 2), (128, 8)])
