@@ -93,10 +93,10 @@ def test_default_rule_slices_launches_of_less_than_a_round(oracle, skl, gpu_ctx)
         g.close()
 
 
-@pytest.mark.parametrize("ss64,expect", [(12, None), (20, "3 chunk slices"), (37, "3 chunk slices"), (157, "4 chunk slices")])
+@pytest.mark.parametrize("ss64,expect", [(12, None), (20, "3 chunk slices"), (37, "3 chunk slices"), (157, "7 chunk slices")])
 def test_any_sketch_size_is_cut_into_whole_stages(oracle, skl, gpu_ctx, set_switch, ss64, expect):
     """Round 4: slices of whole stages (multiples of 8 chunks), the last one shorter -- 20 chunks = 8 + 8 + 4, the 157
-    chunks of `-s 10000` = 40 + 40 + 40 + 37; a sketch of fewer than 16 chunks runs plain.  Self, cross and a row band."""
+    chunks of `-s 10000`  in a launch this small = 6 x 24 + 13; a sketch of fewer than 16 chunks runs plain.  Self, cross and a row band."""
     kmers, n, nq = [13, 17, 21], 150, 40
     bins = synth.set_r(n, kmers, ss64, n_clusters=4)
     qb = synth.set_r(nq, kmers, ss64, n_clusters=4, first_sample=900)
