@@ -159,11 +159,18 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     }
     std::vector<uint32_t> work_row;
     std::vector<uint64_t> work_start;
-    for (size_t x = 0; x < n; ++x) {
-        const size_t i = order[x];
-        for (uint64_t c0 = symmetric ? first[i] : host_offsets[i]; c0 < host_offsets[i + 1]; c0 += 64) {
-            work_row.push_back((uint32_t)i);
-            work_start.push_back(c0);
+    {
+        size_t n_items = 0;   // (sized once: millions of items at a few hundred thousand rows)
+        for (size_t i = 0; i < n; ++i) n_items += (size_t)((host_offsets[i + 1] - (symmetric ? first[i] : host_offsets[i]) + 63) / 64);
+        work_row.resize(n_items);
+        work_start.resize(n_items);
+        size_t at = 0;
+        for (size_t x = 0; x < n; ++x) {
+            const size_t i = order[x];
+            for (uint64_t c0 = symmetric ? first[i] : host_offsets[i]; c0 < host_offsets[i + 1]; c0 += 64, ++at) {
+                work_row[at] = (uint32_t)i;
+                work_start[at] = c0;
+            }
         }
     }
     DevBuf d_wrow, d_wstart, d_keys, d_idx, d_d0;
