@@ -340,6 +340,10 @@ Knobs read_knobs()
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
     k.cand_symmetric = env_int("SKL_CAND_SYMMETRIC", 1) != 0;
     k.cand_row_order = env_int("SKL_CAND_ROW_ORDER", 1) != 0;
+    {
+        const char *ck = getenv("SKL_CAND_KERNEL");
+        k.cand_lanes = ck && strcmp(ck, "lanes") == 0;
+    }
     k.inline_prefix = env_int("SKL_INLINE_PREFIX", 1) != 0;
     const char *sk = getenv("SKL_SKETCH_KERNEL");
     k.sketch_global = sk && strcmp(sk, "global") == 0;

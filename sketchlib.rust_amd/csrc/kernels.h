@@ -212,6 +212,7 @@ struct CandArgs {
     // consecutive work items (rows of one cluster, capi_aux.cpp) stay on ONE XCD, whose L2 then holds the candidates they
     // share: workgroup b takes the items of block (b mod XCDs) * blocks_per_xcd + b / XCDs (set by the launcher)
     uint32_t xcd_shift, blocks_per_xcd;
+    uint32_t lanes_over_candidates;   // 1: round 3's form (every lane walks its own candidate); 0: lanes across the sketch (round 4)
 };
 hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream);
 
