@@ -44,7 +44,7 @@ def test_reference_fixture(oracle, skl, gpu_ctx, ani, knn):
     o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
     offs, cols = candidates(skq)
     idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21, ani), knn, offs, cols)
-    assert "pair_cand_kernel" in gpu_ctx.last_kernel()
+    assert "pair_cand_rows_kernel" in gpu_ctx.last_kernel()
     assert as_pairs(idx, d0) == oracle_pairs(oracle.self_dists_knn_precluster(o, skq, knn, 0, ani))
 
 
@@ -79,6 +79,30 @@ def test_synthetic_ragged_lists(oracle, skl, gpu_ctx, ani, comp):
             np.testing.assert_allclose(d0, exp["d0"], atol=1e-6, rtol=0)
         else:
             assert as_pairs(idx, d0) == oracle_pairs(exp)
+
+
+@pytest.mark.parametrize("ss64", [1, 3, 16, 32, 50, 64, 157])
+def test_both_candidate_kernels_at_many_sketch_sizes(oracle, skl, gpu_ctx, set_switch, ss64):
+    """pair_cand_rows_kernel (lanes across the sketch: half chunks per lane, several trips beyond 32 chunks, idle lanes
+    below) and round 3's pair_cand_kernel (SKL_CAND_KERNEL=lanes) against the oracle and each other, host lists (every
+    pair evaluated) and device lists (symmetric halves)."""
+    kmers, n, knn = [17, 21], 300, 6
+    bins = synth.set_r(n, kmers, ss64, n_clusters=11)
+    rng = np.random.default_rng(ss64)
+    skq = rng.integers(0, 25, size=(n, 4), dtype=np.uint16)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    offs, cols = candidates(skq)
+    exp = oracle.self_dists_knn_precluster(o, skq, knn, 1, False, threads=8)
+    got = {}
+    for kernel in (None, "lanes"):
+        set_switch("SKL_CAND_KERNEL", kernel)
+        idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21), knn, offs, cols)
+        assert ("pair_cand_kernel" if kernel else "pair_cand_rows_kernel") in gpu_ctx.last_kernel()
+        assert as_pairs(idx, d0) == oracle_pairs(exp), (ss64, kernel)
+        idx2, d02, _ = skl.self_dists_knn_shared_bins(gpu_ctx, g, g.set_k(21), knn, skq)
+        assert np.array_equal(idx2, idx) and np.array_equal(d02, d0), (ss64, kernel)
+        got[kernel] = (idx, d0)
+    g.close()
 
 
 def test_reordered_index_and_errors(oracle, skl, gpu_ctx):
