@@ -110,60 +110,39 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_rows_kernel(con
     const uint32_t halves = g.ss64 * 2u;                     // half chunks of 7 planes (56 bytes) per sketch
     const uint2 *pi = reinterpret_cast<const uint2 *>(g.A + (size_t)row * sample_stride + (size_t)g.k_begin * kmer_stride);
     uint32_t mism_mine = 0;
-    // the wave-wide sum of the lanes' partial counts: four row shifts leave each row of 16 lanes' total in its last lane
-    auto wave_total = [](uint32_t part) -> uint32_t {
-        part = SKL_DPP_ADD(part, 0x111);   // row_shr:1
-        part = SKL_DPP_ADD(part, 0x112);   // row_shr:2
-        part = SKL_DPP_ADD(part, 0x114);   // row_shr:4
-        part = SKL_DPP_ADD(part, 0x118);   // row_shr:8
-        return (uint32_t)__builtin_amdgcn_readlane((int)part, 15) + (uint32_t)__builtin_amdgcn_readlane((int)part, 31) +
-               (uint32_t)__builtin_amdgcn_readlane((int)part, 47) + (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
-    };
-    // the other seven planes of a chunk sit in the neighbouring lane (h ^ 1): a bin matches iff all 14 agree
-    auto chunk_count = [&](uint32_t mlo, uint32_t mhi, bool mine) -> uint32_t {
-        mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
-        mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
-        return mine ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
-    };
-    // two candidates per trip: both candidates' loads are in flight before either is looked at
-    for (uint32_t cc = 0; cc < cnt; cc += 2u) {
-        const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)j_mine, (int)cc);   // (cc is wave-uniform)
-        const bool two = cc + 1u < cnt;
-        const uint32_t j1 = two ? (uint32_t)__builtin_amdgcn_readlane((int)j_mine, (int)(cc + 1u)) : j0;
-        // (symmetric lists: the j <= row half is stored from row j's side; the work item starts behind it, so at most the
-        // diagonal padding of idle lanes lands here)
-        const bool do0 = !(c.symmetric && j0 <= row), do1 = two && !(c.symmetric && j1 <= row);
-        if (!do0 && !do1) continue;
-        const uint2 *p0 = reinterpret_cast<const uint2 *>(g.A + (size_t)j0 * sample_stride + (size_t)g.k_begin * kmer_stride);
-        const uint2 *p1 = reinterpret_cast<const uint2 *>(g.A + (size_t)j1 * sample_stride + (size_t)g.k_begin * kmer_stride);
-        uint32_t part0 = 0, part1 = 0;
+    for (uint32_t cc = 0; cc < cnt; ++cc) {
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)j_mine, (int)cc);   // (cc is wave-uniform)
+        if (c.symmetric && j <= row) continue;               // the other half of a symmetric list: stored from row j's side
+        const uint2 *pj = reinterpret_cast<const uint2 *>(g.A + (size_t)j * sample_stride + (size_t)g.k_begin * kmer_stride);
+        uint32_t part = 0;
         for (uint32_t h0 = 0; h0 < halves; h0 += 64u) {
             const uint32_t h = h0 + lane;
-            const bool in = h < halves;
-            uint32_t m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
-            if (in) {
-                uint2 a[7], b0[7], b1[7];
+            uint32_t mlo = 0, mhi = 0;
+            if (h < halves) {
+                uint2 a[7], b[7];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) b0[q] = p0[(size_t)h * 7 + q];     // one plane (lo, hi) each: the wave's 64 x 56 B are contiguous
-#pragma unroll
-                for (int q = 0; q < 7; ++q) b1[q] = p1[(size_t)h * 7 + q];
+                for (int q = 0; q < 7; ++q) b[q] = pj[(size_t)h * 7 + q];      // one plane (lo, hi) each: the wave's 64 x 56 B are contiguous
 #pragma unroll
                 for (int q = 0; q < 7; ++q) a[q] = pi[(size_t)h * 7 + q];      // the row's: the same addresses for every candidate (L1)
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
-                    m0lo = acc_mismatch<true>(m0lo, a[q].x, b0[q].x);
-                    m0hi = acc_mismatch<true>(m0hi, a[q].y, b0[q].y);
-                    m1lo = acc_mismatch<true>(m1lo, a[q].x, b1[q].x);
-                    m1hi = acc_mismatch<true>(m1hi, a[q].y, b1[q].y);
+                    mlo = acc_mismatch<true>(mlo, a[q].x, b[q].x);
+                    mhi = acc_mismatch<true>(mhi, a[q].y, b[q].y);
                 }
             }
-            const bool mine = in && (lane & 1u) == 0u;
-            part0 += chunk_count(m0lo, m0hi, mine);
-            part1 += chunk_count(m1lo, m1hi, mine);
+            // the other seven planes of this chunk sit in the neighbouring lane (h ^ 1): a bin matches iff all 14 agree
+            mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+            mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
+            if ((lane & 1u) == 0u && h < halves) part += (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi);
         }
-        const uint32_t t0 = wave_total(part0), t1 = wave_total(part1);
-        if (do0 && lane == cc) mism_mine = t0;
-        if (do1 && lane == cc + 1u) mism_mine = t1;
+        // sum over the wave: four row shifts leave each row of 16 lanes' total in its last lane
+        part = SKL_DPP_ADD(part, 0x111);   // row_shr:1
+        part = SKL_DPP_ADD(part, 0x112);   // row_shr:2
+        part = SKL_DPP_ADD(part, 0x114);   // row_shr:4
+        part = SKL_DPP_ADD(part, 0x118);   // row_shr:8
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)part, 15) + (uint32_t)__builtin_amdgcn_readlane((int)part, 31) +
+                               (uint32_t)__builtin_amdgcn_readlane((int)part, 47) + (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+        if (lane == cc) mism_mine = total;
     }
     const bool active = lane < cnt && (!c.symmetric || j_mine > row);
     if (active) {
