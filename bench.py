@@ -735,7 +735,8 @@ def main():
         del full, bands, bins
         torch.cuda.empty_cache()
         out["config"]["secondary"] = secondary_legs(torch, np, capi, synth, ctx, device, args.secondary.split(","),
-                                                    sampler=not args.no_clock_sampler and not under_profiler())
+                                                    sampler=not args.no_clock_sampler and not under_profiler(),
+                                                    cpu_too=not args.no_cpu_baseline)
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -761,7 +762,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True):
+def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu_too=False):
     """cfg 2 on Set R, and BASELINE configs[2..4] at FULL size on this one GPU, each with its own kernel
     time (every launch bracketed), clock reading and VALU fraction."""
     from oracle import oracle as O
@@ -818,6 +819,8 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True):
         sec["cfg2_set_R"] = {"pairs_per_s": pairs_r / wall, "ms_per_step": wall * 1e3, "kernel_avg_ms": ksec * 1e3,
                              "valu_frac": v["frac"], "in_kernel_clock": clk, "verified_pairs": cnt, "max_abs_err": worst,
                              "regression_fitted": fitted}
+        if cpu_too:   # the CPU port on Set R too (the regression is exercised there: costlier per pair than on Set U)
+            sec["cfg2_set_R"]["cpu_baseline"] = cpu_baseline(CFG2_N, KMERS, SS64, "R")
         sk_r.close()
         del bins_r, out_r
 
