@@ -1,18 +1,20 @@
 // The CLI's text writer (csrc/host/distance_matrix.cpp: persistent worker pool, two-phase block groups) on its own, no GPU:
 // the dense listing of a 1 500-sample matrix through a file sink and a stream sink, cut into row bands of many heights and
-// formatted by 1 ... 186 workers, must be byte-identical to the single-threaded listing.  argv[1]: a scratch directory.
+// formatted by 1 ... 186 workers, must be byte-identical to the single-threaded listing.  argv[1]: a scratch directory;
+// argv[2]: the number of samples (default 1 500; the ThreadSanitizer build of the test takes 700).
 #include "distance_matrix.hpp"
 #include <iostream>
 #include <sstream>
 #include <fstream>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 using namespace skl_host;
 static std::string slurp(const char *p) { std::ifstream f(p, std::ios::binary); std::stringstream ss; ss << f.rdbuf(); return ss.str(); }
 int main(int argc, char **argv) {
     const std::string scratch = std::string(argc > 1 ? argv[1] : ".") + "/out3.txt";
-    size_t n = 1500;
+    size_t n = argc > 2 ? (size_t)atol(argv[2]) : 1500;
     DistanceMatrix m;
     m.jaccard.kind = DistType::CoreAcc;
     for (size_t i = 0; i < n; ++i) m.ref_names.push_back("s" + std::to_string(i));

@@ -77,16 +77,23 @@ def test_unwritable_output_file_fails(tmp_path):
     assert res.returncode != 0 and "cannot create output file" in res.stderr
 
 
-def test_text_writer_is_byte_identical_for_any_thread_count_and_band_height(tmp_path):
+@pytest.mark.parametrize("sanitizer", ["", "thread"])
+def test_text_writer_is_byte_identical_for_any_thread_count_and_band_height(tmp_path, sanitizer):
     """tests/native/output_writer_check.cpp: the CLI's worker pool / two-phase block writer against its own
-    single-threaded output, through a file sink (positional writes) and a stream sink, no GPU needed."""
+    single-threaded output, through a file sink (positional writes) and a stream sink, no GPU needed.  The second
+    build runs the same program under ThreadSanitizer: the pool's hand-offs (block groups, the ordered stream
+    phase, positional writes) must be free of data races for every thread count."""
     import subprocess
 
     host = os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "host")
     exe = str(tmp_path / "output_writer_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + host, "-I" + os.path.join(ROOT, "include"),
+    flags = ["-O1", "-g", "-fsanitize=thread"] if sanitizer else ["-O2"]
+    subprocess.check_call(["g++", *flags, "-std=c++17", "-I" + host, "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "native", "output_writer_check.cpp"), os.path.join(host, "distance_matrix.cpp"),
                            "-lpthread", "-o", exe])
-    res = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe, str(tmp_path)] + (["700"] if sanitizer else []), capture_output=True, text=True, timeout=900)
+    if sanitizer and "unexpected memory mapping" in res.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert "WARNING: ThreadSanitizer" not in res.stderr, res.stderr[-4000:]
     assert res.returncode == 0 and "DIFFERENT" not in res.stderr, res.stderr[-2000:]
     assert res.stderr.count("same") == 13
