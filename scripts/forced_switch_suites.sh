@@ -1,14 +1,21 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): the whole -m gpu parity suite again under forced switch settings, so that
 # every parity test also goes through the 32-row tiles, the sliced last round, other tile numberings.
-# The four tests that assert the DEFAULT dispatch (kernel names / the slicing rule / kernel variety) are expected to fail
-# under the settings that change it; every parity assertion must hold.
+# The tests that assert the DEFAULT dispatch (kernel names / the slicing rule / kernel variety) are expected to fail
+# under the settings that change it -- they check the names LAST, after all their parity assertions, and the assertion
+# message is printed here; every parity assertion must hold.    forced_switch_suites.sh [first-setting-number [last]]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
+FIRST=${1:-1}
+LAST=${2:-99}
+I=0
+export COLUMNS=230
 for e in "SKL_TILE32_MIN=0" "SKL_TILE32_MIN=-1" "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=2" "SKL_GROUP_SPAN=5" \
          "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=8 SKL_TILE32_MIN=0 SKL_GROUP_SPAN=3" \
          "SKL_ROUND_PRIORITY=0 SKL_KNN_ROW_FLAGS=0" "SKL_XCDS=1 SKL_CAND_ROW_ORDER=0" "SKL_XCDS=4 SKL_TILE32_MIN=0"; do
+  I=$((I + 1))
+  if [ "$I" -lt "$FIRST" ] || [ "$I" -gt "$LAST" ]; then continue; fi
   echo "== $e"
   env $e python3 -m pytest tests -m gpu -q --deselect tests/test_gpu_fullsize_configs.py --deselect tests/test_bench_gpu.py 2>&1 |
     grep -E "^FAILED|^ERROR|passed|failed"

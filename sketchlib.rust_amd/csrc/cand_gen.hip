@@ -234,6 +234,32 @@ hipError_t launch_first_candidate(const uint64_t *row_offsets, const uint32_t *c
     return hipGetLastError();
 }
 
+// The work items of pair_cand_kernel, written where the host counted them: the x-th row of the launch order (row order[x])
+// owns items item_begin[x] .. item_begin[x + 1], one per 64 candidates from `first[row]` (symmetric lists: its first
+// candidate with a larger id; null: the start of its list).
+__global__ void cand_work_items_kernel(const uint32_t *order, const uint64_t *item_begin, const uint64_t *row_offsets,
+                                       const uint64_t *first, uint32_t n, uint32_t *work_row, uint64_t *work_start)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const uint32_t row = order[x];
+    const uint64_t end = row_offsets[row + 1];
+    uint64_t at = item_begin[x];
+    for (uint64_t c0 = first ? first[row] : row_offsets[row]; c0 < end; c0 += 64, ++at) {
+        work_row[at] = row;
+        work_start[at] = c0;
+    }
+}
+
+hipError_t launch_cand_work_items(const uint32_t *order, const uint64_t *item_begin, const uint64_t *row_offsets, const uint64_t *first,
+                                  uint32_t n, uint32_t *work_row, uint64_t *work_start, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cand_work_items_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, order, item_begin, row_offsets, first, n,
+                       work_row, work_start);
+    return hipGetLastError();
+}
+
 hipError_t launch_cand_rows(const CandGenArgs &g, bool fill, hipStream_t stream)
 {
     if (g.n == 0) return hipSuccess;

@@ -130,8 +130,8 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     // symmetric lists: only the candidates with a larger id than the row are evaluated (the
     // kernel stores each key for both rows), so a row's work items start at its first such candidate
     std::vector<uint64_t> first;
+    DevBuf d_first;
     if (symmetric && n) {
-        DevBuf d_first;
         HIP_TRY(hipMalloc(&d_first.p, n * sizeof(uint64_t)));
         HIP_TRY(launch_first_greater(d_off, d_cand, (uint32_t)n, (uint64_t *)d_first.p, ctx->stream));
         first.resize(n);
@@ -157,29 +157,23 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
         for (size_t b = 0; b <= n; ++b) begin[b + 1] += begin[b];
         for (size_t i = 0; i < n; ++i) order[begin[key[i] < n ? key[i] : n]++] = (uint32_t)i;
     }
-    std::vector<uint32_t> work_row;
-    std::vector<uint64_t> work_start;
-    {
-        size_t n_items = 0;   // (sized once: millions of items at a few hundred thousand rows)
-        for (size_t i = 0; i < n; ++i) n_items += (size_t)((host_offsets[i + 1] - (symmetric ? first[i] : host_offsets[i]) + 63) / 64);
-        work_row.resize(n_items);
-        work_start.resize(n_items);
-        size_t at = 0;
-        for (size_t x = 0; x < n; ++x) {
-            const size_t i = order[x];
-            for (uint64_t c0 = symmetric ? first[i] : host_offsets[i]; c0 < host_offsets[i + 1]; c0 += 64, ++at) {
-                work_row[at] = (uint32_t)i;
-                work_start[at] = c0;
-            }
-        }
+    // The work items (a row and up to 64 of its candidates each; millions at a few hundred thousand rows): the host only
+    // counts them per row, in launch order; a kernel writes them out.
+    std::vector<uint64_t> item_begin(n + 1, 0);
+    for (size_t x = 0; x < n; ++x) {
+        const size_t i = order[x];
+        item_begin[x + 1] = item_begin[x] + (host_offsets[i + 1] - (symmetric ? first[i] : host_offsets[i]) + 63) / 64;
     }
-    DevBuf d_wrow, d_wstart, d_keys, d_idx, d_d0;
-    HIP_TRY(hipMalloc(&d_wrow.p, std::max<size_t>(work_row.size() * sizeof(uint32_t), 16)));
-    HIP_TRY(hipMalloc(&d_wstart.p, std::max<size_t>(work_start.size() * sizeof(uint64_t), 16)));
-    if (!work_row.empty()) {
-        HIP_TRY(hipMemcpyAsync(d_wrow.p, work_row.data(), work_row.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_wstart.p, work_start.data(), work_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    }
+    const uint64_t n_items = item_begin[n];
+    DevBuf d_wrow, d_wstart, d_order, d_ibegin, d_keys, d_idx, d_d0;
+    HIP_TRY(hipMalloc(&d_wrow.p, std::max<size_t>(n_items * sizeof(uint32_t), 16)));
+    HIP_TRY(hipMalloc(&d_wstart.p, std::max<size_t>(n_items * sizeof(uint64_t), 16)));
+    HIP_TRY(hipMalloc(&d_order.p, std::max<size_t>(n * sizeof(uint32_t), 16)));
+    HIP_TRY(hipMalloc(&d_ibegin.p, (n + 1) * sizeof(uint64_t)));
+    if (n) HIP_TRY(hipMemcpyAsync(d_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_ibegin.p, item_begin.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_cand_work_items((const uint32_t *)d_order.p, (const uint64_t *)d_ibegin.p, d_off, (const uint64_t *)d_first.p,
+                                   (uint32_t)n, (uint32_t *)d_wrow.p, (uint64_t *)d_wstart.p, ctx->stream));
     HIP_TRY(hipMalloc(&d_keys.p, std::max<size_t>(total * sizeof(float), 16)));
     HIP_TRY(hipMalloc(&d_idx.p, n * knn * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&d_d0.p, n * knn * sizeof(float)));
@@ -194,7 +188,7 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     c.cand = d_cand;
     c.work_row = (const uint32_t *)d_wrow.p;
     c.work_start = (const uint64_t *)d_wstart.p;
-    c.n_work = work_row.size();
+    c.n_work = n_items;
     c.keys = (float *)d_keys.p;
     c.symmetric = symmetric ? 1u : 0u;
     c.lanes_over_candidates = ctx->knobs.cand_lanes ? 1u : 0u;

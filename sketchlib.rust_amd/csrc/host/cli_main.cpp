@@ -7,6 +7,7 @@
 // GPU.  `--device` is the one addition.
 #include <atomic>
 #include <mutex>
+#include <future>
 #include <thread>
 #include <chrono>
 #include <cstdio>
@@ -234,6 +235,10 @@ int run_dist(const DistArgs &a)
     // lib.rs:230-237: verbose -> Info, quiet -> Error, default -> Warn
     const Logger log{a.verbose && !a.quiet, !a.quiet};
     log.info("Using " + std::to_string(a.threads) + " threads");   // cli.rs:75-86 (host threads unused)
+    // The device contexts (HIP runtime start, stream, first allocations: 0.1-0.25 s) come up on their own thread while the
+    // database is read; whatever goes wrong there is reported where the contexts are first needed, after the loading errors.
+    std::future<std::unique_ptr<DeviceSet>> dev_starting =
+        std::async(std::launch::async, [devices = a.devices] { return std::make_unique<DeviceSet>(devices); });
 
     // listings go through a TextSink (regular file: blocks written at offsets from all
     // formatting threads; stdout: in order)
@@ -254,6 +259,27 @@ int run_dist(const DistArgs &a)
         references = MultiSketch::load_metadata(ref_db_name);
     } catch (const std::exception &) {
         throw Panic("Could not read sketch metadata from " + a.ref_db + ".skm");  // lib.rs:322-323
+    }
+    // A distance at one k-mer length only ever reads that slice of each sample (jaccard.rs:6-45 through get_sketch_slice):
+    // of a database with several lengths, only that slice is read, held and uploaded.  Not when the query database lists
+    // other lengths than the reference database: that pair of databases is refused by the library (SKL_ERR_INCOMPATIBLE;
+    // the reference would apply the reference database's k INDEX to the queries, mod.rs:253-269), as before.
+    std::optional<MultiSketch> queries_peeked;
+    if (a.kmer && references.kmer_lengths().size() > 1 && references.get_k_idx(*a.kmer)) {
+        bool same_lengths = true;
+        if (a.query_db) {
+            try {
+                queries_peeked = MultiSketch::load_metadata(strip_sketch_extension(*a.query_db));
+                same_lengths = queries_peeked->kmer_lengths() == references.kmer_lengths();
+            } catch (const std::exception &) {
+                same_lengths = false;   // (reported where the reference reports it, after the reference database is read)
+            }
+        }
+        if (same_lengths) {
+            const size_t k_idx = *references.get_k_idx(*a.kmer);
+            references.select_kmer(k_idx);
+            if (queries_peeked) queries_peeked->select_kmer(k_idx);
+        }
     }
     log.info("Loading sketch data from " + ref_db_name + ".skd");
     try {
@@ -287,7 +313,8 @@ int run_dist(const DistArgs &a)
     if (a.query_db) {
         const std::string query_db_name = strip_sketch_extension(*a.query_db);
         try {
-            queries = MultiSketch::load_metadata(query_db_name);
+            if (queries_peeked) queries = std::move(*queries_peeked);
+            else queries = MultiSketch::load_metadata(query_db_name);
         } catch (const std::exception &) {
             throw Panic("Could not read sketch metadata from " + *a.query_db + ".skm");
         }
@@ -305,7 +332,8 @@ int run_dist(const DistArgs &a)
     for (const auto &w : warnings) log.warn(w);
 
     t_loaded = since_start();
-    DeviceSet dev(a.devices);
+    const std::unique_ptr<DeviceSet> dev_owner = dev_starting.get();
+    DeviceSet &dev = *dev_owner;
     t_device = since_start();
     if (a.devices.size() > 1) log.info("Using " + std::to_string(a.devices.size()) + " GPU contexts (row-band partition)");
     for (size_t d = 0; d < dev.size(); ++d) {
@@ -378,7 +406,7 @@ int run_dist(const DistArgs &a)
     os->flush();
     if (timing) {
         const OutputTiming &t = output_timing();
-        std::fprintf(stderr, "TIMING load=%.3fs device_init=%.3fs dist+output=%.3fs (gpu_wait=%.3fs format=%.3fs sink=%.3fs)\n",
+        std::fprintf(stderr, "TIMING load=%.3fs device_wait=%.3fs dist+output=%.3fs (gpu_wait=%.3fs format=%.3fs sink=%.3fs)\n",
                      t_loaded, t_device - t_loaded, since_start() - t_device, t.wait_s, t.format_s, t.sink_s);
     }
     return 0;
@@ -636,6 +664,9 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     const auto t_start = std::chrono::steady_clock::now();
     auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     const std::string input_prefix = strip_sketch_extension(*ski);
+    // (as in `dist`: the device context comes up while the .ski, the .skq and the .skd are read)
+    std::future<std::unique_ptr<Device>> dev_starting;
+    if (skd && !count) dev_starting = std::async(std::launch::async, [device] { return std::make_unique<Device>(device); });
     // The bitmaps of the index are only needed for --count and for the host candidate search;
     // by default the candidates are found on the device from the .skq alone.
     Inverted inv = Inverted::load(input_prefix, count || host_candidates);   // `?` in the reference: Error, exit 1
@@ -677,6 +708,9 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     } catch (const std::exception &) {
         throw Panic("Could not read sketch metadata from " + ref_db_name + ".skm");
     }
+    if (references.kmer_lengths().size() > 1 && references.get_k_idx(inv.kmer_size)) {
+        references.select_kmer(*references.get_k_idx(inv.kmer_size));   // (as in `dist -k`: the one slice the distances read)
+    }
     log.info("Loading sketch data from " + ref_db_name + ".skd");
     references.read_sketch_data(ref_db_name);
     const size_t n = references.number_samples_loaded();
@@ -708,7 +742,8 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     log.info("Preclustering with k=" + std::to_string(inv.kmer_size) + " and s=" + std::to_string(inv.sketch_size()));
     if (retain) log.info("Retain unmatched mode: " + *retain);
     const double t_loaded = since_start();
-    Device dev(device);
+    const std::unique_ptr<Device> dev_owner = dev_starting.get();
+    Device &dev = *dev_owner;
     const double t_device = since_start();
     if (comp && (skl_ctx_flags(dev.ctx()) & SKL_CTX_FLAG_LOG_UNMATCHED)) log.warn(LOG_UNMATCHED_WARNING);
     const SparseDistanceMatrix d = distances::self_dists_knn_precluster(
@@ -719,7 +754,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
     d.write(*sink, threads);
     os->flush();
     if (timing) {
-        std::fprintf(stderr, "TIMING precluster: load_ski=%.3fs load_skq+skd=%.3fs device_init=%.3fs candidates+distances=%.3fs write=%.3fs\n",
+        std::fprintf(stderr, "TIMING precluster: load_ski=%.3fs load_skq+skd=%.3fs device_wait=%.3fs candidates+distances=%.3fs write=%.3fs\n",
                      t_ski, t_loaded - t_ski, t_device - t_loaded, t_dist - t_device, since_start() - t_dist);
     }
     return 0;

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <fcntl.h>
 #include <set>
 #include <thread>
@@ -237,8 +238,76 @@ void MultiSketch::write_sketch_data(const std::string &file_prefix, const uint64
     f.write((const char *)bins, (std::streamsize)(n_words * sizeof(uint64_t)));  // little-endian host
 }
 
+void MultiSketch::select_kmer(size_t k_idx)
+{
+    if (k_idx >= kmer_lengths_.size()) throw std::runtime_error("select_kmer: no such k-mer length");
+    if (file_k_idx_) throw std::runtime_error("select_kmer: already selected");
+    if (!sketch_bins_.empty()) throw std::runtime_error("select_kmer: the sketch data has been read already");
+    file_k_idx_ = k_idx;
+    file_sample_stride_ = sample_stride_;
+    kmer_lengths_ = {kmer_lengths_[k_idx]};
+    sample_stride_ = kmer_stride_;
+}
+
+namespace {
+// A read-only mapping of a whole file
+struct FileMapping {
+    const char *p = nullptr;
+    size_t bytes = 0;
+    explicit FileMapping(const std::string &path)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) {
+            ::close(fd);
+            throw std::runtime_error("cannot stat " + path);
+        }
+        bytes = (size_t)st.st_size;
+        if (bytes) {
+            void *m = ::mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                ::close(fd);
+                throw std::runtime_error("cannot map " + path);
+            }
+            p = (const char *)m;
+        }
+        ::close(fd);
+    }
+    ~FileMapping()
+    {
+        if (p) ::munmap((void *)p, bytes);
+    }
+    FileMapping(const FileMapping &) = delete;
+    FileMapping &operator=(const FileMapping &) = delete;
+};
+}  // namespace
+
 void MultiSketch::read_sketch_data(const std::string &file_prefix)
 {
+    if (file_k_idx_) {
+        // one slice per sample, picked out of a mapping of the file by several threads
+        const std::string path = file_prefix + ".skd";
+        const FileMapping map(path);
+        const size_t n = sketch_metadata_.size();
+        if (map.bytes / sizeof(uint64_t) < n * file_sample_stride_) throw std::runtime_error(path + " is shorter than its metadata says");
+        sketch_bins_.resize(n * kmer_stride_);
+        const size_t slice_bytes = kmer_stride_ * sizeof(uint64_t);
+        const size_t n_threads = n * slice_bytes >= (64u << 20) ? std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        auto copy_range = [&](size_t t) {
+            const char *src = map.p + *file_k_idx_ * slice_bytes;
+            char *dst = reinterpret_cast<char *>(sketch_bins_.data());
+            for (size_t i = n * t / n_threads, end = n * (t + 1) / n_threads; i < end; ++i) {
+                memcpy(dst + i * slice_bytes, src + i * file_sample_stride_ * sizeof(uint64_t), slice_bytes);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(copy_range, t);
+        copy_range(0);
+        for (auto &t : pool) t.join();
+        block_reindex_.reset();
+        return;
+    }
     // read_all_from_skd streams the whole file (sketch_datafile.rs:159-168); here straight into
     // the bins, in slices read concurrently (a GB-sized .skd is otherwise a second of memcpy)
     const std::string path = file_prefix + ".skd";
@@ -295,8 +364,10 @@ void MultiSketch::read_sketch_data_block(const std::string &file_prefix,
     std::ifstream f(file_prefix + ".skd", std::ios::binary);
     if (!f) throw std::runtime_error("cannot open " + file_prefix + ".skd");
     sketch_bins_.assign(sample_stride_ * read_indices.size(), 0);
+    const size_t in_file_stride = file_k_idx_ ? file_sample_stride_ : sample_stride_;    // (select_kmer: one slice of each sample)
+    const size_t in_sample = file_k_idx_ ? *file_k_idx_ * kmer_stride_ : 0;
     for (size_t i = 0; i < read_indices.size(); ++i) {
-        f.seekg((std::streamoff)(read_indices[i] * sample_stride_ * sizeof(uint64_t)));
+        f.seekg((std::streamoff)((read_indices[i] * in_file_stride + in_sample) * sizeof(uint64_t)));
         f.read((char *)(sketch_bins_.data() + i * sample_stride_),
                (std::streamsize)(sample_stride_ * sizeof(uint64_t)));
         if (!f) throw std::runtime_error(file_prefix + ".skd is shorter than its metadata says");

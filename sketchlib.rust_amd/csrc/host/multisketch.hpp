@@ -65,6 +65,11 @@ class MultiSketch {
     // multisketch.rs:90-103 (including the pre-0.2.0 compatibility rule)
     static MultiSketch load_metadata(const std::string &file_prefix);
     void save_metadata(const std::string &file_prefix) const;     // :80-87
+    // A distance at ONE k-mer length (`dist -k`, precluster) never looks at the other slices of a sample: called before the
+    // data is read, this keeps the k_idx-th k-mer length only -- kmer_lengths() becomes that one length (index 0), and
+    // read_sketch_data* pick its slice out of every sample of the file (a fifth of the bytes of a five-k database to read,
+    // hold and upload).  The file and its metadata on disk are not touched.
+    void select_kmer(size_t k_idx);
     void read_sketch_data(const std::string &file_prefix);        // :167-184
     void read_sketch_data_block(const std::string &file_prefix,   // :187-210
                                 const std::vector<std::string> &names);
@@ -93,6 +98,8 @@ class MultiSketch {
     std::optional<std::vector<size_t>> block_reindex_;
     BinVec sketch_bins_;
     size_t bin_stride_ = 1, kmer_stride_ = 0, sample_stride_ = 0;
+    std::optional<size_t> file_k_idx_;     // select_kmer: the slice kept, and the stride of a sample IN THE FILE
+    size_t file_sample_stride_ = 0;
     std::string sketch_version_;
     std::string hash_type_ = "DNA";  // "DNA" | "PDB" | "AA:<level>"
 };

@@ -258,6 +258,9 @@ hipError_t launch_first_greater(const uint64_t *row_offsets, const uint32_t *can
                                 hipStream_t stream);
 // key[i] = first candidate of row i, 0xFFFFFFFF for an empty row
 hipError_t launch_first_candidate(const uint64_t *row_offsets, const uint32_t *cand, uint32_t n, uint32_t *key, hipStream_t stream);
+// work items of the candidate-list kernel, from the per-row item counts the host made (launch order `order`)
+hipError_t launch_cand_work_items(const uint32_t *order, const uint64_t *item_begin, const uint64_t *row_offsets, const uint64_t *first,
+                                  uint32_t n, uint32_t *work_row, uint64_t *work_start, hipStream_t stream);
 constexpr size_t MAX_DEVICE_CANDGEN_SAMPLES = 158ull * 1024 * 8;   // n-bit bitmap in LDS
 
 struct TopkArgs {

@@ -3,6 +3,7 @@
 //   skl_dbtool roundtrip <in> <out>     load <in>.skm/.skd and write them back as <out>.*
 //   skl_dbtool unframe <in> <out>       decode a snappy-framed file (.skm / .ski) to its payload
 //   skl_dbtool slice <prefix> <i> <k>   print the u64 words of get_sketch_slice(i, k_idx)
+//   skl_dbtool slice-selected <prefix> <sample> <k_idx> [name...]   a slice read through select_kmer
 //   skl_dbtool make <prefix> <bins> <k1,k2,..> <name>...  write <prefix>.skm for an existing .skd
 //   skl_dbtool format <self|cross> <coreacc|jaccard> <n> <nq> <threads> <band_rows> <dists.f32> [out]
 //                                       print a raw f32 distance array as the dense long-form text
@@ -95,6 +96,20 @@ int main(int argc, char **argv)
             MultiSketch m = MultiSketch::load_metadata(prefix);
             m.read_sketch_data(prefix);
             const uint64_t *p = m.get_sketch_slice((size_t)atoll(argv[3]), (size_t)atoll(argv[4]));
+            for (size_t w = 0; w < m.kmer_stride(); ++w) std::cout << p[w] << "\n";
+            return 0;
+        }
+        if (argc >= 5 && std::string(argv[1]) == "slice-selected") {
+            // slice-selected <prefix> <logical sample> <k_idx> [name...]: the same slice through MultiSketch::select_kmer
+            // (only that k-mer length is read from the file); with names, through read_sketch_data_block of those samples
+            const std::string prefix = strip_sketch_extension(argv[2]);
+            MultiSketch m = MultiSketch::load_metadata(prefix);
+            m.select_kmer((size_t)atoll(argv[4]));
+            const std::vector<std::string> names = collect_names(argc, argv, 5);
+            if (names.empty()) m.read_sketch_data(prefix);
+            else m.read_sketch_data_block(prefix, names);
+            if (m.kmer_lengths().size() != 1 || m.bins().size() != m.number_samples_loaded() * m.kmer_stride()) return 3;
+            const uint64_t *p = m.get_sketch_slice((size_t)atoll(argv[3]), 0);
             for (size_t w = 0; w < m.kmer_stride(); ++w) std::cout << p[w] << "\n";
             return 0;
         }

@@ -353,3 +353,29 @@ def test_knn_3000_and_reference_tie_order_through_the_cli(gpu_ctx, oracle, tmp_p
         assert bool(run(prefix, "-k", "21", "--knn", str(knn), "--knn-ties", "canonical") == _sparse_text(names, canon, True))
     res = subprocess.run([CLI, "dist", prefix, "--knn", "5", "--knn-ties", "fifo"], capture_output=True, text=True)
     assert res.returncode == 2 and "possible values: canonical, reference" in res.stderr
+
+
+def test_single_k_runs_read_one_slice_of_a_multi_k_database(gpu_ctx, tmp_path):
+    """`dist -k K` on a database with several k-mer lengths reads only that slice of each sample (MultiSketch::select_kmer,
+    round 4): every listing must be byte for byte the listing of a ONE-k database holding just those slices -- self, cross,
+    --subset, kNN, ANI; a query database that lists OTHER k-mer lengths is still refused."""
+    from sketchlib.rust_amd import synth
+
+    kmers, ss64, n, nq = [15, 19, 23, 27], 8, 37, 11
+    bins = synth.set_r(n, kmers, ss64, n_clusters=5).reshape(n, len(kmers), ss64 * 14)
+    qbins = synth.set_r(nq, kmers, ss64, n_clusters=5, first_sample=500).reshape(nq, len(kmers), ss64 * 14)
+    db4, names = _write_db(tmp_path, "db4", bins, kmers, ss64)
+    q4, _ = _write_db(tmp_path, "q4", qbins, kmers, ss64)
+    subset = tmp_path / "subset.txt"
+    subset.write_text("\n".join(names[i] for i in (30, 2, 17, 5, 9)) + "\n")
+    for ki, k in ((0, 15), (2, 23), (3, 27)):
+        db1, _ = _write_db(tmp_path, f"db1_{k}", bins[:, ki], [k], ss64)
+        q1, _ = _write_db(tmp_path, f"q1_{k}", qbins[:, ki], [k], ss64)
+        for flags in ((), ("--ani",), ("--knn", "4"), ("--knn", "3", "--ani"), ("--subset", str(subset)), ("--subset", str(subset), "--knn", "2")):
+            assert bool(run(db4, "-k", str(k), *flags) == run(db1, "-k", str(k), *flags)), (k, flags)
+        for flags in ((), ("--knn", "5"), ("--ani",)):
+            assert bool(run(db4, q4, "-k", str(k), *flags) == run(db1, q1, "-k", str(k), *flags)), (k, flags)
+    # a query database that lists other lengths is refused as before (whole databases read, then the compatibility check)
+    q_other, _ = _write_db(tmp_path, "q_other", qbins[:, [1, 0, 3, 2]], [19, 15, 27, 23], ss64)
+    res = subprocess.run([CLI, "dist", db4, q_other, "-k", "23"], capture_output=True, text=True)
+    assert res.returncode != 0 and "not compatible" in res.stderr, res.stderr

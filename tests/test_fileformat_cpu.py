@@ -63,6 +63,29 @@ def test_get_sketch_slice_matches_skd_bytes():
     assert np.array_equal(words, raw[1 * sample_stride + 2 * kmer_stride:][:kmer_stride])
 
 
+def test_select_kmer_reads_the_one_slice_of_every_sample():
+    """`dist -k` / precluster read one k-mer length: MultiSketch::select_kmer picks that slice out of each sample of the
+    file (whole database and --subset blocks); it must be the bytes get_sketch_slice returns from the whole database."""
+    prefix = os.path.join(REF_FIXTURES, "legacy_db")
+    raw = np.fromfile(prefix + ".skd", dtype="<u8")
+    kmer_stride, sample_stride = 28, 84
+    names = ["R6.fa.gz", "TIGR4.fa.gz"] if raw.size == 2 * sample_stride else FIXTURE_NAMES
+    for sample in range(len(names)):
+        for k_idx in range(3):
+            want = raw[sample * sample_stride + k_idx * kmer_stride:][:kmer_stride]
+            out = subprocess.check_output([DBTOOL, "slice-selected", prefix, str(sample), str(k_idx)], text=True)
+            assert np.array_equal(np.array([int(x) for x in out.split()], dtype=np.uint64), want), (sample, k_idx)
+    # a subset in another order: logical sample 0 is the LAST sample of the file
+    order = names[::-1]
+    for k_idx in (0, 2):
+        out = subprocess.check_output([DBTOOL, "slice-selected", prefix, "0", str(k_idx), *order], text=True)
+        last = len(names) - 1
+        assert np.array_equal(np.array([int(x) for x in out.split()], dtype=np.uint64),
+                              raw[last * sample_stride + k_idx * kmer_stride:][:kmer_stride])
+    bad = subprocess.run([DBTOOL, "slice-selected", prefix, "0", "3"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "no such k-mer length" in bad.stderr
+
+
 def _py_unframe(data):
     """Independent check of the writer: snappy frame with uncompressed chunks + masked CRC32C."""
     import struct

@@ -83,14 +83,17 @@ def test_chunk_slices_in_sequences_of_launches(oracle, skl, gpu_ctx, monkeypatch
 
 def test_default_rule_slices_launches_of_less_than_a_round(oracle, skl, gpu_ctx):
     kmers, ss64 = [15, 19, 23, 27, 31], 64
+    names = []
     for n, expect in [(90, True), (400, True), (800, True), (1000, False)]:
         bins = synth.set_r(n, kmers, ss64, n_clusters=7)
         g = gpu_ctx.sketches(bins, n, kmers, ss64)
         got = skl.self_dists_all(gpu_ctx, g, g.set_k())
-        assert ("chunk slices" in gpu_ctx.last_kernel()) == expect, (n, gpu_ctx.last_kernel())
+        names.append((n, expect, gpu_ctx.last_kernel()))
         if n <= 400:
             assert np.array_equal(got, oracle.self_dists_all(oracle.Sketches(bins, n, kmers, ss64), threads=8))
         g.close()
+    for n, expect, name in names:      # (after the parity assertions, so that they run under a forced switch setting too)
+        assert ("chunk slices" in name) == expect, (n, name)
 
 
 @pytest.mark.parametrize("ss64,expect", [(12, None), (20, "3 chunk slices"), (37, "3 chunk slices"), (157, "7 chunk slices")])
@@ -104,7 +107,7 @@ def test_any_sketch_size_is_cut_into_whole_stages(oracle, skl, gpu_ctx, set_swit
     o, oq = oracle.Sketches(bins, n, kmers, ss64), oracle.Sketches(qb, nq, kmers, ss64)
     set_switch("SKL_TAIL_MAX_PCT", "100000000")
     got = skl.self_dists_all(gpu_ctx, g, g.set_k())
-    assert (expect in gpu_ctx.last_kernel()) if expect else ("chunk slices" not in gpu_ctx.last_kernel()), gpu_ctx.last_kernel()
+    name = gpu_ctx.last_kernel()      # (checked last: parity first, whatever a forced switch setting made of the slicing)
     assert np.array_equal(got, oracle.self_dists_all(o, threads=8))
     assert np.array_equal(skl.cross_dists_all(gpu_ctx, g, gq, g.set_k()), oracle.cross_dists_all(o, oq, threads=8))
     assert np.array_equal(skl.self_dists_rows(gpu_ctx, g, g.set_k(), 40, 93), oracle.self_dists_all(o, threads=8)[40 * n - 40 * 41 // 2:93 * n - 93 * 94 // 2])
@@ -116,6 +119,7 @@ def test_any_sketch_size_is_cut_into_whole_stages(oracle, skl, gpu_ctx, set_swit
     assert np.array_equal(skl.self_dists_all(gpu_ctx, g, g.set_k()), oracle.self_dists_all(o, threads=8))
     g.close()
     gq.close()
+    assert (expect in name) if expect else ("chunk slices" not in name), name
 
 
 @pytest.mark.parametrize("ss64,slices", [(64, 4), (32, 4), (32, 2), (128, 8)])
