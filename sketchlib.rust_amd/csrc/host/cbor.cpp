@@ -168,6 +168,8 @@ void enc(std::vector<uint8_t> &o, const CborValue &v)
 }
 }  // namespace
 
+void CborWriter::head(int major, uint64_t v) { ::skl_host::head(out_, major, v); }
+
 CborCursor::Head CborCursor::head()
 {
     for (;;) {

@@ -71,6 +71,28 @@ private:
     size_t n_, i_ = 0;
 };
 
+// Push writer over the same subset (definite lengths, as cbor_encode writes them): a document is written value by value
+// into one byte vector -- the CborValue tree of a million-sample .skm is gigabytes of nodes.
+class CborWriter {
+public:
+    void uint(uint64_t v) { head(0, v); }
+    void text(const std::string &s)
+    {
+        head(3, s.size());
+        out_.insert(out_.end(), s.begin(), s.end());
+    }
+    void boolean(bool b) { out_.push_back(b ? 0xF5 : 0xF4); }
+    void null() { out_.push_back(0xF6); }
+    void array(uint64_t n_items) { head(4, n_items); }   // followed by n_items values
+    void map(uint64_t n_pairs) { head(5, n_pairs); }     // followed by n_pairs (key, value) pairs
+    void key(const char *k) { text(k); }
+    std::vector<uint8_t> &bytes() { return out_; }
+
+private:
+    void head(int major, uint64_t v);
+    std::vector<uint8_t> out_;
+};
+
 CborValue cbor_decode(const std::vector<uint8_t> &bytes);
 // Decode a top-level map but do not materialise the value stored under `skip_key`; its element
 // count (array / map length) is returned through skipped_count.

@@ -188,44 +188,63 @@ MultiSketch MultiSketch::load_metadata(const std::string &file_prefix)
 
 void MultiSketch::save_metadata(const std::string &file_prefix) const
 {
-    CborValue root = CborValue::object();
-    root.put("sketch_size", CborValue::uint(sketch_size));
-    root.put("sketchsize64", CborValue::uint(sketchsize64));
-    CborValue ks = CborValue::array();
-    for (size_t k : kmer_lengths_) ks.arr.push_back(CborValue::uint(k));
-    root.put("kmer_lengths", ks);
-    CborValue metas = CborValue::array();
+    // the fields in the order serde writes the struct (multisketch.rs:21-44), straight into the byte stream
+    CborWriter w;
+    w.map(10);
+    w.key("sketch_size");
+    w.uint(sketch_size);
+    w.key("sketchsize64");
+    w.uint(sketchsize64);
+    w.key("kmer_lengths");
+    w.array(kmer_lengths_.size());
+    for (size_t k : kmer_lengths_) w.uint(k);
+    w.key("sketch_metadata");
+    w.array(sketch_metadata_.size());
     for (const auto &s : sketch_metadata_) {
-        CborValue o = CborValue::object();
-        o.put("name", CborValue::text(s.name));
-        o.put("index", s.index ? CborValue::uint(*s.index) : CborValue::null());
-        o.put("rc", CborValue::boolean(s.rc));
-        o.put("reads", CborValue::boolean(s.reads));
-        o.put("seq_length", CborValue::uint(s.seq_length));
-        o.put("densified", CborValue::boolean(s.densified));
-        CborValue acgt = CborValue::array();
-        for (uint64_t c : s.acgt) acgt.arr.push_back(CborValue::uint(c));
-        o.put("acgt", acgt);
-        o.put("non_acgt", CborValue::uint(s.non_acgt));
-        metas.arr.push_back(std::move(o));
+        w.map(8);
+        w.key("name");
+        w.text(s.name);
+        w.key("index");
+        if (s.index) w.uint(*s.index);
+        else w.null();
+        w.key("rc");
+        w.boolean(s.rc);
+        w.key("reads");
+        w.boolean(s.reads);
+        w.key("seq_length");
+        w.uint(s.seq_length);
+        w.key("densified");
+        w.boolean(s.densified);
+        w.key("acgt");
+        w.array(4);
+        for (uint64_t c : s.acgt) w.uint(c);
+        w.key("non_acgt");
+        w.uint(s.non_acgt);
     }
-    root.put("sketch_metadata", metas);
-    CborValue nm = CborValue::object();
-    for (const auto &kv : name_map_order_) nm.put(kv.first, CborValue::uint(kv.second));
-    root.put("name_map", nm);
-    root.put("bin_stride", CborValue::uint(bin_stride_));
-    root.put("kmer_stride", CborValue::uint(kmer_stride_));
-    root.put("sample_stride", CborValue::uint(sample_stride_));
-    root.put("sketch_version", CborValue::text(sketch_version_));
+    w.key("name_map");
+    w.map(name_map_order_.size());
+    for (const auto &kv : name_map_order_) {
+        w.text(kv.first);
+        w.uint(kv.second);
+    }
+    w.key("bin_stride");
+    w.uint(bin_stride_);
+    w.key("kmer_stride");
+    w.uint(kmer_stride_);
+    w.key("sample_stride");
+    w.uint(sample_stride_);
+    w.key("sketch_version");
+    w.text(sketch_version_);
+    w.key("hash_type");
     const size_t colon = hash_type_.find(':');
     if (colon == std::string::npos) {
-        root.put("hash_type", CborValue::text(hash_type_));
+        w.text(hash_type_);
     } else {
-        CborValue o = CborValue::object();
-        o.put(hash_type_.substr(0, colon), CborValue::text(hash_type_.substr(colon + 1)));
-        root.put("hash_type", o);
+        w.map(1);
+        w.text(hash_type_.substr(0, colon));
+        w.text(hash_type_.substr(colon + 1));
     }
-    const std::vector<uint8_t> framed = snappy_frame_encode(cbor_encode(root));
+    const std::vector<uint8_t> framed = snappy_frame_encode(w.bytes());
     std::ofstream f(file_prefix + ".skm", std::ios::binary);
     if (!f) throw std::runtime_error("cannot create " + file_prefix + ".skm");
     f.write((const char *)framed.data(), (std::streamsize)framed.size());
