@@ -108,4 +108,5 @@ def test_kernel_variant_parity(gpu_ctx, env, expect):
         pkg.build_ab_library()
     res = subprocess.run([sys.executable, "-c", CHILD, expect], env={**os.environ, **env}, capture_output=True,
                          text=True, timeout=600)
-    assert res.returncode == 0 and "VARIANT_OK" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
+    name_line = [l for l in res.stderr.splitlines() if "KERNEL NAME" in l]     # (the child checks the kernel's name last)
+    assert res.returncode == 0 and "VARIANT_OK" in res.stdout, name_line[-1] if name_line else (res.stdout[-500:], res.stderr[-2000:])
