@@ -343,7 +343,6 @@ Knobs read_knobs()
     {
         const char *ck = getenv("SKL_CAND_KERNEL");
         k.cand_lanes = ck && strcmp(ck, "lanes") == 0;
-        k.cand_lds = ck && strcmp(ck, "lds") == 0;
     }
     k.inline_prefix = env_int("SKL_INLINE_PREFIX", 1) != 0;
     const char *sk = getenv("SKL_SKETCH_KERNEL");

@@ -192,16 +192,14 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     c.keys = (float *)d_keys.p;
     c.symmetric = symmetric ? 1u : 0u;
     c.lanes_over_candidates = ctx->knobs.cand_lanes ? 1u : 0u;
-    c.lds_form = ctx->knobs.cand_lds ? 1u : 0u;
     {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
         std::pair<hipEvent_t, hipEvent_t> *ev = timing_slot(ctx);
         if (ev) HIP_TRY(hipEventRecord(ev->first, ctx->stream));
         HIP_TRY(launch_pair_cand(c, g, ctx->stream));
         if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
     }
-    ctx->last_kernel = (c.lds_form && g.ss64 <= 32u) ? "skl::pair_cand_lds_kernel (row x 64 candidates per wave, one after the other, each brought into LDS as coalesced 16-byte pieces)"
-                       : ctx->knobs.cand_lanes       ? "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)"
-                                                     : "skl::pair_cand_rows_kernel (row x 64 candidates per wave, one after the other, each read as one contiguous run)";
+    ctx->last_kernel = ctx->knobs.cand_lanes ? "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)"
+                                             : "skl::pair_cand_rows_kernel (row x 64 candidates per wave, one after the other, each read as one contiguous run)";
     if (ctx->knn_ties == SKL_KNN_TIES_REFERENCE) {
         // The reference's tie order: its BinaryHeap replayed over each row's candidates IN THE ORDER THEY ARE LISTED
         // (mod.rs:459-487 pushes in the order Inverted::any_shared_bins returns them: ascending .ski index -- the

@@ -61,7 +61,6 @@ struct Knobs {
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
     bool cand_symmetric = true;       // SKL_CAND_SYMMETRIC=0: evaluate symmetric candidate lists in full
     bool inline_prefix = true;        // SKL_INLINE_PREFIX=0: the tile lookup always searches the prefix table in global memory (A/B only, results are identical)
-    bool cand_lds = false;            // SKL_CAND_KERNEL=lds: candidates staged through LDS as coalesced 16-byte pieces (sketches of up to 32 chunks)
     bool cand_lanes = false;          // SKL_CAND_KERNEL=lanes: round 3's candidate-list kernel (lanes over the candidates; A/B only, results are identical)
     bool cand_row_order = true;       // SKL_CAND_ROW_ORDER=0: candidate-list rows dispatched in sample order, not by first candidate (A/B only, results are identical)
     bool sketch_global = false;       // SKL_SKETCH_KERNEL=global: the unstaged sketching kernel

@@ -213,7 +213,6 @@ struct CandArgs {
     // share: workgroup b takes the items of block (b mod XCDs) * blocks_per_xcd + b / XCDs (set by the launcher)
     uint32_t xcd_shift, blocks_per_xcd;
     uint32_t lanes_over_candidates;   // 1: round 3's form (every lane walks its own candidate); 0: lanes across the sketch (round 4)
-    uint32_t lds_form;                // 1: sketches of up to 32 chunks arrive as coalesced 16-byte pieces through LDS (pair_cand_lds_kernel)
 };
 hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t stream);
 

@@ -178,100 +178,6 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_rows_kernel(con
         }
     }
 }
-// The same with the candidate brought in as FULLY COALESCED 16-byte pieces, straight into LDS (global_load_lds_dwordx4: no
-// register staging), for sketches of up to 32 chunks (one trip).  The form above reads 56 bytes per lane with seven 8-byte
-// loads at a 56-byte stride: every one of the seven instructions touches all 28 cache lines of the candidate.  Here the
-// wave's 64 x 16 bytes per instruction are contiguous (four instructions, eight lines each), the candidate AFTER the one
-// being compared is already in flight into the other half of the wave's LDS, and the 56-byte half chunks are read back
-// from LDS (seven ds_read_b64 per lane).  One wave owns its two buffers: no barrier anywhere.
-#define SKL_CAND_LDS_BUF 3584u   // 32 chunks x 14 planes x 8 bytes
-
-__global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_lds_kernel(const CandArgs c, const PairArgs g)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t stage[WAVES_PER_WG * 2 * SKL_CAND_LDS_BUF];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t blk = (blockIdx.x & ((1u << c.xcd_shift) - 1u)) * c.blocks_per_xcd + (blockIdx.x >> c.xcd_shift);
-    if ((blockIdx.x >> c.xcd_shift) >= c.blocks_per_xcd) return;
-    const uint64_t w = (uint64_t)blk * WAVES_PER_WG + wave;
-    if (w >= c.n_work) return;
-    const uint32_t row = c.work_row[w];
-    const uint64_t start = c.work_start[w];
-    const uint64_t row_end = c.row_offsets[row + 1];
-    const uint32_t cnt = (uint32_t)((row_end - start) < 64ull ? (row_end - start) : 64ull);
-    const uint32_t j_mine = lane < cnt ? c.cand[start + lane] : row;
-    const bool active = lane < cnt && (!c.symmetric || j_mine > row);
-    uint64_t todo = __ballot(active);                          // the candidates this wave evaluates (wave-uniform mask)
-    const size_t kmer_stride = (size_t)g.ss64 * BBITS;
-    const size_t sample_stride = kmer_stride * g.nk;
-    const uint32_t halves = g.ss64 * 2u;                       // half chunks of 7 planes (56 bytes): <= 64
-    const uint32_t pieces = g.ss64 * 7u;                       // 16-byte pieces of a sketch: <= 224
-    const uint32_t n_dma = (pieces + 63u) >> 6;                // instructions per candidate: 1 ... 4
-    const uint32_t my_base = skl_lds_addr(stage) + wave * 2u * SKL_CAND_LDS_BUF;
-    const uint2 *pi = reinterpret_cast<const uint2 *>(g.A + (size_t)row * sample_stride + (size_t)g.k_begin * kmer_stride);
-    uint2 a_row[7];
-#pragma unroll
-    for (int q = 0; q < 7; ++q) a_row[q] = lane < halves ? pi[(size_t)lane * 7 + q] : make_uint2(0u, 0u);
-    uint32_t mism_mine = 0;
-    auto fetch = [&](uint32_t j, uint32_t buf) {               // candidate j -> buffer buf of this wave
-        const uint64_t *pj = g.A + (size_t)j * sample_stride + (size_t)g.k_begin * kmer_stride;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            if (q * 64u + lane < pieces) skl_dma16_saddr(pj, (q * 64u + lane) * 16u, my_base + buf * SKL_CAND_LDS_BUF + q * 1024u);
-        }
-    };
-    uint32_t buf = 0;
-    if (todo) fetch((uint32_t)__builtin_amdgcn_readlane((int)j_mine, (int)__builtin_ctzll(todo)), 0u);
-    while (todo) {
-        const uint32_t cc = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        if (todo) {                                            // the next one goes into the other buffer now ...
-            fetch((uint32_t)__builtin_amdgcn_readlane((int)j_mine, (int)__builtin_ctzll(todo)), buf ^ 1u);
-            // ... and this one's pieces are older than those just issued (VMEM returns in order)
-            if (n_dma == 4u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (n_dma == 3u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (n_dma == 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        uint32_t mlo = 0, mhi = 0;
-        if (lane < halves) {
-            const uint2 *b = reinterpret_cast<const uint2 *>(stage + (size_t)wave * 2u * SKL_CAND_LDS_BUF + (size_t)buf * SKL_CAND_LDS_BUF) + (size_t)lane * 7;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const uint2 bq = b[q];
-                mlo = acc_mismatch<true>(mlo, a_row[q].x, bq.x);
-                mhi = acc_mismatch<true>(mhi, a_row[q].y, bq.y);
-            }
-        }
-        mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
-        mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
-        uint32_t part = ((lane & 1u) == 0u && lane < halves) ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
-        part = SKL_DPP_ADD(part, 0x111);   // row_shr:1
-        part = SKL_DPP_ADD(part, 0x112);   // row_shr:2
-        part = SKL_DPP_ADD(part, 0x114);   // row_shr:4
-        part = SKL_DPP_ADD(part, 0x118);   // row_shr:8
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)part, 15) + (uint32_t)__builtin_amdgcn_readlane((int)part, 31) +
-                               (uint32_t)__builtin_amdgcn_readlane((int)part, 47) + (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
-        if (lane == cc) mism_mine = total;
-        // (the reads of this buffer have returned before the fetch after next is issued: their values were used above)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        buf ^= 1u;
-    }
-    if (active) {
-        const float key = jaccard_out_value(g, row, j_mine, mism_mine);
-        c.keys[start + lane] = key;
-        if (c.symmetric) {   // row j's copy: position of `row` in its (ascending) list
-            uint64_t lo = c.row_offsets[j_mine], hi = c.row_offsets[j_mine + 1];
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (c.cand[mid] < row) lo = mid + 1; else hi = mid;
-            }
-            if (lo < c.row_offsets[j_mine + 1] && c.cand[lo] == row) c.keys[lo] = key;
-        }
-    }
-}
 #undef SKL_DPP_ADD
 
 hipError_t launch_pair_cand(const CandArgs &c_in, const PairArgs &g, hipStream_t stream)
@@ -283,9 +189,7 @@ hipError_t launch_pair_cand(const CandArgs &c_in, const PairArgs &g, hipStream_t
     c.blocks_per_xcd = (uint32_t)((blocks + (1ull << c.xcd_shift) - 1) >> c.xcd_shift);
     const uint64_t grid = (uint64_t)c.blocks_per_xcd << c.xcd_shift;
     if (grid >= (1ull << 31)) return hipErrorInvalidValue;
-    if (c.lds_form && g.ss64 <= 32u) {
-        hipLaunchKernelGGL(pair_cand_lds_kernel, dim3((unsigned)grid), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
-    } else if (c.lanes_over_candidates) {
+    if (c.lanes_over_candidates) {
         hipLaunchKernelGGL(pair_cand_kernel, dim3((unsigned)grid), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
     } else {
         hipLaunchKernelGGL(pair_cand_rows_kernel, dim3((unsigned)grid), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);

@@ -83,10 +83,9 @@ def test_synthetic_ragged_lists(oracle, skl, gpu_ctx, ani, comp):
 
 @pytest.mark.parametrize("ss64", [1, 3, 16, 24, 32, 50, 64, 157])
 def test_candidate_kernels_at_many_sketch_sizes(oracle, skl, gpu_ctx, set_switch, ss64):
-    """pair_cand_rows_kernel (lanes across the sketch: half chunks per lane, several trips beyond 32 chunks, idle lanes
-    below), pair_cand_lds_kernel (the candidate staged through LDS as coalesced pieces, up to 32 chunks) and round 3's
-    pair_cand_kernel (SKL_CAND_KERNEL=lanes) against the oracle and each other, host lists (every pair evaluated) and
-    device lists (symmetric halves)."""
+    """pair_cand_rows_kernel (lanes across the sketch: half chunks per lane; the row's planes stay in registers up to 32
+    chunks, several trips beyond, idle lanes below) and round 3's pair_cand_kernel (SKL_CAND_KERNEL=lanes) against the
+    oracle and each other, host lists (every pair evaluated) and device lists (symmetric halves)."""
     kmers, n, knn = [17, 21], 300, 6
     bins = synth.set_r(n, kmers, ss64, n_clusters=11)
     rng = np.random.default_rng(ss64)
@@ -95,18 +94,10 @@ def test_candidate_kernels_at_many_sketch_sizes(oracle, skl, gpu_ctx, set_switch
     offs, cols = candidates(skq)
     exp = oracle.self_dists_knn_precluster(o, skq, knn, 1, False, threads=8)
     got = {}
-    for kernel in (None, "lanes", "rows", "lds"):
+    for kernel in (None, "lanes"):
         set_switch("SKL_CAND_KERNEL", kernel)
         idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21), knn, offs, cols)
-        name = gpu_ctx.last_kernel()
-        if kernel == "lanes":
-            assert "pair_cand_kernel" in name
-        elif kernel == "lds":      # (sketches of up to 32 chunks; beyond, the several-trips form)
-            assert ("pair_cand_lds_kernel" if ss64 <= 32 else "pair_cand_rows_kernel") in name
-        elif kernel == "rows":
-            assert "pair_cand_rows_kernel" in name
-        else:
-            assert "pair_cand_rows_kernel" in name or "pair_cand_lds_kernel" in name
+        assert ("pair_cand_kernel" if kernel else "pair_cand_rows_kernel") in gpu_ctx.last_kernel()
         assert as_pairs(idx, d0) == oracle_pairs(exp), (ss64, kernel)
         idx2, d02, _ = skl.self_dists_knn_shared_bins(gpu_ctx, g, g.set_k(21), knn, skq)
         assert np.array_equal(idx2, idx) and np.array_equal(d02, d0), (ss64, kernel)
