@@ -92,6 +92,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const Ca
 // VALU instructions per pair of the form above, which is nothing: the kernel waits for memory either way.
 #define SKL_DPP_ADD(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
 
+// TRIPS = 1 ... 5: sketches of up to 32 x TRIPS chunks -- the ROW's planes are read once per work item and stay in
+// registers (7 x 8 bytes per lane and trip), so a candidate costs seven loads per trip and nothing else; TRIPS = 0: any
+// size, the row's planes re-read (from L1) beside every candidate's.
+template <int TRIPS>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_rows_kernel(const CandArgs c, const PairArgs g)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -110,40 +114,26 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_rows_kernel(con
     const uint32_t halves = g.ss64 * 2u;                     // half chunks of 7 planes (56 bytes) per sketch
     const uint2 *pi = reinterpret_cast<const uint2 *>(g.A + (size_t)row * sample_stride + (size_t)g.k_begin * kmer_stride);
     uint32_t mism_mine = 0;
-    const bool one_trip = halves <= 64u;                     // sketches of up to 32 chunks: the row's planes stay in registers
-    uint2 a_row[7];
+    constexpr int KEPT = TRIPS > 0 ? TRIPS : 1;
+    uint2 a_row[KEPT][7];
+    if constexpr (TRIPS > 0) {
 #pragma unroll
-    for (int q = 0; q < 7; ++q) a_row[q] = (one_trip && lane < halves) ? pi[(size_t)lane * 7 + q] : make_uint2(0u, 0u);
+        for (int t = 0; t < TRIPS; ++t) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) a_row[t][q] = (uint32_t)t * 64u + lane < halves ? pi[((size_t)t * 64u + lane) * 7 + q] : make_uint2(0u, 0u);
+        }
+    }
     for (uint32_t cc = 0; cc < cnt; ++cc) {
         const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)j_mine, (int)cc);   // (cc is wave-uniform)
         if (c.symmetric && j <= row) continue;               // the other half of a symmetric list: stored from row j's side
         const uint2 *pj = reinterpret_cast<const uint2 *>(g.A + (size_t)j * sample_stride + (size_t)g.k_begin * kmer_stride);
         uint32_t part = 0;
-        if (one_trip) {
-            uint32_t mlo = 0, mhi = 0;
-            if (lane < halves) {
-                uint2 b[7];
-#pragma unroll
-                for (int q = 0; q < 7; ++q) b[q] = pj[(size_t)lane * 7 + q];
-#pragma unroll
-                for (int q = 0; q < 7; ++q) {
-                    mlo = acc_mismatch<true>(mlo, a_row[q].x, b[q].x);
-                    mhi = acc_mismatch<true>(mhi, a_row[q].y, b[q].y);
-                }
-            }
-            mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
-            mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
-            if ((lane & 1u) == 0u && lane < halves) part = (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi);
-        } else
-        for (uint32_t h0 = 0; h0 < halves; h0 += 64u) {
-            const uint32_t h = h0 + lane;
+        auto one_trip = [&](uint32_t h, const uint2 *a) {    // half chunk h of the candidate against the row's (a: 7 planes)
             uint32_t mlo = 0, mhi = 0;
             if (h < halves) {
-                uint2 a[7], b[7];
+                uint2 b[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) b[q] = pj[(size_t)h * 7 + q];      // one plane (lo, hi) each: the wave's 64 x 56 B are contiguous
-#pragma unroll
-                for (int q = 0; q < 7; ++q) a[q] = pi[(size_t)h * 7 + q];      // the row's: the same addresses for every candidate (L1)
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
                     mlo = acc_mismatch<true>(mlo, a[q].x, b[q].x);
@@ -154,6 +144,18 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_rows_kernel(con
             mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
             mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
             if ((lane & 1u) == 0u && h < halves) part += (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi);
+        };
+        if constexpr (TRIPS > 0) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) one_trip((uint32_t)t * 64u + lane, a_row[t]);
+        } else {
+            for (uint32_t h0 = 0; h0 < halves; h0 += 64u) {
+                const uint32_t h = h0 + lane;
+                uint2 a[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) a[q] = h < halves ? pi[(size_t)h * 7 + q] : make_uint2(0u, 0u);   // the row's: the same addresses for every candidate (L1)
+                one_trip(h, a);
+            }
         }
         // sum over the wave: four row shifts leave each row of 16 lanes' total in its last lane
         part = SKL_DPP_ADD(part, 0x111);   // row_shr:1
@@ -192,7 +194,15 @@ hipError_t launch_pair_cand(const CandArgs &c_in, const PairArgs &g, hipStream_t
     if (c.lanes_over_candidates) {
         hipLaunchKernelGGL(pair_cand_kernel, dim3((unsigned)grid), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
     } else {
-        hipLaunchKernelGGL(pair_cand_rows_kernel, dim3((unsigned)grid), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
+        const dim3 gr((unsigned)grid), bl(LANES * WAVES_PER_WG);
+        switch ((g.ss64 + 31u) / 32u) {      // trips of 32 chunks
+            case 1: hipLaunchKernelGGL(pair_cand_rows_kernel<1>, gr, bl, 0, stream, c, g); break;
+            case 2: hipLaunchKernelGGL(pair_cand_rows_kernel<2>, gr, bl, 0, stream, c, g); break;
+            case 3: hipLaunchKernelGGL(pair_cand_rows_kernel<3>, gr, bl, 0, stream, c, g); break;
+            case 4: hipLaunchKernelGGL(pair_cand_rows_kernel<4>, gr, bl, 0, stream, c, g); break;
+            case 5: hipLaunchKernelGGL(pair_cand_rows_kernel<5>, gr, bl, 0, stream, c, g); break;   // (157 chunks: `sketch -s 10000`)
+            default: hipLaunchKernelGGL(pair_cand_rows_kernel<0>, gr, bl, 0, stream, c, g); break;
+        }
     }
     return hipGetLastError();
 }

@@ -81,7 +81,7 @@ def test_synthetic_ragged_lists(oracle, skl, gpu_ctx, ani, comp):
             assert as_pairs(idx, d0) == oracle_pairs(exp)
 
 
-@pytest.mark.parametrize("ss64", [1, 3, 16, 24, 32, 50, 64, 157])
+@pytest.mark.parametrize("ss64", [1, 3, 16, 24, 32, 50, 64, 80, 128, 157, 170])
 def test_candidate_kernels_at_many_sketch_sizes(oracle, skl, gpu_ctx, set_switch, ss64):
     """pair_cand_rows_kernel (lanes across the sketch: half chunks per lane; the row's planes stay in registers up to 32
     chunks, several trips beyond, idle lanes below) and round 3's pair_cand_kernel (SKL_CAND_KERNEL=lanes) against the
