@@ -28,10 +28,12 @@ skq = parents[cluster]
 mut = rng.random(skq.shape) < 0.3
 skq[mut] = rng.integers(0, 65536, size=int(mut.sum()), dtype=np.uint16)
 p = sk.set_k(21)
+ties = os.environ.get("SKL_BENCH_TIES", "canonical")      # "reference": the CLI's default (BinaryHeap replayed over each list)
+ctx.set_knn_ties(capi.TIES_REFERENCE if ties == "reference" else capi.TIES_CANONICAL)
 capi.self_dists_knn_shared_bins(ctx, sk, p, 50, skq[:4096].copy()) if False else None
 for rep in range(2):
     t0 = time.perf_counter()
     idx, d0, total = capi.self_dists_knn_shared_bins(ctx, sk, p, 50, skq)
     wall = time.perf_counter() - t0
-    print(json.dumps({"mode": "skl_self_dists_knn_shared_bins", "n": n, "cluster": csize, "index_bins": sbins, "sketchsize64": ss64,
+    print(json.dumps({"mode": "skl_self_dists_knn_shared_bins", "n": n, "cluster": csize, "index_bins": sbins, "sketchsize64": ss64, "ties": ties,
                       "candidate_pairs": total, "call_wall_s": wall, "run": rep}), flush=True)

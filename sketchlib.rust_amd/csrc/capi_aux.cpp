@@ -216,6 +216,7 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
         h.out_d0 = (float *)d_d0.p;
         h.row_offsets = d_off;
         h.col_ids = d_cand;
+        h.force_workgroup_form = ctx->knobs.refheap_wave ? 0u : 1u;
         if (knn <= (size_t)REFHEAP_LDS_MAX) {
             HIP_TRY(launch_topk_refheap(h, ctx->stream));
         } else {   // heaps in global memory, rows in batches of at most 1 GiB of it

@@ -352,6 +352,7 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
             h.out_d0 = d_d0 + o;
             h.out_d1 = coreacc ? d_d1 + o : nullptr;
             h.heap_scratch = (float *)big_scratch.p;
+            h.force_workgroup_form = ctx->knobs.refheap_wave ? 0u : 1u;
             HIP_TRY(launch_topk_refheap(h, topk_stream));
         } else {
             TopkArgs t;

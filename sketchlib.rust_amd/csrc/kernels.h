@@ -315,6 +315,7 @@ struct RefHeapArgs {
     const uint64_t *row_offsets;
     const uint32_t *col_ids;
     uint32_t first_row;      // this launch handles rows first_row .. first_row + rows - 1 (heap_scratch slices are per launch)
+    uint32_t force_workgroup_form;   // A/B: one workgroup per row even where one wave per row applies (knn <= 256)
 };
 constexpr uint32_t REFHEAP_LDS_MAX = 2048;
 hipError_t launch_topk_refheap(const RefHeapArgs &args, hipStream_t stream);

@@ -724,12 +724,19 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_refheap_kernel(const RefHea
     }
 }
 
+constexpr uint32_t REFHEAP_WAVE_KNN_ONE_SHOT = 256;   // (= REFHEAP_WAVE_KNN below)
+__global__ void topk_refheap_wave_kernel(const RefHeapArgs g);
+
 hipError_t launch_topk_refheap(const RefHeapArgs &args, hipStream_t stream)
 {
     if (args.rows == 0 || (args.cols == 0 && args.row_offsets == nullptr)) return hipSuccess;
     if (args.knn == 0 || (args.knn > REFHEAP_LDS_MAX && args.heap_scratch == nullptr)) return hipErrorInvalidValue;
     if (args.stride2 != 1 && args.stride2 != 2) return hipErrorInvalidValue;
     if (args.row_offsets != nullptr && (args.col_ids == nullptr || args.stride2 != 1)) return hipErrorInvalidValue;
+    if (args.knn <= REFHEAP_WAVE_KNN_ONE_SHOT && !args.force_workgroup_form) {
+        hipLaunchKernelGGL(topk_refheap_wave_kernel, dim3((args.rows + 3u) / 4u), dim3(256), 0, stream, args);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(topk_refheap_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
     return hipGetLastError();
 }
@@ -785,6 +792,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void refheap_merge_kernel(const RefHe
 // a CU.  Here a workgroup is 4 independent rows: no barrier anywhere (a wave's LDS operations execute in order), the heap
 // and the candidate buffer of a row take 4.6 KB of LDS, and 24-32 rows are in flight per CU to hide each other's drains.
 constexpr uint32_t REFHEAP_WAVE_KNN = 256, REFHEAP_WAVE_CAND = 128;
+static_assert(REFHEAP_WAVE_KNN == REFHEAP_WAVE_KNN_ONE_SHOT, "one constant");
 
 __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMergeArgs g)
 {
@@ -875,6 +883,94 @@ __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMe
         if (lane == 0u) {
             g.h_len[srow] = len;
             g.thr[srow] = len < knn ? 0xFFFFFFFFu : sortable_bits(h.key[0]);
+        }
+    }
+}
+
+// The ONE-SHOT replay (topk_refheap_kernel's job: a whole dense row, or a ragged candidate row of the precluster mode) with
+// one wave per row, for the same reason: the precluster call at 400 000 rows x ~800 listed candidates spent 64 ms in the
+// one-workgroup-per-row form -- as long as the distances themselves -- against 7 ms for the canonical radix select.
+__global__ __launch_bounds__(256) void topk_refheap_wave_kernel(const RefHeapArgs g)
+{
+    __shared__ float heap_mem[4][3 * (REFHEAP_WAVE_KNN + 1)];
+    __shared__ float cand_key[4][REFHEAP_WAVE_CAND], cand_d1[4][REFHEAP_WAVE_CAND];
+    __shared__ uint32_t cand_id[4][REFHEAP_WAVE_CAND];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (blockIdx.x * 4u + wave >= g.rows) return;
+    const uint32_t row = blockIdx.x * 4u + wave + g.first_row;
+    const uint32_t knn = g.knn, stride2 = g.stride2;
+    const bool ragged = g.row_offsets != nullptr;
+    const uint64_t row_base = ragged ? g.row_offsets[row] : 0ull;
+    const uint32_t cols = ragged ? (uint32_t)(g.row_offsets[row + 1] - row_base) : g.cols;
+    const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
+    const float *keys = ragged ? g.keys + row_base * stride2 : g.keys + (size_t)row * g.key_stride;
+    const uint32_t *ids = ragged ? g.col_ids + row_base : nullptr;
+    float *hm = heap_mem[wave];
+    RefHeap h{hm, hm + (knn + 1u), reinterpret_cast<uint32_t *>(hm + 2u * (knn + 1u)), 0u, stride2 == 2u};
+    auto wave_sync = [] {   // orders this wave's LDS traffic as the program states it
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    uint32_t len = 0, ncand = 0;
+    float thr = __builtin_inff();
+    auto drain = [&]() {   // lane 0: the buffered candidates through the exact push / pop sequence, in order
+        wave_sync();
+        if (lane == 0u) {
+            h.len = len;
+            for (uint32_t c = 0; c < ncand; ++c) h.push_heap(RefHeap::Elt{cand_key[wave][c], cand_d1[wave][c], cand_id[wave][c]}, knn);
+            len = h.len;
+            thr = h.len < knn ? __builtin_inff() : h.key[0];
+        }
+        wave_sync();
+        len = __shfl(len, 0);
+        thr = __shfl(thr, 0);
+        ncand = 0;
+    };
+    constexpr uint32_t UNROLL = 4;
+    for (uint32_t q0 = 0; q0 < cols; q0 += 64u * UNROLL) {
+        float k[UNROLL], d[UNROLL];
+        uint32_t id[UNROLL];
+#pragma unroll
+        for (uint32_t j = 0; j < UNROLL; ++j) {   // unconditional (clamped) loads, all in flight together
+            const uint32_t q = min(q0 + j * 64u + lane, cols - 1u);
+            k[j] = __builtin_nontemporal_load(&keys[(size_t)q * stride2]);
+            d[j] = stride2 == 2u ? __builtin_nontemporal_load(&keys[(size_t)q * 2u + 1u]) : 0.0f;
+            id[j] = ids ? ids[q] : q;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < UNROLL; ++j) {
+            const uint32_t q = q0 + j * 64u + lane;
+            const bool open = len < knn;
+            const bool take = q < cols && (ids != nullptr || q != self_id) && (open || k[j] < thr);
+            const uint64_t votes = __ballot(take);
+            if (votes == 0ull) continue;
+            if (take) {
+                const uint32_t pos = ncand + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+                cand_key[wave][pos] = k[j];
+                cand_d1[wave][pos] = d[j];
+                cand_id[wave][pos] = id[j];
+            }
+            ncand += (uint32_t)__popcll(votes);
+            // (while the heap fills, drain at once: the threshold must exist before more is buffered)
+            if (open || ncand + 64u > REFHEAP_WAVE_CAND) drain();
+        }
+    }
+    if (ncand != 0u) drain();
+    wave_sync();
+    if (lane == 0u) {
+        h.len = len;
+        h.into_sorted();
+    }
+    wave_sync();
+    for (uint32_t x = lane; x < knn; x += 64u) {
+        const size_t o = (size_t)row * knn + x;
+        if (x < len) {
+            g.out_idx[o] = h.id[x];
+            g.out_d0[o] = g.ani_undo ? 1.0f - h.key[x] : h.key[x];
+            if (stride2 == 2u && g.out_d1) g.out_d1[o] = h.d1[x];
+        } else if (ragged) {
+            g.out_idx[o] = row;
+            g.out_d0[o] = 1.0f;
         }
     }
 }

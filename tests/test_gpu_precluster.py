@@ -131,11 +131,14 @@ def ref_ties(skl, gpu_ctx):
     gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
 
 
-@pytest.mark.parametrize("ani", [False, True])
-def test_reference_tie_order_over_candidate_lists(oracle, skl, gpu_ctx, ref_ties, ani):
+@pytest.mark.parametrize("ani,wave", [(False, "1"), (True, "1"), (False, "0")])
+def test_reference_tie_order_over_candidate_lists(oracle, skl, gpu_ctx, ref_ties, set_switch, ani, wave):
     """skl_ctx_set_knn_ties(REFERENCE) on the candidate-list path: the reference's BinaryHeap replayed over each row's
     candidates in the order they are listed (mod.rs:459-487: the order any_shared_bins returns them).  A database of
-    near-copies (most keys tie) with ragged lists; host lists and lists built on the device."""
+    near-copies (most keys tie) with ragged lists; host lists and lists built on the device; one wave per row (the
+    default up to 256 neighbours) and one workgroup per row (SKL_REFHEAP_WAVE=0)."""
+    set_switch("SKL_REFHEAP_WAVE", wave)
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)      # (set_switch re-reads the environment)
     kmers, ss64, n = [17, 21, 25], 2, 500
     bins = synth.set_r(n, kmers, ss64, n_clusters=9)
     bins[::3] = bins[0]                                          # a third of the database is one sketch: rows of ties
@@ -145,7 +148,7 @@ def test_reference_tie_order_over_candidate_lists(oracle, skl, gpu_ctx, ref_ties
     o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
     offs, cols = candidates(skq)
     differs = False
-    for knn in (1, 4, 30):
+    for knn in (1, 4, 30, 100):
         idx, d0 = skl.self_dists_knn_candidates(gpu_ctx, g, g.set_k(21, ani), knn, offs, cols)
         exp = oracle.self_dists_knn_precluster(o, skq, knn, 1, ani, ties=oracle.TIES_RUST_HEAP, threads=8)
         assert as_pairs(idx, d0) == oracle_pairs(exp), knn
