@@ -40,7 +40,6 @@ MultiSketch::MultiSketch(std::vector<SketchMeta> meta, uint64_t sketch_size_bins
     sketch_metadata_ = std::move(meta);
     for (size_t i = 0; i < sketch_metadata_.size(); ++i) {
         if (!sketch_metadata_[i].index) sketch_metadata_[i].index = i;
-        name_map_[sketch_metadata_[i].name] = (size_t)*sketch_metadata_[i].index;
         name_map_order_.emplace_back(sketch_metadata_[i].name, (size_t)*sketch_metadata_[i].index);
     }
     bin_stride_ = 1;
@@ -137,7 +136,6 @@ MultiSketch MultiSketch::load_metadata(const std::string &file_prefix)
             for (uint64_t k = 0; c.more(o, k); ++k) {
                 std::string name = want_text("name_map");
                 const size_t idx = (size_t)want_uint("name_map");
-                m.name_map_[name] = idx;
                 m.name_map_order_.emplace_back(std::move(name), idx);
             }
             c.close(o);
@@ -372,8 +370,8 @@ void MultiSketch::read_sketch_data_block(const std::string &file_prefix,
 {
     std::vector<size_t> block_reindex, read_indices;
     for (const auto &name : names) {
-        auto it = name_map_.find(name);
-        if (it == name_map_.end()) {
+        auto it = name_map().find(name);
+        if (it == name_map().end()) {
             throw std::runtime_error("Could not find requested sample " + name + " in sketch metadata");
         }
         const size_t sketch_idx = it->second;
@@ -392,6 +390,15 @@ void MultiSketch::read_sketch_data_block(const std::string &file_prefix,
         if (!f) throw std::runtime_error(file_prefix + ".skd is shorter than its metadata says");
     }
     block_reindex_ = std::move(block_reindex);
+}
+
+const std::unordered_map<std::string, size_t> &MultiSketch::name_map() const
+{
+    std::call_once(name_lookup_->once, [&] {
+        name_lookup_->map.reserve(name_map_order_.size());
+        for (const auto &kv : name_map_order_) name_lookup_->map[kv.first] = kv.second;   // (a repeated name: the last entry, as in a serde map)
+    });
+    return name_lookup_->map;
 }
 
 size_t MultiSketch::number_samples_loaded() const
@@ -421,8 +428,8 @@ std::optional<size_t> MultiSketch::get_sample_index(const std::string &name) con
         }
         return std::nullopt;
     }
-    auto it = name_map_.find(name);
-    if (it == name_map_.end()) return std::nullopt;
+    auto it = name_map().find(name);
+    if (it == name_map().end()) return std::nullopt;
     return it->second;
 }
 

@@ -6,6 +6,8 @@
 
 #include <cstdint>
 #include <map>
+#include <mutex>
+#include <unordered_map>
 #include <optional>
 #include <memory>
 #include <new>
@@ -94,7 +96,14 @@ class MultiSketch {
     std::vector<size_t> kmer_lengths_;
     std::vector<SketchMeta> sketch_metadata_;
     std::vector<std::pair<std::string, size_t>> name_map_order_;  // serialisation order
-    std::map<std::string, size_t> name_map_;
+    // name -> block index, for lookups by name (--subset, completeness files): built from name_map_order_ on first use --
+    // a dist run over a million samples never asks, and a million tree inserts are a third of its .skm load
+    struct LazyNameMap {
+        std::once_flag once;
+        std::unordered_map<std::string, size_t> map;
+    };
+    mutable std::shared_ptr<LazyNameMap> name_lookup_ = std::make_shared<LazyNameMap>();
+    const std::unordered_map<std::string, size_t> &name_map() const;
     std::optional<std::vector<size_t>> block_reindex_;
     BinVec sketch_bins_;
     size_t bin_stride_ = 1, kmer_stride_ = 0, sample_stride_ = 0;
