@@ -1144,6 +1144,20 @@ static int dense_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches
     const size_t band_alloc = (size_t)std::min<uint64_t>(BAND_BYTES, all_pairs * rec);
     SKL_TRY(ctx_scratch(ctx, band_alloc, &dev[0], 0));
     SKL_TRY(ctx_scratch(ctx, all_pairs * rec > BAND_BYTES ? band_alloc : 16, &dev[1], 3));
+    // A copy into pageable host memory does not return before it is done (the runtime stages it), so the copy of band i is
+    // ISSUED after band i + 1's kernels are in the queue: the host blocks in the copy while the device computes.
+    struct PendingCopy {
+        void *dst = nullptr;
+        const void *src = nullptr;
+        size_t bytes = 0;
+        int buf = 0;
+    } pending;
+    auto issue_copy = [&](const PendingCopy &c) -> int {
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->knn_pair_done[c.buf], 0));
+        HIP_TRY(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, ctx->aux_stream));
+        HIP_TRY(hipEventRecord(ctx->knn_topk_done[c.buf], ctx->aux_stream));
+        return SKL_OK;
+    };
     uint64_t b0 = r0;
     size_t it = 0;
     while (b0 < r1) {
@@ -1158,6 +1172,10 @@ static int dense_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches
         const int buf = (int)(it & 1);
         void *band = dev[buf];
         if (pairs * rec > band_alloc) {   // a single row wider than a band: its own buffer
+            if (pending.bytes) {
+                SKL_TRY(issue_copy(pending));
+                pending.bytes = 0;
+            }
             HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
             SKL_TRY(ctx_scratch(ctx, pairs * rec, &dev[buf], buf == 0 ? 0 : 3));
             band = dev[buf];
@@ -1166,13 +1184,16 @@ static int dense_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches
         if (it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
         SKL_TRY(dense_band(ctx, rows, cols, p, mode, jout, self_mode, b0, b1, band));
         HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->knn_pair_done[buf], 0));
+        if (pending.bytes) SKL_TRY(issue_copy(pending));   // the previous band's, behind this band's kernels
         const uint64_t off = (self_mode ? cond_index(b0, b0 + 1, n_cols) : b0 * n_cols) - first;
-        HIP_TRY(hipMemcpyAsync((char *)out + off * rec, band, pairs * rec, hipMemcpyDeviceToHost, ctx->aux_stream));
-        HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], ctx->aux_stream));
+        pending.dst = (char *)out + off * rec;
+        pending.src = band;
+        pending.bytes = pairs * rec;
+        pending.buf = buf;
         b0 = b1;
         ++it;
     }
+    if (pending.bytes) SKL_TRY(issue_copy(pending));
     HIP_TRY(hipStreamSynchronize(ctx->aux_stream));   // host memory is complete on return
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SKL_OK;
