@@ -284,6 +284,8 @@ class Sketches:
         self.nk = len(self.kmers)
         self.ss64 = int(sketchsize64)
         if isinstance(bins, np.ndarray):
+            if bins.dtype == np.int64:      # (what torch hands over: the same bits, no 8-bytes-per-word conversion pass)
+                bins = bins.view(np.uint64)
             bins = np.ascontiguousarray(bins, dtype="<u8").reshape(-1)
             assert bins.size == self.n * self.nk * self.ss64 * 14, "bins size mismatch"
         addr, on_dev = _ptr(bins)
