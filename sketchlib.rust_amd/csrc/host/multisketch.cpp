@@ -255,6 +255,9 @@ void MultiSketch::write_sketch_data(const std::string &file_prefix, const uint64
     f.write((const char *)bins, (std::streamsize)(n_words * sizeof(uint64_t)));  // little-endian host
 }
 
+static std::atomic<bool> g_no_mapping{false};
+void MultiSketch::testing_read_slices_without_mapping(bool on) { g_no_mapping = on; }
+
 void MultiSketch::select_kmer(size_t k_idx)
 {
     if (k_idx >= kmer_lengths_.size()) throw std::runtime_error("select_kmer: no such k-mer length");
@@ -266,13 +269,12 @@ void MultiSketch::select_kmer(size_t k_idx)
     sample_stride_ = kmer_stride_;
 }
 
-namespace {
-// A read-only mapping of a whole file
-struct FileMapping {
-    const char *p = nullptr;
-    size_t bytes = 0;
-    explicit FileMapping(const std::string &path)
-    {
+void MultiSketch::read_sketch_data(const std::string &file_prefix)
+{
+    if (file_k_idx_) {
+        // one slice per sample, picked out of a mapping of the file by several threads (a file that cannot be mapped:
+        // one positional read per slice)
+        const std::string path = file_prefix + ".skd";
         const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
         if (fd < 0) throw std::runtime_error("cannot open " + path);
         struct stat st;
@@ -280,48 +282,43 @@ struct FileMapping {
             ::close(fd);
             throw std::runtime_error("cannot stat " + path);
         }
-        bytes = (size_t)st.st_size;
-        if (bytes) {
-            void *m = ::mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) {
-                ::close(fd);
-                throw std::runtime_error("cannot map " + path);
-            }
-            p = (const char *)m;
-        }
-        ::close(fd);
-    }
-    ~FileMapping()
-    {
-        if (p) ::munmap((void *)p, bytes);
-    }
-    FileMapping(const FileMapping &) = delete;
-    FileMapping &operator=(const FileMapping &) = delete;
-};
-}  // namespace
-
-void MultiSketch::read_sketch_data(const std::string &file_prefix)
-{
-    if (file_k_idx_) {
-        // one slice per sample, picked out of a mapping of the file by several threads
-        const std::string path = file_prefix + ".skd";
-        const FileMapping map(path);
         const size_t n = sketch_metadata_.size();
-        if (map.bytes / sizeof(uint64_t) < n * file_sample_stride_) throw std::runtime_error(path + " is shorter than its metadata says");
+        const size_t file_bytes = (size_t)st.st_size;
+        if (file_bytes / sizeof(uint64_t) < n * file_sample_stride_) {
+            ::close(fd);
+            throw std::runtime_error(path + " is shorter than its metadata says");
+        }
+        void *m = file_bytes && !g_no_mapping ? ::mmap(nullptr, file_bytes, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+        const char *mapped = m == MAP_FAILED ? nullptr : (const char *)m;
         sketch_bins_.resize(n * kmer_stride_);
         const size_t slice_bytes = kmer_stride_ * sizeof(uint64_t);
         const size_t n_threads = n * slice_bytes >= (64u << 20) ? std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::atomic<bool> ok{true};
         auto copy_range = [&](size_t t) {
-            const char *src = map.p + *file_k_idx_ * slice_bytes;
             char *dst = reinterpret_cast<char *>(sketch_bins_.data());
             for (size_t i = n * t / n_threads, end = n * (t + 1) / n_threads; i < end; ++i) {
-                memcpy(dst + i * slice_bytes, src + i * file_sample_stride_ * sizeof(uint64_t), slice_bytes);
+                const size_t at = (i * file_sample_stride_ + *file_k_idx_ * kmer_stride_) * sizeof(uint64_t);
+                if (mapped) {
+                    memcpy(dst + i * slice_bytes, mapped + at, slice_bytes);
+                    continue;
+                }
+                for (size_t got_all = 0; got_all < slice_bytes;) {
+                    const ssize_t got = ::pread(fd, dst + i * slice_bytes + got_all, slice_bytes - got_all, (off_t)(at + got_all));
+                    if (got <= 0) {
+                        ok = false;
+                        return;
+                    }
+                    got_all += (size_t)got;
+                }
             }
         };
         std::vector<std::thread> pool;
         for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(copy_range, t);
         copy_range(0);
         for (auto &t : pool) t.join();
+        if (mapped) ::munmap(m, file_bytes);
+        ::close(fd);
+        if (!ok) throw std::runtime_error("error reading " + path);
         block_reindex_.reset();
         return;
     }

@@ -72,6 +72,7 @@ class MultiSketch {
     // read_sketch_data* pick its slice out of every sample of the file (a fifth of the bytes of a five-k database to read,
     // hold and upload).  The file and its metadata on disk are not touched.
     void select_kmer(size_t k_idx);
+    static void testing_read_slices_without_mapping(bool on);   // (tests: take the positional-read path of a file that cannot be mapped)
     void read_sketch_data(const std::string &file_prefix);        // :167-184
     void read_sketch_data_block(const std::string &file_prefix,   // :187-210
                                 const std::vector<std::string> &names);

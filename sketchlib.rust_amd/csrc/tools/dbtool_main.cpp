@@ -105,7 +105,11 @@ int main(int argc, char **argv)
             const std::string prefix = strip_sketch_extension(argv[2]);
             MultiSketch m = MultiSketch::load_metadata(prefix);
             m.select_kmer((size_t)atoll(argv[4]));
-            const std::vector<std::string> names = collect_names(argc, argv, 5);
+            std::vector<std::string> names = collect_names(argc, argv, 5);
+            if (!names.empty() && names[0] == "--no-mmap") {   // the positional-read path of a file that cannot be mapped
+                MultiSketch::testing_read_slices_without_mapping(true);
+                names.erase(names.begin());
+            }
             if (names.empty()) m.read_sketch_data(prefix);
             else m.read_sketch_data_block(prefix, names);
             if (m.kmer_lengths().size() != 1 || m.bins().size() != m.number_samples_loaded() * m.kmer_stride()) return 3;

@@ -73,8 +73,9 @@ def test_select_kmer_reads_the_one_slice_of_every_sample():
     for sample in range(len(names)):
         for k_idx in range(3):
             want = raw[sample * sample_stride + k_idx * kmer_stride:][:kmer_stride]
-            out = subprocess.check_output([DBTOOL, "slice-selected", prefix, str(sample), str(k_idx)], text=True)
-            assert np.array_equal(np.array([int(x) for x in out.split()], dtype=np.uint64), want), (sample, k_idx)
+            for extra in ([], ["--no-mmap"]):      # through a mapping of the file / one positional read per slice
+                out = subprocess.check_output([DBTOOL, "slice-selected", prefix, str(sample), str(k_idx), *extra], text=True)
+                assert np.array_equal(np.array([int(x) for x in out.split()], dtype=np.uint64), want), (sample, k_idx, extra)
     # a subset in another order: logical sample 0 is the LAST sample of the file
     order = names[::-1]
     for k_idx in (0, 2):
