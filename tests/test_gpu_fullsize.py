@@ -159,3 +159,38 @@ def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx):
     assert len(seen) >= 3, seen      # COREACC all k, JACCARD k-sliced, COUNTS k-sliced
     g.close()
     gpu_ctx.set_stream(None)
+
+
+def test_host_output_in_several_bands_equals_device_output(skl, gpu_ctx):
+    """A host destination is filled in bands of 512 MB through two device buffers, band i's copy issued behind band i + 1's
+    kernels (csrc/capi.cpp dense_rows): 1.6 GB of (core, acc) records = 4 bands (self mode), 0.72 GB of single-k
+    distances = 2 bands (cross mode), and a row range that starts mid-matrix, against the same call left on the device."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    gpu_ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    n, nq = 20000, 60000
+    g = gpu_ctx.sketches(synth.set_u_device(n, 5, SS64, dev), n, K5, SS64)
+    pairs = n * (n - 1) // 2
+    on_dev = torch.empty((pairs, 2), dtype=torch.float32, device=dev)
+    skl.self_dists_all(gpu_ctx, g, g.set_k(), out=on_dev)
+    torch.cuda.synchronize()
+    host = np.full((pairs, 2), np.nan, dtype=np.float32)
+    skl.self_dists_all(gpu_ctx, g, g.set_k(), out=host)
+    assert bool(np.array_equal(host, on_dev.cpu().numpy()))
+    r0, r1 = 3001, 17003                                   # a row range: its own first band offset
+    lo, hi = cond(r0, r0 + 1, n), cond(r1, r1 + 1, n)
+    part = np.full((hi - lo, 2), np.nan, dtype=np.float32)
+    skl.self_dists_rows(gpu_ctx, g, g.set_k(), r0, r1, out=part)
+    assert bool(np.array_equal(part, host[lo:hi]))
+    del on_dev, host, part
+    q = gpu_ctx.sketches(synth.set_u_device(nq, 5, SS64, dev, first_sample=10**6), nq, K5, SS64)
+    nr = 3000
+    cross_dev = torch.empty((nr, nq, 1), dtype=torch.float32, device=dev)
+    skl.cross_dists_rows(gpu_ctx, g, q, g.set_k(23), 0, nr, out=cross_dev)
+    torch.cuda.synchronize()
+    cross_host = np.full((nr, nq, 1), np.nan, dtype=np.float32)
+    skl.cross_dists_rows(gpu_ctx, g, q, g.set_k(23), 0, nr, out=cross_host)
+    assert bool(np.array_equal(cross_host, cross_dev.cpu().numpy()))
+    q.close()
+    g.close()
