@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#include "multisketch.hpp"   // DefaultInitAllocator
+
 namespace skl_host {
 
 // distance_matrix.rs:11-51
@@ -110,8 +112,10 @@ class SparseDistanceMatrix {
     size_t n_distances = 0;
     size_t knn = 0;
     DistType jaccard;
-    std::vector<SparseJaccard> jaccard_dists;   // DistVec::Jaccard
-    std::vector<SparseCoreAcc> coreacc_dists;   // DistVec::CoreAcc
+    // (resize() leaves new records uninitialised: 50 M of them at a million samples are filled by several threads, and
+    // value-initialising 800 MB first is a second, single-threaded pass over the memory)
+    std::vector<SparseJaccard, DefaultInitAllocator<SparseJaccard>> jaccard_dists;   // DistVec::Jaccard
+    std::vector<SparseCoreAcc, DefaultInitAllocator<SparseCoreAcc>> coreacc_dists;   // DistVec::CoreAcc
     std::vector<std::string> ref_names;
     std::optional<std::vector<std::string>> query_names;
 

@@ -36,19 +36,37 @@ DeviceSet::DeviceSet(const std::vector<int> &devices)
 }
 
 namespace {
-SparseDistanceMatrix assemble_knn(const DistType &dist_type, size_t knn, const std::vector<uint64_t> &idx,
-                                         const std::vector<float> &d0, const std::vector<float> &d1)
+// the result arrays of the C ABI: written whole by the call, never read before
+template <class T>
+using RawVec = std::vector<T, DefaultInitAllocator<T>>;
+
+// records [0, n) by several threads (a million samples x 50 neighbours: 50 M records)
+template <class Fill>
+void fill_records(size_t n, const Fill &fill)
+{
+    const size_t n_threads = n >= (1u << 20) ? std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back([&, t] { fill(n * t / n_threads, n * (t + 1) / n_threads); });
+    fill(0, n / n_threads);
+    for (auto &th : pool) th.join();
+}
+
+SparseDistanceMatrix assemble_knn(const DistType &dist_type, size_t knn, const uint64_t *idx, const float *d0, const float *d1, size_t n_records)
 {
     SparseDistanceMatrix out;
     out.jaccard = dist_type;
     out.knn = knn;
-    out.n_distances = idx.size();
+    out.n_distances = n_records;
     if (dist_type.kind == DistType::CoreAcc) {
-        out.coreacc_dists.resize(idx.size());
-        for (size_t i = 0; i < idx.size(); ++i) out.coreacc_dists[i] = {(size_t)idx[i], d0[i], d1[i]};
+        out.coreacc_dists.resize(n_records);
+        fill_records(n_records, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i) out.coreacc_dists[i] = {(size_t)idx[i], d0[i], d1[i]};
+        });
     } else {
-        out.jaccard_dists.resize(idx.size());
-        for (size_t i = 0; i < idx.size(); ++i) out.jaccard_dists[i] = {(size_t)idx[i], d0[i]};
+        out.jaccard_dists.resize(n_records);
+        fill_records(n_records, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i) out.jaccard_dists[i] = {(size_t)idx[i], d0[i]};
+        });
     }
     return out;
 }
@@ -140,26 +158,16 @@ DistanceMatrix cross_dists_all(Device &dev, const MultiSketch &ref_sketches,
 static SparseDistanceMatrix run_knn(Device &dev, skl_sketches *ref, skl_sketches *query, size_t rows,
                                     size_t knn, const DistType &dist_type, double cutoff)
 {
-    SparseDistanceMatrix out;
-    out.jaccard = dist_type;
-    out.knn = knn;
-    out.n_distances = rows * knn;
-    std::vector<uint64_t> idx(out.n_distances);
-    std::vector<float> d0(out.n_distances), d1(out.n_distances);
+    const size_t n_records = rows * knn;
+    RawVec<uint64_t> idx(n_records);
+    RawVec<float> d0(n_records), d1(n_records);
     const skl_dist_params p = to_params(dist_type, cutoff);
     if (query) {
         check(skl_cross_dists_knn(dev.ctx(), ref, query, &p, knn, idx.data(), d0.data(), d1.data(), 0));
     } else {
         check(skl_self_dists_knn(dev.ctx(), ref, &p, knn, idx.data(), d0.data(), d1.data(), 0));
     }
-    if (dist_type.kind == DistType::CoreAcc) {
-        out.coreacc_dists.resize(out.n_distances);
-        for (size_t i = 0; i < out.n_distances; ++i) out.coreacc_dists[i] = {(size_t)idx[i], d0[i], d1[i]};
-    } else {
-        out.jaccard_dists.resize(out.n_distances);
-        for (size_t i = 0; i < out.n_distances; ++i) out.jaccard_dists[i] = {(size_t)idx[i], d0[i]};
-    }
-    return out;
+    return assemble_knn(dist_type, knn, idx.data(), d0.data(), d1.data(), n_records);
 }
 
 SparseDistanceMatrix self_dists_knn(Device &dev, const MultiSketch &sketches, size_t n, size_t knn,
@@ -360,7 +368,7 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
             }
         }
     }
-    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
+    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx.data(), d0.data(), d1.data(), idx.size());
     out.ref_names = sketch_names(sketches);
     return out;
 }
@@ -546,7 +554,7 @@ SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches
                                            coreacc ? d_all.data() : nullptr, 0, p.ani, idx.data() + b[d] * knn,
                                            d0.data() + b[d] * knn, d1.data() + b[d] * knn, 0));
             });
-            SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
+            SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx.data(), d0.data(), d1.data(), idx.size());
             out.ref_names = sketch_names(sketches);
             return out;
         }
@@ -557,7 +565,7 @@ SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches
         check(skl_self_dists_knn_rows(devs[d].ctx(), s.h, &p, knn, b[d], b[d + 1], idx.data() + b[d] * knn,
                                       d0.data() + b[d] * knn, d1.data() + b[d] * knn, 0));
     });
-    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
+    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx.data(), d0.data(), d1.data(), idx.size());
     out.ref_names = sketch_names(sketches);
     return out;
 }
@@ -587,7 +595,7 @@ SparseDistanceMatrix cross_dists_knn(DeviceSet &devs, const MultiSketch &ref_ske
         check(skl_cross_dists_knn_rows(devs[d].ctx(), r.h, q.h, &p, knn, b[d], b[d + 1], idx.data() + b[d] * knn,
                                        d0.data() + b[d] * knn, d1.data() + b[d] * knn, 0));
     });
-    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx, d0, d1);
+    SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx.data(), d0.data(), d1.data(), idx.size());
     out.ref_names = sketch_names(ref_sketches);
     out.query_names = sketch_names(query_sketches);
     return out;
