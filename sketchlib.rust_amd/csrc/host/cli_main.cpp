@@ -235,6 +235,10 @@ int run_dist(const DistArgs &a)
     // lib.rs:230-237: verbose -> Info, quiet -> Error, default -> Warn
     const Logger log{a.verbose && !a.quiet, !a.quiet};
     log.info("Using " + std::to_string(a.threads) + " threads");   // cli.rs:75-86 (host threads unused)
+    if (a.threads > 2 * host_cpu_budget()) {
+        log.info("This process may use " + std::to_string(host_cpu_budget()) + " CPUs (affinity / cgroup quota): the output is formatted by " +
+                 std::to_string(2 * host_cpu_budget()) + " threads");
+    }
     // The device contexts (HIP runtime start, stream, first allocations: 0.1-0.25 s) come up on their own thread while the
     // database is read; whatever goes wrong there is reported where the contexts are first needed, after the loading errors.
     std::future<std::unique_ptr<DeviceSet>> dev_starting =

@@ -1,4 +1,6 @@
 #include "distance_matrix.hpp"
+#include <fstream>
+#include <sched.h>
 
 #include <atomic>
 #include <charconv>
@@ -306,11 +308,45 @@ class OutputPool {
 //      workers pwrite their own blocks there; a stream gets the blocks in order from the calling thread.
 // (Rounds 2-3 passed every block through an ordered section, condition variable or ticket: with 256 workers that
 // section -- 150 000 blocks at 100 000 genomes -- was most of the listing's wall time, profiles/r04_e2e_cfg3.txt.)
+// The CPUs this process may really use: the hardware threads, its affinity mask, and the cgroup's quota (a container that
+// shows 256 hardware threads may be granted 16 CPUs' worth of time: formatting workers beyond twice that only add
+// throttling -- 31 s instead of 16 s for the listing of BASELINE configs[2] at --threads 256, profiles/r04_e2e_cfg3.txt).
+static std::atomic<size_t> g_cpu_budget_override{0};
+void testing_set_host_cpu_budget(size_t n) { g_cpu_budget_override = n; }
+
+size_t host_cpu_budget()
+{
+    if (const size_t forced = g_cpu_budget_override.load()) return forced;
+    static const size_t budget = [] {
+        size_t n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<size_t>(n, (size_t)std::max(1, CPU_COUNT(&set)));
+        auto quota_from = [&](const char *quota_path, const char *period_path) {
+            std::ifstream q(quota_path);
+            std::string a, b;
+            if (!(q >> a)) return;
+            if (period_path) {   // cgroup v1: two files
+                std::ifstream pf(period_path);
+                if (!(pf >> b)) return;
+            } else if (!(q >> b)) {   // cgroup v2: "<quota|max> <period>"
+                return;
+            }
+            if (a == "max" || a == "-1") return;
+            const double quota = std::strtod(a.c_str(), nullptr), period = std::strtod(b.c_str(), nullptr);
+            if (quota > 0 && period > 0) n = std::min<size_t>(n, (size_t)std::max(1.0, std::ceil(quota / period)));
+        };
+        quota_from("/sys/fs/cgroup/cpu.max", nullptr);
+        quota_from("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+        return n;
+    }();
+    return budget;
+}
+
 template <class Format>
 static void write_blocks_in_order(TextSink &sink, size_t n_blocks, size_t threads, Format format)
 {
     if (n_blocks == 0) return;
-    threads = std::max<size_t>(1, std::min(threads, n_blocks));
+    threads = std::max<size_t>(1, std::min({threads, n_blocks, 2 * host_cpu_budget()}));
     OutputPool &pool = OutputPool::instance();
     struct Piece {
         size_t worker, off, len;

@@ -97,6 +97,10 @@ class DistanceMatrix {
     void write_rows(TextSink &sink, size_t r0, size_t r1, const float *band, size_t threads) const;
 };
 
+// CPUs this process may use (hardware threads, affinity mask, cgroup quota): output workers are capped at twice this
+size_t host_cpu_budget();
+void testing_set_host_cpu_budget(size_t n);   // (tests: 0 = measure; n = pretend)
+
 struct SparseJaccard {   // distance_matrix.rs:214
     size_t idx;
     float dist;

@@ -22,6 +22,8 @@ int main(int argc, char **argv) {
     m.distances.resize(m.n_distances * 2);
     for (size_t i = 0; i < m.distances.size(); ++i) m.distances[i] = (float)((i * 2654435761u) % 1000003) / 1000003.0f;
     std::string ref;
+    testing_set_host_cpu_budget(1000);      // (the cap at twice the CPU budget would hide the large worker counts below)
+    fprintf(stderr, "host_cpu_budget forced to %zu\n", host_cpu_budget());
     for (int rep = 0; rep < 12; ++rep) {
         size_t threads = rep == 0 ? 1 : 1 + (rep * 37) % 200;
         size_t rows_per = rep == 0 ? n : 1 + (rep * 131) % 700;
@@ -50,6 +52,9 @@ int main(int argc, char **argv) {
         fprintf(stderr, "rep %d threads %zu rows_per %zu bytes %zu %s\n", rep, threads, rows_per, got.size(), got == ref ? "same" : "DIFFERENT");
         if (got != ref) return 1;
     }
+    testing_set_host_cpu_budget(0);
+    if (host_cpu_budget() < 1 || host_cpu_budget() > 4096) return 2;   // the measured budget: hardware threads / affinity / cgroup quota
+    fprintf(stderr, "host_cpu_budget measured: %zu\n", host_cpu_budget());
     // raw bytes (a .npy band) behind a header
     {
         std::vector<char> raw((20u << 20) + 3);
