@@ -57,7 +57,7 @@ struct Knobs {
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
     bool knn_row_flags = true;        // SKL_KNN_ROW_FLAGS=0: the merge of the transposed band visits every row (A/B only, results are identical)
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
-    bool refheap_wave = true;         // SKL_REFHEAP_WAVE=0: the resumable heap replay runs one workgroup per row even for knn <= 256 (A/B only, results are identical)
+    bool refheap_wave = true;         // SKL_REFHEAP_WAVE=0: the heap replays (one-shot and resumable) run one workgroup per row even for knn <= 256 (A/B only, results are identical)
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
     bool cand_symmetric = true;       // SKL_CAND_SYMMETRIC=0: evaluate symmetric candidate lists in full
     bool inline_prefix = true;        // SKL_INLINE_PREFIX=0: the tile lookup always searches the prefix table in global memory (A/B only, results are identical)
