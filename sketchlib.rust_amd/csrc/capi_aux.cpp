@@ -116,6 +116,36 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
     return SKL_OK;
 }
 
+// The last step of a candidate-list call: the per-row selection of rows [r, r + rows) -- `launch(first_row, rows)` --
+// and the results' way back to the host.  A copy into pageable memory blocks its caller, so large results go in four row
+// batches, batch b's copy issued on the auxiliary stream behind batch b + 1's selection.
+template <class Launch>
+static int select_and_copy_back(skl_ctx *ctx, size_t n, size_t knn, const Launch &launch, const void *d_idx, const void *d_d0,
+                                uint64_t *out_idx, float *out_d0)
+{
+    const size_t n_batches = n * knn * (sizeof(uint64_t) + sizeof(float)) >= (32u << 20) ? 4 : 1;
+    size_t prev0 = 0, prev_rows = 0;
+    auto copy_back = [&](size_t r0, size_t rows, int ev) -> int {
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->knn_pair_done[ev], 0));
+        HIP_TRY(hipMemcpyAsync(out_idx + r0 * knn, (const uint64_t *)d_idx + r0 * knn, rows * knn * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->aux_stream));
+        HIP_TRY(hipMemcpyAsync(out_d0 + r0 * knn, (const float *)d_d0 + r0 * knn, rows * knn * sizeof(float), hipMemcpyDeviceToHost, ctx->aux_stream));
+        return SKL_OK;
+    };
+    for (size_t b = 0; b < n_batches; ++b) {
+        const size_t r0 = n * b / n_batches, r1 = n * (b + 1) / n_batches;
+        if (r1 == r0) continue;
+        SKL_TRY(launch(r0, r1 - r0));
+        HIP_TRY(hipEventRecord(ctx->knn_pair_done[b & 1], ctx->stream));
+        if (prev_rows) SKL_TRY(copy_back(prev0, prev_rows, (int)((b - 1) & 1)));
+        prev0 = r0;
+        prev_rows = r1 - r0;
+    }
+    if (prev_rows) SKL_TRY(copy_back(prev0, prev_rows, (int)((n_batches - 1) & 1)));
+    HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
 // Candidate-list kNN: the device half of the reference's self_dists_knn_precluster
 // (src/distances/mod.rs:399-553).  Host pointers in, host pointers out.
 // Distances + ragged top-k for candidate lists that are already on the device.  host_offsets is
@@ -218,7 +248,15 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
         h.col_ids = d_cand;
         h.force_workgroup_form = ctx->knobs.refheap_wave ? 0u : 1u;
         if (knn <= (size_t)REFHEAP_LDS_MAX) {
-            HIP_TRY(launch_topk_refheap(h, ctx->stream));
+            return select_and_copy_back(
+                ctx, n, knn,
+                [&](size_t r0, size_t rows) -> int {
+                    h.first_row = (uint32_t)r0;
+                    h.rows = (uint32_t)rows;
+                    HIP_TRY(launch_topk_refheap(h, ctx->stream));
+                    return SKL_OK;
+                },
+                d_idx.p, d_d0.p, out_idx, out_d0);
         } else {   // heaps in global memory, rows in batches of at most 1 GiB of it
             DevBuf heaps;
             const size_t per_row = 3 * (knn + 1) * sizeof(float);
@@ -253,7 +291,15 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
     t.row_offsets = d_off;
     t.col_ids = d_cand;
     if (knn <= (size_t)TOPK_LDS_MAX) {
-        HIP_TRY(launch_topk(t, ctx->stream));
+        return select_and_copy_back(
+            ctx, n, knn,
+            [&](size_t r0, size_t rows) -> int {
+                t.first_row = (uint32_t)r0;
+                t.rows = (uint32_t)rows;
+                HIP_TRY(launch_topk(t, ctx->stream));
+                return SKL_OK;
+            },
+            d_idx.p, d_d0.p, out_idx, out_d0);
     } else {
         // more neighbours than the LDS array holds: the selected items of a row are collected and sorted in
         // global memory, rows in batches of at most 1 GiB of it
