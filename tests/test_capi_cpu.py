@@ -184,3 +184,22 @@ def test_register_budget_of_the_shipped_pair_kernels():
         else:
             assert vgpr <= 128 and lds <= 40 * 1024, (name, vgpr, lds)
             assert scratch <= 256, (name, scratch)
+
+
+def test_register_budget_of_the_candidate_list_and_replay_kernels():
+    """pair_cand_rows_kernel<TRIPS> keeps the row's planes in registers (7 x 8 bytes per lane and trip): every form must do
+    so without scratch and stay at 4 waves per SIMD or better (<= 128 VGPRs; one or two trips <= 64: 8 waves); the
+    one-wave-per-row heap replays take <= 20 KB of LDS per workgroup of 4 rows, so that 8 workgroups fit a CU."""
+    import sketchlib.rust_amd as pkg
+
+    pkg.build_library()
+    meta = _kernel_metadata(pkg.library_path())
+    rows = {k: v for k, v in meta.items() if "pair_cand_rows_kernel" in k}
+    assert len(rows) == 6, sorted(rows)
+    for name, (vgpr, scratch, lds) in rows.items():
+        trips = int(re.search(r"pair_cand_rows_kernel<(\d+)>", name).group(1))
+        assert scratch == 0 and lds == 0, (name, scratch, lds)
+        assert vgpr <= (64 if trips <= 2 else 128), (name, vgpr)
+    for kernel in ("topk_refheap_wave_kernel", "refheap_merge_wave_kernel"):
+        (vgpr, scratch, lds), = [v for k, v in meta.items() if kernel in k]
+        assert scratch == 0 and vgpr <= 64 and lds <= 20 * 1024, (kernel, vgpr, scratch, lds)
