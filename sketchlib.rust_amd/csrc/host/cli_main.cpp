@@ -223,6 +223,19 @@ void write_whole(const DistanceMatrix &d, TextSink &sink, size_t n, const DistAr
     sink.finish(sink.begin(bytes, len), bytes, len);
 }
 
+// The listing is complete and flushed: leave without tearing down what the operating system reclaims anyway -- the slabs
+// in HBM, gigabytes of host vectors, the worker pool, the HIP runtime (0.05 s of a 0.19 s run on 1 000 genomes, 0.5 s
+// after a million).  Files are written with pwrite (nothing buffered in the process); SKL_CLI_FAST_EXIT=0 keeps the
+// orderly exit.
+void leave_after_success()
+{
+    std::cout.flush();
+    std::cerr.flush();
+    fflush(nullptr);
+    const char *e = std::getenv("SKL_CLI_FAST_EXIT");
+    if (!(e && e[0] == '0')) std::_Exit(0);
+}
+
 int run_dist(const DistArgs &a)
 {
     if (a.npy && (!a.output || a.knn)) {
@@ -413,6 +426,7 @@ int run_dist(const DistArgs &a)
         std::fprintf(stderr, "TIMING load=%.3fs device_wait=%.3fs dist+output=%.3fs (gpu_wait=%.3fs format=%.3fs sink=%.3fs)\n",
                      t_loaded, t_device - t_loaded, since_start() - t_device, t.wait_s, t.format_s, t.sink_s);
     }
+    leave_after_success();
     return 0;
 }
 
@@ -761,6 +775,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
         std::fprintf(stderr, "TIMING precluster: load_ski=%.3fs load_skq+skd=%.3fs device_wait=%.3fs candidates+distances=%.3fs write=%.3fs\n",
                      t_ski, t_loaded - t_ski, t_device - t_loaded, t_dist - t_device, since_start() - t_dist);
     }
+    leave_after_success();
     return 0;
 }
 
