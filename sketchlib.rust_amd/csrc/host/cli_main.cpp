@@ -233,7 +233,13 @@ void leave_after_success()
     std::cerr.flush();
     fflush(nullptr);
     const char *e = std::getenv("SKL_CLI_FAST_EXIT");
-    if (!(e && e[0] == '0')) std::_Exit(0);
+    if (e && e[0] == '0') return;
+    // a profiler or another preloaded tool writes its results from exit handlers: leave in order for it
+    for (const char *tool : {"LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"}) {
+        const char *v = std::getenv(tool);
+        if (v && v[0]) return;
+    }
+    std::_Exit(0);
 }
 
 int run_dist(const DistArgs &a)
