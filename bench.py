@@ -244,13 +244,11 @@ def sampled(ctx, run, interval_us, expect_s=1.0, enabled=True):
 
 def roofline_pass(ctx, launch, launches, interval_us, sampler=True, expect_s=1.0):
     """The fixed kernel-timing pass: `launches` launches, EVERY one bracketed by HIP events on the launch
-    stream (whatever SKL_TIMING_EVERY the timed region ran with) -- or, with the clock sampler beside them,
+    stream (skl_ctx_timing_enable(1); the timed region runs the library as a caller gets it: no brackets) -- or, with the clock sampler beside them,
     none: an event record is a barrier packet, and with a second queue busy its timestamps come ~10 us late
     (the launches themselves are not slowed: scripts/sampler_cost.py), so that pass reports wall time only.
     -> (average kernel seconds, launches bracketed, wall seconds per launch, clock)."""
-    prev = os.environ.get("SKL_TIMING_EVERY")
-    os.environ["SKL_TIMING_EVERY"] = "1000000000" if sampler else "1"
-    ctx.reload_env()
+    ctx.timing_enable(0 if sampler else 1)
     ctx.timing_reset()
     t = [0.0]
 
@@ -263,11 +261,7 @@ def roofline_pass(ctx, launch, launches, interval_us, sampler=True, expect_s=1.0
 
     clk = sampled(ctx, run, interval_us, expect_s=expect_s, enabled=sampler)
     kernel_ms, bracketed = ctx.kernel_ms() if not sampler else (0.0, 0)
-    if prev is None:
-        os.environ.pop("SKL_TIMING_EVERY", None)
-    else:
-        os.environ["SKL_TIMING_EVERY"] = prev
-    ctx.reload_env()
+    ctx.timing_enable(0)   # the library's default again
     return (kernel_ms / 1e3) / max(bracketed, 1), bracketed, t[0], clk
 
 
@@ -414,11 +408,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return self_launch(args.gpus)      # (before torch is imported or the GPU touched)
 
-    # The library brackets pair-kernel launches with HIP events for skl_ctx_kernel_ms(); an event
-    # record is a barrier packet on the queue and two per launch cost a 0.16 ms step ~5 us.  In the
-    # timed region every 4th launch is bracketed (reported as kernel_avg_ms_timed_region); the roofline's
-    # kernel time comes from the fixed pass after it, where every launch is.
-    os.environ.setdefault("SKL_TIMING_EVERY", "4")
+    # The timed region runs the library in its default configuration: pair-kernel launches are NOT bracketed
+    # with HIP events (skl_ctx_timing_enable is off unless asked for).  The roofline's kernel time comes from
+    # the fixed pass after it, where every launch is bracketed.
 
     import numpy as np
     import torch
@@ -574,13 +566,11 @@ def main():
     for _ in range(warmup):
         step()
     fence()
-    ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms_timed, launches_timed = ctx.kernel_ms()
     kernel_name = ctx.last_kernel()
 
     if dist is not None:
@@ -713,8 +703,7 @@ def main():
                 "kernel_timing": f"fixed pass of {launches} launches right after the timed region (independent of --steps / "
                                  "--warmup), HIP events on the launch stream around EVERY pair-kernel launch",
                 "roofline_pass_ms_per_launch_wall": pass_wall_s * 1e3,
-                "kernel_avg_ms_timed_region": (kernel_ms_timed / max(launches_timed, 1)),
-                "kernel_launches_bracketed_in_timed_region": launches_timed,
+                "kernel_launches_bracketed_in_timed_region": 0,   # the timed region runs the library's default: no event brackets
                 "pairs_per_launch": my_pairs,
                 # SURVEY 8(d)'s named bound, kept as the measure of on-chip reuse it is: both operands
                 # streamed from HBM once per pair.  A tiled kernel is far above it by construction.
@@ -768,13 +757,10 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
     from oracle import oracle as O
 
     nk = len(KMERS)
-    os.environ["SKL_TIMING_EVERY"] = "1"
-    ctx.reload_env()
     sec = {}
 
     def set_timing_every(v):
-        os.environ["SKL_TIMING_EVERY"] = str(v)
-        ctx.reload_env()
+        ctx.timing_enable(v)
 
     def timed(launch, w, s, interval_us, separate_clock_pass=False, clock=True):
         """-> wall per step, PAIR-kernel seconds per step (every launch bracketed), launches, clock.  The clock sampler
@@ -800,7 +786,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
         clk = sampled(ctx, run, interval_us, expect_s=est, enabled=sampler and clock and not separate_clock_pass)
         kms, nl = ctx.kernel_ms()
         if sampler and clock and separate_clock_pass:
-            set_timing_every(1000000000)
+            set_timing_every(0)
             clk = sampled(ctx, run, interval_us, expect_s=est)
             set_timing_every(1)
         return wall[0], kms / 1e3 / s, nl, clk
@@ -843,7 +829,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
         del bins3, out3
         torch.cuda.empty_cache()
 
-    if "cfg4" in which or "cfg5" in which:
+    if "cfg4" in which or "cfg5" in which or "cfg5ca" in which:
         # the 1 M-sketch database of configs[3] and [4]: clustered synthetic sketches (200 relatives per genome)
         keep = [0.97, 0.955, 0.94, 0.925, 0.91]
         nr, nq, ss = 1_000_000, 10_000, SS64_CFG45
@@ -888,6 +874,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
 
             # (not sampled: the kNN driver allocates and frees band buffers inside the call -- device-wide synchronisations
             # that would wait for the sampler)
+            ctx.set_knn_ties(capi.TIES_CANONICAL)   # (the library's default is the reference's order: timed below, beside this one)
             wall, ksec, n_launch, clk = timed(knn_call, 1, 1, 500, clock=False)   # (one untimed call first: it allocates the band buffers)
             idx, d0, _d1 = res[0]
             assert idx.shape == (nr, knn) and bool(np.all(np.diff(d0, axis=1) >= 0)) and not np.any(idx == np.arange(nr, dtype=np.uint64)[:, None])
@@ -919,6 +906,39 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
                            "pair_kernel_s": ksec, "pair_kernel_launches": n_launch, "other_s (top-k merge, copies)": wall - ksec,
                            "valu_frac": v5["frac"], "valu_frac_at_in_kernel_clock": v5.get("frac_at_in_kernel_clock"),
                            "in_kernel_clock": clk, "rows_checked_against_dense": 3}
+        if "cfg5ca" in which or "cfg5" in which:
+            # cfg 5 as the reference's DEFAULT DistType runs it (`sketchlib dist db --knn 50` without -k: CoreAcc, mod.rs:25-37,
+            # kNN arm :195-221): all five k-mer lengths + the regression per pair, rows sorted on the core distance, in the
+            # library's default tie rule (the reference's BinaryHeap order).  ONE call (~1 min): the band buffers it allocates
+            # first are 1-2 s of it.
+            knn = 50
+            p5c = g_r.set_k()
+            ctx.set_knn_ties(capi.TIES_REFERENCE)
+            res = [None]
+
+            def knn_ca_call():
+                res[0] = capi.self_dists_knn(ctx, g_r, p5c, knn)
+
+            wall, ksec, n_launch, clk = timed(knn_ca_call, 0, 1, 500, clock=False)
+            idx, d0, d1 = res[0]
+            assert idx.shape == (nr, knn) and bool(np.all(np.diff(d0, axis=1) >= 0)) and not np.any(idx == np.arange(nr, dtype=np.uint64)[:, None])
+            for i in (0, 77_777, nr - 1):     # three rows: the dense path's (core, acc) row pushed through the oracle's BinaryHeap
+                dense = capi.cross_dists_rows(ctx, g_r, g_r, p5c, i, i + 1)[0]
+                exp = O.heap_replay(np.delete(dense[:, 0], i), knn, ids=np.delete(np.arange(nr, dtype=np.uint64), i))
+                assert np.array_equal(idx[i], exp["idx"]) and np.array_equal(d0[i], exp["d0"]), i
+                assert np.array_equal(d1[i], dense[idx[i].astype(np.int64), 1]), i
+            evaluated = nr * (nr - 1) // 2
+            v5c = valu_block(evaluated, ksec, len(K4), ss, clk)
+            sec["cfg5_coreacc"] = {"workload": "BASELINE configs[4] in the reference's DEFAULT distance type: self kNN-50 over 1M x 1M, core/accessory "
+                                               "(k={13..29}, the regression per pair, rows sorted on the core distance), sketchsize64=32, on ONE GPU, "
+                                               "clustered synthetic sketches; every pair evaluated once; the reference's tie order (library default)",
+                                   "pair_distances_defined": nr * (nr - 1), "pairs_evaluated": evaluated, "s_per_call": wall,
+                                   "s_per_call_note": "the first core/accessory kNN call of the context (it allocates its band buffers: 1-2 s)",
+                                   "pair_distances_per_s": nr * (nr - 1) / wall, "pairs_evaluated_per_s": evaluated / wall,
+                                   "kernel": ctx.last_kernel(), "pair_kernel_s": ksec, "pair_kernel_launches": n_launch,
+                                   "other_s (heap replays, copies)": wall - ksec, "valu_frac": v5c["frac"],
+                                   "algorithmic_bytes_per_pair": 2 * len(K4) * ss * 14 * 8 + 8,
+                                   "rows_checked_against_dense_plus_oracle_heap": 3}
         g_r.close()
         del rbins
     return sec

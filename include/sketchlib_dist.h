@@ -99,10 +99,13 @@ int skl_ctx_synchronize(skl_ctx *ctx);
  * created and never on the launch path; this re-reads them for an existing context (tests and
  * benchmarks that compare two drivers inside one process). */
 int skl_ctx_reload_env(skl_ctx *ctx);
-/* Pair-kernel timing.  Every dense / binmatch / knn call brackets each launch of the
- * pair kernel with HIP events recorded on the context's stream.  reset() forgets them;
- * kernel_ms() synchronises and returns the summed device time and the number of
+/* Pair-kernel timing -- a diagnostic, OFF by default (an event record is a barrier packet on the queue: two per
+ * launch cost a sub-millisecond launch ~5 us).  enable(every): every = 0 turns it off, N >= 1 brackets every N-th
+ * launch of the pair kernel (dense / binmatch / knn calls; also the candidate-list and the sketching kernel) with HIP
+ * events recorded on the context's stream (the environment variable SKL_TIMING_EVERY sets the initial value).
+ * reset() forgets the recorded events; kernel_ms() synchronises and returns the summed device time and the number of
  * launches recorded since the last reset (at most 4096 are kept). */
+int skl_ctx_timing_enable(skl_ctx *ctx, int every);
 int skl_ctx_timing_reset(skl_ctx *ctx);
 int skl_ctx_kernel_ms(skl_ctx *ctx, float *total_ms, int *n_launches);
 /* Name (with tile shape) of the pair kernel the last call dispatched, e.g.
@@ -187,15 +190,18 @@ int skl_cross_dists_rows(skl_ctx *ctx, const skl_sketches *ref, const skl_sketch
  * 2 048 neighbours the running lists live in LDS, longer ones go through global memory.
  *
  * Equal keys (common: every genome without knn relatives ties at 1.0, and single-k Jaccard values are
- * quantised) -- skl_ctx_set_knn_ties() chooses between two rules for the dense kNN calls:
- *   SKL_KNN_TIES_CANONICAL (default)  smallest (key, neighbour index) first: a property of the data alone.
- *                                     The distance multiset of every row equals the reference's.
- *   SKL_KNN_TIES_REFERENCE            the list the reference BINARY prints: candidates j ascending through
- *                                     push_heap (mod.rs:41-48: strict `<` against the heap's maximum) into
- *                                     std::collections::BinaryHeap, then into_sorted_vec (mod.rs:156-191,
- *                                     :335-391) -- which of several equal keys survive, and their order, follow
- *                                     from the heap's history.  Replayed on the device row by row, so the
- *                                     self kNN evaluates every pair twice as the reference does. */
+ * quantised) -- skl_ctx_set_knn_ties() chooses between two rules for every kNN call of the context:
+ *   SKL_KNN_TIES_REFERENCE (default)  the list the reference's self_dists_knn / cross_dists_knn return: candidates j
+ *                                     ascending through push_heap (mod.rs:41-48: strict `<` against the heap's
+ *                                     maximum) into std::collections::BinaryHeap, then into_sorted_vec (mod.rs:156-191,
+ *                                     :335-391) -- which of several equal keys survive, and their order, follow from
+ *                                     the heap's history, which the device replays.  skl_self_dists_knn over the whole
+ *                                     matrix still evaluates every pair ONCE: a row's heap lives in device memory
+ *                                     between the row bands and is fed its candidates in ascending id (rows above its
+ *                                     band reach it through the band's turned copy); row ranges, cross kNN and lists
+ *                                     longer than 2 048 go row by row (every pair of those rows, as the reference does).
+ *   SKL_KNN_TIES_CANONICAL            smallest (key, neighbour index) first: a property of the data alone.  The
+ *                                     distance multiset of every row equals the reference's. */
 #define SKL_KNN_TIES_CANONICAL 0
 #define SKL_KNN_TIES_REFERENCE 1
 int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);

@@ -80,6 +80,8 @@ def lib():
         L.sko_self_dists_knn.restype = C.c_int
         L.sko_self_dists_knn.argtypes = [P, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_double,
                                          C.c_int, C.c_int, C.c_void_p]
+        L.sko_heap_replay.restype = C.c_size_t
+        L.sko_heap_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
         L.sko_cross_dists_knn.restype = C.c_long
         L.sko_cross_dists_knn.argtypes = [P, P, C.c_size_t, C.c_int, C.c_size_t, C.c_int,
                                           C.c_double, C.c_int, C.c_int, C.c_void_p]
@@ -165,6 +167,15 @@ def self_dists_knn(s, knn, dist_type=COREACC, k_idx=0, ani=False, cutoff=0.64,
     if rc:
         raise ValueError(f"oracle self_dists_knn failed rc={rc}")
     return out.reshape(s.n, knn)
+
+
+def heap_replay(keys, knn, ids=None):
+    """mod.rs:41-48 + into_sorted_vec over the candidates (ids[c], keys[c]) in the order given -> items (idx, d0, d1)."""
+    keys = np.ascontiguousarray(keys, dtype=np.float32)
+    ids = np.arange(keys.size, dtype=np.uint64) if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+    out = np.zeros(max(min(keys.size, knn), 1), dtype=SPARSE_DTYPE)
+    m = lib().sko_heap_replay(ids.ctypes.data, keys.ctypes.data, keys.size, knn, out.ctypes.data)
+    return out[:m]
 
 
 def cross_dists_knn(r, q, knn, dist_type=COREACC, k_idx=0, ani=False, cutoff=0.64,

@@ -474,6 +474,27 @@ static void heap_into_sorted(heap_t *h)
     }
 }
 
+/* The heap alone, for tests that pin this restatement on hand-worked cases: candidates (ids[c], keys[c]), c = 0 .. n - 1, go
+ * through push_heap (mod.rs:41-48) in that order into an empty BinaryHeap bounded at knn, then into_sorted_vec.
+ * out: min(n, knn) items; returns their number. */
+size_t sko_heap_replay(const uint64_t *ids, const float *keys, size_t n, size_t knn, sko_sparse *out)
+{
+    heap_t heap;
+    heap.len = 0;
+    heap.data = (sko_sparse *)malloc(sizeof(sko_sparse) * (knn + 1));
+    for (size_t c = 0; c < n; ++c) {
+        sko_sparse item;
+        item.idx = ids[c];
+        item.d0 = keys[c];
+        item.d1 = 0.0f;
+        push_heap(&heap, item, knn);
+    }
+    heap_into_sorted(&heap);
+    for (size_t t = 0; t < heap.len; ++t) out[t] = heap.data[t];
+    free(heap.data);
+    return heap.len;
+}
+
 /* Canonical rule: strict weak order on (d0, idx). */
 static int canon_cmp(const void *a, const void *b)
 {

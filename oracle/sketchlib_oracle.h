@@ -94,6 +94,11 @@ typedef struct {
 #define SKO_TIES_RUST_HEAP 0
 #define SKO_TIES_CANONICAL 1
 
+/* push_heap (mod.rs:41-48) over the candidates (ids[c], keys[c]) in the order given, then into_sorted_vec: the
+ * BinaryHeap restatement by itself (tests/test_oracle_golden.py pins it on hand-worked tie cases).  out: min(n, knn)
+ * items; returns their number. */
+size_t sko_heap_replay(const uint64_t *ids, const float *keys, size_t n, size_t knn, sko_sparse *out);
+
 /* mod.rs:133-224.  out: n*knn items, row-major (row i, neighbours ascending). */
 int sko_self_dists_knn(const sko_sketches *s, size_t knn, int dist_type, size_t k_idx, int ani,
                        double completeness_cutoff, int tie_mode, int threads, sko_sparse *out);

@@ -34,6 +34,7 @@ def run(v):
         k, val = kv.split("=")
         os.environ[k] = val
     ctx.reload_env()
+    ctx.timing_enable()
     ctx.timing_reset()
     t0 = time.perf_counter()
     idx, d0, _ = capi.self_dists_knn(ctx, s, p, 50)

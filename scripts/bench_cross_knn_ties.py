@@ -12,6 +12,7 @@ q = ctx.sketches(synth.set_clustered_device(nq, 5, 32, dev, keep=keep, first_sam
 p = r.set_k(21)
 for mode in ("canonical", "reference", "canonical", "reference"):
     ctx.set_knn_ties(capi.TIES_REFERENCE if mode == "reference" else capi.TIES_CANONICAL)
+    ctx.timing_enable()
     ctx.timing_reset()
     t0 = time.perf_counter()
     idx, d0, _ = capi.cross_dists_knn(ctx, r, q, p, 50)

@@ -22,6 +22,7 @@ ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 def timed(fn, reps=2):
     fn()
     torch.cuda.synchronize()
+    ctx.timing_enable()
     ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -68,6 +69,7 @@ def full_size(which):
         capi.cross_dists_knn(ctx, r, q, r.set_k(21), 50, 0, 4096)   # first call: lane slab, scratch
         for stream in ("1", "0"):
             os.environ["SKL_TOPK_STREAM"] = stream
+            ctx.timing_enable()
             ctx.timing_reset()
             t0 = time.perf_counter()
             idx, d0, d1 = capi.cross_dists_knn(ctx, r, q, r.set_k(21), 50)
@@ -105,6 +107,7 @@ def full_size(which):
         ref = None
         for sym in (("1",) if os.environ.get("BENCH_ONLY_ONCE") else ("1", "0")):
             os.environ["SKL_KNN_SYMMETRIC"] = sym
+            ctx.timing_enable()
             ctx.timing_reset()
             t0 = time.perf_counter()
             idx, d0, d1 = capi.self_dists_knn(ctx, s, s.set_k() if coreacc else s.set_k(21), 50)

@@ -30,6 +30,7 @@ def main():
     offs = np.concatenate([np.sort(rng.choice(length, 19, replace=False)).tolist() + [length] for _ in range(n)])
     offset_begin = np.arange(n + 1, dtype=np.uint64) * 20
     capi.sketch_signs(ctx, codes[:length], code_begin[:2], offs[:20], offset_begin[:2], kmers, 4096)   # warm-up
+    ctx.timing_enable()
     ctx.timing_reset()
     t0 = time.perf_counter()
     capi.sketch_signs(ctx, codes, code_begin, offs, offset_begin, kmers, 4096)

@@ -24,6 +24,7 @@ for ss64 in (16, 32, 64, 128):
         out = torch.empty((pairs, capi.ncols(p)), dtype=torch.float32, device=dev)
         capi.self_dists_all(ctx, sk, p, out=out)
         torch.cuda.synchronize()
+        ctx.timing_enable()
         ctx.timing_reset()
         reps = 5
         for _ in range(reps):

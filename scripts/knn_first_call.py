@@ -32,6 +32,7 @@ def main():
     ctx.set_knn_ties(capi.TIES_REFERENCE if args.ties == "reference" else capi.TIES_CANONICAL)
     walls, kernels = [], []
     for _ in range(2):
+        ctx.timing_enable()
         ctx.timing_reset()
         t0 = time.perf_counter()
         idx, _d0, _d1 = capi.self_dists_knn(ctx, sk, sk.set_k(21), 50)

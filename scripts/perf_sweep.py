@@ -23,6 +23,7 @@ p = sk.set_k() if mode=='coreacc' else sk.set_k(23)
 pairs=n*(n-1)//2
 out=torch.zeros((pairs, 2 if mode=='coreacc' else 1),dtype=torch.float32,device=dev)
 for _ in range(2): capi.self_dists_all(ctx,sk,p,out=out)
+ctx.timing_enable()
 ctx.timing_reset()
 torch.cuda.synchronize(); t0=time.perf_counter()
 for _ in range(reps): capi.self_dists_all(ctx,sk,p,out=out)

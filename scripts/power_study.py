@@ -122,6 +122,7 @@ def main():
 
                 th = threading.Thread(target=poll)
                 th.start()
+                ctx.timing_enable()
                 ctx.timing_reset()
                 ctx.clock_sampler_start(200, 45000)
                 t0 = time.perf_counter()

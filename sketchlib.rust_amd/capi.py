@@ -54,6 +54,7 @@ _SIG = [
     ("skl_ctx_use_default_stream", C.c_int, [_P]),
     ("skl_ctx_synchronize", C.c_int, [_P]),
     ("skl_ctx_reload_env", C.c_int, [_P]),
+    ("skl_ctx_timing_enable", C.c_int, [_P, C.c_int]),
     ("skl_ctx_timing_reset", C.c_int, [_P]),
     ("skl_ctx_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     ("skl_ctx_last_kernel", C.c_char_p, [_P]),
@@ -231,6 +232,10 @@ class Context:
         """Re-read the SKL_* environment switches (they are otherwise read when the context is created)."""
         _check(load().skl_ctx_reload_env(self._h))
 
+    def timing_enable(self, every=1):
+        """Bracket every `every`-th pair-kernel launch with HIP events (0: off, the library's default)."""
+        _check(load().skl_ctx_timing_enable(self._h, int(every)))
+
     def timing_reset(self):
         _check(load().skl_ctx_timing_reset(self._h))
 
@@ -242,7 +247,7 @@ class Context:
         return ms.value, n.value
 
     def set_knn_ties(self, mode):
-        """TIES_CANONICAL (default) or TIES_REFERENCE: see the header."""
+        """TIES_REFERENCE (the library's default: the reference binary's lists) or TIES_CANONICAL: see the header."""
         _check(load().skl_ctx_set_knn_ties(self._h, int(mode)))
 
     def clock_sampler_start(self, interval_us=20, max_samples=1 << 16):

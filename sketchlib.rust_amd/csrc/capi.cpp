@@ -124,6 +124,7 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
     skl_ctx *ctx = new skl_ctx();
     ctx->device = device;
     ctx->knobs = read_knobs();
+    ctx->timing_every = ctx->knobs.timing_every;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
@@ -219,6 +220,18 @@ extern "C" int skl_ctx_reload_env(skl_ctx *ctx)
 {
     SKL_TRY(ctx_bind(ctx));
     ctx->knobs = read_knobs();
+    ctx->timing_every = ctx->knobs.timing_every;
+    return SKL_OK;
+}
+
+// Pair-kernel timing is a diagnostic and OFF unless asked for: an event record is a barrier packet on the queue, and two
+// per launch cost a sub-millisecond launch ~5 us.  every = 0: off (the default); N >= 1: every N-th launch is bracketed.
+extern "C" int skl_ctx_timing_enable(skl_ctx *ctx, int every)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (every < 0) return fail(SKL_ERR_INVALID_ARG, "skl_ctx_timing_enable: every = %d must be >= 0", every);
+    ctx->timing_every = every;
+    ctx->launches_seen = 0;
     return SKL_OK;
 }
 
@@ -292,7 +305,7 @@ extern "C" int skl_ctx_timing_reset(skl_ctx *ctx)
     SKL_TRY(ctx_bind(ctx));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->events_used = 0;
-    ctx->launches_seen = 0;   // SKL_TIMING_EVERY counts from here: the first launch after a reset is bracketed
+    ctx->launches_seen = 0;   // the every-N-th count starts here: the first launch after a reset is bracketed
     return SKL_OK;
 }
 
@@ -321,7 +334,7 @@ static long long env_int(const char *name, long long dflt)
 Knobs read_knobs()
 {
     Knobs k;
-    k.timing_every = std::max(1ll, env_int("SKL_TIMING_EVERY", 1));
+    k.timing_every = std::max(0ll, env_int("SKL_TIMING_EVERY", 0));
     k.sliced_max_pairs = env_int("SKL_SLICED_MAX_PAIRS", -1);
     k.knn_band_rows = std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));
     k.k_slices = (int)env_int("SKL_K_SLICES", 0);
@@ -466,9 +479,9 @@ static hipError_t dispatch_pair_kernel(skl_ctx *ctx, const PairArgs &args_in, in
 int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode)
 {
     constexpr size_t MAX_EVENTS = 4096;
-    // SKL_TIMING_EVERY = N brackets every N-th launch only (default 1 = all): an event record is
-    // a barrier packet on the queue, and two per launch cost a sub-millisecond launch ~5 us
-    const bool sampled = (ctx->launches_seen++ % (size_t)ctx->knobs.timing_every) == 0;
+    // skl_ctx_timing_enable(N) / SKL_TIMING_EVERY = N brackets every N-th launch (default 0 = none: an event
+    // record is a barrier packet on the queue, and two per launch cost a sub-millisecond launch ~5 us)
+    const bool sampled = ctx->timing_every > 0 && (ctx->launches_seen++ % (size_t)ctx->timing_every) == 0;
     if (!sampled || ctx->events_used >= MAX_EVENTS) {
         HIP_TRY(dispatch_pair_kernel(ctx, args, mode, ctx->stream));
         return SKL_OK;
@@ -492,6 +505,7 @@ int timed_pair_launch(skl_ctx *ctx, const PairArgs &args, int mode)
 
 std::pair<hipEvent_t, hipEvent_t> *timing_slot(skl_ctx *ctx)
 {
+    if (ctx->timing_every <= 0) return nullptr;
     if (ctx->events_used == ctx->events.size() && ctx->events.size() < 4096) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess) return nullptr;

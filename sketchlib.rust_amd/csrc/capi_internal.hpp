@@ -42,7 +42,7 @@ struct skl_sketches;
 // knobs that force the banded / sliced forms on small inputs, A/B of the kNN drivers); kernel
 // selection, tile shapes and timing-only ablations exist only in the A/B build (-DSKL_AB).
 struct Knobs {
-    long long timing_every = 1;       // SKL_TIMING_EVERY: bracket every N-th pair-kernel launch with events
+    long long timing_every = 0;       // SKL_TIMING_EVERY: bracket every N-th pair-kernel launch with events (0: none; skl_ctx_timing_enable overrides)
     long long sliced_max_pairs = -1;  // SKL_SLICED_MAX_PAIRS: core/acc launches below this run k-sliced (-1: default)
     long long knn_band_rows = 0;      // SKL_KNN_BAND_ROWS: force the band height of the kNN drivers (tests)
     int k_slices = 0;                 // SKL_K_SLICES: chunk slices per k of k-sliced core/acc launches (0: chosen per launch)
@@ -88,6 +88,7 @@ struct skl_ctx {
     // timing of pair-kernel launches of the last call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    long long timing_every = 0;         // skl_ctx_timing_enable / SKL_TIMING_EVERY: 0 = launches are not bracketed (default)
     size_t launches_seen = 0;           // pair-kernel launches since the last skl_ctx_timing_reset
     std::string last_kernel;
     uint32_t last_count_planes = 1;     // planes the last MODE_COUNTS k-sliced launch wrote (epilogue: n_slices)
@@ -103,7 +104,7 @@ struct skl_ctx {
     uint32_t *sampler_count = nullptr;
     uint32_t sampler_max = 0;
     bool sampler_running = false;
-    int knn_ties = 0;                   // SKL_KNN_TIES_CANONICAL / _REFERENCE (skl_ctx_set_knn_ties)
+    int knn_ties = SKL_KNN_TIES_REFERENCE;   // what self_dists_knn returns (mod.rs:133-224); skl_ctx_set_knn_ties(CANONICAL) opts out
     Knobs knobs;                        // environment switches as of skl_ctx_create
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration
     std::set<skl_sketches *> sketches;  // slabs created on this context

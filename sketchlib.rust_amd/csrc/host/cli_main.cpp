@@ -227,17 +227,26 @@ void write_whole(const DistanceMatrix &d, TextSink &sink, size_t n, const DistAr
 // in HBM, gigabytes of host vectors, the worker pool, the HIP runtime (0.05 s of a 0.19 s run on 1 000 genomes, 0.5 s
 // after a million).  Files are written with pwrite (nothing buffered in the process); SKL_CLI_FAST_EXIT=0 keeps the
 // orderly exit.
-void leave_after_success()
+// (called by main() AFTER its last line of output -- the verbose "Complete in" line -- with the command's exit code; a
+// failed flush of the listing (ENOSPC, EPIPE) turns a success into exit code 1 and takes the orderly way out)
+bool g_listing_complete = false;   // set by run_dist / run_inverted once the listing is written
+
+int leave_after_success(int rc)
 {
     std::cout.flush();
     std::cerr.flush();
-    fflush(nullptr);
+    const bool flushed = std::cout.good() && fflush(nullptr) == 0;
+    if (!flushed) {
+        std::fprintf(stderr, "Error: writing the output failed\n");
+        return rc ? rc : 1;
+    }
+    if (rc != 0 || !g_listing_complete) return rc;
     const char *e = std::getenv("SKL_CLI_FAST_EXIT");
-    if (e && e[0] == '0') return;
+    if (e && e[0] == '0') return rc;
     // a profiler or another preloaded tool writes its results from exit handlers: leave in order for it
     for (const char *tool : {"LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"}) {
         const char *v = std::getenv(tool);
-        if (v && v[0]) return;
+        if (v && v[0]) return rc;
     }
     std::_Exit(0);
 }
@@ -432,7 +441,7 @@ int run_dist(const DistArgs &a)
         std::fprintf(stderr, "TIMING load=%.3fs device_wait=%.3fs dist+output=%.3fs (gpu_wait=%.3fs format=%.3fs sink=%.3fs)\n",
                      t_loaded, t_device - t_loaded, since_start() - t_device, t.wait_s, t.format_s, t.sink_s);
     }
-    leave_after_success();
+    g_listing_complete = true;
     return 0;
 }
 
@@ -781,7 +790,7 @@ int run_inverted(int argc, char **argv, int first, bool verbose, bool quiet)
         std::fprintf(stderr, "TIMING precluster: load_ski=%.3fs load_skq+skd=%.3fs device_wait=%.3fs candidates+distances=%.3fs write=%.3fs\n",
                      t_ski, t_loaded - t_ski, t_device - t_loaded, t_dist - t_device, since_start() - t_dist);
     }
-    leave_after_success();
+    g_listing_complete = true;
     return 0;
 }
 
@@ -826,7 +835,12 @@ int main(int argc, char **argv)
             else verbose = true;
         }
         try {
-            return run_inverted(argc, argv, sub + 1, verbose, quiet);
+            const int rc = run_inverted(argc, argv, sub + 1, verbose, quiet);
+            if (verbose && !quiet) {
+                const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+                std::cerr << "INFO  [sketchlib] Complete in " << s << "s\n";  // lib.rs:949-957
+            }
+            return leave_after_success(rc);
         } catch (const Panic &p) {
             std::cerr << "thread 'main' panicked:\n" << p.what() << "\n";
             return 101;
@@ -851,7 +865,7 @@ int main(int argc, char **argv)
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
             std::cerr << "INFO  [sketchlib] Complete in " << s << "s\n";  // lib.rs:949-957
         }
-        return rc;
+        return leave_after_success(rc);
     } catch (const Panic &p) {
         std::cerr << "thread 'main' panicked:\n" << p.what() << "\n";
         return 101;

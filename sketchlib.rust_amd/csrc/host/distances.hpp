@@ -108,7 +108,7 @@ SparseDistanceMatrix self_dists_knn_precluster(Device &dev, const MultiSketch &s
                                                size_t knn, const DistType &dist_type,
                                                const std::vector<double> *completeness_vec,
                                                double completeness_cutoff, RetainUnmatched retain_unmatched,
-                                               size_t threads, int knn_ties = 0 /* SKL_KNN_TIES_CANONICAL */);
+                                               size_t threads, int knn_ties = 1 /* SKL_KNN_TIES_REFERENCE */);
 // Whether the .ski lists the .skd's samples in the .skd's own order (then "ascending .ski index", the order the
 // reference pushes a row's candidates in, is "ascending sample id", the order lists built on the device have).
 bool ski_order_is_skd_order(const MultiSketch &sketches, const Inverted &inverted_index);

@@ -61,5 +61,8 @@ def gpu_ctx(skl):
     if skl.device_count() == 0:
         pytest.fail("no gfx950 device visible: -m gpu tests must run on the GPU box")
     ctx = skl.Context(0)
+    # The library's default tie rule is the reference binary's (SKL_KNN_TIES_REFERENCE, tests/test_gpu_knn_ties.py); the
+    # session-wide context runs canonical ties -- a property of the data alone -- unless a test sets the mode itself.
+    ctx.set_knn_ties(skl.TIES_CANONICAL)
     yield ctx
     ctx.close()

@@ -95,7 +95,8 @@ def test_bench_line_on_the_drivers_arguments(gpu_ctx):
     assert rf["kernel_launches_timed"] >= 50           # the fixed pass, whatever --steps is
     # the kernel time the roofline uses is consistent with the step time the value uses (same warm device)
     assert rf["kernel_avg_ms"] <= line["ms_per_step"] * 1.05
-    assert abs(rf["kernel_avg_ms"] - rf["kernel_avg_ms_timed_region"]) <= 0.05 * rf["kernel_avg_ms"]
+    # the timed region runs the library's default configuration: no launch of it is bracketed with events
+    assert rf["kernel_launches_bracketed_in_timed_region"] == 0
     # the clock beside the fraction is read DURING the roofline pass's launches, on this box
     clk = rf["in_kernel_clock"]
     assert clk["source"].startswith("live:") and 1.0 < clk["ghz"] < 2.6 and clk["intervals"] >= 50, clk

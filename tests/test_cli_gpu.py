@@ -260,6 +260,18 @@ def precluster_wd(tmp_path):
     return tmp_path
 
 
+def test_verbose_runs_end_with_the_complete_line(gpu_ctx, precluster_wd):
+    """lib.rs:949-957: a verbose run's last line.  The fast exit of a successful run (no teardown of the HIP runtime) leaves
+    from main() AFTER that line, for `dist` and `inverted precluster` alike."""
+    wd = precluster_wd
+    out = run_cli(wd, "-v", "dist", "standard", "--knn", "1", "-k", "21")
+    assert out.stdout.strip() and out.stderr.rstrip().splitlines()[-1].startswith("INFO  [sketchlib] Complete in "), out.stderr
+    out = run_cli(wd, "-v", "inverted", "precluster", "--knn", "1", "--skd", "standard", "inverted.ski")
+    assert out.stdout.strip() and out.stderr.rstrip().splitlines()[-1].startswith("INFO  [sketchlib] Complete in "), out.stderr
+    out = run_cli(wd, "dist", "standard", "--knn", "1", "-k", "21")
+    assert "Complete in" not in out.stderr
+
+
 def test_inverted_precluster_like_reference(gpu_ctx, precluster_wd):
     """tests/inverted.rs:244-349: knn 1, --ani, and knn 50 (clamped, padding not printed)."""
     wd = precluster_wd

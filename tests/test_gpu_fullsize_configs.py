@@ -35,6 +35,7 @@ def torch_ctx(skl):
         pytest.fail("no gfx950 device visible: -m gpu tests must run on the GPU box")
     dev = torch.device("cuda", 0)
     ctx = skl.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_knn_ties(skl.TIES_CANONICAL)   # (the library's default is the reference's order: tests that want it set it)
     yield torch, dev, ctx
     ctx.close()
     torch.cuda.empty_cache()
@@ -202,3 +203,51 @@ def test_cfg5_full_size(oracle, skl, torch_ctx, million):
         got = {int(j): float(d) for j, d in zip(idx[i], d0[i])}
         for j in nb:
             assert np.float32(got[int(j)]) == exp[pos[int(j)]], (i, int(j))
+
+
+def test_cfg5_full_size_coreacc_default_mode(oracle, skl, torch_ctx, million):
+    """cfg 5 as `sketchlib dist db --knn 50` runs it WITHOUT -k: DistType::CoreAcc (mod.rs:25-37), the kNN arm of mod.rs:195-221
+    -- all five k-mer lengths + the regression per pair, rows sorted on the core distance -- in the library's default tie
+    rule (the reference's BinaryHeap order).  5.0e11 pairs x 5 k-mer lengths, every pair evaluated once."""
+    torch, dev, ctx = torch_ctx
+    n, ss64, bins, g = million
+    knn = 50
+    p = g.set_k()
+    ctx.set_knn_ties(skl.TIES_REFERENCE)
+    try:
+        t0 = time.perf_counter()
+        idx, d0, d1 = skl.self_dists_knn(ctx, g, p, knn)
+        wall = time.perf_counter() - t0
+    finally:
+        ctx.set_knn_ties(skl.TIES_CANONICAL)
+    print(f"cfg5 core/accessory full: self kNN-{knn} over {n} x {n} in {wall:.2f} s = {n * (n - 1) / wall:.3g} pair distances/s")
+    assert "COREACC" in ctx.last_kernel()
+    # properties of every row
+    assert idx.shape == (n, knn) and idx.max() < n
+    assert np.all(np.diff(d0, axis=1) >= 0), "rows ascending on the core distance (distance_matrix.rs:245-248)"
+    assert np.all((d0 >= 0) & (d0 <= 1)) and np.all((d1 >= 0) & (d1 <= 1))
+    assert not np.any(idx == np.arange(n, dtype=np.uint64)[:, None]), "self excluded (mod.rs:203)"
+    srt = np.sort(idx, axis=1)
+    assert np.all(srt[:, 1:] != srt[:, :-1]), "no neighbour twice"
+    same_cluster = (idx % (n // 200)) == (np.arange(n, dtype=np.uint64)[:, None] % (n // 200))
+    assert same_cluster.mean() > 0.99, "neighbours are the cluster's members"
+    # sampled rows: the whole row of (core, acc) from the dense path, pushed through the oracle's BinaryHeap in ascending id
+    rng = np.random.default_rng(55)
+    rows = np.concatenate([rng.integers(0, n, 60), [0, 1, n - 1, 2047, 2048]])
+    for i in rows:
+        i = int(i)
+        dense = skl.cross_dists_rows(ctx, g, g, p, i, i + 1)[0]          # [n, 2]
+        ids = np.delete(np.arange(n, dtype=np.uint64), i)
+        exp = oracle.heap_replay(np.delete(dense[:, 0], i), knn, ids=ids)
+        assert np.array_equal(idx[i], exp["idx"]), i
+        assert np.array_equal(d0[i], exp["d0"]), i
+        assert np.array_equal(d1[i], dense[idx[i].astype(np.int64), 1]), i
+    # ... and those neighbours' distances against the oracle's core_acc_dist
+    for i in rows[:24]:
+        i = int(i)
+        o_i, _ = gather_oracle(oracle, torch, bins, [i], K4, ss64)
+        nb = np.sort(idx[i].astype(np.int64))
+        o_nb, pos = gather_oracle(oracle, torch, bins, nb, K4, ss64)
+        exp = oracle.cross_dists_all(o_i, o_nb, oracle.COREACC)[0]         # [50, 2]
+        for j, c, a in zip(idx[i], d0[i], d1[i]):
+            assert np.float32(c) == exp[pos[int(j)], 0] and np.float32(a) == exp[pos[int(j)], 1], (i, int(j))

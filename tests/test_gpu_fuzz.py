@@ -84,7 +84,7 @@ from sketchlib.rust_amd import capi, synth
 from oracle import oracle as O
 kmers, ss64, n = [17, 21, 25, 29], 8, 61
 bins = synth.set_r(n, kmers, ss64, n_clusters=5)
-ctx = capi.Context(0); g = ctx.sketches(bins, n, kmers, ss64); o = O.Sketches(bins, n, kmers, ss64)
+ctx = capi.Context(0); ctx.set_knn_ties(capi.TIES_CANONICAL); g = ctx.sketches(bins, n, kmers, ss64); o = O.Sketches(bins, n, kmers, ss64)
 for p, oa in [(g.set_k(), (O.COREACC, 0, False)), (g.set_k(25, True), (O.JACCARD, 2, True))]:
     idx, d0, d1 = capi.self_dists_knn(ctx, g, p, 9)
     exp = O.self_dists_knn(o, 9, *oa, ties=O.TIES_CANONICAL)

@@ -286,6 +286,7 @@ def test_other_tile_shapes_turn_their_tiles_too(oracle, skl, gpu_ctx, monkeypatc
     monkeypatch.setenv("SKL_KSLICE_SHAPE", shape)
     with skl.using_library(pkg.build_ab_library()):
         ctx = skl.Context(0)
+        ctx.set_knn_ties(skl.TIES_CANONICAL)
         g = ctx.sketches(bins, n, kmers, ss64)
         for p, oargs in ((g.set_k(19), (oracle.JACCARD, 1, False)), (g.set_k(), (oracle.COREACC, 0, False))):
             idx, d0, d1 = _knn(skl, ctx, g, p, knn, monkeypatch, 40, True, with_d1=True)

@@ -140,6 +140,7 @@ def test_one_evaluation_reference_order_on_random_sketches(oracle, skl, gpu_ctx,
     kmers, ss64, n, knn = [13, 17, 21], 8, 12000, 20
     bins = synth.set_u(n, len(kmers), ss64)
     o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    gpu_ctx.timing_enable()
     gpu_ctx.timing_reset()
     idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(17), knn)
     _ms, launches = gpu_ctx.kernel_ms()

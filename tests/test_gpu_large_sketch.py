@@ -122,6 +122,7 @@ def test_counts_scratch_is_bounded(oracle, skl, gpu_ctx):
     g = gpu_ctx.sketches(bins, n, kmers, ss64)
     out = torch.zeros((n, n, 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
+    gpu_ctx.timing_enable()
     gpu_ctx.timing_reset()
     skl.cross_dists_all(gpu_ctx, g, g, g.set_k(), out=out)
     torch.cuda.synchronize()

@@ -188,3 +188,37 @@ def test_db4_samebits_appendix_a(oracle):
     assert bm[5].tolist() == [7167, 6871, 6623, 6342]      # (2,3)
     assert bm[4].tolist() == [7, 1, 1, 3]                  # (1,3): regression on noise
     assert bm[1].tolist() == [12, 0, 1, 0]                 # (0,2): early break
+
+
+def test_binary_heap_restatement_on_hand_worked_ties(oracle):
+    """The BinaryHeap restatement (oracle/sketchlib_oracle.c) against vectors worked BY HAND from the algorithm Rust's std
+    documents and publishes (alloc::collections::binary_heap: push = sift_up with `elt <= parent => stop`; pop = swap the
+    last element into the root, sift_down_to_bottom -- always descend to the child chosen by `left <= right => right`, then
+    sift_up; into_sorted_vec = repeated swap(0, end) + sift_down_range, which stops at `elt >= child`), driven by push_heap
+    (mod.rs:41-48: push when the heap holds fewer than knn items or the key is STRICTLY below its maximum, then pop the
+    maximum).  None of the expected lists below was produced by running this code.
+
+    (a) knn = 3, five equal keys, ids 0..4.  Pushes 0, 1, 2 leave the array [0, 1, 2] (no sift: equal keys stop at once);
+        3 and 4 are not strictly below the maximum.  into_sorted_vec: end = 2: swap(0, 2) -> [2, 1 | 0], sift_down_range(0, 2)
+        has no child pair and `elt < child` fails on equal keys; end = 1: swap(0, 1) -> [1 | 2, 0].  Listed: 1, 2, 0.
+    (b) knn = 3, keys .5 .5 .5 .2 .5 .5.  After 0, 1, 2: [0, 1, 2].  Candidate 3 (.2) is pushed to the end (its parent 1 is
+        larger: no move) -> [0, 1, 2, 3]; pop: 3 goes to the root, the maximum 0 leaves; sift_down_to_bottom: children 1, 2
+        equal -> right child 2 moves up, 3 lands at the bottom -> [2, 1, 3]; sift_up stops (.2 <= .5).  4 and 5 are not
+        strictly below .5.  into_sorted_vec: swap(0, 2) -> [3, 1 | 2]; .2 < .5 -> [1, 3 | 2]; swap(0, 1) -> [3 | 1, 2].
+        Listed: 3, 1, 2 -- of the equal keys it is 1 and 2 that survive, not 0 and 1.
+    (c) knn = 3, keys .7 .5 .5 .5 .5 .5 .3.  [0, 1, 2]; candidate 3 replaces the maximum 0 -> [2, 1, 3]; 4, 5 rejected;
+        candidate 6 (.3): pushed to the end, popped into the root, the maximum 2 leaves, right child 3 moves up ->
+        [3, 1, 6].  into_sorted_vec: swap(0, 2) -> [6, 1 | 3], .3 < .5 -> [1, 6 | 3]; swap(0, 1) -> [6 | 1, 3].
+        Listed: 6, 1, 3 (smallest (key, id) would be 6, 1, 2)."""
+    cases = [
+        ([0.5] * 5, 3, [1, 2, 0], [0.5, 0.5, 0.5]),
+        ([0.5, 0.5, 0.5, 0.2, 0.5, 0.5], 3, [3, 1, 2], [0.2, 0.5, 0.5]),
+        ([0.7, 0.5, 0.5, 0.5, 0.5, 0.5, 0.3], 3, [6, 1, 3], [0.3, 0.5, 0.5]),
+    ]
+    for keys, knn, ids, d0 in cases:
+        got = oracle.heap_replay(np.array(keys, dtype=np.float32), knn)
+        assert got["idx"].tolist() == ids, (keys, got["idx"].tolist())
+        assert got["d0"].tolist() == np.array(d0, dtype=np.float32).tolist()
+    # fewer candidates than knn: everything is kept, ascending
+    got = oracle.heap_replay(np.array([0.9, 0.1], dtype=np.float32), 5)
+    assert got["idx"].tolist() == [1, 0]
