@@ -877,6 +877,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
             ctx.set_knn_ties(capi.TIES_CANONICAL)   # (the library's default is the reference's order: timed below, beside this one)
             wall, ksec, n_launch, clk = timed(knn_call, 1, 1, 500, clock=False)   # (one untimed call first: it allocates the band buffers)
             idx, d0, _d1 = res[0]
+            tiles5, pruned5 = ctx.knn_prune_stats()
             assert idx.shape == (nr, knn) and bool(np.all(np.diff(d0, axis=1) >= 0)) and not np.any(idx == np.arange(nr, dtype=np.uint64)[:, None])
             for i in (0, 77_777, nr - 1):     # three rows against the dense path, top-50 by (key, id)
                 dense = capi.cross_dists_rows(ctx, g_r, g_r, p5, i, i + 1)[0, :, 0]
@@ -904,6 +905,11 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
                                                    "what": "skl_ctx_set_knn_ties(REFERENCE), the CLI's default: ids and order of equal keys as the "
                                                            "reference binary prints them; same distances"},
                            "pair_kernel_s": ksec, "pair_kernel_launches": n_launch, "other_s (top-k merge, copies)": wall - ksec,
+                           "tile_pruning": {"tiles": tiles5, "tiles_left_early": pruned5,
+                                            "what": "a 32 x 128 tile all of whose pairs are, on the chunks walked so far, beyond both samples' "
+                                                    "current knn-th best is left unfinished (same lists; SKL_KNN_PRUNE=0 walks every tile)"},
+                           "valu_frac_note": "counted on ALL pairs of the triangle at the full walk's cost, although pruned tiles are not finished: "
+                                             "a rate of useful answers, not of instructions issued",
                            "valu_frac": v5["frac"], "valu_frac_at_in_kernel_clock": v5.get("frac_at_in_kernel_clock"),
                            "in_kernel_clock": clk, "rows_checked_against_dense": 3}
         if "cfg5ca" in which or "cfg5" in which:

@@ -206,6 +206,14 @@ int skl_cross_dists_rows(skl_ctx *ctx, const skl_sketches *ref, const skl_sketch
 #define SKL_KNN_TIES_REFERENCE 1
 int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);
 
+/* Diagnostic (no reference counterpart): tile pruning of the last skl_self_dists_knn / _partial call of the context.  The
+ * whole-matrix self kNN with single-k keys (Jaccard / ANI, no completeness correction) leaves a 32 x 128 tile of the pair
+ * space unfinished once every pair of it is, on the bins compared so far, already beyond both its samples' current knn-th
+ * best (the key is monotone in the mismatch count).  The neighbour lists are those of the unpruned run in
+ * either tie rule.  tiles: tiles of the launches that could prune; tiles_pruned: those left early.  SKL_KNN_PRUNE=0 turns
+ * pruning off (A/B). */
+int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *tiles_pruned);
+
 /* self_dists_knn (src/distances/mod.rs:133-224); requires 1 <= knn < n. */
 int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
                        uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device);

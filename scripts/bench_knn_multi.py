@@ -48,6 +48,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     kmers = [13, 17, 21, 25, 29]
     ctx = capi.Context(local_rank, stream=torch.cuda.current_stream(device).cuda_stream)
+    ctx.set_knn_ties(capi.TIES_CANONICAL)   # (partial states of disjoint bands merge under the canonical rule only)
     gen = synth.set_clustered_device if args.clustered else synth.set_u_device
     bins = gen(args.n, len(kmers), args.ss64, device)
     sk = ctx.sketches(bins, args.n, kmers, args.ss64)

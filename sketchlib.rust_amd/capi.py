@@ -61,6 +61,7 @@ _SIG = [
     ("skl_log_variant", C.c_int, []),
     ("skl_ctx_flags", C.c_uint, [_P]),
     ("skl_ctx_set_knn_ties", C.c_int, [_P, C.c_int]),
+    ("skl_ctx_knn_prune_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("skl_clock_sampler_start", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("skl_clock_sampler_stop", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -245,6 +246,12 @@ class Context:
         n = C.c_int()
         _check(load().skl_ctx_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def knn_prune_stats(self):
+        """(tiles, tiles left early) of the last self kNN call's prunable launches."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(load().skl_ctx_knn_prune_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_knn_ties(self, mode):
         """TIES_REFERENCE (the library's default: the reference binary's lists) or TIES_CANONICAL: see the header."""

@@ -348,6 +348,7 @@ Knobs read_knobs()
     k.xcds = (int)std::min(8ll, std::max(0ll, env_int("SKL_XCDS", 0)));
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
+    k.knn_prune = env_int("SKL_KNN_PRUNE", 1) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;

@@ -57,6 +57,7 @@ struct Knobs {
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
     bool knn_row_flags = true;        // SKL_KNN_ROW_FLAGS=0: the merge of the transposed band visits every row (A/B only, results are identical)
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
+    bool knn_prune = true;            // SKL_KNN_PRUNE=0: the symmetric self kNN finishes every tile (A/B; results are identical)
     bool refheap_wave = true;         // SKL_REFHEAP_WAVE=0: the heap replays (one-shot and resumable) run one workgroup per row even for knn <= 256 (A/B only, results are identical)
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
     bool cand_symmetric = true;       // SKL_CAND_SYMMETRIC=0: evaluate symmetric candidate lists in full
@@ -79,8 +80,9 @@ struct skl_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only scratch
-    void *scratch[8] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits
-    size_t scratch_bytes[8] = {};
+    void *scratch[11] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits,
+                              // 8: tile-pruning bounds (n u32), 9: bits of the turned bands, 10: pruning counters
+    size_t scratch_bytes[11] = {};
     hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
     // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
     // "producer finished buffer b" / "consumer finished buffer b"
@@ -104,6 +106,7 @@ struct skl_ctx {
     uint32_t *sampler_count = nullptr;
     uint32_t sampler_max = 0;
     bool sampler_running = false;
+    uint64_t knn_tiles = 0, knn_tiles_pruned = 0;   // tile pruning of the last self kNN call (skl_ctx_knn_prune_stats)
     int knn_ties = SKL_KNN_TIES_REFERENCE;   // what self_dists_knn returns (mod.rs:133-224); skl_ctx_set_knn_ties(CANONICAL) opts out
     Knobs knobs;                        // environment switches as of skl_ctx_create
     skl::TileScratch tile_scratch;      // device table of the balanced tile enumeration

@@ -118,6 +118,31 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     void *bits_mem = nullptr;
     SKL_TRY(ctx_scratch(ctx, 2 * band_rows * bit_words * sizeof(uint32_t), &bits_mem, 7));
     uint32_t *row_bits[2] = {(uint32_t *)bits_mem, (uint32_t *)bits_mem + (overlap ? band_rows * bit_words : 0)};
+    // ... and for the turned band one bit per (column, 32-row stretch of the band), so that BOTH merges read marked stretches
+    // only and a tile without a mark need not exist: TILE PRUNING (pair_kslice_walk.inc).  Single-k keys are monotone in the
+    // mismatch count, so before each band a small kernel turns every sample's current knn-th best into the mismatch count
+    // beyond which a pair cannot enter its list, and the pair kernel leaves a tile once every pair of it is beyond both its
+    // samples' bounds on the chunks walked so far.  The bounds come from the same (possibly stale, i.e. too high) thresholds
+    // as the flags: a pair pruned now would be rejected by both lists whenever it arrived, so the lists -- ids AND order, in
+    // either tie rule -- are those of the unpruned run.  Not with a completeness correction (the key then depends on the pair).
+    const size_t tbit_words = (t_stride / 32 + 31) / 32;
+    const bool prune = ctx->knobs.knn_prune && ctx->knobs.knn_row_flags && !coreacc && !(s->d_comp != nullptr) &&
+                       s->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS;
+    uint32_t *tbits[2] = {nullptr, nullptr}, *prune_q = nullptr, *prune_stats = nullptr;
+    if (ctx->knobs.knn_row_flags) {
+        void *tb = nullptr;
+        SKL_TRY(ctx_scratch(ctx, 2 * n * tbit_words * sizeof(uint32_t), &tb, 9));
+        tbits[0] = (uint32_t *)tb;
+        tbits[1] = (uint32_t *)tb + (overlap ? n * tbit_words : 0);
+    }
+    if (prune) {
+        void *pq = nullptr, *ps = nullptr;
+        SKL_TRY(ctx_scratch(ctx, (n + 64) * sizeof(uint32_t), &pq, 8));
+        SKL_TRY(ctx_scratch(ctx, 4 * sizeof(uint32_t), &ps, 10));
+        prune_q = (uint32_t *)pq;
+        prune_stats = (uint32_t *)ps;
+        HIP_TRY(hipMemsetAsync(prune_stats, 0, 4 * sizeof(uint32_t), ctx->stream));
+    }
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
     if (overlap) {   // the states were cleared on the context's stream, the merges run on the other one
         HIP_TRY(hipEventRecord(ctx->knn_pair_done[0], ctx->stream));
@@ -159,6 +184,22 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             g.t_flag_value = flag_value;
             g.t_thr = ref ? st.thr + col0 : st.key + col0 * knn + (knn - 1);      // knn-th best of sample col0 + c
             g.t_thr_stride = ref ? 1u : (uint32_t)knn;
+            HIP_TRY(hipMemsetAsync(tbits[buf] + b1 * tbit_words, 0, (n - b1) * tbit_words * sizeof(uint32_t), ctx->stream));
+            g.t_bits = tbits[buf] + col0 * tbit_words;
+            g.t_bits_stride = (uint32_t)tbit_words;
+        }
+        if (prune) {
+            // every sample's bound as of now (the merges of earlier bands may still be lowering thresholds: stale = too high = safe)
+            HIP_TRY(launch_prune_thresholds(ref ? st.thr : st.key + (knn - 1), ref ? 1u : (uint32_t)knn, (uint32_t)n, g.dtab,
+                                            (uint32_t)(64 * s->ss64), prune_q, ctx->stream));
+            g.prune_q_rows = prune_q;
+            g.prune_q_cols = prune_q + col0;
+            g.prune_stats = prune_stats;
+            if (!g.t_bits) {   // (the last band has no turned copy; the kernel takes "both bit sets given" as the sign that the merges mask)
+                g.t_bits = tbits[buf] + col0 * tbit_words;
+                g.t_bits_stride = (uint32_t)tbit_words;
+            }
+            ctx->knn_tiles += (uint64_t)((b1 - b0 + 31) / 32) * ((g.nB + 127) / 128);
         }
         SKL_TRY(timed_pair_launch(ctx, g, mode));
         if (overlap) {
@@ -188,8 +229,12 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             m.self_id_base = m.state_row_base = (uint32_t)b1;
             m.flag = ctx->knobs.knn_row_flags ? flags[buf] + b1 : nullptr;
             m.flag_value = flag_value;
+            m.seg_bits = ctx->knobs.knn_row_flags ? tbits[buf] + b1 * tbit_words : nullptr;   // (row r of this launch = sample b1 + r)
+            m.seg_bits_stride = (uint32_t)tbit_words;
+            m.seg_shift = 5;
             HIP_TRY(launch_refheap_merge(m, topk_stream));
             m.flag = nullptr;
+            m.seg_shift = 6;
             m.keys = (const float *)kband[buf];
             m.key_stride = (uint64_t)g.nB * m.stride2;
             m.rows = (uint32_t)(b1 - b0);
@@ -235,9 +280,18 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         m.self_id_base = m.state_row_base = (uint32_t)b1;
         m.flag = ctx->knobs.knn_row_flags ? flags[buf] + b1 : nullptr;
         m.flag_value = flag_value;
+        m.seg_bits = ctx->knobs.knn_row_flags ? tbits[buf] + b1 * tbit_words : nullptr;   // (row r of this launch = sample b1 + r)
+        m.seg_bits_stride = (uint32_t)tbit_words;
+        m.seg_shift = 5;
         HIP_TRY(launch_topk_merge(m, topk_stream));
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
         ++it;
+    }
+    if (prune) {   // (read back with the call's last synchronisation: skl_ctx_knn_prune_stats)
+        uint32_t counted = 0;
+        HIP_TRY(hipMemcpyAsync(&counted, prune_stats, sizeof counted, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->knn_tiles_pruned += counted;
     }
     if (overlap && it) {   // the states (and the band buffers) belong to the context's stream again
         HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
@@ -451,6 +505,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         d_d0 = (float *)(d_idx + items);
         d_d1 = d_d0 + items;
     }
+    ctx->knn_tiles = ctx->knn_tiles_pruned = 0;
     if (symmetric) {
         SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0, d_d1));
     } else {
@@ -467,6 +522,14 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *tiles_pruned)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (tiles) *tiles = ctx->knn_tiles;
+    if (tiles_pruned) *tiles_pruned = ctx->knn_tiles_pruned;
     return SKL_OK;
 }
 
@@ -536,6 +599,7 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     }
     KnnState st;
     SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
+    ctx->knn_tiles = ctx->knn_tiles_pruned = 0;
     const bool overlap = ctx->knobs.knn_overlap && list.size() > 1;
     SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
     const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;

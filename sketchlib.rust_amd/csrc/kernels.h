@@ -109,6 +109,21 @@ struct PairArgs {
     const uint32_t *r_thr;
     uint32_t *r_bits;
     uint32_t r_thr_stride, r_bits_stride;
+    // ... and for the turned records one bit per (column, 32-row stretch of the band): bit t of t_bits[c * t_bits_stride + t / 32]
+    // is set when column c received, from rows [row_begin + 32 t, + 32), a record below t_thr.  With it the merges of BOTH
+    // copies read marked stretches only, which is what lets a workgroup leave its tile unwritten (below).  Zeroed by the host.
+    uint32_t *t_bits;
+    uint32_t t_bits_stride;
+    // TILE PRUNING (symmetric self kNN, single-k keys, 32 x 128 k-sliced form; pair_kslice_walk.inc).  The key is monotone in
+    // the mismatch count, so a pair whose count over the chunks walked SO FAR already exceeds allow = the largest count whose
+    // key is still below BOTH samples' knn-th best can enter neither list, and a tile all of whose pairs are in that state
+    // need not be finished: the workgroup leaves without storing (no bit above is set for it, so nothing reads its records).
+    // prune_q_rows[i] / prune_q_cols[c] (row sample id / view column; null = off) = floor(allow / 4) + 1 of that sample (0:
+    // nothing can enter), a per-WAVE bound: the 4 waves of a workgroup split the chunks, and if every wave's own count of a
+    // pair is >= max(q_row, q_col) the pair's total exceeds max(allow_row, allow_col).  Written by launch_prune_thresholds
+    // from the running states before the launch; a stale (too high) threshold prunes less, never wrongly.
+    const uint32_t *prune_q_rows, *prune_q_cols;
+    uint32_t *prune_stats;        // [0] += workgroups that left their tile early (null: not counted)
     // epilogue
     int32_t jout;                 // JaccardOut
     int32_t has_comp;
@@ -337,7 +352,7 @@ struct RefHeapMergeArgs {
     const uint32_t *flag;     // row r is fed only if flag[r] == flag_value (null: every row)
     uint32_t flag_value;
     const uint32_t *seg_bits; // as TopkMergeArgs::seg_bits
-    uint32_t seg_bits_stride;
+    uint32_t seg_bits_stride, seg_shift;
     uint32_t force_workgroup_form;   // 1: one workgroup per row whatever knn is (default: one WAVE per row up to 256 neighbours; A/B, tests)
 };
 hipError_t launch_refheap_merge(const RefHeapMergeArgs &args, hipStream_t stream);
@@ -365,9 +380,15 @@ struct TopkMergeArgs {
     const uint32_t *flag;     // row r is merged only if flag[r] == flag_value (null: every row)
     uint32_t flag_value;
     const uint32_t *seg_bits; // row r: bit b of seg_bits[r * seg_bits_stride + b / 32] clear = no record at positions
-    uint32_t seg_bits_stride; // [64 b, 64 b + 64) can enter the state: not read (null: everything is read)
+    uint32_t seg_bits_stride; // [b << seg_shift, (b + 1) << seg_shift) can enter the state: not read, whatever they hold (null: everything is read)
+    uint32_t seg_shift;       // 6 (64 positions per bit; 0 means 6) or 5
 };
 hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream);
+// Tile pruning thresholds (PairArgs::prune_q_*): q[i] = floor(allow_i / 4) + 1 with allow_i = the largest mismatch count m
+// whose key dtab[total_bins - m] is still STRICTLY below sample i's threshold thr[i * thr_stride] (sortable bits; 0xFFFFFFFF
+// = list not full: everything may enter), 0 when no count is.  dtab: the launch's key table over the bin-match count.
+hipError_t launch_prune_thresholds(const uint32_t *thr, uint32_t thr_stride, uint32_t n, const float *dtab, uint32_t total_bins,
+                                   uint32_t *q, hipStream_t stream);
 // Union of up to MERGE_STATES_MAX partial states of the same rows (disjoint candidate sets) ->
 // one state: the knn smallest (key, id) per row.  n_in * knn <= MERGE_STATES_ITEMS.
 constexpr int MERGE_STATES_MAX = 16;

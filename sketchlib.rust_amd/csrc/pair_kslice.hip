@@ -78,9 +78,13 @@ constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk 
 // 32-row form and for 3 columns per lane, 1 otherwise).
 // BIG: sketches beyond 65 535 bins (k-sliced counts / single-k forms only): the k-mer length is walked in segments
 // whose totals fit the u16 fields and are added up in 32 bits (pair_kslice_walk.inc).
-template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1, int OCC = 0, bool BIG = false>
+// PRUNE: tile pruning of the symmetric self kNN (PairArgs::prune_q_*; the single-k 32 x 128 form only): at a few stage
+// boundaries every wave asks whether each pair's count on ITS chunks has reached the pair's per-wave bound, the 4 answers
+// meet in LDS, and a tile that is hopeless as a whole is left unfinished and unwritten (pair_kslice_walk.inc).
+template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1, int OCC = 0, bool BIG = false, bool PRUNE = false>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R > 16 ? 3 : 4) : (JL == 3 ? 3 : 1))) void pair_kernel_kslice(const PairArgs g)
 {
+    static_assert(!PRUNE || (KSL && MODE == MODE_JACCARD && !BIG && JL == 2), "tile pruning: single-k keys, two columns per lane");
     constexpr int W = WAVES_PER_WG;
     constexpr int CH = R > 16 ? 1 : 2;            // chunks per wave per stage
     constexpr int PIECES = R * CH * 7;            // 16-byte pieces per wave-stage
@@ -116,7 +120,10 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     constexpr int XOV = RED2 ? 0 : PX - XIN;
     constexpr uint32_t TURNED_U4 = (MODE == MODE_COREACC) ? (uint32_t)(JL * 64 * (R + 4) * 8 + 15) / 16u : 0u;   // see the turned tile below
     constexpr uint32_t RED_U4 = RED2 ? (TURNED_U4 > ROWS_U4 ? TURNED_U4 - ROWS_U4 : 0u) : (uint32_t)(W * XOV * LANES) / 4u;
-    __shared__ uint4 lds_all[ROWS_U4 + RED_U4];
+    // PRUNE: behind the row buffers, the column samples' per-wave bounds (JL * 64 words, the same values written by every
+    // wave) and two rotating rows of 4 votes
+    constexpr uint32_t PRUNE_U4 = PRUNE ? (uint32_t)(JL * LANES) / 4u + 2u : 0u;
+    __shared__ uint4 lds_all[ROWS_U4 + RED_U4 + PRUNE_U4];
     uint4 (*lds_rows)[2][BUF_U4] = reinterpret_cast<uint4 (*)[2][BUF_U4]>(&lds_all[0]);
 
     const uint32_t tid = threadIdx.x;
@@ -250,6 +257,12 @@ template <int R, int JL, bool KSL, bool TIGHT = false, int MB = 1, int OCC = 0>
 static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStream_t stream)
 {
     const dim3 block(LANES * WAVES_PER_WG);
+    if constexpr (KSL && R == 32 && OCC == 4) {   // tile pruning: the single-k 32 x 128 form (the symmetric self kNN's bands)
+        if (args.prune_q_rows != nullptr && args.seg_chunks == 0u && mode == MODE_JACCARD) {
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, true, 0, TIGHT, MB, OCC, false, true>), grid, block, 0, stream, args);
+            return hipGetLastError();
+        }
+    }
     if constexpr (KSL && OCC == (R == 32 ? 4 : 0)) {   // (the shipped k-sliced forms only)
         if (args.seg_chunks != 0u) {   // sketches beyond 65 535 bins: the segmented walk
             if (mode == MODE_COUNTS) hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, true, 0, TIGHT, MB, OCC, true>), grid, block, 0, stream, args);
@@ -298,6 +311,11 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     if (!kslice_supported(args, mode, k_sliced)) return hipErrorInvalidValue;
     // beyond 65 535 bins: segments of KSLICE_SEG_CHUNKS chunks (a multiple of every form's chunks per stage)
     args.seg_chunks = args.ss64 > (uint32_t)KSLICE_MAX_U16_CHUNKS ? (uint32_t)KSLICE_SEG_CHUNKS : 0u;
+    // tile pruning exists in the single-k 32 x 128 form, cross-mode launches, both bounds given
+    if (!(shape == 325 && k_sliced && mode == MODE_JACCARD && args.seg_chunks == 0u && args.self_mode == 0u && args.prune_q_cols != nullptr &&
+          args.t_bits != nullptr && args.r_bits != nullptr)) {
+        args.prune_q_rows = args.prune_q_cols = nullptr;
+    }
     if (args.seg_chunks != 0u && shape != 165 && shape != 325) return hipErrorInvalidValue;
     const int R = shape > 1000 ? shape / 100 : shape / 10;   // 165 / 325 (and 165x, 325x in the A/B build): 16 x 128 and 32 x 128 tiles
     const int JL = 2;

@@ -235,10 +235,19 @@ __device__ __forceinline__ void topk_merge_row(const TopkMergeArgs &g, const uin
     const uint32_t stride2 = g.stride2;
     const float *keys = g.keys + (size_t)row * g.key_stride;
     const uint32_t cols = g.cols;
+    // the pair kernel marked the stretches of (1 << seg_shift) records that hold something below this row's knn-th best (as
+    // of a moment ago: never too few).  Unmarked stretches are NOT candidates -- they may not even have been written (a
+    // pruned tile, pair_kslice_walk.inc)
+    const uint32_t *seg_bits = g.seg_bits != nullptr ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr;
+    const uint32_t seg_shift = g.seg_shift != 0u ? g.seg_shift : 6u;
+    auto marked = [&](uint32_t q) {
+        const uint32_t b = q >> seg_shift;
+        return seg_bits == nullptr || ((seg_bits[b >> 5] >> (b & 31u)) & 1u) != 0u;
+    };
 
     auto fresh = [&](uint32_t q, uint32_t &u) {   // new key at position q of this launch
         const uint32_t id = g.id_base + q;
-        if (id < g.skip_below || id == self_id) return false;
+        if (id < g.skip_below || id == self_id || !marked(q)) return false;
         u = sortable_bits(__builtin_nontemporal_load(&keys[(size_t)q * stride2]));   // read once
         return true;
     };
@@ -286,11 +295,10 @@ __device__ __forceinline__ void topk_merge_row(const TopkMergeArgs &g, const uin
             // walks a whole row, so its memory-level parallelism is what the scan runs at)
             constexpr uint32_t UNROLL = 4;
             for (uint32_t q0 = begin; q0 < begin + len; q0 += TOPK_THREADS * UNROLL) {
-                if (g.seg_bits != nullptr) {
-                    // the pair kernel marked the 64-record blocks that hold something below this row's knn-th
-                    // best (as of a moment ago: never too few): a stretch of 1 024 positions without a mark is not read
-                    const uint32_t *bits = g.seg_bits + (size_t)row * g.seg_bits_stride;
-                    const uint32_t b_lo = q0 >> 6, b_hi = (min(q0 + TOPK_THREADS * UNROLL, begin + len) - 1u) >> 6;
+                if (seg_bits != nullptr) {
+                    // a stretch of 1 024 positions without a mark is not read at all
+                    const uint32_t *bits = seg_bits;
+                    const uint32_t b_lo = q0 >> seg_shift, b_hi = (min(q0 + TOPK_THREADS * UNROLL, begin + len) - 1u) >> seg_shift;
                     bool any = false;
                     for (uint32_t w = b_lo >> 5; w <= (b_hi >> 5); ++w) {
                         uint32_t word = bits[w];
@@ -311,7 +319,7 @@ __device__ __forceinline__ void topk_merge_row(const TopkMergeArgs &g, const uin
                 for (uint32_t j = 0; j < UNROLL; ++j) {
                     const uint32_t q = q0 + j * TOPK_THREADS + tid;
                     const uint32_t id = g.id_base + q;
-                    const bool valid = q < begin + len && id >= g.skip_below && id != self_id;
+                    const bool valid = q < begin + len && id >= g.skip_below && id != self_id && marked(q);
                     item[j] = valid ? ((uint64_t)sortable_bits(raw[j]) << 32) | id : ~0ull;
                 }
 #pragma unroll
@@ -400,6 +408,7 @@ hipError_t launch_topk_merge(const TopkMergeArgs &args, hipStream_t stream)
     if (args.rows == 0 || args.cols == 0) return hipSuccess;
     if (args.knn == 0 || args.knn > TOPK_MAX) return hipErrorInvalidValue;
     if (args.stride2 != 1 && !(args.stride2 == 2 && args.run_d1)) return hipErrorInvalidValue;
+    if (args.seg_shift != 0u && args.seg_shift != 5u && args.seg_shift != 6u) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(args.rows), dim3(TOPK_THREADS), 0, stream, args);
     return hipGetLastError();
 }
@@ -589,7 +598,7 @@ struct RefHeapShared {
 // few bits), such stretches are not read.  sh.len / sh.thr describe the heap on entry and on return (whole workgroup).
 template <class IdOf>
 __device__ __forceinline__ void refheap_feed(RefHeap &h, RefHeapShared &sh, const float *keys, uint32_t stride2, uint32_t cols,
-                                             uint32_t knn, const IdOf &id_of, const uint32_t *bits)
+                                             uint32_t knn, const IdOf &id_of, const uint32_t *bits, uint32_t seg_shift = 6u)
 {
     constexpr uint32_t UNROLL = 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -606,7 +615,7 @@ __device__ __forceinline__ void refheap_feed(RefHeap &h, RefHeapShared &sh, cons
     };
     for (uint32_t q0 = 0; q0 < cols; q0 += TOPK_THREADS * UNROLL) {
         if (bits != nullptr) {
-            const uint32_t b_lo = q0 >> 6, b_hi = (min(q0 + TOPK_THREADS * UNROLL, cols) - 1u) >> 6;
+            const uint32_t b_lo = q0 >> seg_shift, b_hi = (min(q0 + TOPK_THREADS * UNROLL, cols) - 1u) >> seg_shift;
             bool marked = false;
             for (uint32_t w = b_lo >> 5; w <= (b_hi >> 5); ++w) {
                 uint32_t word = bits[w];
@@ -632,7 +641,10 @@ __device__ __forceinline__ void refheap_feed(RefHeap &h, RefHeapShared &sh, cons
         for (uint32_t j = 0; j < UNROLL; ++j) {
             const uint32_t q = q0 + j * TOPK_THREADS + tid;
             id[j] = 0u;
-            take[j] = q < cols && id_of(q, id[j]) && (open || k[j] < thr);
+            // (an unmarked stretch is not a candidate: it may not have been written at all -- a pruned tile)
+            const uint32_t sb = q >> seg_shift;
+            const bool seg_ok = bits == nullptr || (q < cols && ((bits[sb >> 5] >> (sb & 31u)) & 1u) != 0u);
+            take[j] = q < cols && seg_ok && id_of(q, id[j]) && (open || k[j] < thr);
             any |= take[j] ? 1 : 0;
         }
         if (!__syncthreads_or(any)) continue;   // (the common case once the heap has settled)
@@ -773,7 +785,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void refheap_merge_kernel(const RefHe
                      id = g.id_base + q;
                      return id >= g.skip_below && id != self_id;
                  },
-                 g.seg_bits ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr);
+                 g.seg_bits ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr, g.seg_shift != 0u ? g.seg_shift : 6u);
     const uint32_t len = sh.len;
     for (uint32_t x = tid; x < len; x += TOPK_THREADS) {
         g.h_key[srow * knn + x] = h.key[x];
@@ -839,11 +851,23 @@ __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMe
     const float *keys = g.keys + (size_t)row * g.key_stride;
     const uint32_t *bits = g.seg_bits ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr;
     constexpr uint32_t UNROLL = 4;
+    const uint32_t seg_shift = g.seg_shift != 0u ? g.seg_shift : 6u;   // 6: one bit per 64 records, 5: per 32
     for (uint32_t q0 = 0; q0 < cols; q0 += 64u * UNROLL) {
         uint32_t mask = (1u << UNROLL) - 1u;   // which 64-record blocks of this trip are read
+        uint32_t lane_ok = mask;               // ... and, per block, whether THIS lane's record is in a marked stretch
         if (bits != nullptr) {
-            const uint32_t b = q0 >> 6;          // (64 * UNROLL = 256 records = bits b .. b + 3, inside one word: b is a multiple of 4)
-            mask &= bits[b >> 5] >> (b & 31u);
+            // (64 * UNROLL = 256 records = bits b .. b + 3 (or b .. b + 7 at 32 records per bit), inside one word)
+            const uint32_t b = q0 >> seg_shift;
+            const uint32_t w = bits[b >> 5] >> (b & 31u);
+            if (seg_shift == 6u) {
+                mask &= w;
+                lane_ok = mask;
+            } else {
+                const uint32_t any2 = (w | (w >> 1)) & 0x55u;            // block j: bits 2 j, 2 j + 1
+                mask &= (any2 & 1u) | ((any2 >> 1) & 2u) | ((any2 >> 2) & 4u) | ((any2 >> 3) & 8u);
+                const uint32_t mine = w >> (lane >> 5);                  // this lane's half of each block
+                lane_ok = (mine & 1u) | ((mine >> 1) & 2u) | ((mine >> 2) & 4u) | ((mine >> 3) & 8u);
+            }
             if (mask == 0u) continue;
         }
         float k[UNROLL], d[UNROLL];
@@ -859,7 +883,7 @@ __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMe
             const uint32_t q = q0 + j * 64u + lane;
             const uint32_t id = g.id_base + q;
             const bool open = len < knn;
-            const bool take = q < cols && id >= g.skip_below && id != self_id && (open || k[j] < thr);
+            const bool take = q < cols && ((lane_ok >> j) & 1u) != 0u && id >= g.skip_below && id != self_id && (open || k[j] < thr);
             const uint64_t votes = __ballot(take);
             if (votes == 0ull) continue;
             if (take) {
@@ -980,6 +1004,7 @@ hipError_t launch_refheap_merge(const RefHeapMergeArgs &args, hipStream_t stream
     if (args.rows == 0 || args.cols == 0) return hipSuccess;
     if (args.knn == 0 || args.knn > REFHEAP_LDS_MAX) return hipErrorInvalidValue;
     if (args.stride2 != 1 && !(args.stride2 == 2 && args.h_d1)) return hipErrorInvalidValue;
+    if (args.seg_shift != 0u && args.seg_shift != 5u && args.seg_shift != 6u) return hipErrorInvalidValue;
     if (args.knn <= REFHEAP_WAVE_KNN && !args.force_workgroup_form) {
         hipLaunchKernelGGL(refheap_merge_wave_kernel, dim3((args.rows + 3u) / 4u), dim3(256), 0, stream, args);
         return hipGetLastError();
@@ -1023,6 +1048,40 @@ hipError_t launch_refheap_finalize(const float *h_key, const uint32_t *h_id, con
     if (knn == 0 || knn > REFHEAP_LDS_MAX || (h_d1 && !out_d1)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(refheap_finalize_kernel, dim3(rows), dim3(64), 0, stream, h_key, h_id, h_d1, h_len, rows, knn, ani_undo,
                        out_idx, out_d0, out_d1);
+    return hipGetLastError();
+}
+
+// Tile-pruning thresholds of the symmetric self kNN (PairArgs::prune_q_*): one thread per sample.  The launch's key is
+// dtab[bin matches] (f32, non-increasing in the matches, so non-decreasing in the mismatch count m = total_bins - matches):
+// allow = the largest m whose key is STRICTLY below the sample's knn-th best (records at or above it never enter a list:
+// push_heap's strict `<`, mod.rs:42; canonical ties: a later id loses), found by bisection; q = floor(allow / 4) + 1 is the
+// count EACH of the 4 waves of a workgroup must reach on its own chunks for the pair's total to exceed allow.
+__global__ void prune_thresholds_kernel(const uint32_t *thr, uint32_t thr_stride, uint32_t n, const float *dtab, uint32_t total_bins,
+                                        uint32_t *q)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = thr[(size_t)i * thr_stride];
+    // below(m): key(m) < t.  Monotone: true for m = 0 .. allow, false beyond.
+    auto below = [&](uint32_t m) { return sortable_bits(dtab[total_bins - m]) < t; };
+    if (!below(0u)) {
+        q[i] = 0u;   // not even an identical sketch would enter: every pair of this sample is hopeless
+        return;
+    }
+    uint32_t lo = 0u, hi = total_bins + 1u;   // below(lo) holds, below(hi) does not (hi = total_bins + 1: out of range, never asked)
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (below(mid)) lo = mid; else hi = mid;
+    }
+    q[i] = lo / 4u + 1u;
+}
+
+hipError_t launch_prune_thresholds(const uint32_t *thr, uint32_t thr_stride, uint32_t n, const float *dtab, uint32_t total_bins,
+                                   uint32_t *q, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!thr || !dtab || !q || thr_stride == 0u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prune_thresholds_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, thr, thr_stride, n, dtab, total_bins, q);
     return hipGetLastError();
 }
 

@@ -1,0 +1,138 @@
+"""Tile pruning of the one-evaluation self kNN (pair_kslice_walk.inc, PRUNE; capi_knn.cpp).
+
+With single-k keys the key is monotone in the mismatch count, so a 32 x 128 tile all of whose pairs are -- on the chunks
+walked so far -- beyond both their samples' current knn-th best is left unfinished and unwritten.  The bar: the neighbour
+lists (ids, order, distances) are those of the oracle in BOTH tie rules, with and without pruning, and tiles really are
+skipped on data where every genome has more than knn relatives."""
+import numpy as np
+import pytest
+
+from sketchlib.rust_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _clustered(n, nk, ss64, n_clusters, keep=0.94):
+    """Sample s belongs to cluster s % n_clusters and keeps each of the cluster's bin values with probability `keep`
+    (J ~ 0.8 inside a cluster, ~0 outside): synth.set_clustered_device, brought to the host for the oracle."""
+    import torch
+
+    t = synth.set_clustered_device(n, nk, ss64, torch.device("cuda", 0), keep=keep, n_clusters=n_clusters)
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _run(skl, ctx, g, p, knn, monkeypatch, band_rows, prune=True, ties=None):
+    monkeypatch.setenv("SKL_KNN_BAND_ROWS", str(band_rows))
+    monkeypatch.setenv("SKL_TILE32_MIN", "0")          # 32 x 128 tiles whatever the launch size (the prunable form)
+    monkeypatch.setenv("SKL_KNN_PRUNE", "1" if prune else "0")
+    ctx.reload_env()
+    if ties is not None:
+        ctx.set_knn_ties(ties)
+    try:
+        idx, d0, _ = skl.self_dists_knn(ctx, g, p, knn)
+    finally:
+        ctx.set_knn_ties(skl.TIES_CANONICAL)
+    return idx, d0, ctx.knn_prune_stats()
+
+
+@pytest.mark.parametrize("ties", ["canonical", "reference"])
+@pytest.mark.parametrize("ani", [False, True], ids=["dist", "ani"])
+@pytest.mark.parametrize("band_rows,ss64", [(32, 32), (64, 32), (96, 16), (160, 37), (64, 157)])
+def test_pruned_run_equals_the_oracle(oracle, skl, gpu_ctx, monkeypatch, ties, ani, band_rows, ss64):
+    """240 clusters of 6 genomes (sample s belongs to cluster s % 240: a genome's relatives sit at id distances 240, 480, ...),
+    knn = 3: once a row has seen three relatives its list holds relatives only, and a tile whose id distances miss every
+    multiple of 240 is hopeless from its first or second stage on.  Sketch sizes: whole stages (32, 16 chunks), a ragged
+    last stage (37), the reference's `-s 10000` (157)."""
+    kmers, n, knn = [17, 21, 25], 1440, 3
+    bins = _clustered(n, len(kmers), ss64, 240)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21, ani)
+    t = skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL
+    idx, d0, (tiles, pruned) = _run(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True, t)
+    assert "R=32, JL=2, JACCARD, k-sliced" in gpu_ctx.last_kernel()
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, ani,
+                                ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
+    assert np.array_equal(d0, exp["d0"])
+    assert tiles > 0 and 0 < pruned < tiles, (tiles, pruned)
+    # ... and without pruning: the same lists, nothing skipped
+    idx0, d00, (_t0, pruned0) = _run(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, False, t)
+    assert pruned0 == 0 and np.array_equal(idx0, idx) and np.array_equal(d00, d0)
+    g.close()
+
+
+@pytest.mark.parametrize("ties", ["canonical", "reference"])
+def test_rows_with_fewer_relatives_than_knn_are_never_pruned_wrongly(oracle, skl, gpu_ctx, monkeypatch, ties):
+    """Clusters SMALLER than knn: every list ends in chance matches (keys just below 1.0) and exact ties at 1.0 -- the bound
+    of such a row admits every count but the very last, so its tiles are walked to the end -- next to clusters larger than
+    knn whose rows do prune."""
+    kmers, ss64, knn = [21], 32, 3
+    big = _clustered(1200, 1, ss64, 240)                           # 5 per cluster
+    small = synth.set_u(240, 1, ss64)                              # no relatives at all
+    bins = np.concatenate([big[:600], small, big[600:]])
+    n = bins.shape[0]
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21)
+    t = skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL
+    idx, d0, (tiles, pruned) = _run(skl, gpu_ctx, g, p, knn, monkeypatch, 64, True, t)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False,
+                                ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"])
+    assert pruned < tiles
+    g.close()
+
+
+@pytest.mark.parametrize("ties", ["canonical", "reference"])
+def test_identical_sketches_prune_everything_once_the_lists_are_full(oracle, skl, gpu_ctx, monkeypatch, ties):
+    """n copies of one sketch: every key is 0, nothing is ever STRICTLY below a full list's maximum (mod.rs:42), so every
+    tile met after that is hopeless before its first stage ends -- and the lists are still the heap's history."""
+    kmers, ss64, n, knn = [21], 32, 300, 7
+    bins = np.tile(synth.set_u(1, 1, ss64), (n, 1))
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    t = skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL
+    idx, d0, (tiles, pruned) = _run(skl, gpu_ctx, g, g.set_k(21), knn, monkeypatch, 32, True, t)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False,
+                                ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]) and np.array_equal(d0, exp["d0"])
+    assert pruned > 0
+    g.close()
+
+
+def test_partial_states_with_pruning_merge_to_the_whole(oracle, skl, gpu_ctx, monkeypatch):
+    """The multi-GPU split (bands dealt over 3 participants, partial states merged) prunes inside every participant's
+    bands against that participant's own running lists: the merged lists are the oracle's."""
+    from sketchlib.rust_amd import multi_gpu
+
+    kmers, ss64, n, knn, band_rows = [17, 21, 25], 32, 1440, 1, 64     # (a participant sees a third of a row's relatives)
+    bins = _clustered(n, len(kmers), ss64, 240)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21)
+    monkeypatch.setenv("SKL_TILE32_MIN", "0")
+    gpu_ctx.reload_env()
+    deal = multi_gpu.knn_band_deal((n + band_rows - 1) // band_rows, 3)
+    states, pruned_total = [], 0
+    for r in range(3):
+        states.append(skl.self_dists_knn_partial(gpu_ctx, g, p, knn, band_rows, deal[r]))
+        pruned_total += gpu_ctx.knn_prune_stats()[1]
+    key = np.stack([s[0] for s in states])
+    idx = np.stack([s[1] for s in states])
+    got = skl.knn_merge_states(gpu_ctx, key, idx, None)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(got[0], exp["idx"]) and np.array_equal(got[1], exp["d0"])
+    assert pruned_total > 0
+    g.close()
+
+
+def test_pruning_is_off_with_a_completeness_correction(oracle, skl, gpu_ctx, monkeypatch):
+    """With completeness the key depends on the pair, not on the mismatch count alone: no bound, no pruning, same lists."""
+    kmers, ss64, n, knn = [21], 32, 300, 7
+    bins = synth.set_r(n, kmers, ss64, n_clusters=6)
+    comp = np.linspace(0.7, 1.0, n)
+    o = oracle.Sketches(bins, n, kmers, ss64, completeness=comp)
+    g = gpu_ctx.sketches(bins, n, kmers, ss64)
+    g.set_completeness(comp)
+    idx, d0, (_tiles, pruned) = _run(skl, gpu_ctx, g, g.set_k(21), knn, monkeypatch, 64)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert pruned == 0 and np.array_equal(idx, exp["idx"])
+    np.testing.assert_allclose(d0, exp["d0"], atol=1e-6, rtol=0)
+    g.close()
