@@ -349,6 +349,9 @@ Knobs read_knobs()
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.knn_prune = env_int("SKL_KNN_PRUNE", 1) != 0;
+#ifdef SKL_AB
+    k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
+#endif
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
@@ -1016,11 +1019,43 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         g.out_base = base;
         g.out = counts;
         SKL_TRY(ensure_ytab(rows));   // (before the pair launch: nothing may fail between it and the epilogue)
+        // FUSED EPILOGUE (round 5): a plain k-sliced launch -- one workgroup per (tile, k-mer length), no chunk slices -- finishes
+        // its pairs itself: the workgroup that completes a tile's k-mer lengths reads the tile's counts back and stores (core, acc)
+        // (pair_kslice.hip, FUSE).  The second launch (10 us at cfg 2, 6 of them the cost of any dependent launch) is gone.
+        bool fused = false;
+#ifdef SKL_AB
+        // (A/B build only, SKL_FUSE_EPILOGUE=1: measured SLOWER than the second launch at cfg 2 -- 0.154 against 0.145 ms per step:
+        // the arrival pattern itself is free, but with the k-major dispatch order every tile completes in the launch's last round
+        // and one workgroup then does a whole tile's regressions alone while the chip empties; profiles/r05_fused_epilogue.md)
+        if (sliced && k_slices == 1u && !two_planes && ctx->knobs.fuse_epilogue && forced_kernel(ctx) == 0 &&
+            rows->nk <= (size_t)MAX_FUSED_K && kslice_supported(g, MODE_COUNTS, true) && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS) {
+            // arrival counters, one per tile of the launch (16-row tiles at most), counted modulo nk: zero once per (buffer, nk)
+            const size_t tiles_max = ((r1 - r0 + 15) / 16 + 1) * ((cols->n + 127) / 128 + 1) + 64;
+            void *fc = nullptr;
+            const size_t had = ctx->scratch_bytes[11];
+            SKL_TRY(ctx_scratch(ctx, tiles_max * sizeof(uint32_t), &fc, 11));
+            if (ctx->scratch_bytes[11] != had || ctx->fuse_counter_k != rows->nk) {
+                HIP_TRY(hipMemsetAsync(fc, 0, ctx->scratch_bytes[11], ctx->stream));
+                ctx->fuse_counter_k = rows->nk;
+            }
+            g.fuse_counter = (uint32_t *)fc;
+            g.fuse_variant = (uint32_t)env_int("SKL_FUSE_VARIANT", 0);
+            g.fuse_out = (float *)dst_dev;
+            g.ytab = rows->d_ytab;
+            for (size_t t = 0; t < rows->nk; ++t) g.kf[t] = (double)rows->kmers[t];
+            g.cutoff = p->completeness_cutoff;
+            fused = true;
+        }
+#endif
         // Plane 1 holds partial counts from the pair launch until the epilogue has re-zeroed it: it is
         // "clean" again only once that epilogue is enqueued.  Any early return in between leaves it marked dirty.
         const void *const plane1_clean = ctx->clean_plane1;
         ctx->clean_plane1 = nullptr;
         SKL_TRY(timed_pair_launch(ctx, g, MODE_COUNTS));
+        if (fused) {
+            ctx->last_kernel += " + fused core/accessory epilogue (last workgroup of a tile)";
+            return SKL_OK;
+        }
         EpilogueArgs e;
         memset(&e, 0, sizeof e);
         e.counts = (uint32_t *)counts;

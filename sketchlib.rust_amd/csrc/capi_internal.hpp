@@ -57,6 +57,7 @@ struct Knobs {
     bool knn_symmetric = true;        // SKL_KNN_SYMMETRIC=0: row-by-row self kNN
     bool knn_row_flags = true;        // SKL_KNN_ROW_FLAGS=0: the merge of the transposed band visits every row (A/B only, results are identical)
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
+    bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
     bool knn_prune = true;            // SKL_KNN_PRUNE=0: the symmetric self kNN finishes every tile (A/B; results are identical)
     bool refheap_wave = true;         // SKL_REFHEAP_WAVE=0: the heap replays (one-shot and resumable) run one workgroup per row even for knn <= 256 (A/B only, results are identical)
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge
@@ -80,9 +81,10 @@ struct skl_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only scratch
-    void *scratch[11] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits,
-                              // 8: tile-pruning bounds (n u32), 9: bits of the turned bands, 10: pruning counters
-    size_t scratch_bytes[11] = {};
+    void *scratch[12] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits,
+                              // 8: tile-pruning bounds (n u32), 9: bits of the turned bands, 10: pruning counters, 11: arrival counters of the fused epilogue
+    size_t scratch_bytes[12] = {};
+    size_t fuse_counter_k = 0;          // k-mer lengths the arrival counters of slot 11 count modulo (fused epilogue)
     hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
     // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
     // "producer finished buffer b" / "consumer finished buffer b"

@@ -271,6 +271,17 @@ __device__ __forceinline__ void store_count(const PairArgs &g, uint32_t i, uint3
     }
 }
 
+// The same store write-through at agent scope (global_store_dword ... sc1): the counts a fused epilogue reads back from
+// another workgroup (pair_kslice.hip, FUSE)
+__device__ __forceinline__ void store_count_agent(const PairArgs &g, uint32_t i, uint32_t jcol,
+                                                  uint32_t kk, uint32_t bins, uint32_t mismatches)
+{
+    if (pair_valid(g, i, jcol)) {
+        __hip_atomic_store(&((uint32_t *)g.out)[pair_out_index(g, i, jcol) * g.cnt_pair_stride + kk * g.cnt_k_stride],
+                           bins - mismatches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // MODE_JACCARD: mod.rs:83-100 (dense) / :173-176 (kNN key)
 __device__ __forceinline__ float jaccard_out_value(const PairArgs &g, uint32_t i, uint32_t jcol,
                                                    uint32_t mismatches)
@@ -325,6 +336,46 @@ __device__ __forceinline__ float2 coreacc_value(const PairArgs &g, uint32_t i, u
                 xsquaresum += k_fl * k_fl;
                 ysquaresum += y * y;
                 n += 1.0;
+            }
+        }
+    }
+    return simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
+}
+
+// ... the same from the bin-match counts themselves, same[t] = samebits of k index t (the fused epilogue of a k-sliced
+// counts launch): core_acc_dist + simple_linear_regression, jaccard.rs:61-142, operation for operation as above
+__device__ __forceinline__ float2 coreacc_value_counts(const PairArgs &g, uint32_t i, uint32_t jcol, const uint32_t *same_k)
+{
+    const uint32_t maxnbits = g.ss64 * 64u;
+    double xsum = 0.0, ysum = 0.0, xysum = 0.0, xsquaresum = 0.0, ysquaresum = 0.0, n = 0.0;
+    double c1 = 0.0, c2 = 0.0;
+    if (g.has_comp) {
+        c1 = g.compA[i];
+        c2 = g.compB[jcol];
+    }
+    bool alive = true;
+#pragma unroll
+    for (uint32_t t = 0; t < (uint32_t)MAX_FUSED_K; ++t) {
+        if (t < g.k_count) {
+            const uint32_t same = same_k[t] <= maxnbits ? same_k[t] : maxnbits;
+            double y;
+            if (!g.has_comp) {
+                y = g.ytab[same];
+            } else {
+                y = glibc_log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff), g.log_variant);
+            }
+            if (alive) {
+                if (y < g.tolerance) {
+                    alive = false;  // jaccard.rs:89-91: break
+                } else {
+                    const double k_fl = g.kf[t];
+                    xsum += k_fl;
+                    ysum += y;
+                    xysum += k_fl * y;
+                    xsquaresum += k_fl * k_fl;
+                    ysquaresum += y * y;
+                    n += 1.0;
+                }
             }
         }
     }

@@ -124,6 +124,15 @@ struct PairArgs {
     // from the running states before the launch; a stale (too high) threshold prunes less, never wrongly.
     const uint32_t *prune_q_rows, *prune_q_cols;
     uint32_t *prune_stats;        // [0] += workgroups that left their tile early (null: not counted)
+    // FUSED CORE/ACCESSORY EPILOGUE of a k-sliced MODE_COUNTS launch (one workgroup per (tile, k-mer length), no chunk slices;
+    // pair_kslice.hip, FUSE): every workgroup stores its k-mer length's counts write-through, then ONE lane adds 1 to
+    // fuse_counter[tile] (agent scope, returning); the workgroup whose add completes the tile's k_count arrivals reads the
+    // tile's k_count count planes back (agent-scope loads) and stores (core, acc) of the tile's pairs to fuse_out -- no
+    // second launch.  The counter is never reset: arrivals are counted modulo k_count (zeroed by the host whenever k_count
+    // or the buffer changes).  Null = off (counts only).
+    uint32_t *fuse_counter;
+    uint32_t fuse_variant;        // EXPERIMENT (SKL_FUSE_VARIANT): 1 plain count stores, 2 the last arriver skips the epilogue (timing only)
+    float *fuse_out;              // [pair] (core, acc), same pair index as the counts
     // epilogue
     int32_t jout;                 // JaccardOut
     int32_t has_comp;

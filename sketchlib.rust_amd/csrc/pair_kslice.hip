@@ -81,10 +81,13 @@ constexpr uint32_t KSL_TILE_BLOCK = 32;   // k-sliced launches: tiles that walk 
 // PRUNE: tile pruning of the symmetric self kNN (PairArgs::prune_q_*; the single-k 32 x 128 form only): at a few stage
 // boundaries every wave asks whether each pair's count on ITS chunks has reached the pair's per-wave bound, the 4 answers
 // meet in LDS, and a tile that is hopeless as a whole is left unfinished and unwritten (pair_kslice_walk.inc).
-template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1, int OCC = 0, bool BIG = false, bool PRUNE = false>
+// FUSE: the core/accessory epilogue of a k-sliced counts launch inside the launch (PairArgs::fuse_counter): the workgroup that
+// completes a tile's k-mer lengths turns the tile's counts into (core, acc).
+template <int R, int JL, int MODE, bool KSL, int ABL = 0, bool TIGHT = false, int MB = 1, int OCC = 0, bool BIG = false, bool PRUNE = false, bool FUSE = false>
 __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R > 16 ? 3 : 4) : (JL == 3 ? 3 : 1))) void pair_kernel_kslice(const PairArgs g)
 {
     static_assert(!PRUNE || (KSL && MODE == MODE_JACCARD && !BIG && JL == 2), "tile pruning: single-k keys, two columns per lane");
+    static_assert(!FUSE || (KSL && MODE == MODE_COUNTS && !BIG && JL == 2), "fused epilogue: k-sliced counts, whole k-mer lengths");
     constexpr int W = WAVES_PER_WG;
     constexpr int CH = R > 16 ? 1 : 2;            // chunks per wave per stage
     constexpr int PIECES = R * CH * 7;            // 16-byte pieces per wave-stage
@@ -251,6 +254,55 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
 #undef SKL_J1
     }
     SKL_TRACE_MARK(3);
+    if constexpr (FUSE) {
+        // FUSED EPILOGUE.  This workgroup's counts (one k-mer length of the tile) were stored write-through (agent scope);
+        // every storing wave drains its stores, the workgroup meets, ONE lane adds to the tile's arrival counter (agent scope,
+        // returning), and the workgroup whose add was the tile's k_count-th reads all k_count planes of the tile back with
+        // agent-scope loads -- it loads only after its add has returned, its other waves after the barrier that lane then
+        // joins -- and finishes the tile's pairs.  No fence on either side, no dependence on where the tile's workgroups
+        // ran (MI355X_MICROARCH.md, inter-workgroup visibility: write-through stores + drained counter add + agent loads).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint32_t *flag = reinterpret_cast<uint32_t *>(&lds_all[0]);   // (the row buffers are dead: every wave is past its last LDS read)
+        if (tid == 0u) {
+            const uint32_t old = __hip_atomic_fetch_add(&g.fuse_counter[xcd * g.tiles_per_xcd + slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[0] = (old + 1u) % g.k_count == 0u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (flag[0] != 0u && !(g.fuse_variant & 2u)) {
+            constexpr uint32_t PER = (uint32_t)(R * JL * 64) / (LANES * W);   // pairs per thread
+            constexpr uint32_t BATCH = 8;                                     // ... taken 8 at a time (registers)
+            constexpr uint32_t ROW_STEP = (LANES * W) / (uint32_t)(JL * 64);
+            const uint32_t *counts = (const uint32_t *)g.out;
+            const uint32_t c = tid % (uint32_t)(JL * 64), jc_ = jb0 * 64u + c;
+#pragma clang loop unroll(disable)
+            for (uint32_t m0 = 0; m0 < PER; m0 += BATCH) {
+                uint32_t same[BATCH][MAX_FUSED_K];
+                uint64_t at_[BATCH];
+                bool ok[BATCH];
+#pragma unroll
+                for (uint32_t m = 0; m < BATCH; ++m) {   // every load of the batch first: independent, all in flight together
+                    const uint32_t i_ = a0 + tid / (uint32_t)(JL * 64) + (m0 + m) * ROW_STEP;
+                    ok[m] = pair_valid(g, i_, jc_);
+                    at_[m] = ok[m] ? pair_out_index(g, i_, jc_) : 0ull;
+#pragma unroll
+                    for (uint32_t t = 0; t < (uint32_t)MAX_FUSED_K; ++t) {
+                        same[m][t] = (ok[m] && t < g.k_count)
+                                         ? __hip_atomic_load(&counts[at_[m] * g.cnt_pair_stride + (uint64_t)t * g.cnt_k_stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0u;
+                    }
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < BATCH; ++m) {
+                    const uint32_t i_ = a0 + tid / (uint32_t)(JL * 64) + (m0 + m) * ROW_STEP;
+                    if (ok[m]) {
+                        if (g.fuse_variant & 4u) ((float2 *)g.fuse_out)[at_[m]] = make_float2((float)(same[m][0] + same[m][1] + same[m][2]), (float)(same[m][3] + same[m][4] + same[m][5]));   // EXPERIMENT
+                        else ((float2 *)g.fuse_out)[at_[m]] = coreacc_value_counts(g, i_, jc_, same[m]);
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int R, int JL, bool KSL, bool TIGHT = false, int MB = 1, int OCC = 0>
@@ -263,6 +315,16 @@ static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStrea
             return hipGetLastError();
         }
     }
+#ifdef SKL_AB
+    // (A/B build only: the fused core/accessory epilogue LOST to the second launch -- profiles/r05_fused_epilogue.md -- and is
+    // kept as the measured record of that)
+    if constexpr (KSL && OCC == (R == 32 ? 4 : 0)) {   // fused core/accessory epilogue: the shipped k-sliced counts forms
+        if (args.fuse_counter != nullptr && args.seg_chunks == 0u && mode == MODE_COUNTS) {
+            hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, true, 0, TIGHT, MB, OCC, false, false, true>), grid, block, 0, stream, args);
+            return hipGetLastError();
+        }
+    }
+#endif
     if constexpr (KSL && OCC == (R == 32 ? 4 : 0)) {   // (the shipped k-sliced forms only)
         if (args.seg_chunks != 0u) {   // sketches beyond 65 535 bins: the segmented walk
             if (mode == MODE_COUNTS) hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_COUNTS, true, 0, TIGHT, MB, OCC, true>), grid, block, 0, stream, args);
@@ -326,6 +388,14 @@ hipError_t launch_pair_kernel_kslice(const PairArgs &args_in, int mode, int shap
     // k-sliced: exactly tiles_per_xcd x k [x slices] workgroups per XCD (the last tile block is short)
     if (!(k_sliced && mode == MODE_COUNTS) || args.k_slices == 0) args.k_slices = 1;
     if (!(k_sliced && mode == MODE_COUNTS)) args.tail_slices = 0;
+    // the fused epilogue (A/B build): whole k-mer lengths only (no chunk slices), the two shipped shapes
+#ifndef SKL_AB
+    if (args.fuse_counter != nullptr) return hipErrorInvalidValue;
+#endif
+    if (args.fuse_counter != nullptr && !(k_sliced && mode == MODE_COUNTS && args.k_slices == 1u && args.tail_slices <= 1u && args.seg_chunks == 0u &&
+                                          (shape == 165 || shape == 325) && args.k_count <= (uint32_t)MAX_FUSED_K && args.fuse_out != nullptr)) {
+        return hipErrorInvalidValue;   // (the caller skips the epilogue launch when it asks for the fused one)
+    }
     if (args.tail_slices > 1u) {
         // whole units for the XCD's whole rounds of resident workgroups, slices for the rest
         // (counted on the real units: the padding slots of the last tile block exit at once)
