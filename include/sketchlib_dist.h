@@ -232,8 +232,8 @@ int skl_self_dists_knn_rows(skl_ctx *ctx, const skl_sketches *s, const skl_dist_
  * skl_knn_merge_states turns the n_states partial states of a row shard -- stacked
  * [n_states][rows][knn] -- into the rows of skl_self_dists_knn's output.
  * Returns SKL_ERR_INVALID_ARG when the configuration has no one-evaluation form (CoreAcc with more than 6
- * k-mer lengths or sketchsize64 > 1023; knn > 2 048; the reference tie order): shard rows with
- * skl_self_dists_knn_rows then. */
+ * k-mer lengths or sketchsize64 > 1023; knn > 2 048): shard rows with skl_self_dists_knn_rows then; and in the reference
+ * tie order (partial heaps do not merge): use skl_self_dists_knn_window below. */
 size_t skl_knn_band_rows(const skl_sketches *s, const skl_dist_params *p, size_t n_participants);
 int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
                                size_t band_rows, const uint32_t *bands, size_t n_bands,
@@ -241,6 +241,33 @@ int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, const skl_di
 int skl_knn_merge_states(skl_ctx *ctx, size_t n_states, size_t rows, size_t knn, const uint32_t *state_key,
                          const uint32_t *state_idx, const float *state_d1, int states_on_device, int ani,
                          uint64_t *out_idx, float *out_d0, float *out_d1, int out_on_device);
+
+/* self_dists_knn in the REFERENCE's tie order over several devices, every pair evaluated once: the column-window pipeline.
+ * A row's BinaryHeap must meet its candidates in ascending id (mod.rs:156-181), so partial heaps of disjoint candidate sets
+ * cannot be merged -- but a heap can travel.  Participant r owns the column window [lo_r, hi_r) (windows ascending with r;
+ * cut them at n * sqrt(r / R) so that the pair counts balance) and, for every row band b = rows [b * band_rows, ...) that
+ * starts below hi_r, in ascending order, calls skl_self_dists_knn_window: the band's rows take the columns
+ * [max(band start, lo_r), hi_r) as candidates, the window's rows below the band take the band's samples.  Before a band
+ * whose rows lie below lo_r, participant r receives those rows' heaps from participant r - 1 (which has finished that band);
+ * after any band it sends the band's rows on to r + 1; the last participant ends up with every row's final heap
+ * (skl_knn_heaps_finalize).  Rows of a participant's own window start empty (skl_knn_heaps_clear).  The heap arrays are the
+ * caller's (device memory): h_key f32 / h_id u32 / h_d1 f32 (CoreAcc only) [n][knn] in heap order, h_len u32 [n], thr u32 [n]
+ * (order-preserving image of the heap's maximum once it is full, 0xFFFFFFFF before).  Tile pruning applies as in the
+ * single-device call.  sketchlib.rust_amd/multi_gpu.py (self_knn_once_reference) is the driver over torch.distributed. */
+int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                              size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
+                              float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr);
+int skl_knn_heaps_clear(skl_ctx *ctx, size_t row_begin, size_t row_end, uint32_t *h_len, uint32_t *thr);
+/* For callers without a device runtime of their own (the C++ host layer sees only this header): device memory on the
+ * context's device for the heap arrays above, and copies between it and host memory (to_device != 0: host -> device),
+ * ordered with the context's stream and complete on return. */
+int skl_device_malloc(skl_ctx *ctx, size_t bytes, void **out);
+int skl_device_free(skl_ctx *ctx, void *ptr);
+int skl_device_memcpy(skl_ctx *ctx, void *dst, const void *src, size_t bytes, int to_device);
+int skl_ctx_get_knn_ties(const skl_ctx *ctx);   /* SKL_KNN_TIES_* of the context */
+/* into_sorted_vec of `rows` heaps (the arrays point at the first of them) -> rows of skl_self_dists_knn's output; device pointers. */
+int skl_knn_heaps_finalize(skl_ctx *ctx, size_t rows, size_t knn, const float *h_key, const uint32_t *h_id, const float *h_d1,
+                           const uint32_t *h_len, int ani, uint64_t *out_idx, float *out_d0, float *out_d1);
 
 /* The same with the candidate lists built on the device as well: skq holds the index sketch
  * (u16 bins, `.skq` layout [sample][sketch_size]) of every sample of `s`, row i = sample i (the

@@ -82,6 +82,10 @@ def lib():
                                          C.c_int, C.c_int, C.c_void_p]
         L.sko_heap_replay.restype = C.c_size_t
         L.sko_heap_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.sko_heap_feed.restype = None
+        L.sko_heap_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        L.sko_heap_sorted.restype = None
+        L.sko_heap_sorted.argtypes = [C.c_void_p, C.c_size_t]
         L.sko_cross_dists_knn.restype = C.c_long
         L.sko_cross_dists_knn.argtypes = [P, P, C.c_size_t, C.c_int, C.c_size_t, C.c_int,
                                           C.c_double, C.c_int, C.c_int, C.c_void_p]
@@ -176,6 +180,28 @@ def heap_replay(keys, knn, ids=None):
     out = np.zeros(max(min(keys.size, knn), 1), dtype=SPARSE_DTYPE)
     m = lib().sko_heap_replay(ids.ctypes.data, keys.ctypes.data, keys.size, knn, out.ctypes.data)
     return out[:m]
+
+
+class Heaps:
+    """n resumable BinaryHeaps (items [n, knn + 1], lengths [n]): the state a row's heap is in between batches of candidates."""
+
+    def __init__(self, n, knn):
+        self.knn = knn
+        self.items = np.zeros((n, knn + 1), dtype=SPARSE_DTYPE)
+        self.len = np.zeros(n, dtype=np.uintp)
+
+    def feed(self, row, ids, keys, d1=None):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        d1 = None if d1 is None else np.ascontiguousarray(d1, dtype=np.float32)
+        lib().sko_heap_feed(self.items[row].ctypes.data, self.len[row:row + 1].ctypes.data, ids.ctypes.data, keys.ctypes.data,
+                            None if d1 is None else d1.ctypes.data, ids.size, self.knn)
+
+    def sorted_rows(self):
+        out = self.items.copy()
+        for r in range(out.shape[0]):
+            lib().sko_heap_sorted(out[r].ctypes.data, int(self.len[r]))
+        return out[:, :self.knn]
 
 
 def cross_dists_knn(r, q, knn, dist_type=COREACC, k_idx=0, ani=False, cutoff=0.64,

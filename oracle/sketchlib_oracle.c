@@ -495,6 +495,32 @@ size_t sko_heap_replay(const uint64_t *ids, const float *keys, size_t n, size_t 
     return heap.len;
 }
 
+/* The same heap kept between calls (the column-window pipeline of the multi-device kNN hands heaps from device to device):
+ * heap[0 .. *len) is a BinaryHeap's array (capacity knn + 1 items); the candidates are pushed through push_heap in the order
+ * given.  sko_heap_sorted: into_sorted_vec in place. */
+void sko_heap_feed(sko_sparse *heap, size_t *len, const uint64_t *ids, const float *keys, const float *d1, size_t n, size_t knn)
+{
+    heap_t h;
+    h.data = heap;
+    h.len = *len;
+    for (size_t c = 0; c < n; ++c) {
+        sko_sparse item;
+        item.idx = ids[c];
+        item.d0 = keys[c];
+        item.d1 = d1 ? d1[c] : 0.0f;
+        push_heap(&h, item, knn);
+    }
+    *len = h.len;
+}
+
+void sko_heap_sorted(sko_sparse *heap, size_t len)
+{
+    heap_t h;
+    h.data = heap;
+    h.len = len;
+    heap_into_sorted(&h);
+}
+
 /* Canonical rule: strict weak order on (d0, idx). */
 static int canon_cmp(const void *a, const void *b)
 {

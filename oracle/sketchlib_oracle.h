@@ -99,6 +99,10 @@ typedef struct {
  * items; returns their number. */
 size_t sko_heap_replay(const uint64_t *ids, const float *keys, size_t n, size_t knn, sko_sparse *out);
 
+/* ... and resumable: heap[0 .. *len) is the BinaryHeap's array between calls (capacity knn + 1 items). */
+void sko_heap_feed(sko_sparse *heap, size_t *len, const uint64_t *ids, const float *keys, const float *d1, size_t n, size_t knn);
+void sko_heap_sorted(sko_sparse *heap, size_t len);
+
 /* mod.rs:133-224.  out: n*knn items, row-major (row i, neighbours ascending). */
 int sko_self_dists_knn(const sko_sketches *s, size_t knn, int dist_type, size_t k_idx, int ani,
                        double completeness_cutoff, int tie_mode, int threads, sko_sparse *out);

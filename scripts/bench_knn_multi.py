@@ -5,9 +5,13 @@
         scripts/bench_knn_multi.py --samples 1000000 --knn 50 [--coreacc] [--clustered]
     python scripts/bench_knn_multi.py --samples 200000            # one GPU (world size 1)
 
-One rank per GPU over RCCL; every rank holds the whole slab, takes its deal of the row bands
-(multi_gpu.knn_band_deal), and the partial top-k states are exchanged with one all-to-all before
-each rank merges its row shard (multi_gpu.self_knn_once).  Rank 0 prints one JSON line: wall
+One rank per GPU over RCCL; every rank holds the whole slab.
+  --ties canonical   every rank takes its deal of the row bands (multi_gpu.knn_band_deal) and the partial top-k states are
+                     exchanged with one all-to-all before each rank merges its row shard (multi_gpu.self_knn_once);
+  --ties reference   (default: the library's rule) every rank owns a window of columns and the rows' BinaryHeaps travel from
+                     rank to rank band by band (multi_gpu.self_knn_once_reference).
+SKL_BENCH_BACKEND=gloo (debugging aid): messages staged through host memory, ranks dealt to the GPUs there are (several
+ranks may share one).  Rank 0 prints one JSON line: wall
 time of the slowest rank (barrier on both sides), pair distances defined per second, and with
 --check the comparison against rank 0 recomputing its shard alone, row by row.
 """
@@ -29,6 +33,7 @@ def main():
     ap.add_argument("--coreacc", action="store_true", help="core/accessory keys (default: Jaccard at k = 21)")
     ap.add_argument("--clustered", action="store_true", help="clustered sketches instead of Set U")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--ties", default="reference", choices=["reference", "canonical"])
     args = ap.parse_args()
 
     import torch
@@ -38,17 +43,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local_rank)
+    gloo = os.environ.get("SKL_BENCH_BACKEND", "nccl") == "gloo"
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if gloo else local_rank
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # a 1-rank torchrun launch initialises RCCL too
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     kmers = [13, 17, 21, 25, 29]
-    ctx = capi.Context(local_rank, stream=torch.cuda.current_stream(device).cuda_stream)
-    ctx.set_knn_ties(capi.TIES_CANONICAL)   # (partial states of disjoint bands merge under the canonical rule only)
+    ctx = capi.Context(dev_index, stream=torch.cuda.current_stream(device).cuda_stream)
+    reference = args.ties == "reference"
+    ctx.set_knn_ties(capi.TIES_REFERENCE if reference else capi.TIES_CANONICAL)
+
+    def knn_once():
+        if reference:
+            return multi_gpu.self_knn_once_reference(ctx, sk, p, args.knn, rank, world, dist, device, host_staged=gloo)
+        return multi_gpu.self_knn_once(ctx, sk, p, args.knn, rank, world, dist, device)
     gen = synth.set_clustered_device if args.clustered else synth.set_u_device
     bins = gen(args.n, len(kmers), args.ss64, device)
     sk = ctx.sketches(bins, args.n, kmers, args.ss64)
@@ -62,15 +78,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    multi_gpu.self_knn_once(ctx, sk, p, args.knn, rank, world, dist, device)   # warm-up: scratch, lane slab
+    knn_once()   # warm-up: scratch, lane slab
     fence()
     t0 = time.perf_counter()
-    r0, r1, idx, d0, d1 = multi_gpu.self_knn_once(ctx, sk, p, args.knn, rank, world, dist, device)
+    r0, r1, idx, d0, d1 = knn_once()
     fence()
     wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    line = {"mode": "self kNN, every pair once, row bands dealt over the ranks + all-to-all of partial states",
+    line = {"mode": ("self kNN, every pair once, the reference's tie order: column windows, heaps travelling from rank to rank band by band"
+                     if reference else "self kNN, every pair once, canonical ties: row bands dealt over the ranks + all-to-all of partial states"),
+            "ties": args.ties, "backend": "gloo (host-staged)" if gloo else "nccl",
             "n": args.n, "knn": args.knn, "sketchsize64": args.ss64, "keys": "core/acc" if args.coreacc else "jaccard k=21",
             "data": "clustered" if args.clustered else "Set U", "n_gpus": world, "wall_s": float(wall.item()),
             "pair_distances_defined": args.n * (args.n - 1),

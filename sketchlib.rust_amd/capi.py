@@ -61,6 +61,13 @@ _SIG = [
     ("skl_log_variant", C.c_int, []),
     ("skl_ctx_flags", C.c_uint, [_P]),
     ("skl_ctx_set_knn_ties", C.c_int, [_P, C.c_int]),
+    ("skl_self_dists_knn_window", C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P]),
+    ("skl_knn_heaps_clear", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, _P]),
+    ("skl_knn_heaps_finalize", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    ("skl_device_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    ("skl_device_free", C.c_int, [_P, _P]),
+    ("skl_device_memcpy", C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
+    ("skl_ctx_get_knn_ties", C.c_int, [_P]),
     ("skl_ctx_knn_prune_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("skl_clock_sampler_start", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("skl_clock_sampler_stop", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -444,6 +451,41 @@ def knn_merge_states(ctx, state_key, state_idx, state_d1, ani=False, out=None):
     _check(load().skl_knn_merge_states(ctx._h, n_states, rows, knn, ka, ia, da, dev, int(ani), oi, o0,
                                        o1 if state_d1 is not None else None, odev))
     return out
+
+
+def knn_heaps_alloc(n, knn, coreacc, device):
+    """Travelling heaps of the reference-order pipeline (skl_self_dists_knn_window): device tensors for ALL n rows, empty."""
+    import torch
+
+    return {"h_key": torch.zeros((n, knn), dtype=torch.float32, device=device),
+            "h_id": torch.zeros((n, knn), dtype=torch.int32, device=device),
+            "h_d1": torch.zeros((n, knn), dtype=torch.float32, device=device) if coreacc else None,
+            "h_len": torch.zeros((n,), dtype=torch.int32, device=device),
+            "thr": torch.full((n,), -1, dtype=torch.int32, device=device)}     # 0xFFFFFFFF: not full
+
+
+def self_dists_knn_window(ctx, s, p, knn, band_rows, band, col_lo, col_hi, heaps):
+    """One row band of one participant's column window (the header's skl_self_dists_knn_window): heaps updated in place."""
+    ptr = lambda t: _ptr(t)[0]
+    _check(load().skl_self_dists_knn_window(ctx._h, s._h, C.byref(p), knn, band_rows, band, col_lo, col_hi, ptr(heaps["h_key"]),
+                                            ptr(heaps["h_id"]), ptr(heaps["h_d1"]), ptr(heaps["h_len"]), ptr(heaps["thr"])))
+
+
+def knn_heaps_finalize(ctx, heaps, r0, r1, knn, ani=False):
+    """into_sorted_vec of the heaps of rows [r0, r1) -> (idx i64, d0 f32, d1 f32 | None) device tensors."""
+    import torch
+
+    dev = heaps["h_key"].device
+    rows = r1 - r0
+    idx = torch.empty((rows, knn), dtype=torch.int64, device=dev)
+    d0 = torch.empty((rows, knn), dtype=torch.float32, device=dev)
+    d1 = torch.empty((rows, knn), dtype=torch.float32, device=dev) if heaps["h_d1"] is not None else None
+    if rows:
+        ptr = lambda t: _ptr(t)[0]
+        _check(load().skl_knn_heaps_finalize(ctx._h, rows, knn, ptr(heaps["h_key"][r0:]), ptr(heaps["h_id"][r0:]),
+                                             ptr(heaps["h_d1"][r0:]) if d1 is not None else None, ptr(heaps["h_len"][r0:]), int(ani),
+                                             ptr(idx), ptr(d0), ptr(d1)))
+    return idx, d0, d1
 
 
 def self_dists_knn_candidates(ctx, s, p, knn, row_offsets, cand):

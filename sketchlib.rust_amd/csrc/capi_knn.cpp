@@ -23,8 +23,10 @@ struct KnnState {
     // (refheap_merge_kernel, topk.hip).  Null in the canonical mode.
     float *h_key = nullptr, *h_d1 = nullptr;
     uint32_t *h_id = nullptr, *h_len = nullptr, *thr = nullptr;
+    bool borrowed = false;   // the arrays belong to the caller (skl_self_dists_knn_window)
     ~KnnState()
     {
+        if (borrowed) return;
         for (void *p : {(void *)key, (void *)idx, (void *)d1, (void *)h_key, (void *)h_d1, (void *)h_id, (void *)h_len, (void *)thr}) {
             if (p) (void)hipFree(p);
         }
@@ -81,10 +83,15 @@ static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
 
 // The bands `bands` (ascending indices; band b = rows [b*band_rows, (b+1)*band_rows)) merged into
 // the running states `st` of all n rows.
+// COLUMN WINDOW (win_lo, win_hi; default: all columns): only the pairs whose COLUMN sample lies in [win_lo, win_hi) are
+// evaluated -- band rows against columns [max(b0, win_lo), win_hi), turned copies to the rows [max(b1, win_lo), win_hi) -- which
+// is one participant's share of the reference-order pipeline over several devices (skl_self_dists_knn_window).
 static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
-                               size_t band_rows, const std::vector<uint32_t> &bands, bool overlap, KnnState &st)
+                               size_t band_rows, const std::vector<uint32_t> &bands, bool overlap, KnnState &st,
+                               size_t win_lo = 0, size_t win_hi = ~(size_t)0)
 {
     const size_t n = s->n;
+    win_hi = std::min(win_hi, n);
     const bool coreacc = p->dist_type == SKL_DIST_COREACC;
     const bool ref = st.h_key != nullptr;   // the reference's tie order: heaps replayed (a row's candidates arrive in ascending id
                                             // over the bands -- turned from the bands above its own, then its own band's columns)
@@ -154,22 +161,25 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     for (const uint32_t band : bands) {
         const size_t b0 = (size_t)band * band_rows;
         const size_t b1 = std::min(n, b0 + band_rows);
+        const size_t c_first = std::max(b0, win_lo);   // first candidate column of the band's own rows
+        const size_t t_first = std::max(b1, win_lo);   // first row that receives the band turned
+        if (c_first >= win_hi) continue;               // the window lies left of this band: nothing of it here
         const int buf = overlap ? (int)(it & 1) : 0;
         if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
-        // the band against the column view that starts at the 64-column block holding b0
-        const size_t col0 = b0 / 64 * 64;
+        // the band against the column view that starts at the 64-column block holding its first candidate column
+        const size_t col0 = c_first / 64 * 64;
         PairArgs g;
         SKL_TRY(fill_args(s, s, p, mode, jout, &g));
-        g.B += (b0 / 64) * jb_words;
-        g.nB = (uint32_t)(n - col0);
+        g.B += (col0 / 64) * jb_words;
+        g.nB = (uint32_t)(win_hi - col0);
         if (g.compB) g.compB += col0;
         g.row_begin = (uint32_t)b0;
         g.row_end = (uint32_t)b1;
         g.self_mode = 0;
         g.out_base = (uint64_t)b0 * g.nB;
         g.out = kband[buf];
-        g.out_t = b1 < n ? (float *)tband[buf] : nullptr;
-        g.t_col_begin = (uint32_t)(b1 - col0);
+        g.out_t = t_first < win_hi ? (float *)tband[buf] : nullptr;
+        g.t_col_begin = (uint32_t)(t_first - col0);
         g.t_stride = (uint32_t)t_stride;
         const uint32_t flag_value = (uint32_t)(it + 1);      // never 0, distinct per band of this call
         if (ctx->knobs.knn_row_flags) {
@@ -184,7 +194,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             g.t_flag_value = flag_value;
             g.t_thr = ref ? st.thr + col0 : st.key + col0 * knn + (knn - 1);      // knn-th best of sample col0 + c
             g.t_thr_stride = ref ? 1u : (uint32_t)knn;
-            HIP_TRY(hipMemsetAsync(tbits[buf] + b1 * tbit_words, 0, (n - b1) * tbit_words * sizeof(uint32_t), ctx->stream));
+            HIP_TRY(hipMemsetAsync(tbits[buf] + t_first * tbit_words, 0, (win_hi - t_first) * tbit_words * sizeof(uint32_t), ctx->stream));
             g.t_bits = tbits[buf] + col0 * tbit_words;
             g.t_bits_stride = (uint32_t)tbit_words;
         }
@@ -222,14 +232,14 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             // them turned, from the bands above).  Either way a row is fed ascending ids over the sequence of launches.
             m.keys = (const float *)tband[buf];
             m.key_stride = (uint64_t)t_stride * m.stride2;
-            m.rows = (uint32_t)(n - b1);
+            m.rows = g.out_t ? (uint32_t)(win_hi - t_first) : 0u;
             m.cols = (uint32_t)(b1 - b0);
             m.id_base = (uint32_t)b0;
             m.skip_below = 0;
-            m.self_id_base = m.state_row_base = (uint32_t)b1;
-            m.flag = ctx->knobs.knn_row_flags ? flags[buf] + b1 : nullptr;
+            m.self_id_base = m.state_row_base = (uint32_t)t_first;
+            m.flag = ctx->knobs.knn_row_flags ? flags[buf] + t_first : nullptr;
             m.flag_value = flag_value;
-            m.seg_bits = ctx->knobs.knn_row_flags ? tbits[buf] + b1 * tbit_words : nullptr;   // (row r of this launch = sample b1 + r)
+            m.seg_bits = ctx->knobs.knn_row_flags ? tbits[buf] + t_first * tbit_words : nullptr;   // (row r of this launch = sample t_first + r)
             m.seg_bits_stride = (uint32_t)tbit_words;
             m.seg_shift = 5;
             HIP_TRY(launch_refheap_merge(m, topk_stream));
@@ -240,7 +250,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             m.rows = (uint32_t)(b1 - b0);
             m.cols = g.nB;
             m.id_base = (uint32_t)col0;
-            m.skip_below = (uint32_t)b0;
+            m.skip_below = (uint32_t)c_first;
             m.self_id_base = m.state_row_base = (uint32_t)b0;
             m.seg_bits = ctx->knobs.knn_row_flags ? row_bits[buf] : nullptr;
             m.seg_bits_stride = (uint32_t)bit_words;
@@ -264,7 +274,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         m.rows = (uint32_t)(b1 - b0);
         m.cols = g.nB;
         m.id_base = (uint32_t)col0;
-        m.skip_below = (uint32_t)b0;
+        m.skip_below = (uint32_t)c_first;
         m.self_id_base = m.state_row_base = (uint32_t)b0;
         m.seg_bits = ctx->knobs.knn_row_flags ? row_bits[buf] : nullptr;
         m.seg_bits_stride = (uint32_t)bit_words;
@@ -273,14 +283,14 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         // rows below the band: the band's samples as their candidates
         m.keys = (const float *)tband[buf];
         m.key_stride = (uint64_t)t_stride * m.stride2;
-        m.rows = (uint32_t)(n - b1);
+        m.rows = g.out_t ? (uint32_t)(win_hi - t_first) : 0u;
         m.cols = (uint32_t)(b1 - b0);
         m.id_base = (uint32_t)b0;
         m.skip_below = 0;
-        m.self_id_base = m.state_row_base = (uint32_t)b1;
-        m.flag = ctx->knobs.knn_row_flags ? flags[buf] + b1 : nullptr;
+        m.self_id_base = m.state_row_base = (uint32_t)t_first;
+        m.flag = ctx->knobs.knn_row_flags ? flags[buf] + t_first : nullptr;
         m.flag_value = flag_value;
-        m.seg_bits = ctx->knobs.knn_row_flags ? tbits[buf] + b1 * tbit_words : nullptr;   // (row r of this launch = sample b1 + r)
+        m.seg_bits = ctx->knobs.knn_row_flags ? tbits[buf] + t_first * tbit_words : nullptr;   // (row r of this launch = sample t_first + r)
         m.seg_bits_stride = (uint32_t)tbit_words;
         m.seg_shift = 5;
         HIP_TRY(launch_topk_merge(m, topk_stream));
@@ -608,6 +618,96 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     HIP_TRY(hipMemcpyAsync(state_idx, st.idx, items * sizeof(uint32_t), kind, ctx->stream));
     if (coreacc) HIP_TRY(hipMemcpyAsync(state_d1, st.d1, items * sizeof(float), kind, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
+    return SKL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The reference's tie order over several devices, every pair evaluated once: the column-window pipeline.
+// ---------------------------------------------------------------------------
+// A row's BinaryHeap must meet its candidates in ascending id (mod.rs:156-181), so partial heaps cannot be merged; but a heap
+// can TRAVEL.  Participant r owns the column window [lo_r, hi_r) (windows ascending with r, cut where the pair counts
+// balance) and evaluates exactly the pairs (i, j) with i < j and j in its window: for each row band [b0, b1) with b0 < hi_r,
+// ascending, the band's rows against the columns [max(b0, lo_r), hi_r) -- the band's own rows take them as candidates, and the
+// window's rows below the band take the band's samples turned.  A row of the window therefore meets, on its owner, every id
+// below its own (turned from the bands above it, ascending) and then its window's ids above; its heap then moves to
+// participant r + 1 -- which feeds it the columns of ITS window when it reaches that row's band -- and so on to the last one,
+// where every heap ends.  The heaps of rows [b0, b1) are handed on as soon as the band is done, so the participants work one
+// band behind each other.  This call is one band on one participant; the caller owns the heap arrays (device memory, the
+// RefHeap layout of skl_knn_heaps_*: h_key / h_id / h_d1 [n][knn], h_len [n], thr [n]) and moves row slices between devices.
+extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                                         size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
+                                         float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr)
+{
+    SKL_TRY(check_params(s, s, p));
+    SKL_TRY(ctx_bind(ctx));
+    const bool coreacc = p->dist_type == SKL_DIST_COREACC;
+    if (!h_key || !h_id || !h_len || !thr || (coreacc && !h_d1)) return fail(SKL_ERR_INVALID_ARG, "heap state pointers are null");
+    const size_t n = s->n;
+    if (n < 2 || knn == 0 || knn > n - 1) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, n ? n - 1 : 0);
+    if (knn > (size_t)REFHEAP_LDS_MAX) return fail(SKL_ERR_INVALID_ARG, "the travelling heaps live in LDS while they are fed: knn=%zu exceeds %u", knn, REFHEAP_LDS_MAX);
+    if (band_rows == 0 || band * band_rows >= n || col_lo > col_hi || col_hi > n) return fail(SKL_ERR_INVALID_ARG, "row band / column window out of range");
+    if (!knn_symmetric_ok(s, p)) return fail(SKL_ERR_INVALID_ARG, "no one-evaluation kNN for this configuration; shard rows with skl_self_dists_knn_rows");
+    KnnState st;
+    st.borrowed = true;
+    st.h_key = h_key;
+    st.h_id = h_id;
+    st.h_d1 = h_d1;
+    st.h_len = h_len;
+    st.thr = thr;
+    const std::vector<uint32_t> one{(uint32_t)band};
+    ctx->knn_tiles = ctx->knn_tiles_pruned = 0;
+    return knn_symmetric_bands(ctx, s, p, knn, band_rows, one, false, st, col_lo, col_hi);
+}
+
+// Empty heaps (h_len = 0, thr = "not full") for rows [row_begin, row_end) of caller-owned state arrays.
+extern "C" int skl_knn_heaps_clear(skl_ctx *ctx, size_t row_begin, size_t row_end, uint32_t *h_len, uint32_t *thr)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!h_len || !thr || row_begin > row_end) return fail(SKL_ERR_INVALID_ARG, "bad heap range");
+    if (row_begin == row_end) return SKL_OK;
+    HIP_TRY(hipMemsetAsync(h_len + row_begin, 0, (row_end - row_begin) * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(thr + row_begin, 0xFF, (row_end - row_begin) * sizeof(uint32_t), ctx->stream));
+    return SKL_OK;
+}
+
+extern "C" int skl_device_malloc(skl_ctx *ctx, size_t bytes, void **out)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!out) return fail(SKL_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return SKL_OK;
+}
+
+extern "C" int skl_device_free(skl_ctx *ctx, void *ptr)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!ptr) return SKL_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(ptr));
+    return SKL_OK;
+}
+
+extern "C" int skl_device_memcpy(skl_ctx *ctx, void *dst, const void *src, size_t bytes, int to_device)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (bytes == 0) return SKL_OK;
+    if (!dst || !src) return fail(SKL_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_get_knn_ties(const skl_ctx *ctx) { return ctx ? ctx->knn_ties : SKL_KNN_TIES_REFERENCE; }
+
+// into_sorted_vec of `rows` heaps (arrays pointing at the first of them) -> the public output form (device pointers).
+extern "C" int skl_knn_heaps_finalize(skl_ctx *ctx, size_t rows, size_t knn, const float *h_key, const uint32_t *h_id, const float *h_d1,
+                                      const uint32_t *h_len, int ani, uint64_t *out_idx, float *out_d0, float *out_d1)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (!h_key || !h_id || !h_len || !out_idx || !out_d0 || (h_d1 && !out_d1)) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (knn == 0 || knn > (size_t)REFHEAP_LDS_MAX) return fail(SKL_ERR_INVALID_ARG, "knn out of range");
+    HIP_TRY(launch_refheap_finalize(h_key, h_id, h_d1, h_len, (uint32_t)rows, (uint32_t)knn, (!h_d1 && ani) ? 1 : 0, out_idx, out_d0, out_d1, ctx->stream));
     return SKL_OK;
 }
 

@@ -78,9 +78,8 @@ void print_help()
         "      --knn-ties <RULE>           Neighbours at EQUAL distance: reference (default) = exactly the ids and order\n"
         "                                  the reference binary prints (its BinaryHeap replayed on the GPU);\n"
         "                                  canonical = lowest index first (a property of the data alone; the distances\n"
-        "                                  per row are the reference's, tied rows may list other ids).  With --gpus N > 1\n"
-        "                                  the reference rule shards rows (every pair evaluated twice, as the reference\n"
-        "                                  does); canonical evaluates every pair once on any number of GPUs\n"
+        "                                  per row are the reference's, tied rows may list other ids).  Either rule\n"
+        "                                  evaluates every pair once on any number of GPUs\n"
         "      --subset <SUBSET>           Sample names to analyse\n"
         "  -k <KMER>                       K-mer length (if provided only calculate Jaccard distance)\n"
         "      --ani                       Calculate ANI rather than Jaccard dists, using Poisson model\n"

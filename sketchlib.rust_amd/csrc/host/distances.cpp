@@ -1,7 +1,10 @@
 #include "distances.hpp"
 
 #include <chrono>
+#include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <deque>
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
@@ -502,11 +505,151 @@ SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches
     std::vector<float> d0(n * knn), d1(n * knn);
     const skl_dist_params p = to_params(dist_type, completeness_cutoff);
     const std::vector<size_t> b = even_bounds(n, devs.size());
-    // Every pair once across the devices (the reference evaluates (i, j) and (j, i), mod.rs:148-171):
+    // THE REFERENCE'S TIE ORDER over several devices, every pair once: partial heaps of disjoint candidate sets do not merge (a
+    // BinaryHeap's state depends on the order its candidates arrive in), so the heaps TRAVEL: device d owns the column window
+    // [cut[d], cut[d + 1]), evaluates the pairs whose column lies in it band by band (skl_self_dists_knn_window), and hands each
+    // band's heaps to device d + 1 as soon as the band is done; the last device ends up with every row's final heap.  Decided up
+    // front: nothing is uploaded for a form the configuration does not have.
+    if (skl_ctx_get_knn_ties(devs[0].ctx()) == SKL_KNN_TIES_REFERENCE && knn <= 2048 && n >= 2) {
+        const size_t W = devs.size();
+        const bool coreacc = p.dist_type == SKL_DIST_COREACC;
+        const size_t words = (coreacc ? 3 : 2) * knn + 2;   // a row's heap on the wire: keys, ids[, second values], length, threshold
+        struct Link {   // device d -> d + 1: bands in order
+            std::mutex m;
+            std::condition_variable cv;
+            std::deque<std::vector<uint32_t>> q;
+            bool broken = false;
+        };
+        std::vector<Link> link(W);
+        std::vector<int> rc(W, SKL_OK);
+        std::vector<std::string> msg(W);
+        std::atomic<bool> no_form{false};
+        size_t band_rows = 0;
+        std::vector<size_t> cut;
+        std::mutex plan_m;
+        auto break_links = [&] {
+            for (auto &l : link) {
+                std::lock_guard<std::mutex> g(l.m);
+                l.broken = true;
+                l.cv.notify_all();
+            }
+        };
+        for_each_device(devs, [&](size_t d) {
+            try {
+                Slab s(devs[d], sketches, completeness_vec);
+                skl_ctx *ctx = devs[d].ctx();
+                {
+                    std::lock_guard<std::mutex> g(plan_m);
+                    if (band_rows == 0) {   // (every device arrives at the same plan)
+                        band_rows = skl_knn_band_rows(s.h, &p, W);
+                        if (band_rows == 0) throw std::runtime_error("skl_knn_band_rows failed");
+                        cut.assign(1, 0);
+                        for (size_t r = 1; r < W; ++r) {   // n * sqrt(r / W) on band boundaries: equal pair counts
+                            const size_t c = (size_t)std::llround((double)n * std::sqrt((double)r / (double)W) / (double)band_rows) * band_rows;
+                            cut.push_back(std::min(std::max(c, cut.back()), n));
+                        }
+                        cut.push_back(n);
+                    }
+                }
+                const size_t lo = cut[d], hi = cut[d + 1];
+                struct DevMem {
+                    skl_ctx *c;
+                    void *p = nullptr;
+                    DevMem(skl_ctx *ctx_, size_t bytes) : c(ctx_) { check(skl_device_malloc(c, bytes, &p)); }
+                    ~DevMem() { skl_device_free(c, p); }
+                };
+                DevMem h_key(ctx, n * knn * 4), h_id(ctx, n * knn * 4), h_d1(ctx, coreacc ? n * knn * 4 : 4), h_len(ctx, n * 4), thr(ctx, n * 4);
+                check(skl_knn_heaps_clear(ctx, 0, n, (uint32_t *)h_len.p, (uint32_t *)thr.p));
+                auto row_ptr = [&](DevMem &m, size_t row, size_t per_row) { return (char *)m.p + row * per_row * 4; };
+                auto export_rows = [&](size_t r0, size_t r1) {
+                    const size_t rows = r1 - r0;
+                    std::vector<uint32_t> buf(rows * words);
+                    uint32_t *w = buf.data();
+                    check(skl_device_memcpy(ctx, w, row_ptr(h_key, r0, knn), rows * knn * 4, 0));
+                    w += rows * knn;
+                    check(skl_device_memcpy(ctx, w, row_ptr(h_id, r0, knn), rows * knn * 4, 0));
+                    w += rows * knn;
+                    if (coreacc) {
+                        check(skl_device_memcpy(ctx, w, row_ptr(h_d1, r0, knn), rows * knn * 4, 0));
+                        w += rows * knn;
+                    }
+                    check(skl_device_memcpy(ctx, w, row_ptr(h_len, r0, 1), rows * 4, 0));
+                    w += rows;
+                    check(skl_device_memcpy(ctx, w, row_ptr(thr, r0, 1), rows * 4, 0));
+                    return buf;
+                };
+                auto import_rows = [&](size_t r0, size_t r1, const std::vector<uint32_t> &buf) {
+                    const size_t rows = r1 - r0;
+                    const uint32_t *w = buf.data();
+                    check(skl_device_memcpy(ctx, row_ptr(h_key, r0, knn), w, rows * knn * 4, 1));
+                    w += rows * knn;
+                    check(skl_device_memcpy(ctx, row_ptr(h_id, r0, knn), w, rows * knn * 4, 1));
+                    w += rows * knn;
+                    if (coreacc) {
+                        check(skl_device_memcpy(ctx, row_ptr(h_d1, r0, knn), w, rows * knn * 4, 1));
+                        w += rows * knn;
+                    }
+                    check(skl_device_memcpy(ctx, row_ptr(h_len, r0, 1), w, rows * 4, 1));
+                    w += rows;
+                    check(skl_device_memcpy(ctx, row_ptr(thr, r0, 1), w, rows * 4, 1));
+                };
+                const size_t n_bands = (n + band_rows - 1) / band_rows;
+                for (size_t band = 0; band < n_bands && !no_form; ++band) {
+                    const size_t b0 = band * band_rows, b1 = std::min(n, b0 + band_rows);
+                    if (b0 >= hi) break;
+                    if (b0 < lo) {   // rows of an earlier window: from the device that has just finished them
+                        Link &in = link[d - 1];
+                        std::unique_lock<std::mutex> g(in.m);
+                        in.cv.wait(g, [&] { return !in.q.empty() || in.broken; });
+                        if (in.q.empty()) {
+                            if (no_form) return;   // (upstream found that the configuration has no one-evaluation form)
+                            throw std::runtime_error("the device upstream of this one failed");
+                        }
+                        std::vector<uint32_t> buf = std::move(in.q.front());
+                        in.q.pop_front();
+                        g.unlock();
+                        import_rows(b0, b1, buf);
+                    }
+                    const int r = skl_self_dists_knn_window(ctx, s.h, &p, knn, band_rows, band, lo, hi, (float *)h_key.p, (uint32_t *)h_id.p,
+                                                            coreacc ? (float *)h_d1.p : nullptr, (uint32_t *)h_len.p, (uint32_t *)thr.p);
+                    if (r == SKL_ERR_INVALID_ARG && band == 0) {   // no one-evaluation form for this configuration: row shards below
+                        no_form = true;
+                        break_links();
+                        return;
+                    }
+                    check(r);
+                    if (d + 1 < W) {
+                        std::vector<uint32_t> buf = export_rows(b0, b1);
+                        Link &out_l = link[d];
+                        std::lock_guard<std::mutex> g(out_l.m);
+                        out_l.q.push_back(std::move(buf));
+                        out_l.cv.notify_all();
+                    }
+                }
+                if (d + 1 == W && !no_form) {   // every heap has ended here: into_sorted_vec, lists to the host
+                    DevMem o_idx(ctx, n * knn * 8), o_d0(ctx, n * knn * 4), o_d1(ctx, coreacc ? n * knn * 4 : 4);
+                    check(skl_knn_heaps_finalize(ctx, n, knn, (const float *)h_key.p, (const uint32_t *)h_id.p, coreacc ? (const float *)h_d1.p : nullptr,
+                                                 (const uint32_t *)h_len.p, p.ani, (uint64_t *)o_idx.p, (float *)o_d0.p, coreacc ? (float *)o_d1.p : nullptr));
+                    check(skl_device_memcpy(ctx, idx.data(), o_idx.p, n * knn * 8, 0));
+                    check(skl_device_memcpy(ctx, d0.data(), o_d0.p, n * knn * 4, 0));
+                    if (coreacc) check(skl_device_memcpy(ctx, d1.data(), o_d1.p, n * knn * 4, 0));
+                }
+            } catch (...) {
+                break_links();   // nobody waits for a band that will not come
+                throw;
+            }
+        });
+        if (!no_form) {
+            SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx.data(), d0.data(), d1.data(), idx.size());
+            out.ref_names = sketch_names(sketches);
+            return out;
+        }
+    } else
+    // CANONICAL TIES: every pair once across the devices (the reference evaluates (i, j) and (j, i), mod.rs:148-171):
     // the row bands are dealt back and forth over the devices (band b costs ~ n - b*band_rows), each
     // device returns its partial top-k states for ALL rows, and every device then merges one row
     // shard of the stacked states.  Configurations without that form fall through to row shards.
-    {
+    if (knn <= 2048) {
         const size_t W = devs.size();
         const bool coreacc = p.dist_type == SKL_DIST_COREACC;
         std::vector<std::vector<uint32_t>> key(W), sid(W);

@@ -15,6 +15,10 @@ The one-evaluation self kNN (every pair {i, j} computed once instead of twice) i
 exception: a pair's key is a candidate of BOTH rows, which belong to different ranks, so every
 rank keeps partial top-k states for all rows and the ranks exchange row shards of them with
 one all-to-all before the final merge (knn_band_deal / exchange_knn_states / self_knn_once).
+That merge is defined for the canonical tie rule.  In the REFERENCE's tie order a row's BinaryHeap must meet its
+candidates in ascending id, so heaps travel instead: rank r owns a window of COLUMNS, feeds every row band the columns
+of its window, and hands each band's heaps to rank r + 1 -- a pipeline one band deep per rank, every pair still evaluated
+once (knn_window_cuts / self_knn_once_reference; include/sketchlib_dist.h, skl_self_dists_knn_window).
 """
 import os
 
@@ -318,3 +322,114 @@ def self_knn_once(ctx, sk, p, knn, rank, world, dist, device):
     if rows:
         capi.knn_merge_states(ctx, k_all, i_all, d_all, ani=bool(p.ani), out=out)
     return bounds[rank], bounds[rank + 1], out[0], out[1], out[2]
+
+
+# ---------------------------------------------------------------------------
+# self kNN, every pair once, in the reference's tie order: travelling heaps
+# ---------------------------------------------------------------------------
+
+def knn_window_cuts(n, band_rows, world):
+    """Column windows [cuts[r], cuts[r + 1]) per rank: cut where the pair counts balance -- rank r evaluates the pairs (i, j),
+    i < j, whose column j lies in its window, ~ (hi^2 - lo^2) / 2 of them -- on band boundaries (a band's rows are then
+    either all inside a window or all outside it)."""
+    cuts = [0]
+    for r in range(1, world):
+        c = int(round(n * (r / world) ** 0.5 / band_rows)) * band_rows
+        cuts.append(min(max(c, cuts[-1]), n))
+    cuts.append(n)
+    return cuts
+
+
+def _pack_heaps(heaps, r0, r1):
+    import torch
+
+    parts = [heaps["h_key"][r0:r1].view(torch.int32), heaps["h_id"][r0:r1]]
+    if heaps["h_d1"] is not None:
+        parts.append(heaps["h_d1"][r0:r1].view(torch.int32))
+    parts += [heaps["h_len"][r0:r1, None], heaps["thr"][r0:r1, None]]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def _unpack_heaps(heaps, r0, r1, packed):
+    import torch
+
+    knn = heaps["h_key"].shape[1]
+    heaps["h_key"][r0:r1] = packed[:, :knn].view(torch.float32)
+    heaps["h_id"][r0:r1] = packed[:, knn:2 * knn]
+    o = 2 * knn
+    if heaps["h_d1"] is not None:
+        heaps["h_d1"][r0:r1] = packed[:, o:o + knn].view(torch.float32)
+        o += knn
+    heaps["h_len"][r0:r1] = packed[:, o]
+    heaps["thr"][r0:r1] = packed[:, o + 1]
+
+
+def self_knn_once_reference(ctx, sk, p, knn, rank, world, dist, device, band_rows=None, stage=None, finalize=None, heaps=None,
+                            host_staged=False):
+    """Self kNN in the reference's tie order over `world` ranks, every pair evaluated once: -> (row0, row1, idx, d0, d1) for
+    this rank's row shard (device tensors; even_row_bounds), like self_knn_once.  Every rank must call it.
+
+    `stage(band, lo, hi, heaps)` feeds one row band the columns [lo, hi) (default: skl_self_dists_knn_window) and
+    `finalize(heaps, r0, r1)` sorts heaps into lists (default: skl_knn_heaps_finalize); the CPU tests of the protocol pass
+    oracle-backed ones.  host_staged: messages go through host memory (the gloo debugging backend, which lets several ranks
+    share one GPU; RCCL moves device tensors)."""
+    import torch
+
+    from . import capi
+
+    n = sk.n
+    coreacc = p.dist_type == capi.COREACC
+    if band_rows is None:
+        band_rows = capi.knn_band_rows(sk, p, world)
+    n_bands = (n + band_rows - 1) // band_rows
+    lo, hi = knn_window_cuts(n, band_rows, world)[rank:rank + 2]
+    if heaps is None:
+        heaps = capi.knn_heaps_alloc(n, knn, coreacc, device)
+    if stage is None:
+        def stage(band, lo_, hi_, h):
+            capi.self_dists_knn_window(ctx, sk, p, knn, band_rows, band, lo_, hi_, h)
+    if finalize is None:
+        def finalize(h, r0, r1):
+            return capi.knn_heaps_finalize(ctx, h, r0, r1, knn, ani=bool(p.ani))
+    width = (3 if coreacc else 2) * knn + 2
+    comm = torch.device("cpu") if host_staged else device
+    sends = []
+    for band in range(n_bands):
+        b0, b1 = band * band_rows, min(n, (band + 1) * band_rows)
+        if b0 >= hi:
+            break                       # the bands from here on hold no pair of this window
+        if b0 < lo:                     # rows of an earlier window: their heaps come from the rank that just finished them
+            packed = torch.empty((b1 - b0, width), dtype=torch.int32, device=comm)
+            dist.recv(packed, src=rank - 1)
+            _unpack_heaps(heaps, b0, b1, packed.to(device))
+        stage(band, lo, hi, heaps)
+        if rank + 1 < world:            # done with this window: on to the next one
+            packed = _pack_heaps(heaps, b0, b1).to(comm)
+            sends.append((dist.isend(packed, dst=rank + 1), packed))
+    for work, _buf in sends:
+        work.wait()
+    # every heap has ended on the last rank: lists there, row shards back to their ranks
+    bounds = even_row_bounds(n, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    if world == 1:
+        idx, d0, d1 = finalize(heaps, 0, n)
+        return 0, n, idx, d0, d1
+    if rank == world - 1:
+        idx, d0, d1 = finalize(heaps, 0, n)
+        out = []
+        for r in range(world - 1):
+            a, b = bounds[r], bounds[r + 1]
+            for t in (idx, d0, d1):
+                if t is not None and b > a:
+                    shard = t[a:b].contiguous().to(comm)
+                    out.append((dist.isend(shard, dst=r), shard))
+        for work, _buf in out:
+            work.wait()
+        return r0, r1, idx[r0:r1], d0[r0:r1], (d1[r0:r1] if d1 is not None else None)
+    idx = torch.empty((r1 - r0, knn), dtype=torch.int64, device=comm)
+    d0 = torch.empty((r1 - r0, knn), dtype=torch.float32, device=comm)
+    d1 = torch.empty((r1 - r0, knn), dtype=torch.float32, device=comm) if coreacc else None
+    for t in (idx, d0, d1):
+        if t is not None and r1 > r0:
+            dist.recv(t, src=world - 1)
+    return r0, r1, idx.to(device), d0.to(device), (d1.to(device) if d1 is not None else None)

@@ -160,3 +160,19 @@ def test_rccl_loopback_gather_at_cfg3_full_size(gpu_ctx):
 def test_knn_multi_rccl_path_with_one_rank(gpu_ctx):
     line = _torchrun(["scripts/bench_knn_multi.py", "--samples", "20000", "--knn", "50", "--clustered", "--check"], 29612)
     assert line["n_gpus"] == 1 and line["shard_equals_row_by_row"] is True
+
+
+def test_knn_multi_canonical_all_to_all_with_one_rank(gpu_ctx):
+    line = _torchrun(["scripts/bench_knn_multi.py", "--samples", "20000", "--knn", "50", "--clustered", "--check", "--ties", "canonical"], 29616)
+    assert line["ties"] == "canonical" and line["shard_equals_row_by_row"] is True
+
+
+@pytest.mark.parametrize("world,coreacc,port", [(2, False, 29631), (3, True, 29633), (4, False, 29635)])
+def test_knn_reference_order_travelling_heaps_with_several_ranks_on_the_one_gpu(gpu_ctx, world, coreacc, port):
+    """The reference's tie order over `world` ranks, every pair evaluated once (skl_self_dists_knn_window + heaps handed
+    from rank to rank band by band, multi_gpu.self_knn_once_reference), all ranks on the box's one GPU over gloo: rank 0's
+    row shard equals the single-device row-by-row replay of the same rows (ids, order, distances)."""
+    args = ["scripts/bench_knn_multi.py", "--samples", "12000", "--knn", "20", "--clustered", "--check", "--ties", "reference"]
+    line = _torchrun_world(world, args + (["--coreacc"] if coreacc else []), port)
+    assert line["n_gpus"] == world and line["ties"] == "reference" and "travelling" in line["mode"]
+    assert line["shard_equals_row_by_row"] is True

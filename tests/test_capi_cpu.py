@@ -46,12 +46,16 @@ def test_product_library_has_no_ab_kernels_or_switches():
     for k in kernels:
         # chunk-split kernel: 16 x 128 and 32 x 128 tiles in the packed-count form only (32 x 128: blocks of 2 rows, held to
         # 4 waves per SIMD), ablation parameter 0; ksplit fallback: 8-row tiles
-        # (last parameter: the segmented walk of sketches beyond 65 535 bins, k-sliced forms only)
-        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [01], true, 0, true, 4, 0, (true|false)>|pair_kernel_kslice<16, 2, [012], false, 0, true, 1, 0, false>|"
-                            r"pair_kernel_kslice<32, 2, [01], true, 0, true, 2, 4, (true|false)>|"
-                            r"pair_kernel_kslice<32, 2, [012], false, 0, true, 2, 4, false>|pair_kernel_ksplit<8, [012], 8, false>", k), k
+        # (last three parameters: the segmented walk of sketches beyond 65 535 bins, k-sliced forms only; tile pruning, the
+        # single-k 32 x 128 form of the symmetric self kNN only; the fused core/accessory epilogue, which lost its A/B
+        # (profiles/r05_fused_epilogue.md) and exists in the A/B build only)
+        assert re.fullmatch(r"pair_kernel_kslice<16, 2, [01], true, 0, true, 4, 0, (true|false), false, false>|"
+                            r"pair_kernel_kslice<16, 2, [012], false, 0, true, 1, 0, false, false, false>|"
+                            r"pair_kernel_kslice<32, 2, [01], true, 0, true, 2, 4, (true|false), false, false>|"
+                            r"pair_kernel_kslice<32, 2, 1, true, 0, true, 2, 4, false, true, false>|"
+                            r"pair_kernel_kslice<32, 2, [012], false, 0, true, 2, 4, false, false, false>|pair_kernel_ksplit<8, [012], 8, false>", k), k
     blob = open(pkg.library_path(), "rb").read()
-    for needle in (b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
+    for needle in (b"SKL_FUSE_EPILOGUE", b"SKL_FUSE_VARIANT", b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
                    b"SKL_LDS_SHAPE", b"SKL_FORCE_NA", b"SKL_PAIR_VARIANT", b"SKL_PERSIST"):
         assert needle not in blob, needle
     # and no getenv on the launch path: what remains is read by read_knobs(), once per context
@@ -172,10 +176,16 @@ def test_register_budget_of_the_shipped_pair_kernels():
 
     pkg.build_library()
     meta = {k: v for k, v in _kernel_metadata(pkg.library_path()).items() if "pair_kernel_kslice" in k}
-    assert len(meta) == 14, sorted(meta)
+    assert len(meta) == 15, sorted(meta)
     for name, (vgpr, scratch, lds) in meta.items():
         r, _jl, _mode, ksl = re.search(r"pair_kernel_kslice<(\d+), (\d+), (\d+), (true|false)", name).groups()
-        if re.search(r", (true|false)>\(", name).group(1) == "true":
+        big, prune, fuse = re.search(r", (true|false), (true|false), (true|false)>\(", name).groups()
+        assert fuse == "false", name
+        if prune == "true":
+            # tile pruning (the single-k 32 x 128 form): + 544 B of LDS for the column bounds and the votes, a handful of values
+            # spilled, one reload of them inside the walk
+            assert vgpr <= 128 and lds <= 40 * 1024 and scratch <= 64, (name, vgpr, scratch, lds)
+        elif big == "true":
             # the segmented walk (sketches beyond 65 535 bins): 32-bit totals in private memory, touched once per 1 016 chunks
             assert vgpr <= 128 and lds <= 40 * 1024 and scratch <= 448, (name, vgpr, scratch, lds)
         elif ksl == "true":

@@ -232,8 +232,9 @@ def test_multi_context_synthetic(gpu_ctx, tmp_path):
     assert run(prefix, "--knn", "10", "--devices", "0,0,0") == knn
     # several bands per device: every pair is evaluated once across the devices, the partial
     # top-k states are merged shard by shard (single-k and core/accessory keys)
-    # (--knn-ties canonical: the one-evaluation split over the devices; the default rule shards rows instead -- the
-    # reference's heap cannot be merged from partial states -- and must give the same text whatever the partition)
+    # (--knn-ties canonical: row bands dealt over the devices + merged partial states; the default, reference rule: column
+    # windows per device and heaps that travel from device to device band by band -- either way every pair once and the
+    # same text whatever the partition)
     for flags in (("--knn", "10"), ("--knn", "7", "-k", "23"), ("--knn", "7", "-k", "23", "--ani")):
         for ties in ((), ("--knn-ties", "canonical")):
             want = run(prefix, *flags, *ties)

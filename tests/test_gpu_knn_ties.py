@@ -274,3 +274,43 @@ def test_random_reference_tie_configuration(oracle, skl, gpu_ctx, seed):
         else:
             os_env["SKL_KNN_BAND_ROWS"] = old
         gpu_ctx.reload_env()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+@pytest.mark.parametrize("dist", ["jaccard", "ani", "coreacc"])
+def test_reference_order_over_column_windows(oracle, skl, gpu_ctx, monkeypatch, world, dist):
+    """skl_self_dists_knn_window: the reference's lists from heaps that travel through `world` column windows, every pair
+    evaluated once.  The participants run one after the other here on one device and one set of heap arrays -- which is
+    exact: a participant never touches a row again after the band that holds it, so the state it would have sent on is the
+    state it leaves behind (the transport itself: tests/test_multi_gpu_cpu.py over gloo, tests/test_bench_gpu.py)."""
+    import torch
+    from sketchlib.rust_amd import multi_gpu
+
+    kmers, ss64, n, knn, band_rows = [17, 21, 25, 29], 8, 613, 9, 64
+    bins = synth.set_r(n, kmers, ss64, n_clusters=5)
+    bins[400] = bins[3]
+    bins[401] = bins[3]
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    if dist == "coreacc":
+        p, oargs = g.set_k(), (oracle.COREACC, 0, False)
+    else:
+        p, oargs = g.set_k(21, dist == "ani"), (oracle.JACCARD, 1, dist == "ani")
+    monkeypatch.setenv("SKL_TILE32_MIN", "0")       # the prunable 32 x 128 form
+    gpu_ctx.reload_env()
+    dev = torch.device("cuda", 0)
+    heaps = skl.knn_heaps_alloc(n, knn, dist == "coreacc", dev)
+    cuts = multi_gpu.knn_window_cuts(n, band_rows, world)
+    for r in range(world):
+        lo, hi = cuts[r], cuts[r + 1]
+        for band in range((n + band_rows - 1) // band_rows):
+            if band * band_rows >= hi:
+                break
+            skl.self_dists_knn_window(gpu_ctx, g, p, knn, band_rows, band, lo, hi, heaps)
+    idx, d0, d1 = skl.knn_heaps_finalize(gpu_ctx, heaps, 0, n, knn, ani=dist == "ani")
+    gpu_ctx.synchronize()
+    exp = oracle.self_dists_knn(o, knn, *oargs, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint64), exp["idx"]), np.argwhere(idx.cpu().numpy() != exp["idx"])[:5]
+    assert np.array_equal(d0.cpu().numpy(), exp["d0"])
+    if dist == "coreacc":
+        assert np.array_equal(d1.cpu().numpy(), exp["d1"])
+    g.close()

@@ -205,3 +205,126 @@ def test_gloo_knn_every_pair_once_exchange(oracle, tmp_path, world):
         env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("KNN_ONCE_OK") == world
+
+
+@pytest.mark.parametrize("n,band_rows,world", [(1000000, 2048, 8), (700, 64, 3), (97, 10, 2), (50, 64, 4), (1000, 16, 1)])
+def test_knn_window_cuts(n, band_rows, world):
+    """Column windows of the travelling-heaps pipeline: ascending, on band boundaries, balanced by pair count."""
+    cuts = multi_gpu.knn_window_cuts(n, band_rows, world)
+    assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == n and cuts == sorted(cuts)
+    assert all(c % band_rows == 0 or c == n for c in cuts[:-1])
+    if n >= 100 * band_rows * world:      # rank r evaluates ~ (hi^2 - lo^2) / 2 pairs
+        area = [(cuts[r + 1] ** 2 - cuts[r] ** 2) / 2 for r in range(world)]
+        assert max(area) / min(area) < 1.05
+
+
+HEAP_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from sketchlib.rust_amd import multi_gpu, synth
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+mode = sys.argv[1]
+n, kmers, ss64, knn, band_rows = 131, [17, 21, 25], 4, 7, 16
+bins = synth.set_r(n, kmers, ss64, n_clusters=3)
+bins[40] = bins[7]; bins[99] = bins[7]; bins[100] = bins[7]       # exact ties inside a cluster
+s = O.Sketches(bins, n, kmers, ss64)
+coreacc = mode == "coreacc"
+dtype, k_idx = (O.COREACC, 0) if coreacc else (O.JACCARD, 1)
+def sub(a, b):
+    return O.Sketches(bins[a:b], b - a, kmers, ss64)
+
+class P:      # what the driver reads of skl_dist_params
+    dist_type = 0 if coreacc else 1
+    ani = 0
+class SK:
+    pass
+SK.n = n
+
+evaluated = [0]
+def load_row(h, row):
+    hp = O.Heaps(1, knn)
+    m = int(h["h_len"][row])
+    hp.len[0] = m
+    hp.items["d0"][0, :m] = h["h_key"][row, :m].numpy()
+    hp.items["idx"][0, :m] = h["h_id"][row, :m].numpy().astype(np.uint64)
+    if coreacc:
+        hp.items["d1"][0, :m] = h["h_d1"][row, :m].numpy()
+    return hp
+def store_row(h, row, hp):
+    m = int(hp.len[0])
+    h["h_len"][row] = m
+    h["h_key"][row, :m] = torch.from_numpy(hp.items["d0"][0, :m].copy())
+    h["h_id"][row, :m] = torch.from_numpy(hp.items["idx"][0, :m].astype(np.int32))
+    if coreacc:
+        h["h_d1"][row, :m] = torch.from_numpy(hp.items["d1"][0, :m].copy())
+
+def stage(band, lo, hi, h):
+    # stand-in for skl_self_dists_knn_window (the GPU half), from the oracle's distances and its resumable BinaryHeap
+    b0, b1 = band * band_rows, min(n, (band + 1) * band_rows)
+    c_first, t_first = max(b0, lo), max(b1, lo)
+    if c_first >= hi:
+        return
+    D = O.cross_dists_all(sub(b0, b1), sub(c_first, hi), dtype, k_idx)       # [band, cols, 1 or 2]
+    evaluated[0] += sum(1 for i in range(b0, b1) for j in range(c_first, hi) if i < j)
+    for j in range(t_first, hi):            # the window's rows below the band: the band's samples, ascending
+        hp = load_row(h, j)
+        hp.feed(0, np.arange(b0, b1), D[:, j - c_first, 0], D[:, j - c_first, 1] if coreacc else None)
+        store_row(h, j, hp)
+    for i in range(b0, b1):                 # the band's own rows: the window's columns from max(b0, lo) on, minus themselves
+        cols = np.array([c for c in range(c_first, hi) if c != i], dtype=np.int64)
+        if cols.size == 0:
+            continue
+        hp = load_row(h, i)
+        hp.feed(0, cols, D[i - b0, cols - c_first, 0], D[i - b0, cols - c_first, 1] if coreacc else None)
+        store_row(h, i, hp)
+
+def finalize(h, r0, r1):
+    idx = torch.zeros((r1 - r0, knn), dtype=torch.int64); d0 = torch.zeros((r1 - r0, knn)); d1 = torch.zeros((r1 - r0, knn)) if coreacc else None
+    for r in range(r0, r1):
+        hp = load_row(h, r)
+        rows = hp.sorted_rows()[0]
+        idx[r - r0] = torch.from_numpy(rows["idx"].astype(np.int64)); d0[r - r0] = torch.from_numpy(rows["d0"].copy())
+        if coreacc:
+            d1[r - r0] = torch.from_numpy(rows["d1"].copy())
+    return idx, d0, d1
+
+heaps = {"h_key": torch.zeros((n, knn)), "h_id": torch.zeros((n, knn), dtype=torch.int32),
+         "h_d1": torch.zeros((n, knn)) if coreacc else None, "h_len": torch.zeros((n,), dtype=torch.int32),
+         "thr": torch.full((n,), -1, dtype=torch.int32)}
+r0, r1, idx, d0, d1 = multi_gpu.self_knn_once_reference(None, SK, P, knn, rank, world, dist, torch.device("cpu"),
+                                                        band_rows=band_rows, stage=stage, finalize=finalize, heaps=heaps)
+exp = O.self_dists_knn(s, knn, dtype, k_idx, False, ties=O.TIES_RUST_HEAP)
+assert (r0, r1) == tuple(multi_gpu.even_row_bounds(n, world)[rank:rank + 2])
+assert np.array_equal(idx.numpy().astype(np.uint64), exp["idx"][r0:r1]), (rank, "ids / order differ from the reference's heap")
+assert np.array_equal(d0.numpy(), exp["d0"][r0:r1])
+if coreacc:
+    assert np.array_equal(d1.numpy(), exp["d1"][r0:r1])
+canon = O.self_dists_knn(s, knn, dtype, k_idx, False, ties=O.TIES_CANONICAL)
+tot = torch.tensor([evaluated[0], int((exp["idx"] != canon["idx"]).any())], dtype=torch.int64)
+dist.all_reduce(tot)
+assert int(tot[0]) == n * (n - 1) // 2, "every pair evaluated exactly once over the ranks"
+assert int(tot[1]) > 0, "the data set is meant to have ties the two rules resolve differently"
+print("HEAPS_OK", rank)
+dist.barrier()
+dist.destroy_process_group()
+""" % ROOT
+
+
+@pytest.mark.parametrize("mode", ["jaccard", "coreacc"])
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_gloo_reference_order_travelling_heaps(oracle, tmp_path, world, mode):
+    """The reference's tie order over several ranks with every pair evaluated once: column windows, heaps handed from rank
+    to rank band by band, lists gathered on the last rank and dealt back -- against the oracle's BinaryHeap replay of whole
+    rows (mod.rs:133-224), with the GPU half replaced by the oracle's distances and its resumable heap."""
+    script = tmp_path / "heap_worker.py"
+    script.write_text(HEAP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+         "--master-addr", "127.0.0.1", "--master-port", str(29560 + world + (10 if mode == "coreacc" else 0)), str(script), mode],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert res.stdout.count("HEAPS_OK") == world
