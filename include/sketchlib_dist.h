@@ -293,6 +293,14 @@ int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *s, const sk
 int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64_t *code_begin,
                      const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
                      const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs);
+/* The same with the bases already at 2 bits each -- what crosses PCIe either way (the one-byte form above is packed by the
+ * library on host threads): `packed` holds, sample after sample, ceil(len / 16) little-endian u32 words per sample, code c of
+ * the sample at bits 2 (c % 16) of its word c / 16, a sample's last word zero-padded; code_begin still counts CODES
+ * (sample s has code_begin[s + 1] - code_begin[s] of them).  A caller that parses sequence files packs as it goes
+ * (csrc/host/sketch_gpu.cpp).  Either form uploads batch i + 1 of the samples under the kernel of batch i. */
+int skl_sketch_signs_packed(skl_ctx *ctx, const uint32_t *packed, const uint64_t *code_begin,
+                            const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
+                            const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs);
 
 /* Candidate-list form of skl_self_dists_knn: the device half of self_dists_knn_precluster
  * (src/distances/mod.rs:399-553).  Row i is compared only with the samples

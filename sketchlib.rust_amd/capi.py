@@ -102,6 +102,7 @@ _SIG = [
     ("skl_knn_merge_states", C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, C.c_int, C.c_int,
                                        _P, _P, _P, C.c_int]),
     ("skl_sketch_signs", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.c_int, _P]),
+    ("skl_sketch_signs_packed", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.c_int, _P]),
     ("skl_self_binmatch", C.c_int, [_P, _P, _P, C.c_int]),
     ("skl_cross_binmatch", C.c_int, [_P, _P, _P, _P, C.c_int]),
     ("skl_self_dists_all_host", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, C.c_size_t,
@@ -526,6 +527,37 @@ def sketch_signs(ctx, codes, code_begin, offsets, offset_begin, kmers, num_bins,
     _check(load().skl_sketch_signs(ctx._h, codes.ctypes.data if codes.size else None, code_begin.ctypes.data,
                                    offsets.ctypes.data if offsets.size else None, offset_begin.ctypes.data, n,
                                    kmers.ctypes.data, kmers.size, num_bins, int(rc), out.ctypes.data))
+    return out
+
+
+def pack_codes(codes, code_begin):
+    """One-byte 2-bit codes -> the packed form skl_sketch_signs_packed takes: per sample ceil(len / 16) u32 words, code c at
+    bits 2 (c % 16) of word c / 16, the last word zero-padded."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    code_begin = np.ascontiguousarray(code_begin, dtype=np.uint64)
+    parts = []
+    for s in range(code_begin.size - 1):
+        c = codes[int(code_begin[s]):int(code_begin[s + 1])] & 3
+        pad = (-c.size) % 16
+        if pad:
+            c = np.concatenate([c, np.zeros(pad, dtype=np.uint8)])
+        c = c.reshape(-1, 16).astype(np.uint32)
+        parts.append((c << (2 * np.arange(16, dtype=np.uint32))[None, :]).sum(axis=1, dtype=np.uint32))
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
+
+
+def sketch_signs_packed(ctx, packed, code_begin, offsets, offset_begin, kmers, num_bins, rc=True):
+    """skl_sketch_signs_packed: as sketch_signs, the bases already at 2 bits each (pack_codes)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint32)
+    code_begin = np.ascontiguousarray(code_begin, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    offset_begin = np.ascontiguousarray(offset_begin, dtype=np.uint64)
+    kmers = np.ascontiguousarray(kmers, dtype=np.uintp)
+    n = code_begin.size - 1
+    out = np.zeros((n, kmers.size, num_bins), dtype=np.uint64)
+    _check(load().skl_sketch_signs_packed(ctx._h, packed.ctypes.data if packed.size else None, code_begin.ctypes.data,
+                                          offsets.ctypes.data if offsets.size else None, offset_begin.ctypes.data, n,
+                                          kmers.ctypes.data, kmers.size, num_bins, int(rc), out.ctypes.data))
     return out
 
 

@@ -177,6 +177,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
         if (ctx->sampler_stream) (void)hipStreamSynchronize(ctx->sampler_stream);
         (void)hipHostFree(ctx->sampler_stop);
     }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->sampler_buf) (void)hipFree(ctx->sampler_buf);
     if (ctx->sampler_count) (void)hipFree(ctx->sampler_count);
     if (ctx->sampler_stream) (void)hipStreamDestroy(ctx->sampler_stream);

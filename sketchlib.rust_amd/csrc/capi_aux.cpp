@@ -4,7 +4,9 @@
 #include "capi_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 using namespace skl;
 
@@ -22,16 +24,74 @@ inline uint64_t h_swapbits033(uint64_t v)
 inline uint64_t h_srol(uint64_t v) { return h_swapbits033(h_rotl1(v)); }
 }  // namespace
 
-extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64_t *code_begin,
-                                const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
-                                const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs)
+// Sixteen one-byte codes -> one word of 2-bit codes (code c at bits 2 c).
+static inline uint32_t pack16(const uint8_t *src)
+{
+    uint64_t lo, hi;
+    memcpy(&lo, src, 8);
+    memcpy(&hi, src + 8, 8);
+    auto squeeze = [](uint64_t v) -> uint32_t {   // 8 bytes of 2 significant bits -> 16 bits
+        v &= 0x0303030303030303ull;
+        v = (v | (v >> 6)) & 0x000F000F000F000Full;
+        v = (v | (v >> 12)) & 0x000000FF000000FFull;
+        v = (v | (v >> 24)) & 0xFFFFull;
+        return (uint32_t)v;
+    };
+    return squeeze(lo) | (squeeze(hi) << 16);
+}
+
+// The bases of samples [s0, s1) packed into dst (the words of sample s start at dst + (word_begin[s] - word_begin[s0])).
+static void pack_samples(const uint8_t *codes, const uint64_t *code_begin, const std::vector<uint64_t> &word_begin, size_t s0, size_t s1,
+                         uint32_t *dst, unsigned threads)
+{
+    // work items: (sample, word range) pieces of at most 1 Mi words
+    struct Piece { size_t s; uint64_t w0, w1; };
+    std::vector<Piece> pieces;
+    for (size_t s = s0; s < s1; ++s) {
+        const uint64_t words = word_begin[s + 1] - word_begin[s];
+        for (uint64_t w = 0; w < words; w += (1ull << 20)) pieces.push_back({s, w, std::min<uint64_t>(words, w + (1ull << 20))});
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t x = next.fetch_add(1);
+            if (x >= pieces.size()) break;
+            const Piece &pc = pieces[x];
+            const uint8_t *src = codes + code_begin[pc.s];
+            const uint64_t n_codes = code_begin[pc.s + 1] - code_begin[pc.s];
+            uint32_t *out = dst + (word_begin[pc.s] - word_begin[s0]);
+            for (uint64_t w = pc.w0; w < pc.w1; ++w) {
+                if (16 * w + 16 <= n_codes) {
+                    out[w] = pack16(src + 16 * w);
+                } else {   // the sample's last word: zero-padded
+                    uint32_t word = 0;
+                    for (uint64_t c = 16 * w; c < n_codes; ++c) word |= (uint32_t)(src[c] & 3u) << (2u * (uint32_t)(c - 16 * w));
+                    out[w] = word;
+                }
+            }
+        }
+    };
+    const unsigned t = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, pieces.size()));
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < t; ++i) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+}
+
+// skl_sketch_signs / skl_sketch_signs_packed.  Round 5: the bases cross PCIe at 2 bits each; the device buffers belong to the
+// context (grow-only) instead of being allocated per call; the samples go in batches of ~8 Mi words, batch i + 1's upload
+// (the auxiliary stream) under batch i's kernel, batch i's signs on their way back under batch i + 1's kernel.  One-byte codes
+// are packed on host threads straight into a pinned two-batch ring, so their upload is a true DMA.
+static int sketch_signs_impl(skl_ctx *ctx, const uint8_t *codes, const uint32_t *packed, const uint64_t *code_begin,
+                             const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
+                             const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs)
 {
     SKL_TRY(ctx_bind(ctx));
     if (!code_begin || !offset_begin || !kmers || !out_signs) return fail(SKL_ERR_INVALID_ARG, "null argument");
     if (n_samples == 0 || nk == 0) return SKL_OK;
     if (num_bins == 0) return fail(SKL_ERR_INVALID_ARG, "num_bins is zero");
     const uint64_t n_codes = code_begin[n_samples], n_offs = offset_begin[n_samples];
-    if ((n_codes && !codes) || (n_offs && !offsets)) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if ((n_codes && !codes && !packed) || (n_offs && !offsets)) return fail(SKL_ERR_INVALID_ARG, "null argument");
     static const uint64_t seeds_f[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x295549f54be24456ull,
                                         0x20323ed082572324ull};   // src/hashing/nthash_tables.rs:4-16
     std::vector<uint32_t> k32(nk);
@@ -54,66 +114,163 @@ extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64
     for (size_t ki = 0; ki < nk; ++ki) kmax = std::max(kmax, kmers[ki]);
     const bool lds_form = kmax <= (size_t)sketch_span_lds() + 1 && !ctx->knobs.sketch_global;
     const uint64_t span = (uint64_t)(lds_form ? sketch_span_lds() : sketch_span());
-    std::vector<uint64_t> span_begin(n_samples + 1, 0);
+    const uint64_t wg = lds_form ? (uint64_t)sketch_wg_lds() : 256u;
+    std::vector<uint64_t> span_begin(n_samples + 1, 0), word_begin(n_samples + 1, 0);
     for (size_t s = 0; s < n_samples; ++s) {
         if (code_begin[s + 1] < code_begin[s] || offset_begin[s + 1] < offset_begin[s]) {
             return fail(SKL_ERR_INVALID_ARG, "sample ranges must not decrease");
         }
-        uint64_t spans = (code_begin[s + 1] - code_begin[s] + span - 1) / span;
-        if (lds_form) spans = (spans + (uint64_t)sketch_wg_lds() - 1) / (uint64_t)sketch_wg_lds() * (uint64_t)sketch_wg_lds();   // whole workgroups per sample
+        const uint64_t len = code_begin[s + 1] - code_begin[s];
+        uint64_t spans = (len + span - 1) / span;
+        spans = (spans + wg - 1) / wg * wg;   // whole workgroups per sample (the staged kernel needs it; batches of samples then
+                                              // start on workgroup boundaries in either form)
         span_begin[s + 1] = span_begin[s] + spans;
+        word_begin[s + 1] = word_begin[s] + (len + 15) / 16;
     }
-    DevBuf d_codes, d_cb, d_offs, d_ob, d_sb, d_k, d_tf, d_tr, d_signs;
-    auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
-        HIP_TRY(hipMalloc(&b.p, std::max<size_t>(bytes, 16)));
-        if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return SKL_OK;
+    const uint64_t total_words = word_begin[n_samples];
+    const size_t sign_words = n_samples * nk * num_bins;
+    // device buffers of the context: packed codes | signs | the small arrays
+    void *d_packed = nullptr, *d_signs = nullptr, *d_small = nullptr;
+    SKL_TRY(ctx_scratch(ctx, std::max<uint64_t>(total_words, 4) * sizeof(uint32_t), &d_packed, 12));
+    SKL_TRY(ctx_scratch(ctx, sign_words * sizeof(uint64_t), &d_signs, 13));
+    const size_t small_words = 4 * (n_samples + 1) + n_offs + 9 * nk + 8;   // u64 each (the k-mer lengths: two per word)
+    SKL_TRY(ctx_scratch(ctx, small_words * sizeof(uint64_t), &d_small, 14));
+    std::vector<uint64_t> small;
+    small.reserve(small_words);
+    auto put = [&](const uint64_t *v, size_t count) {
+        const size_t at = small.size();
+        small.insert(small.end(), v, v + count);
+        return at;
     };
-    SKL_TRY(upload(d_codes, codes, n_codes));
-    SKL_TRY(upload(d_cb, code_begin, (n_samples + 1) * sizeof(uint64_t)));
-    SKL_TRY(upload(d_offs, offsets, n_offs * sizeof(uint64_t)));
-    SKL_TRY(upload(d_ob, offset_begin, (n_samples + 1) * sizeof(uint64_t)));
-    SKL_TRY(upload(d_sb, span_begin.data(), (n_samples + 1) * sizeof(uint64_t)));
-    SKL_TRY(upload(d_k, k32.data(), nk * sizeof(uint32_t)));
-    SKL_TRY(upload(d_tf, top_f.data(), top_f.size() * sizeof(uint64_t)));
-    SKL_TRY(upload(d_tr, top_r.data(), top_r.size() * sizeof(uint64_t)));
-    const size_t sign_bytes = n_samples * nk * num_bins * sizeof(uint64_t);
-    HIP_TRY(hipMalloc(&d_signs.p, sign_bytes));
-    HIP_TRY(hipMemsetAsync(d_signs.p, 0xFF, sign_bytes, ctx->stream));   // u64::MAX
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // pageable uploads done before the vectors die
+    const size_t at_cb = put(code_begin, n_samples + 1), at_ob = put(offset_begin, n_samples + 1), at_sb = put(span_begin.data(), n_samples + 1);
+    const size_t at_wb = put(word_begin.data(), n_samples), at_offs = put(offsets, n_offs);
+    const size_t at_tf = put(top_f.data(), top_f.size()), at_tr = put(top_r.data(), top_r.size());
+    const size_t at_k = small.size();
+    small.resize(at_k + (nk + 1) / 2, 0);
+    memcpy(small.data() + at_k, k32.data(), nk * sizeof(uint32_t));
+    if (small.size() > small_words) return fail(SKL_ERR_INVALID_ARG, "internal: small-array layout");
+    HIP_TRY(hipMemcpyAsync(d_small, small.data(), small.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_signs, 0xFF, sign_words * sizeof(uint64_t), ctx->stream));   // u64::MAX
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // (`small` is pageable: uploaded before it dies; the aux stream starts behind this)
 
     SketchArgs a;
     memset(&a, 0, sizeof a);
-    a.codes = (const uint8_t *)d_codes.p;
-    a.code_begin = (const uint64_t *)d_cb.p;
-    a.offsets = (const uint64_t *)d_offs.p;
-    a.offset_begin = (const uint64_t *)d_ob.p;
-    a.span_begin = (const uint64_t *)d_sb.p;
-    a.n_spans = span_begin[n_samples];
+    const uint64_t *ds = (const uint64_t *)d_small;
+    a.packed = (const uint32_t *)d_packed;
+    a.word_begin = ds + at_wb;
+    a.code_begin = ds + at_cb;
+    a.offsets = ds + at_offs;
+    a.offset_begin = ds + at_ob;
+    a.span_begin = ds + at_sb;
     a.n_samples = (uint32_t)n_samples;
     a.nk = (uint32_t)nk;
-    a.kmers = (const uint32_t *)d_k.p;
-    a.top_f = (const uint64_t *)d_tf.p;
-    a.top_r = (const uint64_t *)d_tr.p;
+    a.kmers = (const uint32_t *)(ds + at_k);
+    a.top_f = ds + at_tf;
+    a.top_r = ds + at_tr;
     a.num_bins = num_bins;
     const uint64_t sign_mod = (1ull << 61) - 1;
     a.bin_size = (sign_mod + num_bins - 1) / num_bins;   // SIGN_MOD.div_ceil(num_bins), sketch/mod.rs:170
     a.inv_bin_size = 1.0 / (double)a.bin_size;
     a.rc = rc ? 1 : 0;
-    a.signs = (uint64_t *)d_signs.p;
+    a.signs = (uint64_t *)d_signs;
     a.lds_form = lds_form ? 1u : 0u;
-    {   // bracketed like the pair kernels, so skl_ctx_kernel_ms() reports it
-        std::pair<hipEvent_t, hipEvent_t> *ev = timing_slot(ctx);
-        if (ev) HIP_TRY(hipEventRecord(ev->first, ctx->stream));
+
+    // batches of whole samples, ~8 Mi words (128 Mi bases) each
+    constexpr uint64_t BATCH_WORDS = 8ull << 20;
+    std::vector<size_t> cuts{0};
+    for (size_t s = 0; s < n_samples; ++s) {
+        if (word_begin[s + 1] - word_begin[cuts.back()] >= BATCH_WORDS && s + 1 < n_samples) cuts.push_back(s + 1);
+    }
+    cuts.push_back(n_samples);
+    const size_t n_batches = cuts.size() - 1;
+    // one-byte codes: packed on host threads into a pinned ring of two batches (grow-only, kept by the context)
+    uint64_t ring_words = 0;
+    if (!packed) {
+        for (size_t b = 0; b < n_batches; ++b) ring_words = std::max(ring_words, word_begin[cuts[b + 1]] - word_begin[cuts[b]]);
+        if (ctx->pinned_words < 2 * ring_words) {
+            if (ctx->pinned) HIP_TRY(hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_words = 0;
+            HIP_TRY(hipHostMalloc((void **)&ctx->pinned, std::max<uint64_t>(2 * ring_words, 4) * sizeof(uint32_t), hipHostMallocDefault));
+            ctx->pinned_words = 2 * ring_words;
+        }
+    }
+    std::vector<hipEvent_t> ev(3 * n_batches, nullptr);   // per batch: uploaded, hashed, (ring slot) free again
+    struct EventGuard {
+        std::vector<hipEvent_t> &e;
+        ~EventGuard() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } guard{ev};
+    for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const unsigned pack_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto upload = [&](size_t b) -> int {
+        const size_t s0 = cuts[b], s1 = cuts[b + 1];
+        const uint64_t w0 = word_begin[s0], words = word_begin[s1] - w0;
+        if (words == 0) {
+            HIP_TRY(hipEventRecord(ev[3 * b], ctx->aux_stream));
+            return SKL_OK;
+        }
+        const uint32_t *src;
+        if (packed) {
+            src = packed + w0;
+        } else {
+            uint32_t *slot = ctx->pinned + (b & 1) * ring_words;
+            if (b >= 2) HIP_TRY(hipEventSynchronize(ev[3 * (b - 2) + 2]));   // that slot's previous upload has left it
+            pack_samples(codes, code_begin, word_begin, s0, s1, slot, pack_threads);
+            src = slot;
+        }
+        HIP_TRY(hipMemcpyAsync((uint32_t *)d_packed + w0, src, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->aux_stream));
+        HIP_TRY(hipEventRecord(ev[3 * b], ctx->aux_stream));
+        HIP_TRY(hipEventRecord(ev[3 * b + 2], ctx->aux_stream));
+        return SKL_OK;
+    };
+    auto launch = [&](size_t b) -> int {
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[3 * b], 0));
+        a.first_span = span_begin[cuts[b]];
+        a.n_spans = span_begin[cuts[b + 1]] - a.first_span;
+        std::pair<hipEvent_t, hipEvent_t> *tev = timing_slot(ctx);   // (bracketed like the pair kernels, batch by batch)
+        if (tev) HIP_TRY(hipEventRecord(tev->first, ctx->stream));
         HIP_TRY(launch_sketch_signs(a, ctx->stream));
-        if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
+        if (tev) HIP_TRY(hipEventRecord(tev->second, ctx->stream));
+        HIP_TRY(hipEventRecord(ev[3 * b + 1], ctx->stream));
+        return SKL_OK;
+    };
+    auto download = [&](size_t b) -> int {   // (a copy into pageable memory blocks its caller: issued after the next batch's launch)
+        const size_t s0 = cuts[b], s1 = cuts[b + 1];
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ev[3 * b + 1], 0));
+        HIP_TRY(hipMemcpyAsync(out_signs + s0 * nk * num_bins, (const uint64_t *)d_signs + s0 * nk * num_bins,
+                               (s1 - s0) * nk * num_bins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->aux_stream));
+        return SKL_OK;
+    };
+    SKL_TRY(upload(0));
+    SKL_TRY(launch(0));
+    for (size_t b = 0; b < n_batches; ++b) {
+        if (b + 1 < n_batches) {
+            SKL_TRY(upload(b + 1));
+            SKL_TRY(launch(b + 1));
+        }
+        SKL_TRY(download(b));
     }
     ctx->last_kernel = lds_form ? "skl::nthash_binmin_lds_kernel (bases staged in LDS as 2-bit codes, 128 window starts per thread, rolling "
                                   "canonical ntHash through a fused 16-entry step table, bin minima in LDS)"
                                 : "skl::nthash_binmin_kernel (256 window starts per thread, rolling canonical ntHash, atomicMin per bin)";
-    HIP_TRY(hipMemcpyAsync(out_signs, d_signs.p, sign_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SKL_OK;
+}
+
+extern "C" int skl_sketch_signs(skl_ctx *ctx, const uint8_t *codes, const uint64_t *code_begin,
+                                const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
+                                const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs)
+{
+    return sketch_signs_impl(ctx, codes, nullptr, code_begin, offsets, offset_begin, n_samples, kmers, nk, num_bins, rc, out_signs);
+}
+
+extern "C" int skl_sketch_signs_packed(skl_ctx *ctx, const uint32_t *packed, const uint64_t *code_begin,
+                                       const uint64_t *offsets, const uint64_t *offset_begin, size_t n_samples,
+                                       const size_t *kmers, size_t nk, uint64_t num_bins, int rc, uint64_t *out_signs)
+{
+    if (!packed && code_begin && n_samples && code_begin[n_samples]) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    return sketch_signs_impl(ctx, nullptr, packed, code_begin, offsets, offset_begin, n_samples, kmers, nk, num_bins, rc, out_signs);
 }
 
 // The last step of a candidate-list call: the per-row selection of rows [r, r + rows) -- `launch(first_row, rows)` --

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -89,23 +90,45 @@ MultiSketch sketch_files_gpu(Device &dev, const std::string &output_prefix, cons
             ++b1;
         }
         const size_t nb = b1 - b0;
-        std::unique_ptr<uint8_t[]> codes(new uint8_t[std::max<uint64_t>(codes_in_batch, 1)]);   // not zero-filled
-        std::vector<uint64_t> code_begin(nb + 1, 0), offset_begin(nb + 1, 0), offsets;
+        // the bases at 2 bits each, 16 per word, every sample on a word boundary (skl_sketch_signs_packed): a quarter of the
+        // bytes to gather here and to send over PCIe
+        std::vector<uint64_t> code_begin(nb + 1, 0), word_begin(nb + 1, 0), offset_begin(nb + 1, 0), offsets;
         for (size_t i = 0; i < nb; ++i) {
             const Sequence &s = seqs[b0 + i];
             code_begin[i + 1] = code_begin[i] + s.codes.size();
+            word_begin[i + 1] = word_begin[i] + (s.codes.size() + 15) / 16;
             offsets.insert(offsets.end(), s.offsets.begin(), s.offsets.end());
             offset_begin[i + 1] = offsets.size();
         }
+        std::unique_ptr<uint32_t[]> packed(new uint32_t[std::max<uint64_t>(word_begin[nb], 1)]);   // not zero-filled
         parallel_for(nb, threads, [&](size_t i) {
-            const Sequence &s = seqs[b0 + i];
-            std::copy(s.codes.begin(), s.codes.end(), codes.get() + code_begin[i]);
+            const std::vector<uint8_t> &c = seqs[b0 + i].codes;
+            uint32_t *out = packed.get() + word_begin[i];
+            const size_t whole = c.size() / 16;
+            for (size_t w = 0; w < whole; ++w) {
+                uint64_t lo, hi;
+                memcpy(&lo, c.data() + 16 * w, 8);
+                memcpy(&hi, c.data() + 16 * w + 8, 8);
+                auto squeeze = [](uint64_t v) -> uint32_t {   // 8 bytes of 2 significant bits -> 16 bits
+                    v &= 0x0303030303030303ull;
+                    v = (v | (v >> 6)) & 0x000F000F000F000Full;
+                    v = (v | (v >> 12)) & 0x000000FF000000FFull;
+                    v = (v | (v >> 24)) & 0xFFFFull;
+                    return (uint32_t)v;
+                };
+                out[w] = squeeze(lo) | (squeeze(hi) << 16);
+            }
+            if (c.size() % 16) {
+                uint32_t word = 0;
+                for (size_t x = 16 * whole; x < c.size(); ++x) word |= (uint32_t)(c[x] & 3u) << (2u * (uint32_t)(x - 16 * whole));
+                out[whole] = word;
+            }
         });
         std::vector<uint64_t> signs(nb * nk * num_bins);
         const double t0 = since();
         t_pack += t0 - (t_parse + t_pack + t_gpu + t_finish);
-        const int rc_ = skl_sketch_signs(dev.ctx(), codes.get(), code_begin.data(), offsets.data(), offset_begin.data(),
-                                         nb, kmers.data(), nk, num_bins, rc ? 1 : 0, signs.data());
+        const int rc_ = skl_sketch_signs_packed(dev.ctx(), packed.get(), code_begin.data(), offsets.data(), offset_begin.data(),
+                                                nb, kmers.data(), nk, num_bins, rc ? 1 : 0, signs.data());
         if (rc_ != SKL_OK) throw std::runtime_error(skl_last_error());
         t_gpu += since() - t0;
         // 3. densify + transpose (host threads)

@@ -242,8 +242,10 @@ hipError_t launch_pair_cand(const CandArgs &c, const PairArgs &g, hipStream_t st
 
 // GPU sketching (sketch_kernel.hip): bin minima of the canonical ntHash of every valid k-mer.
 struct SketchArgs {
-    const uint8_t *codes;          // 2-bit base codes, one byte each, all samples concatenated
-    const uint64_t *code_begin;    // [n_samples + 1]
+    const uint32_t *packed;        // 2-bit base codes, 16 per word (code c of a sample at bits 2 (c % 16) of its word c / 16)
+    const uint64_t *word_begin;    // [n_samples] first word of each sample (a sample's last word is zero-padded)
+    uint64_t first_span;           // this launch handles spans first_span .. first_span + n_spans - 1 (a batch of samples)
+    const uint64_t *code_begin;    // [n_samples + 1] in codes: sample s has code_begin[s + 1] - code_begin[s] of them
     const uint64_t *offsets;       // breaks (N / record ends) in each sample's own coordinates
     const uint64_t *offset_begin;  // [n_samples + 1]
     const uint64_t *span_begin;    // [n_samples + 1] prefix sum of ceil(len / span) per sample

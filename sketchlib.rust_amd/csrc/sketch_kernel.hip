@@ -46,8 +46,8 @@ constexpr int SKETCH_SPAN = 256;   // window starts per thread
 
 __global__ __launch_bounds__(256) void nthash_binmin_kernel(const SketchArgs g)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.n_spans) return;
+    if ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x >= g.n_spans) return;
+    const uint64_t t = g.first_span + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // span -> sample: span_begin is the prefix sum of spans per sample
     uint32_t lo = 0, hi = g.n_samples;
     while (hi - lo > 1u) {
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void nthash_binmin_kernel(const SketchArgs g)
     const uint64_t code0 = g.code_begin[sample], n_codes = g.code_begin[sample + 1] - code0;
     const uint64_t *offs = g.offsets + g.offset_begin[sample];
     const uint32_t n_offs = (uint32_t)(g.offset_begin[sample + 1] - g.offset_begin[sample]);
-    const uint8_t *codes = g.codes + code0;
+    const uint32_t *pk = g.packed + g.word_begin[sample];
+    auto codes = [&](uint64_t x) -> uint32_t { return (pk[x >> 4] >> ((uint32_t)(x & 15u) * 2u)) & 3u; };
+    (void)code0;
     const uint64_t p0 = (t - g.span_begin[sample]) * SKETCH_SPAN;
     const uint64_t p1 = p0 + SKETCH_SPAN < n_codes ? p0 + SKETCH_SPAN : n_codes;
 
@@ -92,15 +94,15 @@ __global__ __launch_bounds__(256) void nthash_binmin_kernel(const SketchArgs g)
                 continue;
             }
             if (have) {
-                const uint32_t old_b = codes[s - 1], new_b = codes[s + k - 1];
+                const uint32_t old_b = codes(s - 1), new_b = codes(s + k - 1);
                 fh = srol(fh ^ top_f[old_b]) ^ hash_fwd(new_b);
                 if (g.rc) rh = sror(rh ^ hash_rc(old_b)) ^ top_r[new_b];
             } else {
                 fh = 0;
                 rh = 0;
-                for (uint32_t i = 0; i < k; ++i) fh = srol(fh) ^ hash_fwd(codes[s + i]);
+                for (uint32_t i = 0; i < k; ++i) fh = srol(fh) ^ hash_fwd(codes(s + i));
                 if (g.rc) {
-                    for (uint32_t i = k; i-- > 0;) rh = srol(rh) ^ hash_rc(codes[s + i]);
+                    for (uint32_t i = k; i-- > 0;) rh = srol(rh) ^ hash_rc(codes(s + i));
                 }
                 have = true;
             }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(WG2) void nthash_binmin_lds_kernel(const SketchArgs
     __shared__ uint4 tabs[16];                 // {Tf.lo, Tf.hi, Tr.lo, Tr.hi} by (old << 2) | new, for the current k-mer length
     __shared__ unsigned long long lbins[LDS_BINS ? LDS_BINS_MAX : 1];
     const uint32_t tid = threadIdx.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * WG2;   // first span of this workgroup
+    const uint64_t t0 = g.first_span + (uint64_t)blockIdx.x * WG2;   // first span of this workgroup
     uint32_t lo = 0, hi = g.n_samples;
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -166,30 +168,16 @@ __global__ __launch_bounds__(WG2) void nthash_binmin_lds_kernel(const SketchArgs
     const uint64_t code0 = g.code_begin[sample], n_codes = g.code_begin[sample + 1] - code0;
     const uint64_t *offs = g.offsets + g.offset_begin[sample];
     const uint32_t n_offs = (uint32_t)(g.offset_begin[sample + 1] - g.offset_begin[sample]);
-    const uint8_t *codes = g.codes + code0;
-    const uint64_t wg0 = (t0 - g.span_begin[sample]) * SPAN2;   // first base of the workgroup
+    const uint32_t *pk = g.packed + g.word_begin[sample];
+    (void)code0;
+    const uint64_t wg0 = (t0 - g.span_begin[sample]) * SPAN2;   // first base of the workgroup (a multiple of 16: whole words)
     if (wg0 >= n_codes) return;                                // (padding spans of the sample)
     const uint64_t wg1 = wg0 + (uint64_t)ROWS2 * SPAN2 < n_codes ? wg0 + (uint64_t)ROWS2 * SPAN2 : n_codes;
     const uint32_t n_staged = (uint32_t)(wg1 - wg0);
-    // stage: one packed dword (16 codes) per thread and trip
+    // stage: one packed dword (16 codes) per thread and trip, as the host packed them (round 5: the bases cross PCIe at 2
+    // bits each; a sample's last word is zero-padded and words past it are not read)
     for (uint32_t d = tid; d < (uint32_t)ROWS2 * (SPAN2 / 16); d += WG2) {
-        uint32_t word = 0;
-        const uint32_t x0 = d * 16u;
-        if (x0 < n_staged) {
-            const uint8_t *src = codes + wg0 + x0;
-            const uint32_t m = n_staged - x0 < 16u ? n_staged - x0 : 16u;
-            if (m == 16u && (((uintptr_t)src) & 3u) == 0u) {
-                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);   // (4-byte aligned)
-                const uint32_t w4[4] = {s32[0], s32[1], s32[2], s32[3]};
-#pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) {
-                    const uint32_t v = w4[c] & 0x03030303u;              // four codes, one per byte
-                    word |= ((v & 3u) | ((v >> 6) & 0xCu) | ((v >> 12) & 0x30u) | ((v >> 18) & 0xC0u)) << (8u * c);
-                }
-            } else {
-                for (uint32_t c = 0; c < m; ++c) word |= (uint32_t)(src[c] & 3u) << (2u * c);
-            }
-        }
+        const uint32_t word = d * 16u < n_staged ? pk[(wg0 >> 4) + d] : 0u;
         staged[(d >> 3) * PITCH2_DW + (d & 7u)] = word;
     }
     if (LDS_BINS) {

@@ -134,3 +134,32 @@ def test_both_kernel_forms_and_bin_counts(skl, gpu_ctx, monkeypatch, num_bins):
         assert np.array_equal(got[s_, 1], oracle_signs(codes, offsets, 31, num_bins, True)), s_
         assert np.array_equal(got[s_, 2], oracle_signs(codes, offsets, 129, num_bins, True)), s_
         assert np.array_equal(big_k[s_, 0], oracle_signs(codes, offsets, 130, num_bins, True)), s_
+
+
+def test_packed_form_and_several_batches(skl, gpu_ctx):
+    """skl_sketch_signs_packed (bases at 2 bits each, every sample on a word boundary, ragged last words) equals the
+    one-byte form, which the library packs itself -- over enough bases for several upload batches (8 Mi words each), so
+    that batch i + 1's upload really runs under batch i's kernel and the pinned two-slot ring is reused."""
+    rng = np.random.default_rng(23)
+    lengths = [45_000_007, 31, 16, 17, 38_000_001, 52_000_003, 5, 44_000_000, 41_234_567, 12_345]     # ~220 M bases: several batches
+    samples = []
+    for ln in lengths:
+        codes = rng.integers(0, 4, size=ln, dtype=np.uint8)
+        cuts = np.sort(rng.choice(np.arange(1, max(ln, 2)), size=min(5, max(ln // 3, 0)), replace=False)).astype(np.int64) if ln > 3 else np.zeros(0, np.int64)
+        samples.append((codes, cuts))
+    kmers, num_bins = [15, 31], 4096
+    codes, cb, offs, ob = pack(samples)
+    byte_form = skl.sketch_signs(gpu_ctx, codes, cb, offs, ob, kmers, num_bins, True)
+    packed = skl.pack_codes(codes, cb)
+    assert packed.size == sum((ln + 15) // 16 for ln in lengths)
+    packed_form = skl.sketch_signs_packed(gpu_ctx, packed, cb, offs, ob, kmers, num_bins, True)
+    assert np.array_equal(byte_form, packed_form)
+    again = skl.sketch_signs(gpu_ctx, codes, cb, offs, ob, kmers, num_bins, True)      # (buffers and the ring reused)
+    assert np.array_equal(again, byte_form)
+    for s_ in (1, 2, 3, 6, 9):      # the short samples against the oracle sketcher
+        for ki, k in enumerate(kmers):
+            assert np.array_equal(byte_form[s_, ki], oracle_signs(*samples[s_], k, num_bins, True)), (s_, k)
+    # a long one: its first megabase on its own must give bin minima >= the whole sample's (a subset of its windows)
+    head = (samples[0][0][:1_000_000], samples[0][1][samples[0][1] < 1_000_000])
+    part = oracle_signs(*head, 15, num_bins, True)
+    assert np.all(byte_form[0, 0] <= part)
