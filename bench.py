@@ -907,7 +907,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
                            "pair_kernel_s": ksec, "pair_kernel_launches": n_launch, "other_s (top-k merge, copies)": wall - ksec,
                            "tile_pruning": {"tiles": tiles5, "tiles_left_early": pruned5,
                                             "what": "a 32 x 128 tile all of whose pairs are, on the chunks walked so far, beyond both samples' "
-                                                    "current knn-th best is left unfinished (same lists; SKL_KNN_PRUNE=0 walks every tile)"},
+                                                    "current knn-th best is left unfinished (same lists; the A/B build's SKL_KNN_PRUNE=0 walks every tile)"},
                            "valu_frac_note": "counted on ALL pairs of the triangle at the full walk's cost, although pruned tiles are not finished: "
                                              "a rate of useful answers, not of instructions issued",
                            "valu_frac": v5["frac"], "valu_frac_at_in_kernel_clock": v5.get("frac_at_in_kernel_clock"),

@@ -11,6 +11,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# (the switches this script flips are "A/B only": read by the A/B build of the library alone)
+os.environ.setdefault("SKL_LIBRARY", os.path.join(ROOT, "sketchlib.rust_amd", "csrc", "_build_ab", "libsketchlib_dist_hip.so"))
 import torch  # noqa: E402
 
 from sketchlib.rust_amd import capi, synth  # noqa: E402

@@ -7,6 +7,10 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
+# (round 5: "A/B only" switches -- SKL_ROUND_PRIORITY, SKL_KNN_ROW_FLAGS, SKL_CAND_ROW_ORDER ... -- are read by the A/B library
+# alone, so the whole suite runs against that build: the product library + the switches)
+export SKL_LIBRARY="$R/sketchlib.rust_amd/csrc/_build_ab/libsketchlib_dist_hip.so"
+python3 -c "import sketchlib.rust_amd as pkg; pkg.build_ab_library()" || exit 1
 FIRST=${1:-1}
 LAST=${2:-99}
 I=0

@@ -335,24 +335,27 @@ static long long env_int(const char *name, long long dflt)
 Knobs read_knobs()
 {
     Knobs k;
+    // The product library reads EIGHT switches: the timing cadence, the device topology the tile order assumes, and the knobs
+    // with which the tests force the banded / sliced / 32-row forms on inputs small enough for the oracle.  Everything that
+    // exists only to time one form against another ("A/B only, results identical") is read by the A/B build alone (-DSKL_AB),
+    // where scripts/ab_sweep.py, scripts/forced_switch_suites.sh and the tests marked `ab_library` find it.
     k.timing_every = std::max(0ll, env_int("SKL_TIMING_EVERY", 0));
     k.sliced_max_pairs = env_int("SKL_SLICED_MAX_PAIRS", -1);
     k.knn_band_rows = std::max(0ll, env_int("SKL_KNN_BAND_ROWS", 0));
-    k.k_slices = (int)env_int("SKL_K_SLICES", 0);
     k.tail_slices = (int)std::min(8ll, std::max(0ll, env_int("SKL_TAIL_SLICES", 4)));
     k.tail_max_pct = env_int("SKL_TAIL_MAX_PCT", 90);
-    k.round_priority = env_int("SKL_ROUND_PRIORITY", 1) != 0;
-    k.half_tiles = env_int("SKL_HALF_TILES", 1) != 0;
     k.tile32_min = env_int("SKL_TILE32_MIN", 8ll << 20);
-    k.mid_band = env_int("SKL_MID_BAND", 1) != 0;
     k.group_span = (int)std::min(64ll, std::max(1ll, env_int("SKL_GROUP_SPAN", 2)));
     k.xcds = (int)std::min(8ll, std::max(0ll, env_int("SKL_XCDS", 0)));
+#ifdef SKL_AB
+    k.k_slices = (int)env_int("SKL_K_SLICES", 0);
+    k.round_priority = env_int("SKL_ROUND_PRIORITY", 1) != 0;
+    k.half_tiles = env_int("SKL_HALF_TILES", 1) != 0;
+    k.mid_band = env_int("SKL_MID_BAND", 1) != 0;
     k.knn_symmetric = env_int("SKL_KNN_SYMMETRIC", 1) != 0;
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.knn_prune = env_int("SKL_KNN_PRUNE", 1) != 0;
-#ifdef SKL_AB
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
-#endif
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
     k.topk_stream = env_int("SKL_TOPK_STREAM", 1) != 0;
@@ -365,7 +368,6 @@ Knobs read_knobs()
     k.inline_prefix = env_int("SKL_INLINE_PREFIX", 1) != 0;
     const char *sk = getenv("SKL_SKETCH_KERNEL");
     k.sketch_global = sk && strcmp(sk, "global") == 0;
-#ifdef SKL_AB
     // SKL_KERNEL = ksplit | kslice forces one implementation (0: dispatcher's choice)
     if (const char *e = getenv("SKL_KERNEL")) k.kernel = strcmp(e, "ksplit") == 0 ? 3 : strcmp(e, "kslice") == 0 ? 4 : 0;
     k.kslice_shape = (int)env_int("SKL_KSLICE_SHAPE", 0);

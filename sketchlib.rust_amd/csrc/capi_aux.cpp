@@ -385,8 +385,10 @@ static int knn_from_device_csr(skl_ctx *ctx, const skl_sketches *s, const skl_di
         HIP_TRY(launch_pair_cand(c, g, ctx->stream));
         if (ev) HIP_TRY(hipEventRecord(ev->second, ctx->stream));
     }
-    ctx->last_kernel = ctx->knobs.cand_lanes ? "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)"
-                                             : "skl::pair_cand_rows_kernel (row x 64 candidates per wave, one after the other, each read as one contiguous run)";
+    ctx->last_kernel = "skl::pair_cand_rows_kernel (row x 64 candidates per wave, one after the other, each read as one contiguous run)";
+#ifdef SKL_AB
+    if (ctx->knobs.cand_lanes) ctx->last_kernel = "skl::pair_cand_kernel (row x 64 candidates per wave, candidate gather from the reference layout)";
+#endif
     if (ctx->knn_ties == SKL_KNN_TIES_REFERENCE) {
         // The reference's tie order: its BinaryHeap replayed over each row's candidates IN THE ORDER THEY ARE LISTED
         // (mod.rs:459-487 pushes in the order Inverted::any_shared_bins returns them: ascending .ski index -- the

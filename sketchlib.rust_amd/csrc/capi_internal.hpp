@@ -38,9 +38,10 @@ SKL_INTERNAL int fail(int code, const char *fmt, ...);
 struct skl_sketches;
 
 // Environment switches.  They are read ONCE, when a context is created (skl_ctx_create), never on
-// the launch path.  The product library knows the few below (timing cadence for benchmarks, test
-// knobs that force the banded / sliced forms on small inputs, A/B of the kNN drivers); kernel
-// selection, tile shapes and timing-only ablations exist only in the A/B build (-DSKL_AB).
+// the launch path.  The product library READS eight of them (capi.cpp read_knobs: timing cadence, topology,
+// the knobs that force the banded / sliced / 32-row forms on small test inputs); every "A/B only, results
+// identical" switch below keeps its default there and is read by the A/B build alone (-DSKL_AB), as are kernel
+// selection, tile shapes and the timing-only ablations.
 struct Knobs {
     long long timing_every = 0;       // SKL_TIMING_EVERY: bracket every N-th pair-kernel launch with events (0: none; skl_ctx_timing_enable overrides)
     long long sliced_max_pairs = -1;  // SKL_SLICED_MAX_PAIRS: core/acc launches below this run k-sliced (-1: default)

@@ -17,6 +17,7 @@ namespace skl {
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr_c;
 
+#ifdef SKL_AB   // (round 3's form, SKL_CAND_KERNEL=lanes: A/B build only)
 __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const CandArgs c, const PairArgs g)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG) void pair_cand_kernel(const Ca
         }
     }
 }
+#endif
 
 // Round 4: the same work item -- a row and up to 64 of its candidates -- with the LANES ACROSS THE SKETCH instead of across the
 // candidates.  The form above has every lane walk its own candidate, 112 bytes per chunk: a wave's request is 64 scattered
@@ -191,9 +193,12 @@ hipError_t launch_pair_cand(const CandArgs &c_in, const PairArgs &g, hipStream_t
     c.blocks_per_xcd = (uint32_t)((blocks + (1ull << c.xcd_shift) - 1) >> c.xcd_shift);
     const uint64_t grid = (uint64_t)c.blocks_per_xcd << c.xcd_shift;
     if (grid >= (1ull << 31)) return hipErrorInvalidValue;
+#ifdef SKL_AB
     if (c.lanes_over_candidates) {
         hipLaunchKernelGGL(pair_cand_kernel, dim3((unsigned)grid), dim3(LANES * WAVES_PER_WG), 0, stream, c, g);
-    } else {
+    } else
+#endif
+    {
         const dim3 gr((unsigned)grid), bl(LANES * WAVES_PER_WG);
         switch ((g.ss64 + 31u) / 32u) {      // trips of 32 chunks
             case 1: hipLaunchKernelGGL(pair_cand_rows_kernel<1>, gr, bl, 0, stream, c, g); break;

@@ -15,7 +15,8 @@ N_REF, N_QUERY, KNN = 2000, 500, 50
 
 
 @pytest.fixture(scope="module")
-def dbs(oracle, skl, gpu_ctx):
+def dbs(oracle, skl, _product_ctx):
+    gpu_ctx = _product_ctx
     # refs and queries drawn from the same 25 clusters (sample s is in cluster s % 25), so a query has
     # ~80 related references with a real regression and ~1 900 unrelated ones at (1, 1)
     rb = synth.set_r(N_REF, K4, SS64, n_clusters=25)

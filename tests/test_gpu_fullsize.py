@@ -23,7 +23,8 @@ def make_related(n, n_clusters=40, chunk=500):
 
 
 @pytest.fixture(scope="module")
-def cfg2(oracle, skl, gpu_ctx):
+def cfg2(oracle, skl, _product_ctx):
+    gpu_ctx = _product_ctx
     n = 1000
     bins = make_related(n)
     bins[777] = bins[3]          # exact duplicates: J = 1 at every k

@@ -76,15 +76,15 @@ VARIANTS = [
     ({"SKL_TAIL_SLICES": "0"}, "k-sliced"),                        # one workgroup per (tile, k)
     ({"SKL_TAIL_SLICES": "2"}, "2 chunk slices"),
     ({"SKL_SLICED_MAX_PAIRS": "0"}, "all k"),                      # all-k fused form
-    ({"SKL_K_SLICES": "1"}, "k-sliced"),                           # k-sliced, whole k-mer lengths
+    ({**AB, "SKL_K_SLICES": "1"}, "k-sliced"),                     # k-sliced, whole k-mer lengths (the uniform slices: an A/B switch)
     ({"SKL_TILE32_MIN": "0"}, "R=32, JL=2, COUNTS, k-sliced"),     # 32 x 128 tiles (large launches' shape)
     ({"SKL_TILE32_MIN": "0", "SKL_SLICED_MAX_PAIRS": "0"}, "R=32, JL=2, COREACC, all k"),
     ({"SKL_GROUP_SPAN": "1"}, "k-sliced"),                         # tile numbering: column group by column group
     ({"SKL_GROUP_SPAN": "3", "SKL_TAIL_SLICES": "0"}, "k-sliced"), # ... 3 groups side by side (default: 2)
     ({"SKL_GROUP_SPAN": "4"}, "k-sliced"),
-    ({"SKL_K_SLICES": "2"}, "k-sliced"),                           # ... cut into 2 / 4 / 8 chunk slices
-    ({"SKL_K_SLICES": "4"}, "k-sliced"),
-    ({"SKL_K_SLICES": "8"}, "k-sliced"),
+    ({**AB, "SKL_K_SLICES": "2"}, "k-sliced"),                     # ... cut into 2 / 4 / 8 chunk slices
+    ({**AB, "SKL_K_SLICES": "4"}, "k-sliced"),
+    ({**AB, "SKL_K_SLICES": "8"}, "k-sliced"),
     # tile order for devices that show fewer than 8 XCDs (partitioned MI355X: the C ABI derives it from the CU count)
     ({"SKL_XCDS": "1"}, "4 chunk slices"),
     ({"SKL_XCDS": "2", "SKL_SLICED_MAX_PAIRS": "0"}, "all k"),

@@ -9,7 +9,7 @@ import pytest
 
 from sketchlib.rust_amd import synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.ab_library]   # (SKL_KNN_SYMMETRIC / SKL_KNN_PRUNE ...: switches of the A/B build)
 
 
 def _clustered(n, nk, ss64, n_clusters, keep=0.94):

@@ -9,7 +9,7 @@ import pytest
 
 from sketchlib.rust_amd import synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.ab_library]   # (SKL_KNN_SYMMETRIC / SKL_KNN_PRUNE ...: switches of the A/B build)
 
 TOL = 1e-6
 

@@ -104,6 +104,7 @@ def test_several_bands_and_row_ranges(oracle, skl, gpu_ctx, ref_ties, set_switch
     g.close()
 
 
+@pytest.mark.ab_library
 @pytest.mark.parametrize("dist", ["jaccard", "ani", "coreacc"])
 @pytest.mark.parametrize("knn,band,flags,wave", [(1, 48, "1", "1"), (7, 64, "1", "1"), (50, 100, "1", "1"), (7, 37, "0", "1"), (50, 64, "1", "0"),
                                                  (300, 96, "1", "1")])

@@ -77,6 +77,7 @@ def test_large_sketch_with_completeness(oracle, skl, gpu_ctx):
     g.close()
 
 
+@pytest.mark.ab_library
 @pytest.mark.parametrize("tile32", [False, True])
 def test_large_sketch_knn(oracle, skl, gpu_ctx, set_switch, tile32):
     """Self kNN (single k): the one-evaluation driver with its turned second store, several bands; cross kNN and

@@ -96,6 +96,7 @@ def test_default_rule_slices_launches_of_less_than_a_round(oracle, skl, gpu_ctx)
         assert ("chunk slices" in name) == expect, (n, name)
 
 
+@pytest.mark.ab_library
 @pytest.mark.parametrize("ss64,expect", [(12, None), (20, "3 chunk slices"), (37, "3 chunk slices"), (157, "7 chunk slices")])
 def test_any_sketch_size_is_cut_into_whole_stages(oracle, skl, gpu_ctx, set_switch, ss64, expect):
     """Round 4: slices of whole stages (multiples of 8 chunks), the last one shorter -- 20 chunks = 8 + 8 + 4, the 157

@@ -81,6 +81,7 @@ def test_synthetic_ragged_lists(oracle, skl, gpu_ctx, ani, comp):
             assert as_pairs(idx, d0) == oracle_pairs(exp)
 
 
+@pytest.mark.ab_library
 @pytest.mark.parametrize("ss64", [1, 3, 16, 24, 32, 50, 64, 80, 128, 157, 170])
 def test_candidate_kernels_at_many_sketch_sizes(oracle, skl, gpu_ctx, set_switch, ss64):
     """pair_cand_rows_kernel (lanes across the sketch: half chunks per lane; the row's planes stay in registers up to 32
@@ -131,6 +132,7 @@ def ref_ties(skl, gpu_ctx):
     gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
 
 
+@pytest.mark.ab_library
 @pytest.mark.parametrize("ani,wave", [(False, "1"), (True, "1"), (False, "0")])
 def test_reference_tie_order_over_candidate_lists(oracle, skl, gpu_ctx, ref_ties, set_switch, ani, wave):
     """skl_ctx_set_knn_ties(REFERENCE) on the candidate-list path: the reference's BinaryHeap replayed over each row's

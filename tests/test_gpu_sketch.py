@@ -107,6 +107,7 @@ def test_cli_gpu_sketch_4k_database_and_errors(gpu_ctx, tmp_path):
     assert res.returncode == cpu.returncode == 101 and "K-mer larger than smallest valid sequence" in res.stderr
 
 
+@pytest.mark.ab_library
 @pytest.mark.parametrize("num_bins", [1000, 5000])
 def test_both_kernel_forms_and_bin_counts(skl, gpu_ctx, monkeypatch, num_bins):
     """The LDS-staged kernel with bin minima in LDS (<= 4096 bins) and in global memory (more),
