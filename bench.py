@@ -195,6 +195,20 @@ def under_profiler():
     return any(k.startswith("ROCPROF") for k in os.environ)
 
 
+def interpreter_binary():
+    """The interpreter for child processes: sys.executable AS IT IS (a symlink is not an exec hop, and resolving it would
+    lose a virtualenv's pyvenv.cfg, i.e. its site-packages) -- provided it leads to an ELF binary, which is what may follow
+    `rocprofv3 ... --` on this pool; a wrapper script there falls back to the resolved path."""
+    exe = sys.executable
+    try:
+        with open(os.path.realpath(exe), "rb") as f:
+            if f.read(4) == b"\x7fELF":
+                return exe
+    except OSError:
+        pass
+    return os.path.realpath(exe)
+
+
 def valu_block(pairs_per_launch, avg_kernel_s, nk, ss64, clock):
     """roofline numbers of one launch shape: lane-operations the pairs need over the launch duration against
     the chip's VALU issue rate at the datasheet clock; beside it the same fraction at the clock the chip held
@@ -310,7 +324,7 @@ def measure_traffic(n, dataset, timeout_s=120):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                   os.path.realpath(sys.executable), os.path.abspath(__file__), "--traffic-probe", "--samples", str(n), "--dataset", dataset]
+                   interpreter_binary(), os.path.abspath(__file__), "--traffic-probe", "--samples", str(n), "--dataset", dataset]
             res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if res.returncode != 0 or not files:
@@ -348,7 +362,7 @@ def self_launch(n_gpus):
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    exe = os.path.realpath(sys.executable)
+    exe = interpreter_binary()
     cmd = [exe, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -877,7 +891,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
             ctx.set_knn_ties(capi.TIES_CANONICAL)   # (the library's default is the reference's order: timed below, beside this one)
             wall, ksec, n_launch, clk = timed(knn_call, 1, 1, 500, clock=False)   # (one untimed call first: it allocates the band buffers)
             idx, d0, _d1 = res[0]
-            tiles5, pruned5 = ctx.knn_prune_stats()
+            prune5 = ctx.knn_prune_stats(full=True)
             assert idx.shape == (nr, knn) and bool(np.all(np.diff(d0, axis=1) >= 0)) and not np.any(idx == np.arange(nr, dtype=np.uint64)[:, None])
             for i in (0, 77_777, nr - 1):     # three rows against the dense path, top-50 by (key, id)
                 dense = capi.cross_dists_rows(ctx, g_r, g_r, p5, i, i + 1)[0, :, 0]
@@ -905,12 +919,13 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
                                                    "what": "skl_ctx_set_knn_ties(REFERENCE), the CLI's default: ids and order of equal keys as the "
                                                            "reference binary prints them; same distances"},
                            "pair_kernel_s": ksec, "pair_kernel_launches": n_launch, "other_s (top-k merge, copies)": wall - ksec,
-                           "tile_pruning": {"tiles": tiles5, "tiles_left_early": pruned5,
+                           "tile_pruning": {**prune5,
                                             "what": "a 32 x 128 tile all of whose pairs are, on the chunks walked so far, beyond both samples' "
                                                     "current knn-th best is left unfinished (same lists; the A/B build's SKL_KNN_PRUNE=0 walks every tile)"},
-                           "valu_frac_note": "counted on ALL pairs of the triangle at the full walk's cost, although pruned tiles are not finished: "
-                                             "a rate of useful answers, not of instructions issued",
-                           "valu_frac": v5["frac"], "valu_frac_at_in_kernel_clock": v5.get("frac_at_in_kernel_clock"),
+                           "valu_frac_note": "valu_frac counts the bin comparisons actually MADE (the pairs' full cost x the share of the walk made); "
+                                             "valu_frac_as_if_every_pair_were_walked is the rate of answers against the same peak",
+                           "valu_frac": v5["frac"] * prune5["share_of_the_walk_made"],
+                           "valu_frac_as_if_every_pair_were_walked": v5["frac"], "valu_frac_at_in_kernel_clock": v5.get("frac_at_in_kernel_clock"),
                            "in_kernel_clock": clk, "rows_checked_against_dense": 3}
         if "cfg5ca" in which or "cfg5" in which:
             # cfg 5 as the reference's DEFAULT DistType runs it (`sketchlib dist db --knn 50` without -k: CoreAcc, mod.rs:25-37,

@@ -55,11 +55,12 @@ def main():
                     wall = time.perf_counter() - t0
                     kms, nl = ctx.kernel_ms()
                     ctx.timing_enable(0)
-                    tiles, pruned = ctx.knn_prune_stats()
+                    st = ctx.knn_prune_stats(full=True)
+                    tiles, pruned = st["tiles"], st["tiles_left_early"]
                     lists[prune] = (idx, d0)
                     row = {"n": n, "sketchsize64": ss64, "knn": args.knn, "ties": ties, "prune": prune == "1", "wall_s": wall,
                            "pair_kernel_s": kms / 1e3, "pair_kernel_launches": nl, "pair_distances_per_s": n * (n - 1) / wall,
-                           "tiles": tiles, "tiles_left_early": pruned, "kernel": ctx.last_kernel().split(" (")[0],
+                           "tiles": tiles, "tiles_left_early": pruned, "share_of_the_walk_made": st["share_of_the_walk_made"], "kernel": ctx.last_kernel().split(" (")[0],
                            "idx_checksum": int(idx.sum())}
                     if len(lists) == 2:
                         a, b = lists["1"], lists["0"]

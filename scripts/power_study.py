@@ -12,6 +12,10 @@ Variants (A/B library: it re-reads its switches at every call and contains the s
   tile16           16 x 128 tiles (SKL_TILE32_MIN=-1): twice the lane-slab bytes per pair
   no_hist          timing only: per-k totals not parked in private memory (SKL_KSLICE_ABLATE=16; outputs wrong)
   zeros            the shipped form on all-zero sketches: same instruction stream, no bit toggling in the datapath
+  c100 / c4 / c1   (round 5) the shipped form on RELATED genomes instead of random bits: samples drawn from 100 / 4 / 1
+                   clusters (a genome keeps each of its cluster's bin values with probability 0.97 ... 0.91 falling with k,
+                   so J inside a cluster is ~0.9 ... 0.7): 1 % / 25 % / 100 % of the pairs are related -- Set R's share, and
+                   what an all-vs-all over ONE species looks like (the reference's use case)
 """
 import argparse
 import json
@@ -34,7 +38,11 @@ VARIANTS = [
     ("tile16", {"SKL_TILE32_MIN": "-1"}, False),
     ("no_hist", {"SKL_KSLICE_ABLATE": "16"}, False),
     ("zeros", {}, True),
+    ("c100", {}, 100),
+    ("c4", {}, 4),
+    ("c1", {}, 1),
 ]
+KEEP = [0.97, 0.955, 0.94, 0.925, 0.91]
 
 
 def smi_power():
@@ -66,6 +74,7 @@ def main():
     from sketchlib.rust_amd import capi, synth
 
     n = args.samples
+    nq = 0
     want = args.variants.split(",")
     cfg4 = args.shape == "cfg4"
     ss = 32 if cfg4 else 64
@@ -75,6 +84,7 @@ def main():
         ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
         if cfg4:
             n, nq = 1_000_000, 10_000
+            args.samples = n
             sk = ctx.sketches(synth.set_u_device(n, 5, ss, dev), n, kmers, ss)
             q = ctx.sketches(synth.set_u_device(nq, 5, ss, dev, first_sample=10 ** 7), nq, kmers, ss)
             zeros = torch.zeros((n, 5 * ss * 14), dtype=torch.int64, device=dev)
@@ -92,9 +102,22 @@ def main():
             pairs = n * (n - 1) // 2
             out = torch.zeros((pairs, 2), dtype=torch.float32, device=dev)
 
+        related = {}      # n_clusters -> (slab, query slab | None), built on first use
+
+        def related_slabs(c):
+            if c not in related:
+                r = ctx.sketches(synth.set_clustered_device(n, 5, ss, dev, keep=KEEP, n_clusters=c), n, kmers, ss)
+                rq = ctx.sketches(synth.set_clustered_device(nq, 5, ss, dev, keep=KEEP, n_clusters=c, first_sample=10 ** 7), nq, kmers, ss) if cfg4 else None
+                related[c] = (r, rq)
+            return related[c]
+
         def launch(s, p):
             if cfg4:
-                capi.cross_dists_all(ctx, s, q0 if s is sk0 else q, p, out=out)
+                qs = q0 if s is sk0 else q
+                for r, rq in related.values():
+                    if s is r:
+                        qs = rq
+                capi.cross_dists_all(ctx, s, qs, p, out=out)
             else:
                 capi.self_dists_all(ctx, s, p, out=out)
 
@@ -107,7 +130,7 @@ def main():
                 for k in SWITCHES:
                     os.environ.pop(k, None)
                 os.environ.update(env)
-                s = sk0 if zero else sk
+                s = sk0 if zero is True else (sk if zero is False else related_slabs(zero)[0])
                 p = s.set_k()
                 launch(s, p)      # warm (and the clock settles)
                 ctx.synchronize()
@@ -146,7 +169,7 @@ def main():
                                   "pair_cycles": ksec * clk["ghz"] * 1e9 / pairs if clk["ghz"] else None}), flush=True)
         for k in SWITCHES:
             os.environ.pop(k, None)
-        for h in (sk, sk0, q, q0):
+        for h in [sk, sk0, q, q0] + [x for pair in related.values() for x in pair]:
             if h is not None:
                 h.close()
         ctx.close()

@@ -298,10 +298,12 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         ++it;
     }
     if (prune) {   // (read back with the call's last synchronisation: skl_ctx_knn_prune_stats)
-        uint32_t counted = 0;
-        HIP_TRY(hipMemcpyAsync(&counted, prune_stats, sizeof counted, hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t counted[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(counted, prune_stats, sizeof counted, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        ctx->knn_tiles_pruned += counted;
+        ctx->knn_tiles_pruned += counted[0];
+        ctx->knn_pruned_stages += (uint64_t)counted[2] | ((uint64_t)counted[3] << 32);
+        ctx->knn_tile_stages = (s->ss64 + 3) / 4;   // stages of a whole 32 x 128 tile: 4 waves, one chunk each per stage
     }
     if (overlap && it) {   // the states (and the band buffers) belong to the context's stream again
         HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
@@ -515,7 +517,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         d_d0 = (float *)(d_idx + items);
         d_d1 = d_d0 + items;
     }
-    ctx->knn_tiles = ctx->knn_tiles_pruned = 0;
+    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     if (symmetric) {
         SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0, d_d1));
     } else {
@@ -535,11 +537,14 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     return SKL_OK;
 }
 
-extern "C" int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *tiles_pruned)
+extern "C" int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *tiles_pruned, uint64_t *stages_per_tile,
+                                       uint64_t *stages_walked_in_pruned_tiles)
 {
     SKL_TRY(ctx_bind(ctx));
     if (tiles) *tiles = ctx->knn_tiles;
     if (tiles_pruned) *tiles_pruned = ctx->knn_tiles_pruned;
+    if (stages_per_tile) *stages_per_tile = ctx->knn_tile_stages;
+    if (stages_walked_in_pruned_tiles) *stages_walked_in_pruned_tiles = ctx->knn_pruned_stages;
     return SKL_OK;
 }
 
@@ -609,7 +614,7 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     }
     KnnState st;
     SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
-    ctx->knn_tiles = ctx->knn_tiles_pruned = 0;
+    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     const bool overlap = ctx->knobs.knn_overlap && list.size() > 1;
     SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
     const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -655,7 +660,7 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
     st.h_len = h_len;
     st.thr = thr;
     const std::vector<uint32_t> one{(uint32_t)band};
-    ctx->knn_tiles = ctx->knn_tiles_pruned = 0;
+    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     return knn_symmetric_bands(ctx, s, p, knn, band_rows, one, false, st, col_lo, col_hi);
 }
 

@@ -225,7 +225,8 @@ class OutputPool {
         static OutputPool pool;
         return pool;
     }
-    // fn(tid) on workers 0 .. threads-1 (the caller runs as worker 0); returns when all are done.  Not re-entrant.
+    // fn(tid) on workers 0 .. threads-1 (the caller runs as worker 0); returns when all are done.  One job at a time: a
+    // second caller (two matrices written at once from two threads of a binding) waits for the first one's job to finish.
     void run(size_t threads, const std::function<void(size_t)> &fn)
     {
         threads = std::max<size_t>(1, threads);
@@ -233,6 +234,7 @@ class OutputPool {
             fn(0);
             return;
         }
+        std::lock_guard<std::mutex> one_job(run_mu_);
         {
             std::lock_guard<std::mutex> lk(mu_);
             while (workers_.size() + 1 < threads) {
@@ -291,6 +293,7 @@ class OutputPool {
         }
     }
     std::mutex mu_;
+    std::mutex run_mu_;   // held for the whole of run(): the job slot (job_, pending_, generation_) serves one caller
     std::condition_variable cv_, done_cv_;
     std::vector<std::thread> workers_;
     std::vector<std::unique_ptr<TextBlock>> blocks_;

@@ -288,7 +288,11 @@ void MultiSketch::read_sketch_data(const std::string &file_prefix)
             ::close(fd);
             throw std::runtime_error(path + " is shorter than its metadata says");
         }
-        void *m = file_bytes && !g_no_mapping ? ::mmap(nullptr, file_bytes, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+        // Positional reads by default (round 5): a file truncated or replaced while it is read -- NFS, a concurrent `sketch`
+        // run -- then gives the clean "error reading" below instead of a SIGBUS out of a mapping; the slices are read by
+        // several threads either way.  SKL_SKD_MMAP=1 maps the file instead.
+        static const bool want_mapping = [] { const char *e = std::getenv("SKL_SKD_MMAP"); return e && e[0] == '1'; }();
+        void *m = file_bytes && want_mapping && !g_no_mapping ? ::mmap(nullptr, file_bytes, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
         const char *mapped = m == MAP_FAILED ? nullptr : (const char *)m;
         sketch_bins_.resize(n * kmer_stride_);
         const size_t slice_bytes = kmer_stride_ * sizeof(uint64_t);
