@@ -931,6 +931,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
     const uint64_t base = self_mode ? cond_index(r0, r0 + 1, n_cols) : r0 * n_cols;
     const uint64_t pairs = self_mode ? self_rows_pairs(r0, r1, n_cols) : (r1 - r0) * n_cols;
     if (pairs == 0) return SKL_OK;
+    const RoctxRange range_(mode == MODE_COREACC ? "skl:dense_band core/accessory" : mode == MODE_JACCARD ? "skl:dense_band single k" : "skl:dense_band bin-match counts");
 
     const bool coreacc = mode == MODE_COREACC;
     // Small core/acc launches run as (tile, k) workgroups producing counts + the epilogue

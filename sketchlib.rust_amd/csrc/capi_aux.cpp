@@ -203,6 +203,7 @@ static int sketch_signs_impl(skl_ctx *ctx, const uint8_t *codes, const uint32_t 
     for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const unsigned pack_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     auto upload = [&](size_t b) -> int {
+        const RoctxRange range_("skl:sketch_batch pack + upload");
         const size_t s0 = cuts[b], s1 = cuts[b + 1];
         const uint64_t w0 = word_begin[s0], words = word_begin[s1] - w0;
         if (words == 0) {
@@ -224,6 +225,7 @@ static int sketch_signs_impl(skl_ctx *ctx, const uint8_t *codes, const uint32_t 
         return SKL_OK;
     };
     auto launch = [&](size_t b) -> int {
+        const RoctxRange range_("skl:sketch_batch hash + bin minima");
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[3 * b], 0));
         a.first_span = span_begin[cuts[b]];
         a.n_spans = span_begin[cuts[b + 1]] - a.first_span;
@@ -495,6 +497,7 @@ extern "C" int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s
                                              size_t knn, const uint64_t *row_offsets, const uint32_t *cand,
                                              uint64_t *out_idx, float *out_d0)
 {
+    const RoctxRange range_("skl:candidate-list kNN (precluster)");
     SKL_TRY(check_candidate_call(ctx, s, p, knn));
     if (!row_offsets || !out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "null argument");
     const size_t n = s->n;
@@ -525,6 +528,7 @@ extern "C" int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *
                                               size_t knn, const uint16_t *skq, size_t sketch_size,
                                               uint64_t *out_idx, float *out_d0, uint64_t *out_n_candidates)
 {
+    const RoctxRange range_("skl:shared-bins candidates + kNN (precluster)");
     SKL_TRY(check_candidate_call(ctx, s, p, knn));
     if (!skq || !out_idx || !out_d0) return fail(SKL_ERR_INVALID_ARG, "null argument");
     const size_t n = s->n;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "roctx_ranges.hpp"
 
 #define SKL_INTERNAL __attribute__((visibility("hidden")))
 

@@ -164,6 +164,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         const size_t c_first = std::max(b0, win_lo);   // first candidate column of the band's own rows
         const size_t t_first = std::max(b1, win_lo);   // first row that receives the band turned
         if (c_first >= win_hi) continue;               // the window lies left of this band: nothing of it here
+        const RoctxRange range_("skl:knn_band pair kernel + merges (every pair once)");
         const int buf = overlap ? (int)(it & 1) : 0;
         if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));
         // the band against the column view that starts at the 64-column block holding its first candidate column
@@ -376,6 +377,7 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
     size_t it = 0;
     for (size_t b0 = r0; b0 < r1; b0 += band_rows, ++it) {
         const size_t b1 = std::min(r1, b0 + band_rows);
+        const RoctxRange range_("skl:knn_band pair kernel + top-k (row by row)");
         const int buf = overlap ? (int)(it & 1) : 0;
         // the top-k that read this buffer two bands ago must be done before it is overwritten
         if (overlap && it >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[buf], 0));

@@ -1,0 +1,48 @@
+// roctx_ranges.hpp -- named ranges around the library's phases for `rocprofv3 --marker-trace` (the reference has
+// no tracing; the build adds roctx ranges beside the rocprofv3 counter recipes).  The marker library is looked up at run time
+// (no link dependency: the product library must load on a box without the profiler's packages); without it, or without a
+// profiler attached, a range costs two predictable branches.
+#pragma once
+
+#include <dlfcn.h>
+
+namespace skl {
+
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi()
+    {
+        for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+    static const RoctxApi &get()
+    {
+        static const RoctxApi api;
+        return api;
+    }
+};
+
+// RAII range on the calling host thread: what the kernels enqueued inside it belong to.
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(RoctxApi::get().push != nullptr)
+    {
+        if (on) (void)RoctxApi::get().push(name);
+    }
+    ~RoctxRange()
+    {
+        if (on) (void)RoctxApi::get().pop();
+    }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
+}  // namespace skl

@@ -277,9 +277,9 @@ def test_random_reference_tie_configuration(oracle, skl, gpu_ctx, seed):
         gpu_ctx.reload_env()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3, 5])
+@pytest.mark.parametrize("world,band_rows", [(1, 64), (2, 64), (3, 64), (5, 64), (3, 48), (4, 100), (2, 16)])
 @pytest.mark.parametrize("dist", ["jaccard", "ani", "coreacc"])
-def test_reference_order_over_column_windows(oracle, skl, gpu_ctx, monkeypatch, world, dist):
+def test_reference_order_over_column_windows(oracle, skl, gpu_ctx, monkeypatch, world, band_rows, dist):
     """skl_self_dists_knn_window: the reference's lists from heaps that travel through `world` column windows, every pair
     evaluated once.  The participants run one after the other here on one device and one set of heap arrays -- which is
     exact: a participant never touches a row again after the band that holds it, so the state it would have sent on is the
@@ -287,7 +287,8 @@ def test_reference_order_over_column_windows(oracle, skl, gpu_ctx, monkeypatch, 
     import torch
     from sketchlib.rust_amd import multi_gpu
 
-    kmers, ss64, n, knn, band_rows = [17, 21, 25, 29], 8, 613, 9, 64
+    # (band heights that are / are not multiples of the tile and of the 64-column block: a window then starts inside a block)
+    kmers, ss64, n, knn = [17, 21, 25, 29], 8, 613, 9
     bins = synth.set_r(n, kmers, ss64, n_clusters=5)
     bins[400] = bins[3]
     bins[401] = bins[3]
