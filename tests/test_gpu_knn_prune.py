@@ -136,3 +136,38 @@ def test_pruning_is_off_with_a_completeness_correction(oracle, skl, gpu_ctx, mon
     assert pruned == 0 and np.array_equal(idx, exp["idx"])
     np.testing.assert_allclose(d0, exp["d0"], atol=1e-6, rtol=0)
     g.close()
+
+
+FUZZ_SEEDS = int(__import__("os").environ.get("SKL_FUZZ_SEEDS", "10"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
+def test_random_pruned_configuration(oracle, skl, gpu_ctx, monkeypatch, seed):
+    """Random sizes, cluster structures (relatives at regular id distances, so that whole tiles are free of them), sketch
+    sizes (ragged last stages included), band heights, neighbour counts, keys and tie rules: the pruned run's lists are the
+    oracle's.  A soak run sets SKL_FUZZ_SEEDS."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(300, 1700))
+    n_clusters = int(rng.choice([max(2, n // 3), max(2, n // 5), max(2, n // 8), 7, n]))      # n: no relatives at all
+    knn = int(rng.integers(1, 6))
+    ss64 = int(rng.choice([8, 13, 16, 32, 37, 64]))
+    band_rows = int(rng.choice([16, 32, 48, 64, 96, 160, 256]))
+    ani = bool(rng.integers(0, 2))
+    ties = ["canonical", "reference"][int(rng.integers(0, 2))]
+    keep = float(rng.choice([0.98, 0.94, 0.85]))
+    kmers = [17, 21]
+    bins = _clustered(n, len(kmers), ss64, n_clusters, keep=keep)
+    if rng.integers(0, 2):      # a few exact duplicates: ties at key 0
+        for _ in range(3):
+            a, b = rng.integers(0, n, 2)
+            bins[a] = bins[b]
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21, ani)
+    t = skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL
+    idx, d0, (tiles, pruned) = _run(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True, t)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, ani,
+                                ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    cfg = dict(n=n, n_clusters=n_clusters, knn=knn, ss64=ss64, band_rows=band_rows, ani=ani, ties=ties, keep=keep, tiles=tiles, pruned=pruned)
+    assert np.array_equal(idx, exp["idx"]), (cfg, np.argwhere(idx != exp["idx"])[:5])
+    assert np.array_equal(d0, exp["d0"]), cfg
+    g.close()
