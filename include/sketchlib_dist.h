@@ -210,9 +210,10 @@ int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);
  * whole-matrix self kNN with single-k keys (Jaccard / ANI, no completeness correction) leaves a 32 x 128 tile of the pair
  * space unfinished once every pair of it is, on the bins compared so far, already beyond both its samples' current knn-th
  * best (the key is monotone in the mismatch count).  The neighbour lists are those of the unpruned run in
- * either tie rule.  tiles: tiles of the launches that could prune; tiles_pruned: those left early; stages_per_tile: stage
- * boundaries of a whole tile's walk (4 chunks each); stages_walked_in_pruned_tiles: how many of them the pruned tiles had
- * walked when they left (so the share of the pair space's bin comparisons actually made is known).  (The A/B build of the
+ * either tie rule.  tiles: tiles of the launches that could prune; tiles_pruned: those left early -- most of them by a probe
+ * over two of the fourteen planes before the walk begins (no stage walked), the rest at a stage boundary of the walk;
+ * stages_per_tile: stage boundaries of a whole tile's walk (4 chunks each); stages_walked_in_pruned_tiles: how many of them
+ * the pruned tiles had walked when they left (so the share of the pair space's full bin comparisons actually made is known).  (The A/B build of the
  * library reads SKL_KNN_PRUNE=0: every tile walked, same lists.) */
 int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *tiles_pruned, uint64_t *stages_per_tile,
                             uint64_t *stages_walked_in_pruned_tiles);

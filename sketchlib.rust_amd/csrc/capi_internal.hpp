@@ -112,6 +112,7 @@ struct skl_ctx {
     uint32_t *sampler_count = nullptr;
     uint32_t sampler_max = 0;
     bool sampler_running = false;
+    uint64_t knn_tiles_probe_pruned = 0;   // ... of the pruned tiles, those the plane-pair probe settled before the walk began
     uint64_t knn_pruned_stages = 0, knn_tile_stages = 0;   // ... stages the pruned tiles had walked / stages of a whole tile
     uint64_t knn_tiles = 0, knn_tiles_pruned = 0;   // tile pruning of the last self kNN call (skl_ctx_knn_prune_stats)
     int knn_ties = SKL_KNN_TIES_REFERENCE;   // what self_dists_knn returns (mod.rs:133-224); skl_ctx_set_knn_ties(CANONICAL) opts out

@@ -145,10 +145,10 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     if (prune) {
         void *pq = nullptr, *ps = nullptr;
         SKL_TRY(ctx_scratch(ctx, (n + 64) * sizeof(uint32_t), &pq, 8));
-        SKL_TRY(ctx_scratch(ctx, 4 * sizeof(uint32_t), &ps, 10));
+        SKL_TRY(ctx_scratch(ctx, 4096 * sizeof(uint32_t), &ps, 10));
         prune_q = (uint32_t *)pq;
         prune_stats = (uint32_t *)ps;
-        HIP_TRY(hipMemsetAsync(prune_stats, 0, 4 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(hipMemsetAsync(prune_stats, 0, 4096 * sizeof(uint32_t), ctx->stream));
     }
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
     if (overlap) {   // the states were cleared on the context's stream, the merges run on the other one
@@ -206,6 +206,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             g.prune_q_rows = prune_q;
             g.prune_q_cols = prune_q + col0;
             g.prune_stats = prune_stats;
+
             if (!g.t_bits) {   // (the last band has no turned copy; the kernel takes "both bit sets given" as the sign that the merges mask)
                 g.t_bits = tbits[buf] + col0 * tbit_words;
                 g.t_bits_stride = (uint32_t)tbit_words;
@@ -299,11 +300,14 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         ++it;
     }
     if (prune) {   // (read back with the call's last synchronisation: skl_ctx_knn_prune_stats)
-        uint32_t counted[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(counted, prune_stats, sizeof counted, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<uint32_t> counted(4096, 0u);
+        HIP_TRY(hipMemcpyAsync(counted.data(), prune_stats, counted.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        ctx->knn_tiles_pruned += counted[0];
-        ctx->knn_pruned_stages += (uint64_t)counted[2] | ((uint64_t)counted[3] << 32);
+        for (size_t x = 0; x < 1024; ++x) {
+            ctx->knn_tiles_pruned += (uint64_t)counted[4 * x] + counted[4 * x + 1];
+            ctx->knn_tiles_probe_pruned += counted[4 * x];
+            ctx->knn_pruned_stages += counted[4 * x + 2];
+        }
         ctx->knn_tile_stages = (s->ss64 + 3) / 4;   // stages of a whole 32 x 128 tile: 4 waves, one chunk each per stage
     }
     if (overlap && it) {   // the states (and the band buffers) belong to the context's stream again
@@ -519,7 +523,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         d_d0 = (float *)(d_idx + items);
         d_d1 = d_d0 + items;
     }
-    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     if (symmetric) {
         SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0, d_d1));
     } else {
@@ -616,7 +620,7 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     }
     KnnState st;
     SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
-    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     const bool overlap = ctx->knobs.knn_overlap && list.size() > 1;
     SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
     const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -662,7 +666,7 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
     st.h_len = h_len;
     st.thr = thr;
     const std::vector<uint32_t> one{(uint32_t)band};
-    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     return knn_symmetric_bands(ctx, s, p, knn, band_rows, one, false, st, col_lo, col_hi);
 }
 

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     constexpr uint32_t RED_U4 = RED2 ? (TURNED_U4 > ROWS_U4 ? TURNED_U4 - ROWS_U4 : 0u) : (uint32_t)(W * XOV * LANES) / 4u;
     // PRUNE: behind the row buffers, the column samples' per-wave bounds (JL * 64 words, the same values written by every
     // wave) and two rotating rows of 4 votes
-    constexpr uint32_t PRUNE_U4 = PRUNE ? (uint32_t)(JL * LANES) / 4u + 2u : 0u;
+    constexpr uint32_t PRUNE_U4 = PRUNE ? (uint32_t)(JL * LANES) / 4u + 2u + (uint32_t)R / 4u : 0u;   // column bounds, votes, row bounds
     __shared__ uint4 lds_all[ROWS_U4 + RED_U4 + PRUNE_U4];
     uint4 (*lds_rows)[2][BUF_U4] = reinterpret_cast<uint4 (*)[2][BUF_U4]>(&lds_all[0]);
 
