@@ -5,6 +5,8 @@ SKL_KNN_PRUNE=1 (default) and =0, in both tie rules.  One JSON line per (n, sket
 kernels' share, tiles walked / left early, and whether the pruned lists equal the unpruned ones (ids AND distances).
 
     python scripts/bench_knn_prune.py [--samples 1000000] [--ss64 32] [--knn 50] [--ties reference,canonical]
+    python scripts/bench_knn_prune.py --queries 16384     # cross kNN: that many queries (drawn from the same clusters) against
+                                                          # the --samples references, fed in column panels (capi_knn.cpp)
 """
 import argparse
 import json
@@ -27,6 +29,7 @@ def main():
     ap.add_argument("--prune", default="1,0")
     ap.add_argument("--cluster", type=int, default=200)
     ap.add_argument("--keep", type=float, default=0.94)
+    ap.add_argument("--queries", type=int, default=0)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -42,6 +45,12 @@ def main():
             del bins
             torch.cuda.empty_cache()
             p = sk.set_k(21)
+            qk = None
+            if args.queries:
+                qbins = synth.set_clustered_device(args.queries, 1, ss64, dev, cluster_size=args.cluster, keep=args.keep,
+                                                   first_sample=n, n_clusters=n // args.cluster)
+                qk = ctx.sketches(qbins, args.queries, [21], ss64)
+                del qbins
             for ties in args.ties.split(","):
                 ctx.set_knn_ties(capi.TIES_REFERENCE if ties == "reference" else capi.TIES_CANONICAL)
                 lists = {}
@@ -51,7 +60,10 @@ def main():
                     ctx.timing_enable()
                     ctx.timing_reset()
                     t0 = time.perf_counter()
-                    idx, d0, _ = capi.self_dists_knn(ctx, sk, p, args.knn)
+                    if qk is not None:
+                        idx, d0, _ = capi.cross_dists_knn(ctx, sk, qk, p, args.knn)
+                    else:
+                        idx, d0, _ = capi.self_dists_knn(ctx, sk, p, args.knn)
                     wall = time.perf_counter() - t0
                     kms, nl = ctx.kernel_ms()
                     ctx.timing_enable(0)
@@ -59,7 +71,8 @@ def main():
                     tiles, pruned = st["tiles"], st["tiles_left_early"]
                     lists[prune] = (idx, d0)
                     row = {"n": n, "sketchsize64": ss64, "knn": args.knn, "ties": ties, "prune": prune == "1", "wall_s": wall,
-                           "pair_kernel_s": kms / 1e3, "pair_kernel_launches": nl, "pair_distances_per_s": n * (n - 1) / wall,
+                           "pair_kernel_s": kms / 1e3, "pair_kernel_launches": nl, "queries": args.queries,
+                           "pair_distances_per_s": (args.queries * n if args.queries else n * (n - 1)) / wall,
                            "tiles": tiles, "tiles_left_early": pruned, "share_of_the_walk_made": st["share_of_the_walk_made"], "kernel": ctx.last_kernel().split(" (")[0],
                            "idx_checksum": int(idx.sum())}
                     if len(lists) == 2:
@@ -68,6 +81,8 @@ def main():
                     print(json.dumps(row), flush=True)
             os.environ.pop("SKL_KNN_PRUNE", None)
             sk.close()
+            if qk is not None:
+                qk.close()
             torch.cuda.empty_cache()
     ctx.close()
 

@@ -60,6 +60,7 @@ struct Knobs {
     bool knn_row_flags = true;        // SKL_KNN_ROW_FLAGS=0: the merge of the transposed band visits every row (A/B only, results are identical)
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
+    long long knn_panel = 0;          // A/B build, SKL_KNN_PANEL: column-panel width of the row-by-row kNN forced (tests; 0: by size)
     bool knn_prune = true;            // SKL_KNN_PRUNE=0: the symmetric self kNN finishes every tile (A/B; results are identical)
     bool refheap_wave = true;         // SKL_REFHEAP_WAVE=0: the heap replays (one-shot and resumable) run one workgroup per row even for knn <= 256 (A/B only, results are identical)
     bool topk_stream = true;          // SKL_TOPK_STREAM=0: radix select instead of the streaming merge

@@ -86,11 +86,24 @@ static bool knn_symmetric_ok(const skl_sketches *s, const skl_dist_params *p)
 // COLUMN WINDOW (win_lo, win_hi; default: all columns): only the pairs whose COLUMN sample lies in [win_lo, win_hi) are
 // evaluated -- band rows against columns [max(b0, win_lo), win_hi), turned copies to the rows [max(b1, win_lo), win_hi) -- which
 // is one participant's share of the reference-order pipeline over several devices (skl_self_dists_knn_window).
+// CROSS FORM (`cols` given): the rows of `s` against the columns [win_lo, win_hi) of another slab (or of the same one, row
+// ranges of the self kNN: self_rows), no symmetry, nothing turned -- one COLUMN PANEL of the row-by-row kNN.  The drivers
+// call it panel after panel, ascending, so a row meets its candidates in ascending id, its list tightens from panel to panel,
+// and from the second panel on the pair kernel prunes against the rows' bounds (the columns have no lists: bound 0).
+struct KnnCross {
+    const skl_sketches *cols = nullptr;   // null: the symmetric form
+    bool self_rows = false;               // rows and columns are the same sample set: a row is not its own candidate
+    size_t row_lo = 0, row_hi = ~(size_t)0;   // rows of the call (bands are clipped to them)
+};
+
 static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
                                size_t band_rows, const std::vector<uint32_t> &bands, bool overlap, KnnState &st,
-                               size_t win_lo = 0, size_t win_hi = ~(size_t)0)
+                               size_t win_lo = 0, size_t win_hi = ~(size_t)0, const KnnCross &cross = KnnCross())
 {
-    const size_t n = s->n;
+    const bool is_cross = cross.cols != nullptr;
+    const skl_sketches *cs = is_cross ? cross.cols : s;
+    const size_t n = cs->n;            // columns (= samples in the symmetric form)
+    const size_t n_rows = s->n;
     win_hi = std::min(win_hi, n);
     const bool coreacc = p->dist_type == SKL_DIST_COREACC;
     const bool ref = st.h_key != nullptr;   // the reference's tie order: heaps replayed (a row's candidates arrive in ascending id
@@ -100,13 +113,14 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     const size_t rec = coreacc ? 2 * sizeof(float) : sizeof(float);
     const size_t t_stride = (band_rows + 31) / 32 * 32;   // whole tiles of either height (16 or 32 rows: dispatch_pair_kernel)
     void *kband[2] = {nullptr, nullptr}, *tband[2] = {nullptr, nullptr};
-    SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[0], 0));
-    SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[0], 4));
+    const size_t k_cols = is_cross ? win_hi - win_lo / 64 * 64 : n;   // columns of a band's records (cross form: the panel's)
+    SKL_TRY(ctx_scratch(ctx, band_rows * k_cols * rec, &kband[0], 0));
+    if (!is_cross) SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[0], 4));
     kband[1] = kband[0];
     tband[1] = tband[0];
     if (overlap) {
-        SKL_TRY(ctx_scratch(ctx, band_rows * n * rec, &kband[1], 3));
-        SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[1], 5));
+        SKL_TRY(ctx_scratch(ctx, band_rows * k_cols * rec, &kband[1], 3));
+        if (!is_cross) SKL_TRY(ctx_scratch(ctx, n * t_stride * rec, &tband[1], 5));
     }
     // Row flags of the transposed band (one array per band buffer): the pair kernel marks the rows that
     // received a record below their knn-th best so far with the band's number, and the merge of the
@@ -121,7 +135,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     HIP_TRY(hipMemsetAsync(flag_mem, 0, 2 * n * sizeof(uint32_t), ctx->stream));
     // ... and for the band's own rows one bit per 64-column block (the merge of the band reads only the
     // marked stretches of a row): band_rows x ceil(columns / 2048) words per band buffer, behind the flags
-    const size_t bit_words = (n / 64 + 1 + 31) / 32;
+    const size_t bit_words = ((is_cross ? k_cols : n) / 64 + 1 + 31) / 32;   // (bit = 64-column block of the band's view)
     void *bits_mem = nullptr;
     SKL_TRY(ctx_scratch(ctx, 2 * band_rows * bit_words * sizeof(uint32_t), &bits_mem, 7));
     uint32_t *row_bits[2] = {(uint32_t *)bits_mem, (uint32_t *)bits_mem + (overlap ? band_rows * bit_words : 0)};
@@ -132,23 +146,24 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     // samples' bounds on the chunks walked so far.  The bounds come from the same (possibly stale, i.e. too high) thresholds
     // as the flags: a pair pruned now would be rejected by both lists whenever it arrived, so the lists -- ids AND order, in
     // either tie rule -- are those of the unpruned run.  Not with a completeness correction (the key then depends on the pair).
-    const size_t tbit_words = (t_stride / 32 + 31) / 32;
+    const size_t tbit_words = is_cross ? 0 : (t_stride / 32 + 31) / 32;   // (cross form: nothing turned; the array is only a non-null mark)
     const bool prune = ctx->knobs.knn_prune && ctx->knobs.knn_row_flags && !coreacc && !(s->d_comp != nullptr) &&
                        s->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS;
     uint32_t *tbits[2] = {nullptr, nullptr}, *prune_q = nullptr, *prune_stats = nullptr;
     if (ctx->knobs.knn_row_flags) {
         void *tb = nullptr;
-        SKL_TRY(ctx_scratch(ctx, 2 * n * tbit_words * sizeof(uint32_t), &tb, 9));
+        SKL_TRY(ctx_scratch(ctx, std::max<size_t>(2 * n * tbit_words, 64) * sizeof(uint32_t), &tb, 9));
         tbits[0] = (uint32_t *)tb;
         tbits[1] = (uint32_t *)tb + (overlap ? n * tbit_words : 0);
     }
     if (prune) {
         void *pq = nullptr, *ps = nullptr;
-        SKL_TRY(ctx_scratch(ctx, (n + 64) * sizeof(uint32_t), &pq, 8));
+        SKL_TRY(ctx_scratch(ctx, (n_rows + 64 + (is_cross ? n + 64 : 0)) * sizeof(uint32_t), &pq, 8));
         SKL_TRY(ctx_scratch(ctx, 4096 * sizeof(uint32_t), &ps, 10));
         prune_q = (uint32_t *)pq;
         prune_stats = (uint32_t *)ps;
         HIP_TRY(hipMemsetAsync(prune_stats, 0, 4096 * sizeof(uint32_t), ctx->stream));
+        if (is_cross) HIP_TRY(hipMemsetAsync(prune_q + n_rows + 64, 0, (n + 64) * sizeof(uint32_t), ctx->stream));   // the columns have no lists: bound 0
     }
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
     if (overlap) {   // the states were cleared on the context's stream, the merges run on the other one
@@ -159,10 +174,11 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
     size_t it = 0;
     for (const uint32_t band : bands) {
-        const size_t b0 = (size_t)band * band_rows;
-        const size_t b1 = std::min(n, b0 + band_rows);
-        const size_t c_first = std::max(b0, win_lo);   // first candidate column of the band's own rows
-        const size_t t_first = std::max(b1, win_lo);   // first row that receives the band turned
+        const size_t b0 = std::max((size_t)band * band_rows, cross.row_lo);
+        const size_t b1 = std::min(std::min(n_rows, (size_t)band * band_rows + band_rows), cross.row_hi);
+        if (b1 <= b0) continue;
+        const size_t c_first = is_cross ? win_lo : std::max(b0, win_lo);   // first candidate column of the band's own rows
+        const size_t t_first = is_cross ? win_hi : std::max(b1, win_lo);   // first row that receives the band turned (cross form: none)
         if (c_first >= win_hi) continue;               // the window lies left of this band: nothing of it here
         const RoctxRange range_("skl:knn_band pair kernel + merges (every pair once)");
         const int buf = overlap ? (int)(it & 1) : 0;
@@ -170,7 +186,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         // the band against the column view that starts at the 64-column block holding its first candidate column
         const size_t col0 = c_first / 64 * 64;
         PairArgs g;
-        SKL_TRY(fill_args(s, s, p, mode, jout, &g));
+        SKL_TRY(fill_args(s, cs, p, mode, jout, &g));
         g.B += (col0 / 64) * jb_words;
         g.nB = (uint32_t)(win_hi - col0);
         if (g.compB) g.compB += col0;
@@ -201,10 +217,10 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         }
         if (prune) {
             // every sample's bound as of now (the merges of earlier bands may still be lowering thresholds: stale = too high = safe)
-            HIP_TRY(launch_prune_thresholds(ref ? st.thr : st.key + (knn - 1), ref ? 1u : (uint32_t)knn, (uint32_t)n, g.dtab,
+            HIP_TRY(launch_prune_thresholds(ref ? st.thr : st.key + (knn - 1), ref ? 1u : (uint32_t)knn, (uint32_t)n_rows, g.dtab,
                                             (uint32_t)(64 * s->ss64), prune_q, ctx->stream));
             g.prune_q_rows = prune_q;
-            g.prune_q_cols = prune_q + col0;
+            g.prune_q_cols = (is_cross ? prune_q + n_rows + 64 : prune_q) + col0;
             g.prune_stats = prune_stats;
 
             if (!g.t_bits) {   // (the last band has no turned copy; the kernel takes "both bit sets given" as the sign that the merges mask)
@@ -253,7 +269,8 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             m.cols = g.nB;
             m.id_base = (uint32_t)col0;
             m.skip_below = (uint32_t)c_first;
-            m.self_id_base = m.state_row_base = (uint32_t)b0;
+            m.state_row_base = (uint32_t)b0;
+            m.self_id_base = (is_cross && !cross.self_rows) ? 0xFFFFFFFFu : (uint32_t)b0;
             m.seg_bits = ctx->knobs.knn_row_flags ? row_bits[buf] : nullptr;
             m.seg_bits_stride = (uint32_t)bit_words;
             HIP_TRY(launch_refheap_merge(m, topk_stream));
@@ -277,7 +294,8 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         m.cols = g.nB;
         m.id_base = (uint32_t)col0;
         m.skip_below = (uint32_t)c_first;
-        m.self_id_base = m.state_row_base = (uint32_t)b0;
+        m.state_row_base = (uint32_t)b0;
+        m.self_id_base = (is_cross && !cross.self_rows) ? 0xFFFFFFFFu : (uint32_t)b0;
         m.seg_bits = ctx->knobs.knn_row_flags ? row_bits[buf] : nullptr;
         m.seg_bits_stride = (uint32_t)bit_words;
         HIP_TRY(launch_topk_merge(m, topk_stream));
@@ -364,6 +382,49 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
     const bool ref_ties = ctx->knn_ties == SKL_KNN_TIES_REFERENCE;
     const bool big = knn > (size_t)TOPK_LDS_MAX;
     const bool streaming_state = !ref_ties && !big;
+    // COLUMN PANELS (round 5): a row-by-row kNN over many candidates -- cross kNN against a large reference set, a row range of
+    // the self kNN -- is fed its candidates in ascending panels of columns instead of all at once: the rows' lists tighten
+    // from panel to panel, and from the second panel on the pair kernel leaves the tiles whose pairs are beyond their ROW's
+    // bound (tile pruning, as in the symmetric driver; the columns have no lists here).  Same lists in either tie rule: a
+    // row still meets its candidates in ascending id.  Single-k keys without a completeness correction, lists that fit the
+    // LDS forms, at least 4 panels of 32 Ki columns and launches large enough for the prunable 32 x 128 tiles.
+    {
+        // (A/B build: SKL_KNN_PANEL forces a panel width -- and lifts the size conditions -- so that tests reach this path on
+        // inputs small enough for the oracle)
+        const size_t forced_panel = (size_t)std::max(0ll, ctx->knobs.knn_panel) / 128 * 128;
+        const size_t panel = forced_panel ? forced_panel : std::max<size_t>(32768, (n_cand / 8 + 127) / 128 * 128);
+        const bool eligible = ctx->knobs.knn_prune && ctx->knobs.knn_row_flags && !coreacc && !(rows->d_comp && cands->d_comp) &&
+                              rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS && !big && knn <= (size_t)REFHEAP_LDS_MAX && forced_kernel(ctx) == 0 &&
+                              (forced_panel ? n_cand > panel : (n_cand >= 4 * panel && (r1 - r0) * panel >= (size_t)(16u << 20)));
+        if (eligible) {
+            // bands of rows whose records of one panel fit a quarter of the budget the caller sized `band_rows` for
+            size_t rows_per = std::max<size_t>(32, std::min<size_t>(r1 - r0, band_rows * n_cand / panel) / 32 * 32);
+            if (ctx->knobs.knn_band_rows) rows_per = std::max<size_t>(1, (size_t)ctx->knobs.knn_band_rows);   // (test knob)
+            rows_per = std::min(rows_per, (size_t)1 << 20);
+            KnnState pst;
+            SKL_TRY(knn_state_init(pst, rows->n, knn, false, ctx->stream, ref_ties));
+            std::vector<uint32_t> bands;
+            for (size_t b = r0 / rows_per; b * rows_per < r1; ++b) bands.push_back((uint32_t)b);
+            KnnCross cross;
+            cross.cols = cands;
+            cross.self_rows = self_mode != 0;
+            cross.row_lo = r0;
+            cross.row_hi = r1;
+            ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+            for (size_t c0 = 0; c0 < n_cand; c0 += panel) {
+                SKL_TRY(knn_symmetric_bands(ctx, rows, p, knn, rows_per, bands, overlap && bands.size() > 1, pst, c0, std::min(n_cand, c0 + panel), cross));
+            }
+            const int ani_undo = p->ani ? 1 : 0;
+            if (ref_ties) {
+                HIP_TRY(launch_refheap_finalize(pst.h_key + r0 * knn, pst.h_id + r0 * knn, nullptr, pst.h_len + r0, (uint32_t)(r1 - r0), (uint32_t)knn,
+                                                ani_undo, d_idx, d_d0, d_d1, ctx->stream));
+            } else {
+                HIP_TRY(launch_topk_finalize(pst.key + r0 * knn, pst.idx + r0 * knn, nullptr, (r1 - r0) * knn, ani_undo, d_idx, d_d0, d_d1, ctx->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(ctx->stream));   // the running states are freed on return
+            return SKL_OK;
+        }
+    }
     KnnState st;
     DevBuf big_scratch;
     if (streaming_state) {

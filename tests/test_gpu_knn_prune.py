@@ -171,3 +171,60 @@ def test_random_pruned_configuration(oracle, skl, gpu_ctx, monkeypatch, seed):
     assert np.array_equal(idx, exp["idx"]), (cfg, np.argwhere(idx != exp["idx"])[:5])
     assert np.array_equal(d0, exp["d0"]), cfg
     g.close()
+
+
+@pytest.mark.parametrize("ties", ["canonical", "reference"])
+@pytest.mark.parametrize("ani", [False, True], ids=["dist", "ani"])
+@pytest.mark.parametrize("panel,band_rows", [(256, 64), (384, 96), (128, 33)])
+def test_cross_knn_in_column_panels(oracle, skl, gpu_ctx, monkeypatch, ties, ani, panel, band_rows):
+    """Row-by-row kNN (cross mode) fed its candidates in ascending column panels, pruned from the second panel on against the
+    query rows' bounds: the oracle's lists in both tie rules.  (SKL_KNN_PANEL -- A/B build -- forces panels on a reference
+    set small enough for the oracle; the product takes them from 131 072 references on.)"""
+    kmers, ss64, nr, nq, knn = [17, 21], 16, 1500, 333, 4
+    rb = _clustered(nr, len(kmers), ss64, 250)                     # 6 per cluster, relatives at id distances 250, 500, ...
+    import torch
+    qb = synth.set_clustered_device(nq, len(kmers), ss64, torch.device("cuda", 0), keep=0.94, n_clusters=250,
+                                    first_sample=10 ** 6).cpu().numpy().view(np.uint64)
+    qb[7] = rb[31]                                                  # a query that IS a reference: key 0
+    o_r, o_q = oracle.Sketches(rb, nr, kmers, ss64), oracle.Sketches(qb, nq, kmers, ss64)
+    g_r, g_q = gpu_ctx.sketches(rb, nr, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
+    monkeypatch.setenv("SKL_KNN_PANEL", str(panel))
+    monkeypatch.setenv("SKL_KNN_BAND_ROWS", str(band_rows))
+    monkeypatch.setenv("SKL_TILE32_MIN", "0")
+    gpu_ctx.reload_env()
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL)
+    try:
+        idx, d0, _ = skl.cross_dists_knn(gpu_ctx, g_r, g_q, g_r.set_k(21, ani), knn)
+    finally:
+        gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+    tiles, pruned = gpu_ctx.knn_prune_stats()
+    exp = oracle.cross_dists_knn(o_r, o_q, knn, oracle.JACCARD, 1, ani,
+                                 ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
+    assert np.array_equal(d0, exp["d0"])
+    assert tiles > 0 and pruned > 0, (tiles, pruned)
+    g_r.close()
+    g_q.close()
+
+
+@pytest.mark.parametrize("ties", ["canonical", "reference"])
+def test_self_knn_row_range_in_column_panels(oracle, skl, gpu_ctx, monkeypatch, ties):
+    """A row range of the self kNN (what a rank of a row-sharded run computes) through the same panels: a row is not its own
+    candidate, and the panels on either side of it arrive in ascending id."""
+    kmers, ss64, n, knn = [21], 16, 1400, 3
+    bins = _clustered(n, 1, ss64, 200)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    monkeypatch.setenv("SKL_KNN_PANEL", "256")
+    monkeypatch.setenv("SKL_KNN_BAND_ROWS", "64")
+    monkeypatch.setenv("SKL_TILE32_MIN", "0")
+    gpu_ctx.reload_env()
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL)
+    try:
+        idx, d0, _ = skl.self_dists_knn(gpu_ctx, g, g.set_k(21), knn, 301, 777)
+    finally:
+        gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False,
+                                ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"][301:777]) and np.array_equal(d0, exp["d0"][301:777])
+    assert gpu_ctx.knn_prune_stats()[1] > 0
+    g.close()
