@@ -213,10 +213,13 @@ int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);
  * either tie rule.  tiles: tiles of the launches that could prune; tiles_pruned: those left early -- most of them by a probe
  * over two of the fourteen planes before the walk begins (no stage walked), the rest at a stage boundary of the walk;
  * stages_per_tile: stage boundaries of a whole tile's walk (4 chunks each); stages_walked_in_pruned_tiles: how many of them
- * the pruned tiles had walked when they left (so the share of the pair space's full bin comparisons actually made is known).  (The A/B build of the
- * library reads SKL_KNN_PRUNE=0: every tile walked, same lists.) */
+ * the pruned tiles had walked when they left (so the share of the pair space's full bin comparisons actually made is known);
+ * tiles_sparse: tiles the probe could NOT dismiss but in which at most 4 rows held a pair still in the running -- typically one
+ * relative among the tile's 4 096 pairs -- and whose walk was made for those rows only (every other pair of the tile gets the
+ * worst key there is: it lies beyond both its samples' bounds, like a pruned tile's pairs).  Any argument may be null.  (The A/B
+ * build of the library reads SKL_KNN_PRUNE=0: every tile walked, same lists; SKL_KNN_SPARSE=0: survivors walked whole.) */
 int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *tiles_pruned, uint64_t *stages_per_tile,
-                            uint64_t *stages_walked_in_pruned_tiles);
+                            uint64_t *stages_walked_in_pruned_tiles, uint64_t *tiles_sparse);
 
 /* self_dists_knn (src/distances/mod.rs:133-224); requires 1 <= knn < n. */
 int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,

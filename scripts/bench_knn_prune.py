@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--cluster", type=int, default=200)
     ap.add_argument("--keep", type=float, default=0.94)
     ap.add_argument("--queries", type=int, default=0)
+    ap.add_argument("--scatter", type=int, default=0, help="1: relatives at random ids (synth.set_clustered_device scatter=True)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -40,7 +41,7 @@ def main():
     ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
     for n in [int(x) for x in args.samples.split(",")]:
         for ss64 in [int(x) for x in args.ss64.split(",")]:
-            bins = synth.set_clustered_device(n, 1, ss64, dev, cluster_size=args.cluster, keep=args.keep)
+            bins = synth.set_clustered_device(n, 1, ss64, dev, cluster_size=args.cluster, keep=args.keep, scatter=bool(args.scatter))
             sk = ctx.sketches(bins, n, [21], ss64)
             del bins
             torch.cuda.empty_cache()
@@ -48,7 +49,7 @@ def main():
             qk = None
             if args.queries:
                 qbins = synth.set_clustered_device(args.queries, 1, ss64, dev, cluster_size=args.cluster, keep=args.keep,
-                                                   first_sample=n, n_clusters=n // args.cluster)
+                                                   first_sample=n, n_clusters=n // args.cluster, scatter=bool(args.scatter))
                 qk = ctx.sketches(qbins, args.queries, [21], ss64)
                 del qbins
             for ties in args.ties.split(","):
@@ -73,7 +74,8 @@ def main():
                     row = {"n": n, "sketchsize64": ss64, "knn": args.knn, "ties": ties, "prune": prune == "1", "wall_s": wall,
                            "pair_kernel_s": kms / 1e3, "pair_kernel_launches": nl, "queries": args.queries,
                            "pair_distances_per_s": (args.queries * n if args.queries else n * (n - 1)) / wall,
-                           "tiles": tiles, "tiles_left_early": pruned, "share_of_the_walk_made": st["share_of_the_walk_made"], "kernel": ctx.last_kernel().split(" (")[0],
+                           "scatter": args.scatter, "sparse_walk": os.environ.get("SKL_KNN_SPARSE", "1") != "0",
+                           "tiles": tiles, "tiles_left_early": pruned, "tiles_sparse_walk": st["tiles_sparse_walk"], "share_of_the_walk_made": st["share_of_the_walk_made"], "kernel": ctx.last_kernel().split(" (")[0],
                            "idx_checksum": int(idx.sum())}
                     if len(lists) == 2:
                         a, b = lists["1"], lists["0"]

@@ -68,7 +68,8 @@ _SIG = [
     ("skl_device_free", C.c_int, [_P, _P]),
     ("skl_device_memcpy", C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     ("skl_ctx_get_knn_ties", C.c_int, [_P]),
-    ("skl_ctx_knn_prune_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("skl_ctx_knn_prune_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64)]),
     ("skl_clock_sampler_start", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("skl_clock_sampler_stop", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -258,12 +259,12 @@ class Context:
     def knn_prune_stats(self, full=False):
         """(tiles, tiles left early) of the last self kNN call's prunable launches; full=True: + (stages of a whole tile,
         stages the pruned tiles had walked) and the share of the walk actually made."""
-        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
-        _check(load().skl_ctx_knn_prune_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        a, b, c, d, e = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(load().skl_ctx_knn_prune_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
         if not full:
             return a.value, b.value
         walked = ((a.value - b.value) * c.value + d.value) / (a.value * c.value) if a.value and c.value else 1.0
-        return {"tiles": a.value, "tiles_left_early": b.value, "stages_per_tile": c.value, "stages_walked_in_pruned_tiles": d.value,
+        return {"tiles": a.value, "tiles_left_early": b.value, "tiles_sparse_walk": e.value, "stages_per_tile": c.value, "stages_walked_in_pruned_tiles": d.value,
                 "share_of_the_walk_made": walked}
 
     def set_knn_ties(self, mode):

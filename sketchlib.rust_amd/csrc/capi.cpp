@@ -356,6 +356,7 @@ Knobs read_knobs()
     k.knn_overlap = env_int("SKL_KNN_OVERLAP", 1) != 0;
     k.knn_prune = env_int("SKL_KNN_PRUNE", 1) != 0;
     k.knn_panel = env_int("SKL_KNN_PANEL", 0);
+    k.knn_sparse = env_int("SKL_KNN_SPARSE", 1) != 0;
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;

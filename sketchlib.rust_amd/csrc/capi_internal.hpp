@@ -60,6 +60,7 @@ struct Knobs {
     bool knn_row_flags = true;        // SKL_KNN_ROW_FLAGS=0: the merge of the transposed band visits every row (A/B only, results are identical)
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
+    bool knn_sparse = true;           // A/B build, SKL_KNN_SPARSE=0: tiles that survive the probe are walked whole (results identical)
     long long knn_panel = 0;          // A/B build, SKL_KNN_PANEL: column-panel width of the row-by-row kNN forced (tests; 0: by size)
     bool knn_prune = true;            // SKL_KNN_PRUNE=0: the symmetric self kNN finishes every tile (A/B; results are identical)
     bool refheap_wave = true;         // SKL_REFHEAP_WAVE=0: the heap replays (one-shot and resumable) run one workgroup per row even for knn <= 256 (A/B only, results are identical)
@@ -113,6 +114,7 @@ struct skl_ctx {
     uint32_t *sampler_count = nullptr;
     uint32_t sampler_max = 0;
     bool sampler_running = false;
+    uint64_t knn_tiles_sparse = 0;         // tiles that survived the probe and were finished by the sparse walk (alive rows only)
     uint64_t knn_tiles_probe_pruned = 0;   // ... of the pruned tiles, those the plane-pair probe settled before the walk began
     uint64_t knn_pruned_stages = 0, knn_tile_stages = 0;   // ... stages the pruned tiles had walked / stages of a whole tile
     uint64_t knn_tiles = 0, knn_tiles_pruned = 0;   // tile pruning of the last self kNN call (skl_ctx_knn_prune_stats)

@@ -222,6 +222,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             g.prune_q_rows = prune_q;
             g.prune_q_cols = (is_cross ? prune_q + n_rows + 64 : prune_q) + col0;
             g.prune_stats = prune_stats;
+            g.prune_flags = ctx->knobs.knn_sparse ? 0u : 1u;
 
             if (!g.t_bits) {   // (the last band has no turned copy; the kernel takes "both bit sets given" as the sign that the merges mask)
                 g.t_bits = tbits[buf] + col0 * tbit_words;
@@ -325,6 +326,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             ctx->knn_tiles_pruned += (uint64_t)counted[4 * x] + counted[4 * x + 1];
             ctx->knn_tiles_probe_pruned += counted[4 * x];
             ctx->knn_pruned_stages += counted[4 * x + 2];
+            ctx->knn_tiles_sparse += counted[4 * x + 3];
         }
         ctx->knn_tile_stages = (s->ss64 + 3) / 4;   // stages of a whole 32 x 128 tile: 4 waves, one chunk each per stage
     }
@@ -410,7 +412,7 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
             cross.self_rows = self_mode != 0;
             cross.row_lo = r0;
             cross.row_hi = r1;
-            ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+            ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
             for (size_t c0 = 0; c0 < n_cand; c0 += panel) {
                 SKL_TRY(knn_symmetric_bands(ctx, rows, p, knn, rows_per, bands, overlap && bands.size() > 1, pst, c0, std::min(n_cand, c0 + panel), cross));
             }
@@ -584,7 +586,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         d_d0 = (float *)(d_idx + items);
         d_d1 = d_d0 + items;
     }
-    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     if (symmetric) {
         SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0, d_d1));
     } else {
@@ -605,9 +607,10 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
 }
 
 extern "C" int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *tiles_pruned, uint64_t *stages_per_tile,
-                                       uint64_t *stages_walked_in_pruned_tiles)
+                                       uint64_t *stages_walked_in_pruned_tiles, uint64_t *tiles_sparse)
 {
     SKL_TRY(ctx_bind(ctx));
+    if (tiles_sparse) *tiles_sparse = ctx->knn_tiles_sparse;
     if (tiles) *tiles = ctx->knn_tiles;
     if (tiles_pruned) *tiles_pruned = ctx->knn_tiles_pruned;
     if (stages_per_tile) *stages_per_tile = ctx->knn_tile_stages;
@@ -681,7 +684,7 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     }
     KnnState st;
     SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
-    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     const bool overlap = ctx->knobs.knn_overlap && list.size() > 1;
     SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
     const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -727,7 +730,7 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
     st.h_len = h_len;
     st.thr = thr;
     const std::vector<uint32_t> one{(uint32_t)band};
-    ctx->knn_tiles = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
     return knn_symmetric_bands(ctx, s, p, knn, band_rows, one, false, st, col_lo, col_hi);
 }
 

@@ -124,7 +124,9 @@ struct PairArgs {
     // from the running states before the launch; a stale (too high) threshold prunes less, never wrongly.
     const uint32_t *prune_q_rows, *prune_q_cols;
     uint32_t *prune_stats;        // 1 024 slots of 4 words (slot = blockIdx & 1023: adds to one address would queue up): [0] += workgroups that
-                                  // left their tile at the probe, [1] += ... at a stage boundary, [2] += the stages those had walked (null: not counted)
+                                  // left their tile at the probe, [1] += ... at a stage boundary, [2] += the stages those had walked,
+                                  // [3] += workgroups that finished their tile by the sparse walk (null: not counted)
+    uint32_t prune_flags;         // bit 0: no sparse walk (A/B build, SKL_KNN_SPARSE=0: the probe's survivors are walked whole)
     // FUSED CORE/ACCESSORY EPILOGUE of a k-sliced MODE_COUNTS launch (one workgroup per (tile, k-mer length), no chunk slices;
     // pair_kslice.hip, FUSE): every workgroup stores its k-mer length's counts write-through, then ONE lane adds 1 to
     // fuse_counter[tile] (agent scope, returning); the workgroup whose add completes the tile's k_count arrivals reads the

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     constexpr uint32_t RED_U4 = RED2 ? (TURNED_U4 > ROWS_U4 ? TURNED_U4 - ROWS_U4 : 0u) : (uint32_t)(W * XOV * LANES) / 4u;
     // PRUNE: behind the row buffers, the column samples' per-wave bounds (JL * 64 words, the same values written by every
     // wave) and two rotating rows of 4 votes
-    constexpr uint32_t PRUNE_U4 = PRUNE ? (uint32_t)(JL * LANES) / 4u + 2u + (uint32_t)R / 4u : 0u;   // column bounds, votes, row bounds
+    constexpr uint32_t PRUNE_U4 = PRUNE ? (uint32_t)(JL * LANES) / 4u + 2u + (uint32_t)R / 4u + 2u : 0u;   // column bounds, votes, row bounds, the probe's masks
     __shared__ uint4 lds_all[ROWS_U4 + RED_U4 + PRUNE_U4];
     uint4 (*lds_rows)[2][BUF_U4] = reinterpret_cast<uint4 (*)[2][BUF_U4]>(&lds_all[0]);
 
@@ -310,7 +310,7 @@ static hipError_t launch_rjk(const PairArgs &args, int mode, dim3 grid, hipStrea
 {
     const dim3 block(LANES * WAVES_PER_WG);
     if constexpr (KSL && R == 32 && OCC == 4) {   // tile pruning: the single-k 32 x 128 form (the symmetric self kNN's bands)
-        if (args.prune_q_rows != nullptr && args.seg_chunks == 0u && mode == MODE_JACCARD) {
+        if (args.prune_q_rows != nullptr && args.seg_chunks == 0u && mode == MODE_JACCARD && !args.has_comp) {   // (keys of the count alone)
             hipLaunchKernelGGL((pair_kernel_kslice<R, JL, MODE_JACCARD, true, 0, TIGHT, MB, OCC, false, true>), grid, block, 0, stream, args);
             return hipGetLastError();
         }

@@ -135,14 +135,17 @@ def set_u_device(n, nk, ss64, device, first_sample=0, seed=SEED_U, chunk=4096):
 
 
 def set_clustered_device(n, nk, ss64, device, cluster_size=200, keep=0.9, seed=SEED_R, chunk=2048,
-                         first_sample=0, n_clusters=None):
+                         first_sample=0, n_clusters=None, scatter=False):
     """Clustered sketches generated on `device` for large runs: sample s belongs to cluster
     s % n_clusters (default n / cluster_size) and keeps each of its cluster's bin values with
     probability `keep` -- one number, or one per k-mer length so that J falls with k and the
     core/accessory regression has a slope to fit -- and an independent 14-bit value otherwise, so a
     row has ~cluster_size close neighbours scattered over the whole id range and every other
     distance sits at ~1.  `first_sample` offsets the ids the samples' own draws come from (a query
-    set drawn from the same clusters as a reference set).  Returns an int64 tensor [n, words]
+    set drawn from the same clusters as a reference set).  `scatter`: the cluster of sample s is a hash of s (mod n_clusters)
+    instead -- relatives at RANDOM ids rather than at regular id distances (s % n_clusters puts a tile's related pairs on a
+    diagonal: either every row of a 32 x 128 tile has one or none has; scattered, a tile that holds a relative usually holds
+    exactly one).  Returns an int64 tensor [n, words]
     whose bit pattern is the uint64 slab (fill_usigs layout, src/sketch/mod.rs:215-223)."""
     import torch
 
@@ -161,7 +164,8 @@ def set_clustered_device(n, nk, ss64, device, cluster_size=200, keep=0.9, seed=S
         s1 = min(n, s0 + chunk)
         ids = torch.arange(first_sample + s0, first_sample + s1, dtype=torch.int64, device=device)
         own = _mix_t(_mix_t(ids + seed, torch)[:, None] + w[None, :], torch)
-        par = _mix_t(_mix_t((ids % n_clusters) + (seed ^ 0xA5A5), torch)[:, None] + w[None, :], torch)
+        cl = ((_mix_t(ids + (seed ^ 0x5C5C), torch) >> 1) & 0x3FFFFFFFFFFF) % n_clusters if scatter else ids % n_clusters
+        par = _mix_t(_mix_t(cl + (seed ^ 0xA5A5), torch)[:, None] + w[None, :], torch)
         coin = ((own >> 14) & 0xFFFF).view(s1 - s0, nk, ss64, 64)
         vals = torch.where(coin < thresh, (par & 0x3FFF).view(s1 - s0, nk, ss64, 64),
                            (own & 0x3FFF).view(s1 - s0, nk, ss64, 64))

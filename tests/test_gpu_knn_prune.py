@@ -12,16 +12,21 @@ from sketchlib.rust_amd import synth
 pytestmark = [pytest.mark.gpu, pytest.mark.ab_library]   # (SKL_KNN_SYMMETRIC / SKL_KNN_PRUNE ...: switches of the A/B build)
 
 
-def _clustered(n, nk, ss64, n_clusters, keep=0.94):
+def _clustered(n, nk, ss64, n_clusters, keep=0.94, shuffle=None):
     """Sample s belongs to cluster s % n_clusters and keeps each of the cluster's bin values with probability `keep`
-    (J ~ 0.8 inside a cluster, ~0 outside): synth.set_clustered_device, brought to the host for the oracle."""
+    (J ~ 0.8 inside a cluster, ~0 outside): synth.set_clustered_device, brought to the host for the oracle.  `shuffle` (a
+    seed): the samples in a random order -- relatives at random ids instead of regular id distances."""
     import torch
 
     t = synth.set_clustered_device(n, nk, ss64, torch.device("cuda", 0), keep=keep, n_clusters=n_clusters)
-    return t.cpu().numpy().view(np.uint64)
+    bins = t.cpu().numpy().view(np.uint64)
+    if shuffle is not None:
+        bins = np.ascontiguousarray(bins[np.random.default_rng(shuffle).permutation(n)])
+    return bins
 
 
-def _run(skl, ctx, g, p, knn, monkeypatch, band_rows, prune=True, ties=None):
+def _run(skl, ctx, g, p, knn, monkeypatch, band_rows, prune=True, ties=None, sparse=True):
+    monkeypatch.setenv("SKL_KNN_SPARSE", "1" if sparse else "0")
     monkeypatch.setenv("SKL_KNN_BAND_ROWS", str(band_rows))
     monkeypatch.setenv("SKL_TILE32_MIN", "0")          # 32 x 128 tiles whatever the launch size (the prunable form)
     monkeypatch.setenv("SKL_KNN_PRUNE", "1" if prune else "0")
@@ -58,6 +63,33 @@ def test_pruned_run_equals_the_oracle(oracle, skl, gpu_ctx, monkeypatch, ties, a
     # ... and without pruning: the same lists, nothing skipped
     idx0, d00, (_t0, pruned0) = _run(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, False, t)
     assert pruned0 == 0 and np.array_equal(idx0, idx) and np.array_equal(d00, d0)
+    g.close()
+
+
+@pytest.mark.parametrize("n,band_rows,ss64,ties,ani", [(8192, 64, 16, "reference", False), (8192, 96, 13, "canonical", True),
+                                                        (8192, 160, 16, "canonical", False), (4096, 64, 72, "reference", True),
+                                                        (4096, 64, 157, "canonical", False), (4096, 96, 157, "reference", False)])
+def test_probe_survivors_take_the_sparse_walk(oracle, skl, gpu_ctx, monkeypatch, n, band_rows, ss64, ties, ani):
+    """Clusters of 4 genomes at RANDOM ids, knn = 1, sets large enough that a 32 x 128 tile holds one or two related pairs
+    (4 096 x 3 / n): a tile that survives the probe does so for those pairs, and is walked for their rows only (at most 4 alive
+    rows; more fall back to the whole walk).  Sketch sizes: one batch of the sparse walk's row staging, waves with unequal
+    chunk counts (13), one batch and a bit (72 -> 18 chunks per wave), several batches (157 -> 40)."""
+    kmers, knn = [17, 21], 1
+    bins = _clustered(n, len(kmers), ss64, n // 4, shuffle=77)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21, ani)
+    t = skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL
+    idx, d0, (tiles, pruned) = _run(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True, t)
+    sparse = gpu_ctx.knn_prune_stats(full=True)["tiles_sparse_walk"]
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, ani,
+                                ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
+    assert np.array_equal(d0, exp["d0"])
+    assert tiles > 0 and 0 < pruned < tiles and 0 < sparse <= tiles - pruned, (tiles, pruned, sparse)
+    # ... the survivors walked whole instead: the same lists
+    idx1, d01, _ = _run(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True, t, sparse=False)
+    assert gpu_ctx.knn_prune_stats(full=True)["tiles_sparse_walk"] == 0
+    assert np.array_equal(idx1, idx) and np.array_equal(d01, d0)
     g.close()
 
 
@@ -156,7 +188,8 @@ def test_random_pruned_configuration(oracle, skl, gpu_ctx, monkeypatch, seed):
     ties = ["canonical", "reference"][int(rng.integers(0, 2))]
     keep = float(rng.choice([0.98, 0.94, 0.85]))
     kmers = [17, 21]
-    bins = _clustered(n, len(kmers), ss64, n_clusters, keep=keep)
+    shuffle = int(rng.integers(1, 1 << 30)) if rng.integers(0, 2) else None      # relatives at random ids: sparse walks
+    bins = _clustered(n, len(kmers), ss64, n_clusters, keep=keep, shuffle=shuffle)
     if rng.integers(0, 2):      # a few exact duplicates: ties at key 0
         for _ in range(3):
             a, b = rng.integers(0, n, 2)
@@ -167,7 +200,8 @@ def test_random_pruned_configuration(oracle, skl, gpu_ctx, monkeypatch, seed):
     idx, d0, (tiles, pruned) = _run(skl, gpu_ctx, g, p, knn, monkeypatch, band_rows, True, t)
     exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 1, ani,
                                 ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
-    cfg = dict(n=n, n_clusters=n_clusters, knn=knn, ss64=ss64, band_rows=band_rows, ani=ani, ties=ties, keep=keep, tiles=tiles, pruned=pruned)
+    cfg = dict(n=n, n_clusters=n_clusters, knn=knn, ss64=ss64, band_rows=band_rows, ani=ani, ties=ties, keep=keep, tiles=tiles, pruned=pruned,
+               shuffle=shuffle, sparse=gpu_ctx.knn_prune_stats(full=True)["tiles_sparse_walk"])
     assert np.array_equal(idx, exp["idx"]), (cfg, np.argwhere(idx != exp["idx"])[:5])
     assert np.array_equal(d0, exp["d0"]), cfg
     g.close()
