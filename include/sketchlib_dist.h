@@ -321,7 +321,10 @@ int skl_self_dists_knn_candidates(skl_ctx *ctx, const skl_sketches *s, const skl
                                   uint64_t *out_idx, float *out_d0);
 
 /* cross_dists_knn (src/distances/mod.rs:306-395): rows = queries, neighbours
- * index refs; knn must already be clamped to <= n_ref (mod.rs:325). */
+ * index refs; knn must already be clamped to <= n_ref (mod.rs:325).
+ * Against 131 072 references or more (single-k keys, no completeness correction) the references reach a query in ascending
+ * panels of columns and the tiles of the later panels are pruned against the queries' running lists, as in the self kNN
+ * (skl_ctx_knn_prune_stats reports them): same lists in either tie rule, 16 384 x 1 M top-50 in 0.16 s instead of 0.36 s. */
 int skl_cross_dists_knn(skl_ctx *ctx, const skl_sketches *ref, const skl_sketches *query,
                         const skl_dist_params *p, size_t knn, uint64_t *out_idx, float *out_d0,
                         float *out_d1, int out_on_device);
