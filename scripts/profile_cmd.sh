@@ -22,8 +22,11 @@ fi
 # The profiler's preloaded library initialises the GPU before the program starts (with --pmc it does), and on this
 # pool a process that has initialised the GPU must not exec another program: what follows `--` has to be the
 # interpreter BINARY itself (an ELF file), never env / bash -c / taskset / numactl or a `#!/usr/bin/env` script.
-PROG=$(command -v -- "$1" || true)
-PROG=$(readlink -f -- "${PROG:-$1}")
+# (the checks look at what the name resolves to; the command runs the name as given -- a symlink is not an exec hop, and a
+# virtualenv's interpreter finds its pyvenv.cfg only next to the unresolved path)
+ASGIVEN=$(command -v -- "$1" || true)
+ASGIVEN=${ASGIVEN:-$1}
+PROG=$(readlink -f -- "$ASGIVEN")
 case "$(basename -- "$PROG")" in
   env|bash|sh|dash|taskset|numactl|nice|timeout|stdbuf) echo "$0: '$1' would exec the real program after the GPU is initialised: name the interpreter itself" >&2; exit 2;;
 esac
@@ -32,7 +35,7 @@ if [ ! -x "$PROG" ] || [ "$(head -c 4 -- "$PROG" | od -An -c | tr -d ' ')" != "1
   exit 2
 fi
 shift
-set -- "$PROG" "$@"
+set -- "$ASGIVEN" "$@"
 [ "$PASSES" = "all" ] && PASSES=stats,fetch,write,sq,tcc,stall_a,stall_b
 [ "$PASSES" = "traffic" ] && PASSES=stats,fetch,write
 OUT=$R/gpurun_out/prof_$TAG
