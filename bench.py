@@ -908,6 +908,25 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
             assert np.array_equal(d0_r, d0), "the two tie rules list the same distances per row"
             ref_rows_differ = int((idx_r != idx).any(axis=1).sum())
             del idx_r, d0_r
+            # ... and a database of the same size whose relatives sit at RANDOM ids (the generator above puts them at regular id
+            # distances: a tile then holds a whole diagonal of related pairs or none).  Scattered, most tiles hold one relative
+            # among their 4 096 pairs: the probe cannot dismiss them, and they are finished for that row alone (sparse walk).
+            sbins = synth.set_clustered_device(nr, 1, ss, device, cluster_size=200, keep=keep[2], scatter=True)
+            g_s = ctx.sketches(sbins, nr, [K4[2]], ss)
+            del sbins
+            ctx.set_knn_ties(capi.TIES_REFERENCE)
+            t_s = time.perf_counter()
+            idx_s, d0_s, _ = capi.self_dists_knn(ctx, g_s, g_s.set_k(K4[2]), knn)
+            scat_s = time.perf_counter() - t_s
+            prune_s = ctx.knn_prune_stats(full=True)
+            for i in (3, 555_555):            # two rows: the dense path's row pushed through the oracle's BinaryHeap
+                dense = capi.cross_dists_rows(ctx, g_s, g_s, g_s.set_k(K4[2]), i, i + 1)[0, :, 0]
+                exp = O.heap_replay(np.delete(dense, i), knn, ids=np.delete(np.arange(nr, dtype=np.uint64), i))
+                assert np.array_equal(idx_s[i], exp["idx"]) and np.array_equal(d0_s[i], exp["d0"]), i
+            ctx.set_knn_ties(capi.TIES_CANONICAL)
+            g_s.close()
+            del idx_s, d0_s
+            torch.cuda.empty_cache()
             evaluated = nr * (nr - 1) // 2            # every pair once (symmetric driver)
             v5 = valu_block(evaluated, ksec, 1, ss, clk)
             sec["cfg5"] = {"workload": "BASELINE configs[4]: self kNN-50 over 1M x 1M, single-k Jaccard (k=21), sketchsize64=32, on ONE "
@@ -918,6 +937,11 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
                            "reference_tie_order": {"s_per_call": ref_s, "rows_whose_ids_differ_from_canonical": ref_rows_differ,
                                                    "what": "skl_ctx_set_knn_ties(REFERENCE), the CLI's default: ids and order of equal keys as the "
                                                            "reference binary prints them; same distances"},
+                           "relatives_at_random_ids": {"s_per_call": scat_s, "ties": "reference", "tile_pruning": prune_s,
+                                                       "what": "the same call over a database of the same size and cluster structure whose "
+                                                               "relatives sit at random ids: tiles that hold one relative are finished "
+                                                               "for that row alone (tiles_sparse_walk); two rows checked against the dense "
+                                                               "path + the oracle's heap replay"},
                            "pair_kernel_s": ksec, "pair_kernel_launches": n_launch, "other_s (top-k merge, copies)": wall - ksec,
                            "tile_pruning": {**prune5,
                                             "what": "a 32 x 128 tile all of whose pairs are, on the chunks walked so far, beyond both samples' "

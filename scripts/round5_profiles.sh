@@ -18,6 +18,9 @@ bash scripts/profile_cmd.sh r05_cfg5_prune 'pair_kernel|refheap|prune_thresholds
 bash scripts/profile_cmd.sh r05_cfg5_noprune 'pair_kernel|refheap|prune_thresholds|topk' stats -- python3 scripts/bench_knn_prune.py --samples 1000000 --ties reference --prune 0 > "$OUT/profile_cfg5_noprune.log" 2>&1
 python3 scripts/bench_knn_prune.py --samples 1000000 --ties reference,canonical > "$OUT/knn_prune_1m.jsonl" 2>/dev/null
 python3 scripts/bench_knn_prune.py --samples 400000 --ss64 157 --ties reference > "$OUT/knn_prune_157.jsonl" 2>/dev/null
+# ... the same size with the relatives at random ids (sparse finish of the probe's survivors), and the cross kNN in column panels
+bash scripts/profile_cmd.sh r05_cfg5_scatter 'pair_kernel|refheap|prune_thresholds|topk' stats -- python3 scripts/bench_knn_prune.py --samples 1000000 --ties reference --prune 1 --scatter 1 > "$OUT/profile_cfg5_scatter.log" 2>&1
+bash scripts/profile_cmd.sh r05_cross_panels 'pair_kernel|refheap|prune_thresholds|topk' stats -- python3 scripts/bench_knn_prune.py --samples 1000000 --queries 16384 --ties reference --prune 1 > "$OUT/profile_cross_panels.log" 2>&1
 # GPU sketching: the call and its kernels
 BENCH_KERNEL_ONLY=1 bash scripts/profile_cmd.sh r05_sketch 'nthash' stats -- python3 scripts/bench_sketch.py 512 > "$OUT/profile_sketch.log" 2>&1
 python3 scripts/bench_sketch.py 512 > "$OUT/bench_sketch_512.txt" 2>&1

@@ -262,3 +262,45 @@ def test_self_knn_row_range_in_column_panels(oracle, skl, gpu_ctx, monkeypatch, 
     assert np.array_equal(idx, exp["idx"][301:777]) and np.array_equal(d0, exp["d0"][301:777])
     assert gpu_ctx.knn_prune_stats()[1] > 0
     g.close()
+
+
+def test_sparse_walks_inside_column_windows_and_partial_states(oracle, skl, gpu_ctx, monkeypatch):
+    """The two multi-device forms over a set whose relatives sit at random ids (tiles that survive the probe for one pair):
+    the reference's order from heaps travelling through 3 column windows, and canonical partial states of 3 participants
+    merged -- both the oracle's lists, the windows with tiles finished by the sparse walk on the way."""
+    import torch
+    from sketchlib.rust_amd import multi_gpu
+
+    kmers, ss64, n, knn, band_rows, world = [21], 16, 8192, 1, 96, 3
+    bins = _clustered(n, 1, ss64, n // 4, shuffle=5)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k(21)
+    monkeypatch.setenv("SKL_TILE32_MIN", "0")
+    gpu_ctx.reload_env()
+    n_bands = (n + band_rows - 1) // band_rows
+    # (a) travelling heaps
+    heaps = skl.knn_heaps_alloc(n, knn, False, torch.device("cuda", 0))
+    cuts = multi_gpu.knn_window_cuts(n, band_rows, world)
+    sparse = 0
+    for r in range(world):
+        for band in range(n_bands):
+            if band * band_rows >= cuts[r + 1]:
+                break
+            skl.self_dists_knn_window(gpu_ctx, g, p, knn, band_rows, band, cuts[r], cuts[r + 1], heaps)
+            sparse += gpu_ctx.knn_prune_stats(full=True)["tiles_sparse_walk"]
+    idx, d0, _ = skl.knn_heaps_finalize(gpu_ctx, heaps, 0, n, knn)
+    gpu_ctx.synchronize()
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint64), exp["idx"]) and np.array_equal(d0.cpu().numpy(), exp["d0"])
+    assert sparse > 0
+    # (b) partial states
+    deal = multi_gpu.knn_band_deal(n_bands, world)
+    states, sparse = [], 0
+    for r in range(world):
+        states.append(skl.self_dists_knn_partial(gpu_ctx, g, p, knn, band_rows, deal[r]))
+        sparse += gpu_ctx.knn_prune_stats(full=True)["tiles_sparse_walk"]
+    got = skl.knn_merge_states(gpu_ctx, np.stack([s[0] for s in states]), np.stack([s[1] for s in states]), None)
+    exp = oracle.self_dists_knn(o, knn, oracle.JACCARD, 0, False, ties=oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(got[0], exp["idx"]) and np.array_equal(got[1], exp["d0"])
+    # (a participant's own lists see a third of the ids: few of its tiles have all 160 bounds tight -- parity is the point here)
+    g.close()
