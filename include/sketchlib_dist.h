@@ -206,6 +206,17 @@ int skl_cross_dists_rows(skl_ctx *ctx, const skl_sketches *ref, const skl_sketch
 #define SKL_KNN_TIES_REFERENCE 1
 int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);
 
+/* Diagnostic (no reference counterpart): the early break of the core/accessory calls.  core_acc_dist leaves its loop over
+ * the k-mer lengths at the first one whose Jaccard index is 0 (src/distances/jaccard.rs:89-91), and a fit over fewer than
+ * three lengths is (1, 1) (:117).  With more than three lengths and no completeness correction the dense calls therefore
+ * count only the first three for every pair and complete the pairs that share a bin at each of them one by one -- when a
+ * sample of 4 096 pairs, taken the first time a slab meets a column slab, says that at most 4 % of the pairs are such
+ * (between unrelated genomes ~1 % at 4 096 bins, 0.2 % at 2 048; between close relatives all of them: then every length is
+ * counted for every pair as before).  Same (core, acc) bit for bit either way.  pairs: pairs of the early-break launches
+ * since the context was made; completed_one_by_one: those among them that were still in the running (counter wraps at
+ * 2^32).  Either argument may be null.  (The A/B build reads SKL_EARLY_BREAK=0: off.) */
+int skl_ctx_early_break_stats(skl_ctx *ctx, uint64_t *pairs, uint64_t *completed_one_by_one);
+
 /* Diagnostic (no reference counterpart): tile pruning of the last skl_self_dists_knn / _partial call of the context.  The
  * whole-matrix self kNN with single-k keys (Jaccard / ANI, no completeness correction) leaves a 32 x 128 tile of the pair
  * space unfinished once every pair of it is, on the bins compared so far, already beyond both its samples' current knn-th

@@ -68,6 +68,7 @@ _SIG = [
     ("skl_device_free", C.c_int, [_P, _P]),
     ("skl_device_memcpy", C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     ("skl_ctx_get_knn_ties", C.c_int, [_P]),
+    ("skl_ctx_early_break_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("skl_ctx_knn_prune_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]),
     ("skl_clock_sampler_start", C.c_int, [_P, C.c_uint32, C.c_uint32]),
@@ -255,6 +256,12 @@ class Context:
         n = C.c_int()
         _check(load().skl_ctx_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def early_break_stats(self):
+        """(pairs of early-break core/accessory launches, pairs among them completed one by one) since the context was made."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(load().skl_ctx_early_break_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def knn_prune_stats(self, full=False):
         """(tiles, tiles left early) of the last self kNN call's prunable launches; full=True: + (stages of a whole tile,

@@ -178,6 +178,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
         (void)hipHostFree(ctx->sampler_stop);
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->eb_counter) (void)hipFree(ctx->eb_counter);
     if (ctx->sampler_buf) (void)hipFree(ctx->sampler_buf);
     if (ctx->sampler_count) (void)hipFree(ctx->sampler_count);
     if (ctx->sampler_stream) (void)hipStreamDestroy(ctx->sampler_stream);
@@ -227,6 +228,19 @@ extern "C" int skl_ctx_reload_env(skl_ctx *ctx)
 
 // Pair-kernel timing is a diagnostic and OFF unless asked for: an event record is a barrier packet on the queue, and two
 // per launch cost a sub-millisecond launch ~5 us.  every = 0: off (the default); N >= 1: every N-th launch is bracketed.
+extern "C" int skl_ctx_early_break_stats(skl_ctx *ctx, uint64_t *pairs, uint64_t *completed_one_by_one)
+{
+    SKL_TRY(ctx_bind(ctx));
+    uint32_t done = 0;
+    if (ctx->eb_counter) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(&done, ctx->eb_counter, sizeof done, hipMemcpyDeviceToHost));
+    }
+    if (pairs) *pairs = ctx->eb_pairs;
+    if (completed_one_by_one) *completed_one_by_one = done;
+    return SKL_OK;
+}
+
 extern "C" int skl_ctx_timing_enable(skl_ctx *ctx, int every)
 {
     SKL_TRY(ctx_bind(ctx));
@@ -357,6 +371,7 @@ Knobs read_knobs()
     k.knn_prune = env_int("SKL_KNN_PRUNE", 1) != 0;
     k.knn_panel = env_int("SKL_KNN_PANEL", 0);
     k.knn_sparse = env_int("SKL_KNN_SPARSE", 1) != 0;
+    k.early_break = (int)std::min(7ll, std::max(0ll, env_int("SKL_EARLY_BREAK", 1)));
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
@@ -923,6 +938,60 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
     return slice_plan((uint32_t)ss64, S, &chunks);   // (slices that hold something: a short sketch gets fewer)
 }
 
+// EARLY BREAK (round 5).  core_acc_dist leaves its loop over the k-mer lengths at the first one whose Jaccard index is 0
+// (jaccard.rs:89-91) and a fit over fewer than three lengths is (1, 1) (:117): a pair without a shared bin at one of the
+// first three lengths is decided by them alone, and between unrelated genomes that is nearly every pair (a chance match
+// at each of three lengths: 1.1 % of pairs at 4 096 bins, 0.2-0.4 % at 2 048).  The counts + epilogue form can then count
+// only the first ke >= 3 lengths for everybody and let the epilogue complete the few pairs still in the running, one wave
+// per pair (kernels.hip).  Whether that pays depends on the data: completing a pair costs ~180 x what the tile kernel
+// spends on a pair and length (7-14 KB from HBM per pair and length with no reuse; measured: 3.7 ns against 0.022 ns at
+// 2 048 bins, 8.4 against 0.042 ns at 4 096), and between close relatives every pair stays in the running.  So the first
+// dense call of a slab against a column slab samples 4 096 pairs (one wave each, ~50 us, kept with the slab), and the
+// early break is taken with the ke of {3, 4} that minimises  ke + 180 x share(ke)  -- if that is at most 0.9 x nk.
+// *lengths = ke, or 0 for "count them all".
+static int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketches *cols, int self_mode, int *lengths)
+{
+    skl_sketches *rows = const_cast<skl_sketches *>(crows);
+    *lengths = 0;
+    const int knob = ctx->knobs.early_break;
+    if (knob == 0 || rows->nk < 4 || rows->nk > 8 || rows->d_comp != nullptr || cols->d_comp != nullptr) return SKL_OK;
+    if (rows->n * cols->n < 65536) return SKL_OK;
+    if (!ctx->eb_counter) {
+        HIP_TRY(hipMalloc((void **)&ctx->eb_counter, 16 * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(ctx->eb_counter, 0, 16 * sizeof(uint32_t), ctx->stream));
+    }
+    if (knob >= 3) {   // forced (tests)
+        *lengths = knob < (int)rows->nk ? knob : 0;
+        return SKL_OK;
+    }
+    if (rows->eb_cols != cols || rows->eb_cols_n != cols->n) {
+        constexpr uint32_t SAMPLES = 4096;
+        uint32_t hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemsetAsync(ctx->eb_counter + 1, 0, 9 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(launch_early_break_sample(rows->d_rows, cols->d_rows, (uint32_t)rows->n, (uint32_t)cols->n, (uint32_t)rows->nk,
+                                          (uint32_t)rows->ss64, (uint32_t)self_mode, SAMPLES, ctx->eb_counter + 1, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(hist, ctx->eb_counter + 1, sizeof hist, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        rows->eb_cols = cols;
+        rows->eb_cols_n = cols->n;
+        rows->eb_lengths = 0;
+        rows->eb_alive_share = 0.0;
+        double best = 0.9 * (double)rows->nk;
+        for (int ke = 3; ke <= 4 && ke < (int)rows->nk; ++ke) {
+            uint32_t still = 0;
+            for (int m = ke; m <= 8; ++m) still += hist[m];
+            const double share = (double)still / SAMPLES, cost = (double)ke + 180.0 * share;
+            if (cost <= best) {
+                best = cost;
+                rows->eb_lengths = ke;
+                rows->eb_alive_share = share;
+            }
+        }
+    }
+    *lengths = rows->eb_lengths;
+    return SKL_OK;
+}
+
 // Core of every dense call: rows [r0, r1) of the pair space into `dst` (device).
 // elem_bytes is the output record size per pair.
 int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
@@ -938,13 +1007,19 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
     const bool coreacc = mode == MODE_COREACC;
     // Small core/acc launches run as (tile, k) workgroups producing counts + the epilogue
     // kernel (pair_kslice.hip): 5x the workgroups of the fused kernel and two columns per lane.
-    const bool sliced = coreacc && coreacc_runs_sliced(ctx, rows, pairs);
+    int eb_lengths = 0;
+    if (coreacc && (forced_kernel(ctx) == 0 || forced_kernel(ctx) == 4)) SKL_TRY(early_break_lengths(ctx, rows, cols, self_mode, &eb_lengths));
+    const bool early = eb_lengths > 0;
+    // (with the early break every launch takes the counts + epilogue form, whatever its size: three of the k-mer lengths,
+    // 12 bytes of counts per pair through HBM -- nothing beside the two lengths not walked)
+    const bool sliced = coreacc && (coreacc_runs_sliced(ctx, rows, pairs) || (early && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS));
     if (coreacc && (sliced || !fused_coreacc_ok(rows))) {
         // unfused: counts -> scratch2 -> epilogue kernel
         // (the counts scratch is bounded: a band whose counts would not fit COUNTS_SCRATCH_MAX is computed in two halves
         // of equal pair count, each into its slice of the destination -- only sketches beyond 65 535 bins or more than 6
         // k-mer lengths come here with that many pairs)
-        if (pairs * rows->nk * sizeof(uint32_t) > COUNTS_SCRATCH_MAX && r1 - r0 > 1) {
+        const size_t nkw = early ? (size_t)eb_lengths : rows->nk;   // k-mer lengths the pair kernel counts
+        if (pairs * nkw * sizeof(uint32_t) > COUNTS_SCRATCH_MAX && r1 - r0 > 1) {
             uint64_t mid = r0 + (r1 - r0) / 2;
             if (self_mode) {   // the row that splits the pairs evenly
                 uint64_t lo = r0 + 1, hi = r1 - 1;
@@ -960,6 +1035,10 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         }
         PairArgs g;
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
+        if (early) {
+            g.k_count = (uint32_t)nkw;
+            g.cnt_pair_stride = nkw;
+        }
         void *counts = nullptr;
         const uint32_t k_slices = sliced ? choose_k_slices(ctx, rows->ss64) : 1u;
         // A launch with fewer (tile, k) units than resident workgroup slots cannot fill the chip with one
@@ -970,7 +1049,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // whole launch is that partial round; the partial round of a longer launch gains nothing,
         // profiles/r02_ab_tail_slices.jsonl).  Slice 0 of a unit stores, the others add into a second
         // plane that is zero on entry and re-zeroed by the epilogue.
-        const uint64_t est_units = pairs * rows->nk / 2048;
+        const uint64_t est_units = pairs * nkw / 2048;
         const uint64_t slots = 4ull * (uint64_t)ctx->n_cu;
         // (launches of less than 1/16 round -- ~200 genomes -- are cut twice as fine when the sketch allows it)
         // (round 4: any sketch size is cut -- slices of whole stages, the last one shorter, slice_plan() -- e.g. the 157
@@ -987,7 +1066,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // round decides: 32 x 128 tiles with THAT round cut into 2 chunk slices are 0.7-4.6 % ahead of 16 x 128 tiles
         // there (profiles/r03_ab_mid_sizes.jsonl, r03_ab_mid_band.jsonl); plain 32-row tiles are not (+-4 %).  Above the
         // band plain 32-row tiles, below it 16-row tiles (cfg 2: 0.156 against 0.162 ms).
-        const uint64_t evals = pairs * rows->nk;
+        const uint64_t evals = pairs * nkw;
         const long long t32 = ctx->knobs.tile32_min;
         const bool mid_band = ctx->knobs.mid_band && !tail && sliced && k_slices == 1u && t32 > 0 && tail_slices > 1u &&
                               forced_kernel(ctx) == 0 && rows->ss64 >= 16 && evals * 2 >= (uint64_t)t32 && evals < (uint64_t)t32;
@@ -997,7 +1076,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             tail_slices_eff = slice_plan((uint32_t)rows->ss64, 2u, &tail_chunks_eff);
         }
         const bool two_planes = tail;
-        const size_t plane_bytes = pairs * rows->nk * sizeof(uint32_t);
+        const size_t plane_bytes = pairs * nkw * sizeof(uint32_t);
         SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(two_planes ? 2u : 1u, k_slices), &counts, 1));
         if (sliced) {   // k-major scratch: coalesced stores from the (tile, k[, chunk slice]) workgroups
             g.cnt_pair_stride = 1;
@@ -1033,7 +1112,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // (A/B build only, SKL_FUSE_EPILOGUE=1: measured SLOWER than the second launch at cfg 2 -- 0.154 against 0.145 ms per step:
         // the arrival pattern itself is free, but with the k-major dispatch order every tile completes in the launch's last round
         // and one workgroup then does a whole tile's regressions alone while the chip empties; profiles/r05_fused_epilogue.md)
-        if (sliced && k_slices == 1u && !two_planes && ctx->knobs.fuse_epilogue && forced_kernel(ctx) == 0 &&
+        if (sliced && !early && k_slices == 1u && !two_planes && ctx->knobs.fuse_epilogue && forced_kernel(ctx) == 0 &&
             rows->nk <= (size_t)MAX_FUSED_K && kslice_supported(g, MODE_COUNTS, true) && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS) {
             // arrival counters, one per tile of the launch (16-row tiles at most), counted modulo nk: zero once per (buffer, nk)
             const size_t tiles_max = ((r1 - r0 + 15) / 16 + 1) * ((cols->n + 127) / 128 + 1) + 64;
@@ -1068,7 +1147,15 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.pair_stride = g.cnt_pair_stride;
         e.k_stride = g.cnt_k_stride;
         e.n_pairs = pairs;
-        e.nk = (uint32_t)rows->nk;
+        e.nk = (uint32_t)nkw;
+        if (early) {
+            e.nk_total = (uint32_t)rows->nk;
+            e.rows_ref = rows->d_rows;
+            e.cols_ref = cols->d_rows;
+            e.alive_count = ctx->eb_counter;
+            ctx->eb_pairs += pairs;
+            ctx->last_kernel += " + early break: " + std::to_string(nkw) + " of " + std::to_string(rows->nk) + " k-mer lengths counted, the pairs still in the running completed by the epilogue";
+        }
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
         e.rezero_plane1 = sliced && ctx->last_tail ? 1u : 0u;

@@ -60,6 +60,8 @@ struct Knobs {
     bool knn_row_flags = true;        // SKL_KNN_ROW_FLAGS=0: the merge of the transposed band visits every row (A/B only, results are identical)
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
+    int early_break = 1;              // A/B build, SKL_EARLY_BREAK: 0 core/accessory launches count every k-mer length; 1 (default) the early break where a
+                                      // sample of the pairs says it pays; 3..7 forced with that many lengths counted (tests).  Results identical.
     bool knn_sparse = true;           // A/B build, SKL_KNN_SPARSE=0: tiles that survive the probe are walked whole (results identical)
     long long knn_panel = 0;          // A/B build, SKL_KNN_PANEL: column-panel width of the row-by-row kNN forced (tests; 0: by size)
     bool knn_prune = true;            // SKL_KNN_PRUNE=0: the symmetric self kNN finishes every tile (A/B; results are identical)
@@ -117,6 +119,8 @@ struct skl_ctx {
     uint64_t knn_tiles_sparse = 0;         // tiles that survived the probe and were finished by the sparse walk (alive rows only)
     uint64_t knn_tiles_probe_pruned = 0;   // ... of the pruned tiles, those the plane-pair probe settled before the walk began
     uint64_t knn_pruned_stages = 0, knn_tile_stages = 0;   // ... stages the pruned tiles had walked / stages of a whole tile
+    uint32_t *eb_counter = nullptr;        // device word: pairs the early-break epilogue completed (skl_ctx_early_break_stats)
+    uint64_t eb_pairs = 0;                 // ... out of this many pairs of early-break launches since the context was made
     uint64_t knn_tiles = 0, knn_tiles_pruned = 0;   // tile pruning of the last self kNN call (skl_ctx_knn_prune_stats)
     int knn_ties = SKL_KNN_TIES_REFERENCE;   // what self_dists_knn returns (mod.rs:133-224); skl_ctx_set_knn_ties(CANONICAL) opts out
     Knobs knobs;                        // environment switches as of skl_ctx_create
@@ -134,6 +138,12 @@ struct skl_sketches {
     double *d_ytab = nullptr;    // ln J table [64*ss64+1]
     double *d_kf = nullptr;      // k-mer lengths as f64 [nk]
     std::map<std::pair<int, size_t>, float *> d_dtab;  // (jout, k_idx) -> f32 table
+    // early break (capi.cpp dense_band): the last column slab this one was sampled against, and whether counting only the
+    // first three k-mer lengths paid (few enough pairs stay in the running)
+    const skl_sketches *eb_cols = nullptr;
+    size_t eb_cols_n = 0;
+    int eb_lengths = 0;          // lengths to count (0: all of them, no early break)
+    double eb_alive_share = 0.0; // sampled share of the pairs still in the running after them
     size_t sample_words() const { return nk * ss64 * skl::BBITS; }
 };
 

@@ -218,8 +218,21 @@ struct EpilogueArgs {
     int32_t jout;               // JaccardOut
     double kf0;                 // k-mer length of the one k (ANI outputs)
     const float *dtab;          // [64*ss64 + 1] f32 output per bin-match count (no completeness correction)
+    // EARLY BREAK (round 5; core/accessory, no completeness correction).  The reference's loop over the k-mer lengths leaves
+    // at the first one whose Jaccard index is 0 (jaccard.rs:89-91), and a fit over fewer than three lengths is (1, 1)
+    // (jaccard.rs:117): a pair without a shared bin at one of the FIRST THREE lengths is decided by them alone -- 98.9 % of
+    // unrelated pairs at 4 096 bins, 99.8 % at 2 048.  The pair kernel then counts only `nk` = 3 of the `nk_total` lengths,
+    // and the few pairs that are still in the running get their remaining counts here: the wave that holds such a pair
+    // compares its two sketches cooperatively (a lane per chunk, reference layout) length by length until the break.
+    // nk_total == 0 or == nk: off.  rows_ref / cols_ref: the two slabs in the reference's layout.
+    uint32_t nk_total;
+    const uint64_t *rows_ref, *cols_ref;
+    uint32_t *alive_count;      // += pairs completed here (diagnostic / the driver's switch; may be null)
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
+// early break: hist[m] (9 words) += the sampled pairs that share a bin at each of their first m k-mer lengths and not at the next (kernels.hip)
+hipError_t launch_early_break_sample(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t n_rows, uint32_t n_cols, uint32_t nk,
+                                     uint32_t ss64, uint32_t self_mode, uint32_t n_samples, uint32_t *hist, hipStream_t stream);
 // one-wave shader-clock sampler (kernels.hip): (s_memtime, s_memrealtime) pairs until *stop != 0 or max_samples
 hipError_t launch_clock_sampler(const uint32_t *stop, uint64_t *samples, uint32_t max_samples, uint32_t sleeps,
                                 uint32_t *count, hipStream_t stream);

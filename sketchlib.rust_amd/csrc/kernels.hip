@@ -157,13 +157,15 @@ hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint3
 
 __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArgs g)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= g.n_pairs) return;
+    const uint64_t p_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool early = g.nk_total > g.nk;     // (early break: every lane of a wave stays, the completion below is cooperative)
+    if (p_raw >= g.n_pairs && !early) return;
+    const bool in_range = p_raw < g.n_pairs;
+    const uint64_t p = in_range ? p_raw : g.n_pairs - 1;   // (lanes past the end shadow the last pair and store nothing)
     double c1 = 0.0, c2 = 0.0;
-    if (g.has_comp) {
-        // recover (i, j) from the flat index of this launch
+    // (i, j) of this thread's pair from the flat index of this launch
+    auto pair_of = [&](uint64_t &i, uint64_t &j) {
         const uint64_t flat = p + g.out_base;
-        uint64_t i, j;
         if (g.self_mode) {
             // invert the condensed index by a row search (rows are short ranges; the
             // closed form of distance_matrix.rs:46-51 needs an f64 sqrt and a fix-up)
@@ -181,6 +183,10 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
             i = flat / g.nB_cols;
             j = flat % g.nB_cols;
         }
+    };
+    if (g.has_comp) {
+        uint64_t i, j;
+        pair_of(i, j);
         c1 = g.compA[i];
         c2 = g.compB[j];
     }
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
                 same[u] = cnt[t * g.k_stride];
                 for (uint32_t sl = 1; sl < g.n_slices; ++sl) same[u] += cnt[((uint64_t)sl * g.nk + t) * g.k_stride];
                 // plane 1 goes back to zero for the next tail-sliced launch, whether or not k index t is used
-                if (g.rezero_plane1) cnt[((uint64_t)g.nk + t) * g.k_stride] = 0u;
+                if (g.rezero_plane1 && in_range) cnt[((uint64_t)g.nk + t) * g.k_stride] = 0u;   // (a lane that shadows the last pair must not clear what that pair's own lane has yet to read)
             }
         }
         if (!g.has_comp) {
@@ -249,6 +255,47 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
             ysquaresum += y * y;
             n += 1.0;
         }
+    }
+    if (early) {
+        // the pairs of this wave that are still in the running (a shared bin at each of the first g.nk lengths), one after the
+        // other: all 64 lanes count the bins the pair shares at the next length -- lane c the chunks c, c + 64, ... of the two
+        // samples' slices in the reference's layout -- until a length without one (the reference's break) or the last
+        const bool alive = in_range && !stopped;
+        uint64_t i_mine = 0, j_mine = 0;
+        if (alive) pair_of(i_mine, j_mine);
+        uint64_t todo = __ballot(alive);
+        if (g.alive_count != nullptr && todo != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(g.alive_count, (uint32_t)__popcll(todo));
+        const uint32_t lane = threadIdx.x & 63u;
+        while (todo != 0ull) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint64_t i_l = __shfl(i_mine, l), j_l = __shfl(j_mine, l);
+            for (uint32_t t = g.nk; t < g.nk_total; ++t) {
+                const uint64_t *a = g.rows_ref + ((i_l * g.nk_total + t) * g.ss64) * BBITS;
+                const uint64_t *b = g.cols_ref + ((j_l * g.nk_total + t) * g.ss64) * BBITS;
+                uint32_t m = 0u;
+                for (uint32_t c = lane; c < g.ss64; c += 64u) {
+                    uint64_t differ = 0ull;
+#pragma unroll
+                    for (uint32_t pl = 0; pl < (uint32_t)BBITS; ++pl) differ |= a[(uint64_t)c * BBITS + pl] ^ b[(uint64_t)c * BBITS + pl];
+                    m += (uint32_t)__popcll(~differ);
+                }
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) m += (uint32_t)__shfl_xor((int)m, sh);
+                const double y = g.ytab[m <= maxnbits ? m : maxnbits];
+                if (y < g.tolerance) break;   // (wave-uniform: m is) jaccard.rs:89-91
+                if ((int)lane == l) {
+                    const double k_fl = g.kf[t];
+                    xsum += k_fl;
+                    ysum += y;
+                    xysum += k_fl * y;
+                    xsquaresum += k_fl * k_fl;
+                    ysquaresum += y * y;
+                    n += 1.0;
+                }
+            }
+        }
+        if (!in_range) return;
     }
     ((float2 *)g.out)[p] =
         simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
@@ -296,6 +343,51 @@ hipError_t launch_clock_sampler(const uint32_t *stop, uint64_t *samples, uint32_
                                 uint32_t *count, hipStream_t stream)
 {
     hipLaunchKernelGGL(clock_sampler_kernel, dim3(1), dim3(64), 0, stream, stop, samples, max_samples, sleeps, count);
+    return hipGetLastError();
+}
+
+// EARLY BREAK, the driver's question before it counts only the first few k-mer lengths: how many pairs would still be in
+// the running after them?  One wave per sampled pair (a fixed pseudo-random choice of rows and columns) compares the two
+// samples length by length in the reference's layout until one without a shared bin; hist[m] += pairs that share a bin at
+// each of their first m lengths and not at the next (m = nk: at all of them).  hist has 9 words (m <= 8 kept apart).
+__global__ __launch_bounds__(256) void early_break_sample_kernel(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t n_rows,
+                                                                 uint32_t n_cols, uint32_t nk, uint32_t ss64, uint32_t self_mode,
+                                                                 uint32_t n_samples, uint32_t *hist)
+{
+    const uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (s >= n_samples) return;
+    uint64_t h = ((uint64_t)s + 1u) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    const uint32_t i = (uint32_t)(h % n_rows);
+    uint32_t j = (uint32_t)((h >> 20) % n_cols);
+    if (self_mode && j == i) j = (j + 1u) % n_cols;
+    uint32_t lead = 0u;
+    for (uint32_t t = 0; t < nk && t < 8u; ++t) {
+        const uint64_t *a = rows_ref + (((uint64_t)i * nk + t) * ss64) * BBITS;
+        const uint64_t *b = cols_ref + (((uint64_t)j * nk + t) * ss64) * BBITS;
+        uint32_t m = 0u;
+        for (uint32_t c = lane; c < ss64; c += 64u) {
+            uint64_t differ = 0ull;
+#pragma unroll
+            for (uint32_t pl = 0; pl < (uint32_t)BBITS; ++pl) differ |= a[(uint64_t)c * BBITS + pl] ^ b[(uint64_t)c * BBITS + pl];
+            m += (uint32_t)__popcll(~differ);
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) m += (uint32_t)__shfl_xor((int)m, sh);
+        if (m == 0u) break;
+        ++lead;
+    }
+    if (lane == 0u) atomicAdd(&hist[lead], 1u);
+}
+
+hipError_t launch_early_break_sample(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t n_rows, uint32_t n_cols, uint32_t nk,
+                                     uint32_t ss64, uint32_t self_mode, uint32_t n_samples, uint32_t *hist, hipStream_t stream)
+{
+    if (n_samples == 0 || n_rows == 0 || n_cols == 0) return hipSuccess;
+    hipLaunchKernelGGL(early_break_sample_kernel, dim3((n_samples * 64u + 255u) / 256u), dim3(256), 0, stream, rows_ref, cols_ref, n_rows,
+                       n_cols, nk, ss64, self_mode, n_samples, hist);
     return hipGetLastError();
 }
 
