@@ -56,7 +56,7 @@ def test_product_library_has_no_ab_kernels_or_switches():
                             r"pair_kernel_kslice<32, 2, [012], false, 0, true, 2, 4, false, false, false>|pair_kernel_ksplit<8, [012], 8, false>", k), k
     blob = open(pkg.library_path(), "rb").read()
     for needle in (b"SKL_KNN_SYMMETRIC", b"SKL_TOPK_STREAM", b"SKL_KNN_ROW_FLAGS", b"SKL_CAND_KERNEL", b"SKL_CAND_ROW_ORDER", b"SKL_CAND_SYMMETRIC",
-                   b"SKL_REFHEAP_WAVE", b"SKL_ROUND_PRIORITY", b"SKL_MID_BAND", b"SKL_K_SLICES", b"SKL_KNN_PRUNE", b"SKL_KNN_SPARSE", b"SKL_KNN_PANEL", b"SKL_HALF_TILES",
+                   b"SKL_REFHEAP_WAVE", b"SKL_ROUND_PRIORITY", b"SKL_MID_BAND", b"SKL_K_SLICES", b"SKL_KNN_PRUNE", b"SKL_KNN_SPARSE", b"SKL_KNN_PANEL", b"SKL_EARLY_BREAK", b"SKL_HALF_TILES",
                    b"SKL_INLINE_PREFIX", b"SKL_KNN_OVERLAP", b"SKL_SKETCH_KERNEL", b"pair_cand_kernel",
                    b"SKL_FUSE_EPILOGUE", b"SKL_FUSE_VARIANT", b"pair_kernel_lds", b"SKL_KSLICE_ABLATE", b"SKL_LDS_ABLATE", b"SKL_KERNEL", b"SKL_KSLICE_SHAPE",
                    b"SKL_LDS_SHAPE", b"SKL_FORCE_NA", b"SKL_PAIR_VARIANT", b"SKL_PERSIST"):
