@@ -949,7 +949,7 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 // dense call of a slab against a column slab samples 4 096 pairs (one wave each, ~50 us, kept with the slab), and the
 // early break is taken with the ke of {3, 4} that minimises  ke + 180 x share(ke)  -- if that is at most 0.9 x nk.
 // *lengths = ke, or 0 for "count them all".
-static int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketches *cols, int self_mode, int *lengths)
+int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketches *cols, int self_mode, int *lengths)
 {
     skl_sketches *rows = const_cast<skl_sketches *>(crows);
     *lengths = 0;

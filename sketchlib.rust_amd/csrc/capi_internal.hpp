@@ -174,6 +174,8 @@ SKL_INTERNAL int timed_pair_launch(skl_ctx *ctx, const skl::PairArgs &args, int 
 SKL_INTERNAL std::pair<hipEvent_t, hipEvent_t> *timing_slot(skl_ctx *ctx);
 SKL_INTERNAL int check_params(const skl_sketches *a, const skl_sketches *b, const skl_dist_params *p);
 SKL_INTERNAL bool fused_coreacc_ok(const skl_sketches *s);
+// early break of the core/accessory calls (capi.cpp): k-mer lengths the pair kernel should count (0: all of them)
+SKL_INTERNAL int early_break_lengths(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols, int self_mode, int *lengths);
 // operand / epilogue fields common to every launch: `rows` is the scalar operand (A), `cols` the lane operand (B)
 SKL_INTERNAL int fill_args(const skl_sketches *rows, const skl_sketches *cols, const skl_dist_params *p, int mode,
                            int jout, skl::PairArgs *g);

@@ -171,6 +171,14 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[0], 0));
     }
 
+    // EARLY BREAK (core/accessory keys; capi.cpp early_break_lengths): from the call's second band on -- every list then holds
+    // knn candidates, so a pair that left the reference's loop early, (1, 1), marks nothing -- the band is COUNTED at its first
+    // eb_lengths k-mer lengths (k-sliced counts launch) and coreacc_epilogue_knn_kernel writes the records, the marks and the
+    // turned copy (pre-filled with (1, 1)), completing the pairs still in the running.  Same records as the fused kernel's.
+    int eb_lengths = 0;
+    if (coreacc && !is_cross && fused_coreacc_ok(s) && forced_kernel(ctx) == 0 && ctx->knobs.knn_row_flags) {
+        SKL_TRY(early_break_lengths(ctx, s, cs, 1, &eb_lengths));
+    }
     const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
     size_t it = 0;
     for (const uint32_t band : bands) {
@@ -230,7 +238,66 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             }
             ctx->knn_tiles += (uint64_t)((b1 - b0 + 31) / 32) * ((g.nB + 127) / 128);
         }
-        SKL_TRY(timed_pair_launch(ctx, g, mode));
+        if (eb_lengths > 0 && it >= 1) {
+            const size_t pairs_view = (b1 - b0) * (size_t)g.nB;
+            void *counts = nullptr;
+            SKL_TRY(ctx_scratch(ctx, pairs_view * (size_t)eb_lengths * sizeof(uint32_t), &counts, 1));
+            ctx->clean_plane1 = nullptr;   // (the counts scratch holds another layout now)
+            PairArgs c;
+            SKL_TRY(fill_args(s, cs, p, MODE_COUNTS, 0, &c));
+            c.B += (col0 / 64) * jb_words;
+            c.nB = g.nB;
+            c.row_begin = g.row_begin;
+            c.row_end = g.row_end;
+            c.self_mode = 0;
+            c.out_base = g.out_base;
+            c.k_count = (uint32_t)eb_lengths;
+            c.cnt_pair_stride = 1;
+            c.cnt_k_stride = pairs_view;
+            c.k_sliced = 1;
+            c.k_slices = 1;
+            c.out = counts;
+            SKL_TRY(timed_pair_launch(ctx, c, MODE_COUNTS));
+            if (g.out_t != nullptr) {   // every pair that left the loop before its third length
+                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tband[buf], 0x3F800000, (win_hi - t_first) * t_stride * 2, ctx->stream));
+            }
+            EpilogueKnnArgs e;
+            memset(&e, 0, sizeof e);
+            e.counts = (const uint32_t *)counts;
+            e.n_pairs = pairs_view;
+            e.rows = (uint32_t)(b1 - b0);
+            e.nB = g.nB;
+            e.nk = (uint32_t)eb_lengths;
+            e.nk_total = (uint32_t)s->nk;
+            e.ss64 = (uint32_t)s->ss64;
+            e.row_sample0 = (uint32_t)b0;
+            e.col_sample0 = (uint32_t)col0;
+            e.ytab = s->d_ytab;
+            e.kf = s->d_kf;
+            e.tolerance = g.tolerance;
+            e.rows_ref = s->d_rows;
+            e.cols_ref = cs->d_rows;
+            e.out = (float *)kband[buf];
+            e.r_thr = g.r_thr;
+            e.r_thr_stride = g.r_thr_stride;
+            e.r_bits = g.r_bits;
+            e.r_bits_stride = g.r_bits_stride;
+            e.out_t = g.out_t;
+            e.t_col_begin = g.t_col_begin;
+            e.t_stride = g.t_stride;
+            e.t_thr = g.t_thr;
+            e.t_thr_stride = g.t_thr_stride;
+            e.t_flag = g.t_flag;
+            e.t_flag_value = g.t_flag_value;
+            e.t_bits = g.t_bits;
+            e.t_bits_stride = g.t_bits_stride;
+            e.alive_count = ctx->eb_counter;
+            ctx->eb_pairs += pairs_view;
+            HIP_TRY(launch_coreacc_epilogue_knn(e, ctx->stream));
+            ctx->last_kernel += " + early break: " + std::to_string(eb_lengths) + " of " + std::to_string(s->nk) + " k-mer lengths counted, the pairs still in the running completed by the band's epilogue";
+        } else {
+            SKL_TRY(timed_pair_launch(ctx, g, mode));
+        }
         if (overlap) {
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
             HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));

@@ -230,6 +230,38 @@ struct EpilogueArgs {
     uint32_t *alive_count;      // += pairs completed here (diagnostic / the driver's switch; may be null)
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
+// EARLY BREAK in the one-evaluation core/accessory self kNN (capi_knn.cpp): a row band's view of the columns was counted at
+// its first `nk` k-mer lengths (k-major counts, counts[t * n_pairs + row * nB + c]); this launch turns them into the band's
+// (core, acc) records -- completing the pairs still in the running like coreacc_epilogue_kernel -- and does what the fused
+// pair kernel's epilogue does for the symmetric driver: the band's records row-major, one bit per (row, 64-column block)
+// that holds a key below the row's knn-th best, and the TURNED copy.  The turned band is pre-filled with (1, 1) by the host
+// (a memset: what every pair that left the loop early is); only the other records are stored into it, with their marks.
+struct EpilogueKnnArgs {
+    const uint32_t *counts;
+    uint64_t n_pairs;            // rows * nB
+    uint32_t rows, nB;           // the band's rows, the view's columns
+    uint32_t row_base;           // (set by the launcher: a launch covers at most 32 768 rows)
+    uint32_t nk, nk_total, ss64;
+    uint32_t row_sample0, col_sample0;   // sample ids of row 0 / view column 0
+    const double *ytab, *kf;
+    double tolerance;
+    const uint64_t *rows_ref, *cols_ref;
+    float *out;                  // [rows][nB] float2
+    const uint32_t *r_thr;       // knn-th best (sortable bits) of row r at r_thr[r * r_thr_stride]; null: no marks
+    uint32_t r_thr_stride;
+    uint32_t *r_bits;
+    uint32_t r_bits_stride;
+    float *out_t;                // turned band [view column - t_col_begin][t_stride] float2, or null
+    uint32_t t_col_begin, t_stride;
+    const uint32_t *t_thr;       // indexed by view column (as PairArgs::t_thr)
+    uint32_t t_thr_stride;
+    uint32_t *t_flag;
+    uint32_t t_flag_value;
+    uint32_t *t_bits;
+    uint32_t t_bits_stride;
+    uint32_t *alive_count;
+};
+hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t stream);
 // early break: hist[m] (9 words) += the sampled pairs that share a bin at each of their first m k-mer lengths and not at the next (kernels.hip)
 hipError_t launch_early_break_sample(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t n_rows, uint32_t n_cols, uint32_t nk,
                                      uint32_t ss64, uint32_t self_mode, uint32_t n_samples, uint32_t *hist, hipStream_t stream);

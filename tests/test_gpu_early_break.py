@@ -95,3 +95,30 @@ def test_the_product_library_samples_and_decides(oracle, skl, gpu_ctx):
     assert np.array_equal(got.view(np.uint32), oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2).view(np.uint32))
     assert "early break" not in gpu_ctx.last_kernel() and gpu_ctx.early_break_stats() == mid
     g.close()
+
+
+@pytest.mark.parametrize("ties", ["reference", "canonical"])
+@pytest.mark.parametrize("band_rows,knn", [(64, 5), (96, 12), (16, 40), (200, 3)])
+def test_symmetric_core_accessory_knn_takes_the_early_break(oracle, skl, gpu_ctx, set_switch, ties, band_rows, knn):
+    """The one-evaluation core/accessory self kNN, several row bands: from the second band on the band is counted at its first
+    lengths and the band's epilogue writes records, marks and the turned copy (pre-filled with (1, 1)).  Most lists of this
+    set END in (1, 1) entries -- the first that arrived, in the reference's order -- and with bands lower than knn (16 rows,
+    knn = 40) lists are still filling when the early break starts, so (1, 1) records themselves are candidates.  Ids, order
+    and both distances = the oracle's."""
+    kmers, ss64, n = [15, 19, 23, 27, 31], 16, 700
+    bins, _ = _graded(n, len(kmers), ss64, seed=5)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    set_switch("SKL_KNN_BAND_ROWS", band_rows)
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL)
+    before = gpu_ctx.early_break_stats()
+    try:
+        idx, d0, d1 = skl.self_dists_knn(gpu_ctx, g, g.set_k(), knn)
+    finally:
+        gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+    after = gpu_ctx.early_break_stats()
+    exp = oracle.self_dists_knn(o, knn, oracle.COREACC, 0, False,
+                                ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
+    assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
+    assert np.array_equal(d0.view(np.uint32), exp["d0"].view(np.uint32)) and np.array_equal(d1.view(np.uint32), exp["d1"].view(np.uint32))
+    assert "early break: 3 of 5" in gpu_ctx.last_kernel() and after[0] > before[0] and after[1] > before[1]
+    g.close()
