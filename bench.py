@@ -992,7 +992,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
                 assert np.array_equal(idx[i], exp["idx"]) and np.array_equal(d0[i], exp["d0"]), i
                 assert np.array_equal(d1[i], dense[idx[i].astype(np.int64), 1]), i
             evaluated = nr * (nr - 1) // 2
-            v5c = valu_block(evaluated, ksec, len(K4), ss, clk)
+            v5c = valu_block(evaluated, ksec, len(K4), ss, clk, counted_lengths(ctx.last_kernel(), len(K4)))
             sec["cfg5_coreacc"] = {"workload": "BASELINE configs[4] in the reference's DEFAULT distance type: self kNN-50 over 1M x 1M, core/accessory "
                                                "(k={13..29}, the regression per pair, rows sorted on the core distance), sketchsize64=32, on ONE GPU, "
                                                "clustered synthetic sketches; every pair evaluated once; the reference's tie order (library default)",
@@ -1000,7 +1000,9 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
                                    "s_per_call_note": "the first core/accessory kNN call of the context (it allocates its band buffers: 1-2 s)",
                                    "pair_distances_per_s": nr * (nr - 1) / wall, "pairs_evaluated_per_s": evaluated / wall,
                                    "kernel": ctx.last_kernel(), "pair_kernel_s": ksec, "pair_kernel_launches": n_launch,
-                                   "other_s (heap replays, copies)": wall - ksec, "valu_frac": v5c["frac"],
+                                   "other_s (heap replays, copies, band epilogues)": wall - ksec, "valu_frac": v5c["frac"],
+                                   "valu_frac_as_if_every_length_were_counted": v5c.get("frac_as_if_every_length_were_counted"),
+                                   "k_mer_lengths_counted": v5c["k_mer_lengths_counted"], "early_break": v5c.get("early_break"),
                                    "algorithmic_bytes_per_pair": 2 * len(K4) * ss * 14 * 8 + 8,
                                    "rows_checked_against_dense_plus_oracle_heap": 3}
         g_r.close()
