@@ -87,9 +87,9 @@ struct skl_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only scratch
-    void *scratch[15] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits,
-                              // 8: tile-pruning bounds (n u32), 9: bits of the turned bands, 10: pruning counters, 11: arrival counters of the fused epilogue, 12-14: GPU sketching (packed bases, signs, small arrays)
-    size_t scratch_bytes[15] = {};
+    void *scratch[16] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits,
+                              // 8: tile-pruning bounds (n u32), 9: bits of the turned bands, 10: pruning counters, 11: arrival counters of the fused epilogue, 12-14: GPU sketching (packed bases, signs, small arrays), 15: second counts band (early break of the core/accessory kNN)
+    size_t scratch_bytes[16] = {};
     uint32_t *pinned = nullptr;         // pinned host ring of the sketching upload (two batches of packed bases; grow-only)
     uint64_t pinned_words = 0;
     size_t fuse_counter_k = 0;          // k-mer lengths the arrival counters of slot 11 count modulo (fused epilogue)

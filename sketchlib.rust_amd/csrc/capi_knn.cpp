@@ -175,9 +175,19 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     // knn candidates, so a pair that left the reference's loop early, (1, 1), marks nothing -- the band is COUNTED at its first
     // eb_lengths k-mer lengths (k-sliced counts launch) and coreacc_epilogue_knn_kernel writes the records, the marks and the
     // turned copy (pre-filled with (1, 1)), completing the pairs still in the running.  Same records as the fused kernel's.
+    // The counts kernel stays on the context's stream; the band's epilogue goes with the merges (the other stream when bands
+    // overlap): it is bound by memory and by the latency of the one-by-one completions, the counts kernel by the VALUs.
     int eb_lengths = 0;
-    if (coreacc && !is_cross && fused_coreacc_ok(s) && forced_kernel(ctx) == 0 && ctx->knobs.knn_row_flags) {
+    void *eb_counts[2] = {nullptr, nullptr};
+    if (coreacc && !is_cross && fused_coreacc_ok(s) && forced_kernel(ctx) == 0 && ctx->knobs.knn_row_flags && bands.size() > 1) {
         SKL_TRY(early_break_lengths(ctx, s, cs, 1, &eb_lengths));
+        if (eb_lengths > 0) {
+            const size_t bytes = band_rows * n * (size_t)eb_lengths * sizeof(uint32_t);   // (the largest view a band can have)
+            SKL_TRY(ctx_scratch(ctx, bytes, &eb_counts[0], 1));
+            ctx->clean_plane1 = nullptr;   // (the counts scratch holds another layout now)
+            eb_counts[1] = eb_counts[0];
+            if (overlap) SKL_TRY(ctx_scratch(ctx, bytes, &eb_counts[1], 15));
+        }
     }
     const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
     size_t it = 0;
@@ -238,11 +248,11 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             }
             ctx->knn_tiles += (uint64_t)((b1 - b0 + 31) / 32) * ((g.nB + 127) / 128);
         }
-        if (eb_lengths > 0 && it >= 1) {
+        const bool eb_band = eb_lengths > 0 && it >= 1;
+        EpilogueKnnArgs e;
+        if (eb_band) {
             const size_t pairs_view = (b1 - b0) * (size_t)g.nB;
-            void *counts = nullptr;
-            SKL_TRY(ctx_scratch(ctx, pairs_view * (size_t)eb_lengths * sizeof(uint32_t), &counts, 1));
-            ctx->clean_plane1 = nullptr;   // (the counts scratch holds another layout now)
+            void *counts = eb_counts[buf];
             PairArgs c;
             SKL_TRY(fill_args(s, cs, p, MODE_COUNTS, 0, &c));
             c.B += (col0 / 64) * jb_words;
@@ -258,10 +268,6 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             c.k_slices = 1;
             c.out = counts;
             SKL_TRY(timed_pair_launch(ctx, c, MODE_COUNTS));
-            if (g.out_t != nullptr) {   // every pair that left the loop before its third length
-                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tband[buf], 0x3F800000, (win_hi - t_first) * t_stride * 2, ctx->stream));
-            }
-            EpilogueKnnArgs e;
             memset(&e, 0, sizeof e);
             e.counts = (const uint32_t *)counts;
             e.n_pairs = pairs_view;
@@ -293,7 +299,6 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             e.t_bits_stride = g.t_bits_stride;
             e.alive_count = ctx->eb_counter;
             ctx->eb_pairs += pairs_view;
-            HIP_TRY(launch_coreacc_epilogue_knn(e, ctx->stream));
             ctx->last_kernel += " + early break: " + std::to_string(eb_lengths) + " of " + std::to_string(s->nk) + " k-mer lengths counted, the pairs still in the running completed by the band's epilogue";
         } else {
             SKL_TRY(timed_pair_launch(ctx, g, mode));
@@ -301,6 +306,12 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         if (overlap) {
             HIP_TRY(hipEventRecord(ctx->knn_pair_done[buf], ctx->stream));
             HIP_TRY(hipStreamWaitEvent(topk_stream, ctx->knn_pair_done[buf], 0));
+        }
+        if (eb_band) {   // counts -> records, marks, turned copy: with the merges, behind the counts kernel
+            if (g.out_t != nullptr) {   // (1, 1): every pair that left the loop before its third length
+                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tband[buf], 0x3F800000, (win_hi - t_first) * t_stride * 2, topk_stream));
+            }
+            HIP_TRY(launch_coreacc_epilogue_knn(e, topk_stream));
         }
         if (ref) {
             RefHeapMergeArgs m;
