@@ -231,10 +231,13 @@ extern "C" int skl_ctx_reload_env(skl_ctx *ctx)
 extern "C" int skl_ctx_early_break_stats(skl_ctx *ctx, uint64_t *pairs, uint64_t *completed_one_by_one)
 {
     SKL_TRY(ctx_bind(ctx));
-    uint32_t done = 0;
+    uint64_t done = 0;
     if (ctx->eb_counter) {
+        std::vector<uint32_t> slots(1024, 0u);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        HIP_TRY(hipMemcpy(&done, ctx->eb_counter, sizeof done, hipMemcpyDeviceToHost));
+        HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+        HIP_TRY(hipMemcpy(slots.data(), ctx->eb_counter, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (const uint32_t v : slots) done += v;
     }
     if (pairs) *pairs = ctx->eb_pairs;
     if (completed_one_by_one) *completed_one_by_one = done;
@@ -943,11 +946,11 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 // first three lengths is decided by them alone, and between unrelated genomes that is nearly every pair (a chance match
 // at each of three lengths: 1.1 % of pairs at 4 096 bins, 0.2-0.4 % at 2 048).  The counts + epilogue form can then count
 // only the first ke >= 3 lengths for everybody and let the epilogue complete the few pairs still in the running, one wave
-// per pair (kernels.hip).  Whether that pays depends on the data: completing a pair costs ~180 x what the tile kernel
-// spends on a pair and length (7-14 KB from HBM per pair and length with no reuse; measured: 3.7 ns against 0.022 ns at
-// 2 048 bins, 8.4 against 0.042 ns at 4 096), and between close relatives every pair stays in the running.  So the first
-// dense call of a slab against a column slab samples 4 096 pairs (one wave each, ~50 us, kept with the slab), and the
-// early break is taken with the ke of {3, 4} that minimises  ke + 180 x share(ke)  -- if that is at most 0.9 x nk.
+// per pair (kernels.hip).  Whether that pays depends on the data: completing a pair costs ~40 x what the tile kernel
+// spends on a pair and length (7-14 KB per pair and length with no reuse; measured: ~1.7 ns against 0.042 ns at 4 096
+// bins), and between close relatives every pair stays in the running.  So the first dense call of a slab against a
+// column slab samples 4 096 pairs (one wave each, ~50 us, kept with the slab), and the early break is taken with the ke
+// of {3, 4} that minimises  ke + 40 x share(ke)  -- if that is at most 0.9 x nk.
 // *lengths = ke, or 0 for "count them all".
 int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketches *cols, int self_mode, int *lengths)
 {
@@ -957,8 +960,8 @@ int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketc
     if (knob == 0 || rows->nk < 4 || rows->nk > 8 || rows->d_comp != nullptr || cols->d_comp != nullptr) return SKL_OK;
     if (rows->n * cols->n < 65536) return SKL_OK;
     if (!ctx->eb_counter) {
-        HIP_TRY(hipMalloc((void **)&ctx->eb_counter, 16 * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(ctx->eb_counter, 0, 16 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(hipMalloc((void **)&ctx->eb_counter, (1024 + 16) * sizeof(uint32_t)));   // 1 024 counter slots, then the sample's histogram
+        HIP_TRY(hipMemsetAsync(ctx->eb_counter, 0, (1024 + 16) * sizeof(uint32_t), ctx->stream));
     }
     if (knob >= 3) {   // forced (tests)
         *lengths = knob < (int)rows->nk ? knob : 0;
@@ -967,10 +970,10 @@ int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketc
     if (rows->eb_cols != cols || rows->eb_cols_n != cols->n) {
         constexpr uint32_t SAMPLES = 4096;
         uint32_t hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemsetAsync(ctx->eb_counter + 1, 0, 9 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->eb_counter + 1024, 0, 9 * sizeof(uint32_t), ctx->stream));
         HIP_TRY(launch_early_break_sample(rows->d_rows, cols->d_rows, (uint32_t)rows->n, (uint32_t)cols->n, (uint32_t)rows->nk,
-                                          (uint32_t)rows->ss64, (uint32_t)self_mode, SAMPLES, ctx->eb_counter + 1, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(hist, ctx->eb_counter + 1, sizeof hist, hipMemcpyDeviceToHost, ctx->stream));
+                                          (uint32_t)rows->ss64, (uint32_t)self_mode, SAMPLES, ctx->eb_counter + 1024, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(hist, ctx->eb_counter + 1024, sizeof hist, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         rows->eb_cols = cols;
         rows->eb_cols_n = cols->n;
@@ -980,7 +983,7 @@ int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketc
         for (int ke = 3; ke <= 4 && ke < (int)rows->nk; ++ke) {
             uint32_t still = 0;
             for (int m = ke; m <= 8; ++m) still += hist[m];
-            const double share = (double)still / SAMPLES, cost = (double)ke + 180.0 * share;
+            const double share = (double)still / SAMPLES, cost = (double)ke + 40.0 * share;
             if (cost <= best) {
                 best = cost;
                 rows->eb_lengths = ke;

@@ -227,7 +227,7 @@ struct EpilogueArgs {
     // nk_total == 0 or == nk: off.  rows_ref / cols_ref: the two slabs in the reference's layout.
     uint32_t nk_total;
     const uint64_t *rows_ref, *cols_ref;
-    uint32_t *alive_count;      // += pairs completed here (diagnostic / the driver's switch; may be null)
+    uint32_t *alive_count;      // 1 024 words, slot blockIdx & 1023 += pairs completed here (diagnostic; may be null)
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
 // EARLY BREAK in the one-evaluation core/accessory self kNN (capi_knn.cpp): a row band's view of the columns was counted at

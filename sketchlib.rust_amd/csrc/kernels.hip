@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArg
         uint64_t i_mine = 0, j_mine = 0;
         if (alive) pair_of(i_mine, j_mine);
         uint64_t todo = __ballot(alive);
-        if (g.alive_count != nullptr && todo != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(g.alive_count, (uint32_t)__popcll(todo));
+        // (counted in one of 1 024 slots: a million adds to ONE address per launch queue up behind each other -- 10 of this
+        // kernel's 12 ms at n = 16 000, the lesson of the kNN's pruning counters once more)
+        if (g.alive_count != nullptr && todo != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(todo));
         const uint32_t lane = threadIdx.x & 63u;
         while (todo != 0ull) {
             const int l = __builtin_ctzll(todo);
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_knn_kernel(const Epilogu
     // the pairs of this wave still in the running, one after the other (as in coreacc_epilogue_kernel)
     const bool alive = in_range && !stopped && g.nk_total > g.nk;
     uint64_t todo = __ballot(alive);
-    if (g.alive_count != nullptr && todo != 0ull && lane == 0u) atomicAdd(g.alive_count, (uint32_t)__popcll(todo));
+    if (g.alive_count != nullptr && todo != 0ull && lane == 0u) atomicAdd(&g.alive_count[(blockIdx.x + blockIdx.y * 7u) & 1023u], (uint32_t)__popcll(todo));   // (1 024 slots, as above)
     const uint64_t i_s = (uint64_t)g.row_sample0 + row;
     while (todo != 0ull) {
         const int l = __builtin_ctzll(todo);
