@@ -950,7 +950,7 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 // spends on a pair and length (7-14 KB per pair and length with no reuse; measured: ~1.7 ns against 0.042 ns at 4 096
 // bins), and between close relatives every pair stays in the running.  So the first dense call of a slab against a
 // column slab samples 4 096 pairs (one wave each, ~50 us, kept with the slab), and the early break is taken with the ke
-// of {3, 4} that minimises  ke + 40 x share(ke)  -- if that is at most 0.9 x nk.
+// of {2, 3, 4} that minimises  ke + 40 x share(ke)  -- if that is at most 0.9 x nk.
 // *lengths = ke, or 0 for "count them all".
 int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketches *cols, int self_mode, int *lengths)
 {
@@ -963,7 +963,7 @@ int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketc
         HIP_TRY(hipMalloc((void **)&ctx->eb_counter, (1024 + 16) * sizeof(uint32_t)));   // 1 024 counter slots, then the sample's histogram
         HIP_TRY(hipMemsetAsync(ctx->eb_counter, 0, (1024 + 16) * sizeof(uint32_t), ctx->stream));
     }
-    if (knob >= 3) {   // forced (tests)
+    if (knob >= 2) {   // forced (tests)
         *lengths = knob < (int)rows->nk ? knob : 0;
         return SKL_OK;
     }
@@ -980,7 +980,9 @@ int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketc
         rows->eb_lengths = 0;
         rows->eb_alive_share = 0.0;
         double best = 0.9 * (double)rows->nk;
-        for (int ke = 3; ke <= 4 && ke < (int)rows->nk; ++ke) {
+        // (two lengths decide nothing by themselves -- a fit needs three -- but a pair without a shared bin at one of them is
+        // decided all the same: (1, 1); ke = 2 leaves more pairs to complete and pays where few share a bin at all: 2 048 bins)
+        for (int ke = 2; ke <= 4 && ke < (int)rows->nk; ++ke) {
             uint32_t still = 0;
             for (int m = ke; m <= 8; ++m) still += hist[m];
             const double share = (double)still / SAMPLES, cost = (double)ke + 40.0 * share;

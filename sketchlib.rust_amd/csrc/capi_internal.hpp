@@ -61,7 +61,7 @@ struct Knobs {
     bool knn_overlap = true;          // SKL_KNN_OVERLAP=0: top-k and pair kernel on one stream
     bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
     int early_break = 1;              // A/B build, SKL_EARLY_BREAK: 0 core/accessory launches count every k-mer length; 1 (default) the early break where a
-                                      // sample of the pairs says it pays; 3..7 forced with that many lengths counted (tests).  Results identical.
+                                      // sample of the pairs says it pays; 2..7 forced with that many lengths counted (tests).  Results identical.
     bool knn_sparse = true;           // A/B build, SKL_KNN_SPARSE=0: tiles that survive the probe are walked whole (results identical)
     long long knn_panel = 0;          // A/B build, SKL_KNN_PANEL: column-panel width of the row-by-row kNN forced (tests; 0: by size)
     bool knn_prune = true;            // SKL_KNN_PRUNE=0: the symmetric self kNN finishes every tile (A/B; results are identical)

@@ -41,7 +41,7 @@ CASES = [(520, [15, 19, 23, 27, 31], 64), (520, [13, 17, 21, 25], 8), (300, [11,
 
 
 @pytest.mark.ab_library
-@pytest.mark.parametrize("lengths", [3, 4, 1, 0], ids=["three", "four", "sampled", "off"])
+@pytest.mark.parametrize("lengths", [2, 3, 4, 1, 0], ids=["two", "three", "four", "sampled", "off"])
 @pytest.mark.parametrize("n,kmers,ss64", CASES)
 def test_every_break_position_self_and_cross(oracle, skl, gpu_ctx, monkeypatch, n, kmers, ss64, lengths):
     """SKL_EARLY_BREAK (A/B build): 3 / 4 lengths counted whatever the sample says, the sampled choice, off -- the whole self
@@ -59,7 +59,7 @@ def test_every_break_position_self_and_cross(oracle, skl, gpu_ctx, monkeypatch, 
     got = skl.self_dists_all(gpu_ctx, g, g.set_k())
     after = gpu_ctx.early_break_stats()
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), np.argwhere(got != exp)[:5]
-    if lengths >= 3 and lengths < len(kmers):
+    if lengths >= 2 and lengths < len(kmers):
         assert "early break: %d of %d" % (lengths, len(kmers)) in gpu_ctx.last_kernel()
         assert after[0] - before[0] == n * (n - 1) // 2 and after[1] > before[1]      # pairs were completed one by one
     if lengths == 0:
@@ -87,7 +87,7 @@ def test_the_product_library_samples_and_decides(oracle, skl, gpu_ctx):
     got = skl.self_dists_all(gpu_ctx, g, g.set_k())
     mid = gpu_ctx.early_break_stats()
     assert np.array_equal(got.view(np.uint32), oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2).view(np.uint32))
-    assert "early break: 3 of 5" in gpu_ctx.last_kernel() and mid[0] - before[0] == n * (n - 1) // 2
+    assert "early break: " in gpu_ctx.last_kernel() and mid[0] - before[0] == n * (n - 1) // 2
     g.close()
     rel = synth.set_r(n, kmers, ss64, n_clusters=1)
     o, g = oracle.Sketches(rel, n, kmers, ss64), gpu_ctx.sketches(rel, n, kmers, ss64)
@@ -120,5 +120,5 @@ def test_symmetric_core_accessory_knn_takes_the_early_break(oracle, skl, gpu_ctx
                                 ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
     assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
     assert np.array_equal(d0.view(np.uint32), exp["d0"].view(np.uint32)) and np.array_equal(d1.view(np.uint32), exp["d1"].view(np.uint32))
-    assert "early break: 3 of 5" in gpu_ctx.last_kernel() and after[0] > before[0] and after[1] > before[1]
+    assert "early break: " in gpu_ctx.last_kernel() and after[0] > before[0] and after[1] > before[1]
     g.close()
