@@ -18,7 +18,7 @@ export COLUMNS=230
 for e in "SKL_TILE32_MIN=0" "SKL_TILE32_MIN=-1" "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=2" "SKL_GROUP_SPAN=5" \
          "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=8 SKL_TILE32_MIN=0 SKL_GROUP_SPAN=3" \
          "SKL_ROUND_PRIORITY=0 SKL_KNN_ROW_FLAGS=0" "SKL_XCDS=1 SKL_CAND_ROW_ORDER=0" "SKL_XCDS=4 SKL_TILE32_MIN=0" \
-         "SKL_EARLY_BREAK=3" "SKL_EARLY_BREAK=4 SKL_TILE32_MIN=0" "SKL_EARLY_BREAK=0 SKL_KNN_SPARSE=0"; do
+         "SKL_EARLY_BREAK=3" "SKL_EARLY_BREAK=4 SKL_TILE32_MIN=0" "SKL_EARLY_BREAK=2" "SKL_EARLY_BREAK=0 SKL_KNN_SPARSE=0"; do
   I=$((I + 1))
   if [ "$I" -lt "$FIRST" ] || [ "$I" -gt "$LAST" ]; then continue; fi
   echo "== $e"
