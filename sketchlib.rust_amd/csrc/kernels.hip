@@ -411,15 +411,19 @@ __global__ __launch_bounds__(256) void coreacc_epilogue_knn_kernel(const Epilogu
         }
     }
     const float2 v = simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
-    if (in_range) ((float2 *)g.out)[p] = v;
-    // does this 64-column block bring the row anything below its knn-th best?  (the key is the core distance)
+    // does this 64-column block bring the row anything below its knn-th best?  (the key is the core distance)  The merge reads
+    // the marked blocks of a row only, so an unmarked block's 64 records are not even stored.
+    bool store = in_range;
     if (g.r_bits != nullptr) {
         const uint32_t thr_ = g.r_thr[(size_t)row * g.r_thr_stride];
-        if (__ballot(in_range && sortable_bits(v.x) < thr_) != 0ull && lane == 0u) {
+        const bool marked = __ballot(in_range && sortable_bits(v.x) < thr_) != 0ull;
+        if (marked && lane == 0u) {
             const uint32_t blk = c_raw >> 6;
             atomicOr(&g.r_bits[(size_t)row * g.r_bits_stride + (blk >> 5)], 1u << (blk & 31u));
         }
+        store = store && marked;
     }
+    if (store) ((float2 *)g.out)[p] = v;
     // the turned copy: pre-filled with (1, 1); everything else is stored, and marked where it beats the column's knn-th best
     if (g.out_t != nullptr && in_range && c >= g.t_col_begin) {
         const bool plain = __float_as_uint(v.x) == 0x3F800000u && __float_as_uint(v.y) == 0x3F800000u;
