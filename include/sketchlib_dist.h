@@ -208,7 +208,7 @@ int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);
 
 /* Diagnostic (no reference counterpart): the early break of the core/accessory calls.  core_acc_dist leaves its loop over
  * the k-mer lengths at the first one whose Jaccard index is 0 (src/distances/jaccard.rs:89-91), and a fit over fewer than
- * three lengths is (1, 1) (:117).  With more than three lengths and no completeness correction the dense calls therefore
+ * three lengths is (1, 1) (:117).  With three to eight lengths and no completeness correction the dense calls therefore
  * count only the first two to four for every pair and complete the pairs that share a bin at each of them one by one -- when a
  * sample of 4 096 pairs, taken the first time a slab meets a column slab, says that at most 4 % of the pairs are such
  * (between unrelated genomes ~1 % at 4 096 bins, 0.2 % at 2 048; between close relatives all of them: then every length is

@@ -957,7 +957,7 @@ int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketc
     skl_sketches *rows = const_cast<skl_sketches *>(crows);
     *lengths = 0;
     const int knob = ctx->knobs.early_break;
-    if (knob == 0 || rows->nk < 4 || rows->nk > 8 || rows->d_comp != nullptr || cols->d_comp != nullptr) return SKL_OK;
+    if (knob == 0 || rows->nk < 3 || rows->nk > 8 || rows->d_comp != nullptr || cols->d_comp != nullptr) return SKL_OK;
     if (rows->n * cols->n < 65536) return SKL_OK;
     if (!ctx->eb_counter) {
         HIP_TRY(hipMalloc((void **)&ctx->eb_counter, (1024 + 16) * sizeof(uint32_t)));   // 1 024 counter slots, then the sample's histogram

@@ -37,7 +37,8 @@ def _graded(n, nk, ss64, seed=1):
     return np.ascontiguousarray(synth.bitslice(vals).reshape(n, -1)), lead
 
 
-CASES = [(520, [15, 19, 23, 27, 31], 64), (520, [13, 17, 21, 25], 8), (300, [11, 15, 19, 23, 27, 31], 70), (700, [15, 19, 23, 27, 31], 16)]
+CASES = [(520, [15, 19, 23, 27, 31], 64), (520, [13, 17, 21, 25], 8), (300, [11, 15, 19, 23, 27, 31], 70), (700, [15, 19, 23, 27, 31], 16),
+         (600, [15, 23, 31], 32)]
 
 
 @pytest.mark.ab_library

@@ -116,7 +116,9 @@ def test_large_launch_spot_checks(oracle, skl, gpu_ctx, n):
     assert np.array_equal(dj[:, 0], exp)
 
 
-def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx):
+@pytest.mark.ab_library      # (SKL_EARLY_BREAK=0: the all-k fused kernel on Set U, which the sampled early break replaces there)
+@pytest.mark.parametrize("early_break", ["0", "1"], ids=["every_length_counted", "early_break"])
+def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx, monkeypatch, early_break):
     """4.5e8 pairs into NaN-filled device buffers while the forms of the pair kernel alternate on ONE
     context, as they do in a caller's process: all-k fused core/accessory, k-sliced single-k Jaccard,
     raw counts, core/accessory over row bands small enough to run k-sliced + epilogue.  Every launch
@@ -129,6 +131,8 @@ def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx):
 
     n = 30000
     dev = torch.device("cuda", 0)
+    monkeypatch.setenv("SKL_EARLY_BREAK", early_break)
+    gpu_ctx.reload_env()
     # the NaN fill is torch work on the default stream: run the context there too
     gpu_ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     g = gpu_ctx.sketches(synth.set_u_device(n, 5, SS64, dev), n, K5, SS64)
@@ -156,8 +160,12 @@ def test_every_pair_written_when_kernels_alternate(skl, gpu_ctx):
         torch.cuda.synchronize()
         assert bool((banded == whole).all().item()) and bool((again == whole).all().item()), round_
         del banded, again
-    assert "all k" in first_kernel, first_kernel
-    assert len(seen) >= 3, seen      # COREACC all k, JACCARD k-sliced, COUNTS k-sliced
+    if early_break == "0":
+        assert "all k" in first_kernel, first_kernel
+        assert len(seen) >= 3, seen      # COREACC all k, JACCARD k-sliced, COUNTS k-sliced
+    else:
+        assert "early break" in first_kernel, first_kernel
+        assert len(seen) >= 2, seen      # COUNTS k-sliced (+ the completing epilogue), JACCARD k-sliced
     g.close()
     gpu_ctx.set_stream(None)
 

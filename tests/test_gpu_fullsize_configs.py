@@ -221,7 +221,7 @@ def test_cfg5_full_size_coreacc_default_mode(oracle, skl, torch_ctx, million):
     finally:
         ctx.set_knn_ties(skl.TIES_CANONICAL)
     print(f"cfg5 core/accessory full: self kNN-{knn} over {n} x {n} in {wall:.2f} s = {n * (n - 1) / wall:.3g} pair distances/s")
-    assert "COREACC" in ctx.last_kernel()
+    assert "COREACC" in ctx.last_kernel() or "early break" in ctx.last_kernel()   # (fused all-k bands, or counted bands + band epilogue)
     # properties of every row
     assert idx.shape == (n, knn) and idx.max() < n
     assert np.all(np.diff(d0, axis=1) >= 0), "rows ascending on the core distance (distance_matrix.rs:245-248)"

@@ -21,6 +21,7 @@ def ab_ctx(skl, monkeypatch):
     """A context of the A/B library (its switches are re-read at every entry point)."""
     import sketchlib.rust_amd as pkg
 
+    monkeypatch.setenv("SKL_EARLY_BREAK", "0")   # (the fused epilogue finishes launches that count every k-mer length)
     with skl.using_library(pkg.build_ab_library()):
         ctx = skl.Context(0)
         yield ctx

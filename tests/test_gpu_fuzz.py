@@ -96,6 +96,7 @@ print("BANDS_OK")
     assert res.returncode == 0 and "BANDS_OK" in res.stdout, res.stderr[-2000:]
 
 
+@pytest.mark.ab_library      # (SKL_EARLY_BREAK: the "fused" cases are the all-k kernel with every k-mer length counted)
 @pytest.mark.parametrize("sliced_max,tail,tile32", [("0", "0", None), ("1000000000000", "0", None), ("1000000000000", "1", None),
                                                      ("0", "0", "-1"), ("1000000000000", "0", "-1"), ("1000000000000", "1", "-1")],
                          ids=["fused", "k_sliced", "k_sliced_tail", "fused_16_rows", "k_sliced_16_rows", "k_sliced_16_rows_tail"])
@@ -112,6 +113,8 @@ def test_cross_large_launch_ragged_tiles(oracle, skl, gpu_ctx, monkeypatch, slic
     o_r, g_r = oracle.Sketches(rb, nr, kmers, ss64), gpu_ctx.sketches(rb, nr, kmers, ss64)
     o_q, g_q = oracle.Sketches(qb, nq, kmers, ss64), gpu_ctx.sketches(qb, nq, kmers, ss64)
     monkeypatch.setenv("SKL_SLICED_MAX_PAIRS", sliced_max)
+    if sliced_max == "0":
+        monkeypatch.setenv("SKL_EARLY_BREAK", "0")
     monkeypatch.setenv("SKL_TAIL_MAX_PCT", "100000000" if tail == "1" else "90")
     if tile32 is not None:
         monkeypatch.setenv("SKL_TILE32_MIN", tile32)
