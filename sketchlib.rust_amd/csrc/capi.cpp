@@ -958,6 +958,7 @@ int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketc
     *lengths = 0;
     const int knob = ctx->knobs.early_break;
     if (knob == 0 || rows->nk < 3 || rows->nk > 8 || rows->d_comp != nullptr || cols->d_comp != nullptr) return SKL_OK;
+    if (rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS) return SKL_OK;   // (beyond 65 535 bins: the segmented counts form, left as it is)
     if (rows->n * cols->n < 65536) return SKL_OK;
     if (!ctx->eb_counter) {
         HIP_TRY(hipMalloc((void **)&ctx->eb_counter, (1024 + 16) * sizeof(uint32_t)));   // 1 024 counter slots, then the sample's histogram

@@ -38,7 +38,7 @@ def _graded(n, nk, ss64, seed=1):
 
 
 CASES = [(520, [15, 19, 23, 27, 31], 64), (520, [13, 17, 21, 25], 8), (300, [11, 15, 19, 23, 27, 31], 70), (700, [15, 19, 23, 27, 31], 16),
-         (600, [15, 23, 31], 32)]
+         (600, [15, 23, 31], 32), (400, [11, 13, 15, 17, 19, 21, 23], 8)]
 
 
 @pytest.mark.ab_library
