@@ -599,12 +599,14 @@ def main():
     for _ in range(warmup):
         step()
     fence()
+    eb_before = ctx.early_break_stats()     # (a synchronisation outside the timed region)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_name = ctx.last_kernel()
+    eb_after = ctx.early_break_stats()
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -719,6 +721,15 @@ def main():
                                     "(the clock needs tens of ms of sustained load to settle; the driver's 25 steps last 4 ms)"
                                     if precond_launches else "none"),
                 "output_checksum_first_1e8_pairs": checksum,
+                "early_break": {
+                    "k_mer_lengths_counted_for_every_pair": counted_lengths(kernel_name, nk), "of": nk,
+                    "pairs_in_the_timed_region": eb_after[0] - eb_before[0],
+                    "of_them_completed_one_by_one": eb_after[1] - eb_before[1],
+                    "what": "core_acc_dist leaves its loop at the first k-mer length without a shared bin (jaccard.rs:89-91) and fewer "
+                            "than three lengths give (1, 1) (:117): the pair kernel counts the first few lengths for every pair, the "
+                            "epilogue completes the pairs still in the running; taken when a sample of the pairs says it pays "
+                            "(DESIGN.md 4.2; the A/B build's SKL_EARLY_BREAK=0 counts every length: 3.4e9 pairs/s here); results "
+                            "bit-identical (tests/test_gpu_early_break.py)"},
                 **(verified or {}),
                 **({"cold_pairs_per_s": cold["pairs_per_s"], "cold": cold} if cold else {}),
                 **({"n1_same_workload": n1_same} if n1_same else {}),
