@@ -70,3 +70,20 @@ def test_condensed_index_matches_the_reference_formula():
     assert flat == list(range(n * (n - 1) // 2))
     ii, jj = np.array([0, 5, 35]), np.array([1, 9, 36])
     assert b.cond_index(ii, jj, n).tolist() == [0, b.cond_index(5, 9, n), n * (n - 1) // 2 - 1]
+
+
+def test_counted_lengths_and_the_roofline_block_of_an_early_break_launch():
+    """bench.py prices the k-mer lengths the pair kernel COUNTED (the library's kernel description says how many) and puts the
+    rate of answers beside it."""
+    import bench
+
+    name = ("skl::pair_kernel_kslice<R=16, JL=2, COUNTS, k-sliced, tight> (16x128 tiles) + early break: 3 of 5 k-mer lengths counted, "
+            "the pairs still in the running completed by the epilogue")
+    assert bench.counted_lengths(name, 5) == 3
+    assert bench.counted_lengths(name, 6) == 6                      # (a description of another launch shape: not taken)
+    assert bench.counted_lengths("skl::pair_kernel_kslice<R=32, JL=2, COREACC, all k, tight>", 5) == 5
+    assert bench.counted_lengths(None, 5) == 5
+    full = bench.valu_block(499500, 1.0e-4, 5, 64, None)
+    part = bench.valu_block(499500, 1.0e-4, 5, 64, None, counted=3)
+    assert part["k_mer_lengths_counted"] == 3 and abs(part["frac"] - 0.6 * full["frac"]) < 1e-12
+    assert abs(part["frac_as_if_every_length_were_counted"] - full["frac"]) < 1e-12 and "frac_as_if_every_length_were_counted" not in full
