@@ -94,6 +94,10 @@ struct KnnCross {
     const skl_sketches *cols = nullptr;   // null: the symmetric form
     bool self_rows = false;               // rows and columns are the same sample set: a row is not its own candidate
     size_t row_lo = 0, row_hi = ~(size_t)0;   // rows of the call (bands are clipped to them)
+    // (symmetric form, one band per call -- skl_self_dists_knn_window: every list the band meets already holds knn candidates,
+    // as from a whole-matrix call's second band on: the early break of the core/accessory keys may start with the call's
+    // first band)
+    bool lists_hold_knn = false;
 };
 
 static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
@@ -179,7 +183,8 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     // overlap): it is bound by memory and by the latency of the one-by-one completions, the counts kernel by the VALUs.
     int eb_lengths = 0;
     void *eb_counts[2] = {nullptr, nullptr};
-    if (coreacc && !is_cross && fused_coreacc_ok(s) && forced_kernel(ctx) == 0 && ctx->knobs.knn_row_flags && bands.size() > 1) {
+    if (coreacc && !is_cross && fused_coreacc_ok(s) && forced_kernel(ctx) == 0 && ctx->knobs.knn_row_flags &&
+        (bands.size() > 1 || cross.lists_hold_knn)) {
         SKL_TRY(early_break_lengths(ctx, s, cs, 1, &eb_lengths));
         if (eb_lengths > 0) {
             const size_t bytes = band_rows * n * (size_t)eb_lengths * sizeof(uint32_t);   // (the largest view a band can have)
@@ -248,7 +253,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             }
             ctx->knn_tiles += (uint64_t)((b1 - b0 + 31) / 32) * ((g.nB + 127) / 128);
         }
-        const bool eb_band = eb_lengths > 0 && it >= 1;
+        const bool eb_band = eb_lengths > 0 && (it >= 1 || cross.lists_hold_knn);
         EpilogueKnnArgs e;
         if (eb_band) {
             const size_t pairs_view = (b1 - b0) * (size_t)g.nB;
@@ -809,7 +814,9 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
     st.thr = thr;
     const std::vector<uint32_t> one{(uint32_t)band};
     ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
-    return knn_symmetric_bands(ctx, s, p, knn, band_rows, one, false, st, col_lo, col_hi);
+    KnnCross form;   // (the symmetric form)
+    form.lists_hold_knn = band >= 1 && band_rows >= knn;   // (bands 0 .. band - 1 of this window, or the windows before it, have fed every list)
+    return knn_symmetric_bands(ctx, s, p, knn, band_rows, one, false, st, col_lo, col_hi, form);
 }
 
 // Empty heaps (h_len = 0, thr = "not full") for rows [row_begin, row_end) of caller-owned state arrays.

@@ -123,3 +123,36 @@ def test_symmetric_core_accessory_knn_takes_the_early_break(oracle, skl, gpu_ctx
     assert np.array_equal(d0.view(np.uint32), exp["d0"].view(np.uint32)) and np.array_equal(d1.view(np.uint32), exp["d1"].view(np.uint32))
     assert "early break: " in gpu_ctx.last_kernel() and after[0] > before[0] and after[1] > before[1]
     g.close()
+
+
+@pytest.mark.parametrize("world,band_rows,knn", [(3, 64, 5), (2, 96, 12), (4, 48, 7)])
+def test_column_windows_take_the_early_break_from_their_second_band(oracle, skl, gpu_ctx, world, band_rows, knn):
+    """skl_self_dists_knn_window (the reference's order over several devices: heaps that travel through column windows), core/
+    accessory keys: from band 1 on each call counts its band at the first lengths and finishes it with the band epilogue.
+    The participants run one after the other on one device and one set of heap arrays (exact: tests/test_gpu_knn_ties.py)."""
+    import torch
+    from sketchlib.rust_amd import multi_gpu
+
+    kmers, ss64, n = [15, 19, 23, 27, 31], 16, 700
+    bins, _ = _graded(n, len(kmers), ss64, seed=9)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k()
+    heaps = skl.knn_heaps_alloc(n, knn, True, torch.device("cuda", 0))
+    cuts = multi_gpu.knn_window_cuts(n, band_rows, world)
+    before = gpu_ctx.early_break_stats()
+    names = set()
+    for r in range(world):
+        for band in range((n + band_rows - 1) // band_rows):
+            if band * band_rows >= cuts[r + 1]:
+                break
+            skl.self_dists_knn_window(gpu_ctx, g, p, knn, band_rows, band, cuts[r], cuts[r + 1], heaps)
+            names.add("early break" in gpu_ctx.last_kernel())
+    idx, d0, d1 = skl.knn_heaps_finalize(gpu_ctx, heaps, 0, n, knn)
+    gpu_ctx.synchronize()
+    after = gpu_ctx.early_break_stats()
+    exp = oracle.self_dists_knn(o, knn, oracle.COREACC, 0, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint64), exp["idx"]), np.argwhere(idx.cpu().numpy() != exp["idx"])[:5]
+    assert np.array_equal(d0.cpu().numpy().view(np.uint32), exp["d0"].view(np.uint32))
+    assert np.array_equal(d1.cpu().numpy().view(np.uint32), exp["d1"].view(np.uint32))
+    assert names == {True, False} and after[0] > before[0]      # band 0 of a window fused, the later ones counted + epilogue
+    g.close()
