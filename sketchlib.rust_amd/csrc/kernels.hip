@@ -351,7 +351,7 @@ hipError_t launch_clock_sampler(const uint32_t *stop, uint64_t *samples, uint32_
 // The early-break epilogue of a row band of the symmetric core/accessory self kNN: see EpilogueKnnArgs (kernels.h).
 // Thread (blockIdx.y, blockIdx.x * 256 + threadIdx.x) = (row of the band, view column): a wave is 64 consecutive columns of
 // one row, i.e. one of the 64-column blocks the row bits stand for (the view starts on a block boundary).
-__global__ __launch_bounds__(256) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
 {
     const uint32_t row = g.row_base + blockIdx.y, c_raw = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
     const bool in_range = c_raw < g.nB;
