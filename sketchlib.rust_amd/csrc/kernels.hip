@@ -155,7 +155,7 @@ hipError_t launch_relayout(const uint64_t *ref_layout, uint4 *lane_layout, uint3
 // unfused core/acc epilogue (any number of k-mer lengths / any sketch size)
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void coreacc_epilogue_kernel(const EpilogueArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void coreacc_epilogue_kernel(const EpilogueArgs g)
 {
     const uint64_t p_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool early = g.nk_total > g.nk;     // (early break: every lane of a wave stays, the completion below is cooperative)
