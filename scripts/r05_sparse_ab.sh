@@ -1,3 +1,7 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): the sparse finish of probe survivors against the binary BEFORE it, on one box (the record is
+# profiles/r05_knn_sparse_ab.jsonl).  The previous binary is not kept in the tree: build the A/B library of the commit before
+# 0d88953 into sketchlib.rust_amd/csrc/_build_exp_prev/ to repeat this.
 OLD=$PWD/sketchlib.rust_amd/csrc/_build_exp_prev/libsketchlib_dist_hip.so
 python -m pytest tests/test_gpu_knn_prune.py -q 2>&1 | tail -15 > gpurun_out/r05s_tests.txt
 B="python scripts/bench_knn_prune.py --samples 1000000 --ties reference --prune 1"
