@@ -207,15 +207,23 @@ int skl_cross_dists_rows(skl_ctx *ctx, const skl_sketches *ref, const skl_sketch
 int skl_ctx_set_knn_ties(skl_ctx *ctx, int mode);
 
 /* Diagnostic (no reference counterpart): the early break of the core/accessory calls.  core_acc_dist leaves its loop over
- * the k-mer lengths at the first one whose Jaccard index is 0 (src/distances/jaccard.rs:89-91), and a fit over fewer than
- * three lengths is (1, 1) (:117).  With three to eight lengths and no completeness correction the dense calls therefore
- * count only the first two to four for every pair and complete the pairs that share a bin at each of them one by one -- when a
- * sample of 4 096 pairs, taken the first time a slab meets a column slab, says that at most 4 % of the pairs are such
- * (between unrelated genomes ~1 % at 4 096 bins, 0.2 % at 2 048; between close relatives all of them: then every length is
- * counted for every pair as before).  Same (core, acc) bit for bit either way.  pairs: pairs of the early-break launches
- * since the context was made; completed_one_by_one: those among them that were still in the running (counter wraps at
- * 2^32).  Either argument may be null.  (The A/B build reads SKL_EARLY_BREAK=0: off.) */
+ * the k-mer lengths at the first one whose ln J lies below the tolerance -- a pair that shares no more bins than chance,
+ * expected_samebits (src/distances/jaccard.rs:26-31, :89-91) -- and a fit over fewer than three lengths is (1, 1) (:117).
+ * With three to eight lengths the dense calls therefore count only the first two to four for the pairs of a BLOCK of the
+ * pair space and complete the pairs still in the running afterwards, grouped by row (csrc/epilogue.hip) -- where a sample
+ * of the block's pairs, taken the first time a slab meets a column slab, says that pays (between unrelated genomes ~1 % of
+ * the pairs stay in the running at 4 096 bins, 0.2 % at 2 048; between close relatives all of them: such blocks count every
+ * length as before).  With or without a completeness correction, any sketch size.  Same (core, acc) bit for bit either way.
+ * pairs: pairs of the early-break launches since the context was made; completed_one_by_one: those among them that were
+ * still in the running (counter wraps at 2^32).  Either argument may be null.  (The A/B build reads SKL_EARLY_BREAK=0: off.) */
 int skl_ctx_early_break_stats(skl_ctx *ctx, uint64_t *pairs, uint64_t *completed_one_by_one);
+/* ... and what the last dense core/accessory call of the context decided: the pair space is cut into blk_rows x blk_cols blocks
+ * of (row sample >> shift_rows, column sample >> shift_cols); pooled_lengths = the k-mer lengths counted when all blocks agree
+ * (0: every length, no early break); mixed = 1 when they do not, and block_lengths[r * blk_cols + c] (capacity >= blk_rows x
+ * blk_cols bytes) then holds each block's count (nk: every length).  Any pointer may be null.  Reference behaviour matched:
+ * the per-pair `break` of jaccard.rs:89-91 -- the result never depends on the decision, only the time does. */
+int skl_ctx_early_break_blocks(skl_ctx *ctx, uint32_t *blk_rows, uint32_t *blk_cols, uint32_t *shift_rows, uint32_t *shift_cols,
+                               int *pooled_lengths, int *mixed, uint8_t *block_lengths, size_t capacity);
 
 /* Diagnostic (no reference counterpart): tile pruning of the last skl_self_dists_knn / _partial call of the context.  The
  * whole-matrix self kNN with single-k keys (Jaccard / ANI, no completeness correction) leaves a 32 x 128 tile of the pair

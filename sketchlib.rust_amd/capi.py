@@ -69,6 +69,8 @@ _SIG = [
     ("skl_device_memcpy", C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     ("skl_ctx_get_knn_ties", C.c_int, [_P]),
     ("skl_ctx_early_break_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("skl_ctx_early_break_blocks", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int), _P, C.c_size_t]),
     ("skl_ctx_knn_prune_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]),
     ("skl_clock_sampler_start", C.c_int, [_P, C.c_uint32, C.c_uint32]),
@@ -262,6 +264,19 @@ class Context:
         a, b = C.c_uint64(), C.c_uint64()
         _check(load().skl_ctx_early_break_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def early_break_blocks(self):
+        """What the last dense core/accessory call decided: {"blocks": (rows, cols), "shifts": (rows, cols), "pooled_lengths": ke or 0,
+        "mixed": bool, "block_lengths": uint8 [rows, cols] or None}."""
+        br, bc, sr, sc = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        pooled, mixed = C.c_int(), C.c_int()
+        _check(load().skl_ctx_early_break_blocks(self._h, C.byref(br), C.byref(bc), C.byref(sr), C.byref(sc), C.byref(pooled), C.byref(mixed), None, 0))
+        table = None
+        if mixed.value:
+            table = np.zeros((br.value, bc.value), dtype=np.uint8)
+            _check(load().skl_ctx_early_break_blocks(self._h, None, None, None, None, None, None, table.ctypes.data, table.size))
+        return {"blocks": (br.value, bc.value), "shifts": (sr.value, sc.value), "pooled_lengths": pooled.value, "mixed": bool(mixed.value),
+                "block_lengths": table}
 
     def knn_prune_stats(self, full=False):
         """(tiles, tiles left early) of the last self kNN call's prunable launches; full=True: + (stages of a whole tile,

@@ -11,6 +11,7 @@
 #include "glibc_log.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -153,6 +154,8 @@ extern "C" int skl_ctx_create(int device, skl_ctx **out)
 }
 
 static void free_sketches_locked(skl_sketches *s);
+void free_plans(skl_ctx *ctx);
+uint64_t next_generation();
 
 extern "C" int skl_ctx_destroy(skl_ctx *ctx)
 {
@@ -178,6 +181,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
         (void)hipHostFree(ctx->sampler_stop);
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    free_plans(ctx);
     if (ctx->eb_counter) (void)hipFree(ctx->eb_counter);
     if (ctx->sampler_buf) (void)hipFree(ctx->sampler_buf);
     if (ctx->sampler_count) (void)hipFree(ctx->sampler_count);
@@ -375,6 +379,8 @@ Knobs read_knobs()
     k.knn_panel = env_int("SKL_KNN_PANEL", 0);
     k.knn_sparse = env_int("SKL_KNN_SPARSE", 1) != 0;
     k.early_break = (int)std::min(7ll, std::max(0ll, env_int("SKL_EARLY_BREAK", 1)));
+    k.epilogue_span = std::max(0ll, env_int("SKL_EPILOGUE_SPAN", 0));
+    k.epilogue_r5 = env_int("SKL_EPILOGUE_R5", 0) != 0;
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
@@ -645,6 +651,15 @@ static int ensure_ytab(const skl_sketches *cs)
     const size_t m = 64 * s->ss64 + 1;
     std::vector<double> tab(m);
     for (size_t b = 0; b < m; ++b) tab[b] = std::log(host_jaccard((uint32_t)b, s->ss64));
+    {   // the break test of jaccard.rs:89-91 on the count itself: ln J(count) < tolerance <=> count < min_alive -- if the table is
+        // monotone there (it is; checked, not assumed: 0xFFFFFFFF makes the kernels ask the table)
+        const double tolerance = std::log(2.0 / (double)((s->ss64 * 64ull) * 64ull));
+        size_t first = 0;
+        while (first < m && tab[first] < tolerance) ++first;
+        bool monotone = true;
+        for (size_t b = first; b < m; ++b) monotone = monotone && !(tab[b] < tolerance);
+        s->min_alive = monotone ? (uint32_t)first : 0xFFFFFFFFu;
+    }
     double *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, m * sizeof(double)));
     const hipError_t e = hipMemcpy(d, tab.data(), m * sizeof(double), hipMemcpyHostToDevice);
@@ -706,6 +721,7 @@ extern "C" int skl_sketches_create(skl_ctx *ctx, const uint64_t *bins, int on_de
     }
     skl_sketches *s = new skl_sketches();
     s->ctx = ctx;
+    s->gen = next_generation();
     {
         std::lock_guard<std::mutex> lock(g_registry_mutex);
         g_live_sketches.insert(s);
@@ -755,6 +771,7 @@ extern "C" int skl_sketches_set_completeness(skl_sketches *s, const double *comp
 {
     if (!s) return fail(SKL_ERR_INVALID_ARG, "null sketches");
     SKL_TRY(ctx_bind(s->ctx));
+    s->gen = next_generation();   // (a sampled early-break decision belongs to the slab AND its completeness vector)
     if (!comp) {
         if (s->d_comp) {
             HIP_TRY(hipStreamSynchronize(s->ctx->stream));
@@ -941,60 +958,230 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
     return slice_plan((uint32_t)ss64, S, &chunks);   // (slices that hold something: a short sketch gets fewer)
 }
 
-// EARLY BREAK (round 5).  core_acc_dist leaves its loop over the k-mer lengths at the first one whose Jaccard index is 0
-// (jaccard.rs:89-91) and a fit over fewer than three lengths is (1, 1) (:117): a pair without a shared bin at one of the
-// first three lengths is decided by them alone, and between unrelated genomes that is nearly every pair (a chance match
-// at each of three lengths: 1.1 % of pairs at 4 096 bins, 0.2-0.4 % at 2 048).  The counts + epilogue form can then count
-// only the first ke >= 3 lengths for everybody and let the epilogue complete the few pairs still in the running, one wave
-// per pair (kernels.hip).  Whether that pays depends on the data: completing a pair costs ~40 x what the tile kernel
-// spends on a pair and length (7-14 KB per pair and length with no reuse; measured: ~1.7 ns against 0.042 ns at 4 096
-// bins), and between close relatives every pair stays in the running.  So the first dense call of a slab against a
-// column slab samples 4 096 pairs (one wave each, ~50 us, kept with the slab), and the early break is taken with the ke
-// of {2, 3, 4} that minimises  ke + 40 x share(ke)  -- if that is at most 0.9 x nk.
-// *lengths = ke, or 0 for "count them all".
-int early_break_lengths(skl_ctx *ctx, const skl_sketches *crows, const skl_sketches *cols, int self_mode, int *lengths)
+// EARLY BREAK.  core_acc_dist leaves its loop over the k-mer lengths at the first one whose ln J lies below the tolerance
+// (jaccard.rs:89-91: J = 0, i.e. no more shared bins than chance -- expected_samebits, :26-31) and a fit over fewer than three
+// lengths is (1, 1) (:117): a pair that fails the test at one of its first lengths is decided by them alone, and between
+// unrelated genomes that is nearly every pair (a chance match at each of three lengths: 1.1 % of pairs at 4 096 bins,
+// 0.2-0.4 % at 2 048).  The counts + epilogue form can then count only the first ke lengths and let the epilogue complete the
+// pairs still in the running (epilogue.hip).  Whether that pays depends on the data -- completing a pair costs EB_COST x what
+// the tile kernel spends on a pair and length (a whole column slice read for ONE pair), and between close relatives every
+// pair stays in the running -- so the first dense call of a slab against a column slab SAMPLES the pair space: it is cut
+// into blocks of (row >> shift, column >> shift) sample ids (up to 64 x 64 of them, each a multiple of 256 samples), a few
+// dozen pairs of every block run the reference's loop, and every block takes the ke of {2, 3, 4} that minimises
+//     ke + EB_COST x share_alive(ke)      if that is at most 0.9 x nk,
+// else every length.  A database that is half one species therefore takes the early break between the species and skips
+// it within (round 5 decided once per slab pair).  Blocks of one mind give a plain launch; otherwise the pair kernel's
+// (tile, k index) workgroups look their block up and leave when k index >= its ke.
+constexpr double EB_COST = 24.0;
+constexpr uint32_t EB_BLOCKS_MAX = 64;      // blocks per side
+constexpr uint32_t EB_SAMPLES_MIN = 64;     // sampled pairs per block
+constexpr uint32_t EB_SAMPLES_TOTAL = 4096; // ... and at least this many in all
+
+static std::atomic<uint64_t> g_next_gen{1};
+uint64_t next_generation() { return g_next_gen.fetch_add(1); }
+
+static void free_plan(EbPlan *p)
 {
-    skl_sketches *rows = const_cast<skl_sketches *>(crows);
-    *lengths = 0;
-    const int knob = ctx->knobs.early_break;
-    if (knob == 0 || rows->nk < 3 || rows->nk > 8 || rows->d_comp != nullptr || cols->d_comp != nullptr) return SKL_OK;
-    if (rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS) return SKL_OK;   // (beyond 65 535 bins: the segmented counts form, left as it is)
-    if (rows->n * cols->n < 65536) return SKL_OK;
-    if (!ctx->eb_counter) {
-        HIP_TRY(hipMalloc((void **)&ctx->eb_counter, (1024 + 16) * sizeof(uint32_t)));   // 1 024 counter slots, then the sample's histogram
-        HIP_TRY(hipMemsetAsync(ctx->eb_counter, 0, (1024 + 16) * sizeof(uint32_t), ctx->stream));
-    }
-    if (knob >= 2) {   // forced (tests)
-        *lengths = knob < (int)rows->nk ? knob : 0;
-        return SKL_OK;
-    }
-    if (rows->eb_cols != cols || rows->eb_cols_n != cols->n) {
-        constexpr uint32_t SAMPLES = 4096;
-        uint32_t hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemsetAsync(ctx->eb_counter + 1024, 0, 9 * sizeof(uint32_t), ctx->stream));
-        HIP_TRY(launch_early_break_sample(rows->d_rows, cols->d_rows, (uint32_t)rows->n, (uint32_t)cols->n, (uint32_t)rows->nk,
-                                          (uint32_t)rows->ss64, (uint32_t)self_mode, SAMPLES, ctx->eb_counter + 1024, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(hist, ctx->eb_counter + 1024, sizeof hist, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        rows->eb_cols = cols;
-        rows->eb_cols_n = cols->n;
-        rows->eb_lengths = 0;
-        rows->eb_alive_share = 0.0;
-        double best = 0.9 * (double)rows->nk;
-        // (two lengths decide nothing by themselves -- a fit needs three -- but a pair without a shared bin at one of them is
-        // decided all the same: (1, 1); ke = 2 leaves more pairs to complete and pays where few share a bin at all: 2 048 bins)
-        for (int ke = 2; ke <= 4 && ke < (int)rows->nk; ++ke) {
-            uint32_t still = 0;
-            for (int m = ke; m <= 8; ++m) still += hist[m];
-            const double share = (double)still / SAMPLES, cost = (double)ke + 40.0 * share;
-            if (cost <= best) {
-                best = cost;
-                rows->eb_lengths = ke;
-                rows->eb_alive_share = share;
-            }
+    if (!p) return;
+    if (p->d_block_ke) (void)hipFree(p->d_block_ke);
+    delete p;
+}
+
+void free_plans(skl_ctx *ctx)
+{
+    for (EbPlan *p : ctx->eb_plans) free_plan(p);
+    ctx->eb_plans.clear();
+    ctx->eb_last_plan = nullptr;
+}
+
+// ke of {2, 3, 4} with the lowest modelled cost for a histogram of `total` sampled pairs (hist[m]: pairs that pass the test at
+// exactly their first m lengths), or 0 when counting every length is cheaper
+static int best_lengths(const uint32_t *hist, uint32_t total, size_t nk, double *share_out, int only = 0)
+{
+    int best_ke = 0;
+    double best = 0.9 * (double)nk;
+    if (total == 0) return 0;
+    // (two lengths decide nothing by themselves -- a fit needs three -- but a pair that fails the test at one of them is
+    // decided all the same: (1, 1); ke = 2 leaves more pairs to complete and pays where few share a bin at all: 2 048 bins)
+    for (int ke = 2; ke <= 4 && ke < (int)nk; ++ke) {
+        if (only && ke != only) continue;
+        uint32_t still = 0;
+        for (int m = ke; m <= 8; ++m) still += hist[m];
+        const double share = (double)still / (double)total, cost = (double)ke + EB_COST * share;
+        if (cost <= best) {
+            best = cost;
+            best_ke = ke;
+            if (share_out) *share_out = share;
         }
     }
-    *lengths = rows->eb_lengths;
+    return best_ke;
+}
+
+int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols, int self_mode, double cutoff, const EbPlan **out)
+{
+    *out = nullptr;
+    const int knob = ctx->knobs.early_break;
+    if (knob == 0 || rows->nk < 3 || rows->nk > 8) return SKL_OK;
+    if (rows->n * cols->n < 65536) return SKL_OK;
+    if (!ctx->eb_counter) {
+        HIP_TRY(hipMalloc((void **)&ctx->eb_counter, 1024 * sizeof(uint32_t)));   // 1 024 counter slots (diagnostic)
+        HIP_TRY(hipMemsetAsync(ctx->eb_counter, 0, 1024 * sizeof(uint32_t), ctx->stream));
+    }
+    const bool has_comp = rows->d_comp != nullptr && cols->d_comp != nullptr;
+    for (const EbPlan *p : ctx->eb_plans) {
+        if (p->rows_gen == rows->gen && p->cols_gen == cols->gen && p->self_mode == self_mode && (!has_comp || p->cutoff == cutoff)) {
+            *out = p;
+            return SKL_OK;
+        }
+    }
+    EbPlan *plan = new EbPlan();
+    plan->rows_gen = rows->gen;
+    plan->cols_gen = cols->gen;
+    plan->self_mode = self_mode;
+    plan->cutoff = cutoff;
+    auto keep = [&]() {
+        if (ctx->eb_plans.size() >= 8) {   // (nothing in flight reads an old plan's table: the sample below synchronises the stream)
+            if (ctx->eb_last_plan == ctx->eb_plans.front()) ctx->eb_last_plan = nullptr;
+            free_plan(ctx->eb_plans.front());
+            ctx->eb_plans.erase(ctx->eb_plans.begin());
+        }
+        ctx->eb_plans.push_back(plan);
+        *out = plan;
+    };
+    if (knob >= 2) {   // forced (A/B build, tests)
+        plan->lengths = knob < (int)rows->nk ? knob : 0;
+        keep();
+        return SKL_OK;
+    }
+    // blocks: a power of two of samples per side, at least 256, at most EB_BLOCKS_MAX per side
+    auto shift_for = [](size_t n) {
+        uint32_t sh = 8;
+        while (((n + ((size_t)1 << sh) - 1) >> sh) > EB_BLOCKS_MAX) ++sh;
+        return sh;
+    };
+    plan->shift_r = shift_for(rows->n);
+    plan->shift_c = self_mode ? plan->shift_r : shift_for(cols->n);
+    plan->blk_rows = (uint32_t)((rows->n + ((size_t)1 << plan->shift_r) - 1) >> plan->shift_r);
+    plan->blk_cols = (uint32_t)((cols->n + ((size_t)1 << plan->shift_c) - 1) >> plan->shift_c);
+    const uint32_t n_blocks = plan->blk_rows * plan->blk_cols;
+    const uint32_t live_blocks = self_mode ? plan->blk_rows * (plan->blk_rows + 1) / 2 : n_blocks;
+    const uint32_t samples = std::max(EB_SAMPLES_MIN, (EB_SAMPLES_TOTAL + live_blocks - 1) / live_blocks);
+    SKL_TRY(ensure_ytab(rows));
+    DevBuf d_hist;
+    HIP_TRY(hipMalloc(&d_hist.p, (size_t)n_blocks * 9 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_hist.p, 0, (size_t)n_blocks * 9 * sizeof(uint32_t), ctx->stream));
+    EbSampleArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.rows_ref = rows->d_rows;
+    sa.cols_ref = cols->d_rows;
+    sa.n_rows = (uint32_t)rows->n;
+    sa.n_cols = (uint32_t)cols->n;
+    sa.nk = (uint32_t)rows->nk;
+    sa.ss64 = (uint32_t)rows->ss64;
+    sa.self_mode = (uint32_t)self_mode;
+    sa.samples = samples;
+    sa.blk_shift_r = plan->shift_r;
+    sa.blk_shift_c = plan->shift_c;
+    sa.blk_rows = plan->blk_rows;
+    sa.blk_cols = plan->blk_cols;
+    sa.min_alive = rows->min_alive;
+    sa.has_comp = has_comp ? 1 : 0;
+    if (has_comp) {
+        const int v = host_log_variant();
+        sa.log_variant = v < 0 ? (int)SKL_LOG_FMA : v;
+    }
+    sa.ytab = rows->d_ytab;
+    sa.compA = rows->d_comp;
+    sa.compB = cols->d_comp;
+    sa.cutoff = cutoff;
+    sa.tolerance = std::log(2.0 / (double)((rows->ss64 * 64ull) * 64ull));  // jaccard.rs:75
+    sa.hist = (uint32_t *)d_hist.p;
+    HIP_TRY(launch_early_break_sample(sa, ctx->stream));
+    std::vector<uint32_t> hist((size_t)n_blocks * 9);
+    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // the pooled decision (the kNN drivers' and the one-block case's)
+    uint32_t pooled[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pooled_n = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        for (int m = 0; m <= 8; ++m) {
+            pooled[m] += hist[(size_t)b * 9 + m];
+            pooled_n += hist[(size_t)b * 9 + m];
+        }
+    }
+    plan->lengths = best_lengths(pooled, pooled_n, rows->nk, &plan->alive_share);
+    if (live_blocks > 1) {
+        // per block.  Pass 1: every block's own best; pass 2: the blocks that take the early break agree on the ke that is best
+        // for their POOLED sample (64 pairs a block cannot tell 2 from 3 lengths; 10 000 can) wherever it pays for them too.
+        const uint8_t all = (uint8_t)rows->nk;
+        std::vector<uint8_t> ke(n_blocks, all);
+        uint32_t cold[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cold_n = 0;
+        for (uint32_t b = 0; b < n_blocks; ++b) {
+            uint32_t tot = 0;
+            for (int m = 0; m <= 8; ++m) tot += hist[(size_t)b * 9 + m];
+            const int own = best_lengths(&hist[(size_t)b * 9], tot, rows->nk, nullptr);
+            if (own > 0) {
+                ke[b] = (uint8_t)own;
+                for (int m = 0; m <= 8; ++m) cold[m] += hist[(size_t)b * 9 + m];
+                cold_n += tot;
+            }
+        }
+        const int common = best_lengths(cold, cold_n, rows->nk, nullptr);
+        bool differ = false;
+        uint8_t first = 0;
+        for (uint32_t b = 0; b < n_blocks; ++b) {
+            if (self_mode && b % plan->blk_cols < b / plan->blk_cols) continue;   // below the diagonal: no pair
+            if (ke[b] != all && common > 0) {
+                uint32_t tot = 0;
+                for (int m = 0; m <= 8; ++m) tot += hist[(size_t)b * 9 + m];
+                if (best_lengths(&hist[(size_t)b * 9], tot, rows->nk, nullptr, common) == common) ke[b] = (uint8_t)common;
+            }
+            if (first == 0) first = ke[b];
+            else if (ke[b] != first) differ = true;
+        }
+        if (differ) {
+            if (self_mode) {   // (mirror: a tile on the diagonal may look a block up from either side)
+                for (uint32_t r = 0; r < plan->blk_rows; ++r) {
+                    for (uint32_t c = 0; c < r && c < plan->blk_cols; ++c) ke[(size_t)r * plan->blk_cols + c] = ke[(size_t)c * plan->blk_cols + r];
+                }
+            }
+            plan->mixed = true;
+            plan->block_ke = ke;
+            HIP_TRY(hipMalloc((void **)&plan->d_block_ke, ke.size()));
+            HIP_TRY(hipMemcpy(plan->d_block_ke, ke.data(), ke.size(), hipMemcpyHostToDevice));
+        } else {
+            plan->lengths = first == all ? 0 : (int)first;   // one mind: a plain launch
+        }
+    }
+    keep();
+    return SKL_OK;
+}
+
+int early_break_lengths(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols, int self_mode, int *lengths)
+{
+    *lengths = 0;
+    // (the kNN bands' epilogue has no completeness branch and no segmented counts: capi_knn.cpp)
+    if (rows->d_comp != nullptr || cols->d_comp != nullptr || rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS) return SKL_OK;
+    const EbPlan *plan = nullptr;
+    SKL_TRY(early_break_plan(ctx, rows, cols, self_mode, 0.0, &plan));
+    if (plan) *lengths = plan->lengths;
+    return SKL_OK;
+}
+
+extern "C" int skl_ctx_early_break_blocks(skl_ctx *ctx, uint32_t *blk_rows, uint32_t *blk_cols, uint32_t *shift_rows, uint32_t *shift_cols,
+                                          int *pooled_lengths, int *mixed, uint8_t *block_lengths, size_t capacity)
+{
+    SKL_TRY(ctx_bind(ctx));
+    const EbPlan *p = ctx->eb_last_plan;
+    if (blk_rows) *blk_rows = p ? p->blk_rows : 0u;
+    if (blk_cols) *blk_cols = p ? p->blk_cols : 0u;
+    if (shift_rows) *shift_rows = p ? p->shift_r : 0u;
+    if (shift_cols) *shift_cols = p ? p->shift_c : 0u;
+    if (pooled_lengths) *pooled_lengths = p ? p->lengths : 0;
+    if (mixed) *mixed = p && p->mixed ? 1 : 0;
+    if (p && p->mixed && block_lengths) {
+        if (capacity < p->block_ke.size()) return fail(SKL_ERR_INVALID_ARG, "skl_ctx_early_break_blocks: %zu blocks, room for %zu", p->block_ke.size(), capacity);
+        memcpy(block_lengths, p->block_ke.data(), p->block_ke.size());
+    }
     return SKL_OK;
 }
 
@@ -1013,18 +1200,23 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
     const bool coreacc = mode == MODE_COREACC;
     // Small core/acc launches run as (tile, k) workgroups producing counts + the epilogue
     // kernel (pair_kslice.hip): 5x the workgroups of the fused kernel and two columns per lane.
-    int eb_lengths = 0;
-    if (coreacc && (forced_kernel(ctx) == 0 || forced_kernel(ctx) == 4)) SKL_TRY(early_break_lengths(ctx, rows, cols, self_mode, &eb_lengths));
-    const bool early = eb_lengths > 0;
+    const EbPlan *plan = nullptr;
+    if (coreacc && (forced_kernel(ctx) == 0 || forced_kernel(ctx) == 4)) {
+        SKL_TRY(early_break_plan(ctx, rows, cols, self_mode, p ? p->completeness_cutoff : 0.0, &plan));
+        ctx->eb_last_plan = plan;
+    }
+    const bool eb_mixed = plan != nullptr && plan->mixed;               // the early break decided block by block
+    const int eb_lengths = plan != nullptr && !eb_mixed ? plan->lengths : 0;
+    const bool early = eb_lengths > 0 || eb_mixed;
     // (with the early break every launch takes the counts + epilogue form, whatever its size: three of the k-mer lengths,
     // 12 bytes of counts per pair through HBM -- nothing beside the two lengths not walked)
-    const bool sliced = coreacc && (coreacc_runs_sliced(ctx, rows, pairs) || (early && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS));
+    const bool sliced = coreacc && (coreacc_runs_sliced(ctx, rows, pairs) || early);
     if (coreacc && (sliced || !fused_coreacc_ok(rows))) {
         // unfused: counts -> scratch2 -> epilogue kernel
         // (the counts scratch is bounded: a band whose counts would not fit COUNTS_SCRATCH_MAX is computed in two halves
         // of equal pair count, each into its slice of the destination -- only sketches beyond 65 535 bins or more than 6
         // k-mer lengths come here with that many pairs)
-        const size_t nkw = early ? (size_t)eb_lengths : rows->nk;   // k-mer lengths the pair kernel counts
+        const size_t nkw = eb_lengths > 0 ? (size_t)eb_lengths : rows->nk;   // k-mer lengths the pair kernel counts (block by block: planes)
         if (pairs * nkw * sizeof(uint32_t) > COUNTS_SCRATCH_MAX && r1 - r0 > 1) {
             uint64_t mid = r0 + (r1 - r0) / 2;
             if (self_mode) {   // the row that splits the pairs evenly
@@ -1044,6 +1236,12 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         if (early) {
             g.k_count = (uint32_t)nkw;
             g.cnt_pair_stride = nkw;
+        }
+        if (eb_mixed) {
+            g.block_ke = plan->d_block_ke;
+            g.blk_shift_r = plan->shift_r;
+            g.blk_shift_c = plan->shift_c;
+            g.blk_cols = plan->blk_cols;
         }
         void *counts = nullptr;
         const uint32_t k_slices = sliced ? choose_k_slices(ctx, rows->ss64) : 1u;
@@ -1154,13 +1352,27 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.k_stride = g.cnt_k_stride;
         e.n_pairs = pairs;
         e.nk = (uint32_t)nkw;
+        e.nk_total = (uint32_t)rows->nk;
         if (early) {
-            e.nk_total = (uint32_t)rows->nk;
             e.rows_ref = rows->d_rows;
             e.cols_ref = cols->d_rows;
             e.alive_count = ctx->eb_counter;
             ctx->eb_pairs += pairs;
-            ctx->last_kernel += " + early break: " + std::to_string(nkw) + " of " + std::to_string(rows->nk) + " k-mer lengths counted, the pairs still in the running completed by the epilogue";
+            if (eb_mixed) {
+                e.block_ke = plan->d_block_ke;
+                e.blk_shift_r = plan->shift_r;
+                e.blk_shift_c = plan->shift_c;
+                e.blk_cols = plan->blk_cols;
+                ctx->last_kernel += " + early break: block by block (" + std::to_string(plan->blk_rows) + " x " + std::to_string(plan->blk_cols) + " blocks of sample ids), the pairs still in the running completed by the epilogue";
+            } else {
+                ctx->last_kernel += " + early break: " + std::to_string(nkw) + " of " + std::to_string(rows->nk) + " k-mer lengths counted, the pairs still in the running completed by the epilogue";
+            }
+        }
+        e.min_alive = rows->min_alive;
+        {   // groups of 64 pairs per wave: enough waves to fill the chip twice over, at most 16 groups
+            const uint64_t units = (pairs + 63) / 64, slots = (uint64_t)ctx->n_cu * 4ull * 4ull;
+            const long long forced_span = ctx->knobs.epilogue_span;
+            e.span = forced_span > 0 ? (uint32_t)std::min(64ll, forced_span) : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, units / (2 * slots)));
         }
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
@@ -1180,7 +1392,13 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.tolerance = g.tolerance;
         e.kf = rows->d_kf;
         e.out = (float *)dst_dev;
-        HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));
+#ifdef SKL_AB
+        if (ctx->knobs.epilogue_r5 && !eb_mixed && !(early && (e.has_comp || rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS))) {
+            if (!early) e.nk_total = 0;
+            HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));   // round 5's epilogue: alive pairs completed where they are found (A/B timing)
+        } else
+#endif
+        HIP_TRY(launch_coreacc_epilogue_rows(e, ctx->stream));
         // (an empty launch, or one another kernel took, leaves plane 1 not known to be zero)
         if (two_planes && ctx->last_tail) ctx->clean_plane1 = plane1_clean;
         return SKL_OK;

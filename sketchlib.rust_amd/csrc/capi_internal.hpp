@@ -62,6 +62,8 @@ struct Knobs {
     bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
     int early_break = 1;              // A/B build, SKL_EARLY_BREAK: 0 core/accessory launches count every k-mer length; 1 (default) the early break where a
                                       // sample of the pairs says it pays; 2..7 forced with that many lengths counted (tests).  Results identical.
+    long long epilogue_span = 0;      // A/B build, SKL_EPILOGUE_SPAN: groups of 64 pairs per wave of the core/accessory epilogue forced (0: by launch size)
+    bool epilogue_r5 = false;         // A/B build, SKL_EPILOGUE_R5=1: round 5's epilogue (alive pairs completed where they are found; timing)
     bool knn_sparse = true;           // A/B build, SKL_KNN_SPARSE=0: tiles that survive the probe are walked whole (results identical)
     long long knn_panel = 0;          // A/B build, SKL_KNN_PANEL: column-panel width of the row-by-row kNN forced (tests; 0: by size)
     bool knn_prune = true;            // SKL_KNN_PRUNE=0: the symmetric self kNN finishes every tile (A/B; results are identical)
@@ -80,6 +82,23 @@ struct Knobs {
 #endif
 };
 SKL_INTERNAL Knobs read_knobs();
+
+// EARLY BREAK of the core/accessory calls, as decided for one (row slab, column slab) pair (capi.cpp early_break_plan): how many
+// k-mer lengths the pair kernel counts before the epilogue completes the pairs still in the running -- for the whole pair
+// space (`lengths`; what the kNN drivers take) and, when its blocks of (row >> shift_r, column >> shift_c) sample ids
+// disagree, per block.  Kept by the CONTEXT, keyed by the slabs' generation ids (never reused), not written through the
+// caller's const slab.
+struct EbPlan {
+    uint64_t rows_gen = 0, cols_gen = 0;
+    int self_mode = 0;
+    double cutoff = 0.0;                // completeness cutoff the sample was taken with (a correction changes ln J)
+    int lengths = 0;                    // pooled decision: lengths to count (0: all of them, no early break)
+    double alive_share = 0.0;           // sampled share of the pairs still in the running after them
+    bool mixed = false;                 // the blocks disagree: d_block_ke holds each block's count (nk: all of them)
+    uint32_t shift_r = 31, shift_c = 31, blk_rows = 1, blk_cols = 1;
+    std::vector<uint8_t> block_ke;      // [blk_rows * blk_cols], host copy (skl_ctx_early_break_blocks)
+    uint8_t *d_block_ke = nullptr;
+};
 
 struct skl_ctx {
     int device = 0;
@@ -121,6 +140,8 @@ struct skl_ctx {
     uint64_t knn_pruned_stages = 0, knn_tile_stages = 0;   // ... stages the pruned tiles had walked / stages of a whole tile
     uint32_t *eb_counter = nullptr;        // device word: pairs the early-break epilogue completed (skl_ctx_early_break_stats)
     uint64_t eb_pairs = 0;                 // ... out of this many pairs of early-break launches since the context was made
+    std::vector<EbPlan *> eb_plans;        // early-break decisions of the last few slab pairs (newest last)
+    const EbPlan *eb_last_plan = nullptr;  // the plan of the last dense core/accessory call (skl_ctx_early_break_blocks)
     uint64_t knn_tiles = 0, knn_tiles_pruned = 0;   // tile pruning of the last self kNN call (skl_ctx_knn_prune_stats)
     int knn_ties = SKL_KNN_TIES_REFERENCE;   // what self_dists_knn returns (mod.rs:133-224); skl_ctx_set_knn_ties(CANONICAL) opts out
     Knobs knobs;                        // environment switches as of skl_ctx_create
@@ -138,12 +159,8 @@ struct skl_sketches {
     double *d_ytab = nullptr;    // ln J table [64*ss64+1]
     double *d_kf = nullptr;      // k-mer lengths as f64 [nk]
     std::map<std::pair<int, size_t>, float *> d_dtab;  // (jout, k_idx) -> f32 table
-    // early break (capi.cpp dense_band): the last column slab this one was sampled against, and whether counting only the
-    // first three k-mer lengths paid (few enough pairs stay in the running)
-    const skl_sketches *eb_cols = nullptr;
-    size_t eb_cols_n = 0;
-    int eb_lengths = 0;          // lengths to count (0: all of them, no early break)
-    double eb_alive_share = 0.0; // sampled share of the pairs still in the running after them
+    uint64_t gen = 0;            // generation id, unique per slab AND per completeness vector over the life of the process
+    uint32_t min_alive = 0xFFFFFFFFu;   // ln J(count) < tolerance <=> count < min_alive (set with d_ytab; 0xFFFFFFFF: ask the table)
     size_t sample_words() const { return nk * ss64 * skl::BBITS; }
 };
 
@@ -174,7 +191,11 @@ SKL_INTERNAL int timed_pair_launch(skl_ctx *ctx, const skl::PairArgs &args, int 
 SKL_INTERNAL std::pair<hipEvent_t, hipEvent_t> *timing_slot(skl_ctx *ctx);
 SKL_INTERNAL int check_params(const skl_sketches *a, const skl_sketches *b, const skl_dist_params *p);
 SKL_INTERNAL bool fused_coreacc_ok(const skl_sketches *s);
-// early break of the core/accessory calls (capi.cpp): k-mer lengths the pair kernel should count (0: all of them)
+// early break of the core/accessory calls (capi.cpp): the decision for this slab pair (sampled once, kept by the context);
+// *plan = null: not applicable (fewer than 3 or more than 8 k-mer lengths, a tiny pair space, switched off)
+SKL_INTERNAL int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols, int self_mode, double cutoff,
+                                  const EbPlan **plan);
+// ... its pooled form, for the kNN drivers: k-mer lengths the pair kernel should count (0: all of them)
 SKL_INTERNAL int early_break_lengths(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols, int self_mode, int *lengths);
 // operand / epilogue fields common to every launch: `rows` is the scalar operand (A), `cols` the lane operand (B)
 SKL_INTERNAL int fill_args(const skl_sketches *rows, const skl_sketches *cols, const skl_dist_params *p, int mode,

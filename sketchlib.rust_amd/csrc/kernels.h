@@ -127,6 +127,12 @@ struct PairArgs {
                                   // left their tile at the probe, [1] += ... at a stage boundary, [2] += the stages those had walked,
                                   // [3] += workgroups that finished their tile by the sparse walk (null: not counted)
     uint32_t prune_flags;         // bit 0: no sparse walk (A/B build, SKL_KNN_SPARSE=0: the probe's survivors are walked whole)
+    // EARLY BREAK DECIDED PER BLOCK (k-sliced MODE_COUNTS; capi.cpp early_break_plan): the workgroup of (tile, k index kk)
+    // leaves at once when kk >= the k-mer lengths the tile's block(s) of (row >> blk_shift_r, column >> blk_shift_c) sample ids
+    // count -- block_ke[row block * blk_cols + column block]; blocks are multiples of 256 samples, so a tile's 128 columns lie in
+    // one and its rows in at most two (the larger count wins).  Null: every tile counts k_count lengths.
+    const uint8_t *block_ke;
+    uint32_t blk_shift_r, blk_shift_c, blk_cols;
     // FUSED CORE/ACCESSORY EPILOGUE of a k-sliced MODE_COUNTS launch (one workgroup per (tile, k-mer length), no chunk slices;
     // pair_kslice.hip, FUSE): every workgroup stores its k-mer length's counts write-through, then ONE lane adds 1 to
     // fuse_counter[tile] (agent scope, returning); the workgroup whose add completes the tile's k_count arrivals reads the
@@ -228,8 +234,19 @@ struct EpilogueArgs {
     uint32_t nk_total;
     const uint64_t *rows_ref, *cols_ref;
     uint32_t *alive_count;      // 1 024 words, slot blockIdx & 1023 += pairs completed here (diagnostic; may be null)
+    // Round 6 (epilogue.hip, coreacc_epilogue_rows_kernel): a wave takes `span` groups of 64 consecutive pairs and the
+    // workgroup completes its alive pairs together, grouped by row.
+    uint32_t span;              // 64-pair groups per wave (0: 1)
+    uint32_t min_alive;         // no completeness correction: ln J(count) < tolerance <=> count < min_alive (0xFFFFFFFF: ask ytab)
+    uint32_t cnt_u16;           // 1: the counts are u16 records (sketches of up to 1 023 chunks, no chunk slices)
+    // EARLY BREAK DECIDED PER BLOCK: block_ke[(i >> blk_shift_r) * blk_cols + (j >> blk_shift_c)] = k-mer lengths the pair kernel
+    // counted for the pairs of that block of (row sample, column sample) ids (nk_total: all of them); `nk` is then the number
+    // of count planes (= nk_total).  Null: `nk` lengths for every pair.
+    const uint8_t *block_ke;
+    uint32_t blk_shift_r, blk_shift_c, blk_cols;
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
+hipError_t launch_coreacc_epilogue_rows(const EpilogueArgs &args, hipStream_t stream);   // core/accessory records only (epilogue.hip)
 // EARLY BREAK in the one-evaluation core/accessory self kNN (capi_knn.cpp): a row band's view of the columns was counted at
 // its first `nk` k-mer lengths (k-major counts, counts[t * n_pairs + row * nB + c]); this launch turns them into the band's
 // (core, acc) records -- completing the pairs still in the running like coreacc_epilogue_kernel -- and does what the fused
@@ -262,9 +279,23 @@ struct EpilogueKnnArgs {
     uint32_t *alive_count;
 };
 hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t stream);
-// early break: hist[m] (9 words) += the sampled pairs that share a bin at each of their first m k-mer lengths and not at the next (kernels.hip)
-hipError_t launch_early_break_sample(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t n_rows, uint32_t n_cols, uint32_t nk,
-                                     uint32_t ss64, uint32_t self_mode, uint32_t n_samples, uint32_t *hist, hipStream_t stream);
+// EARLY BREAK, the driver's question before it counts only the first few k-mer lengths of a block of pairs: how many of them
+// would still be in the running after those?  The pair space is cut into blocks of (row >> blk_shift_r, column >> blk_shift_c)
+// sample ids; `samples` pairs of every block (a fixed pseudo-random choice; one wave each) run the reference's loop,
+// jaccard.rs:77-91, and hist[block * 9 + m] += the pairs that pass its test at each of their first m lengths and not at the
+// next (m = nk: at all of them; m <= 8).  Self mode: blocks below the diagonal stay empty.  The test is the epilogue's
+// (min_alive / the restated logarithm with a completeness correction).
+struct EbSampleArgs {
+    const uint64_t *rows_ref, *cols_ref;
+    uint32_t n_rows, n_cols, nk, ss64, self_mode;
+    uint32_t samples, blk_shift_r, blk_shift_c, blk_rows, blk_cols;   // blk_rows x blk_cols blocks
+    uint32_t min_alive;
+    int32_t has_comp, log_variant;
+    const double *ytab, *compA, *compB;
+    double cutoff, tolerance;
+    uint32_t *hist;
+};
+hipError_t launch_early_break_sample(const EbSampleArgs &args, hipStream_t stream);
 // one-wave shader-clock sampler (kernels.hip): (s_memtime, s_memrealtime) pairs until *stop != 0 or max_samples
 hipError_t launch_clock_sampler(const uint32_t *stop, uint64_t *samples, uint32_t max_samples, uint32_t sleeps,
                                 uint32_t *count, hipStream_t stream);

@@ -451,51 +451,6 @@ hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t 
     return hipSuccess;
 }
 
-// EARLY BREAK, the driver's question before it counts only the first few k-mer lengths: how many pairs would still be in
-// the running after them?  One wave per sampled pair (a fixed pseudo-random choice of rows and columns) compares the two
-// samples length by length in the reference's layout until one without a shared bin; hist[m] += pairs that share a bin at
-// each of their first m lengths and not at the next (m = nk: at all of them).  hist has 9 words (m <= 8 kept apart).
-__global__ __launch_bounds__(256) void early_break_sample_kernel(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t n_rows,
-                                                                 uint32_t n_cols, uint32_t nk, uint32_t ss64, uint32_t self_mode,
-                                                                 uint32_t n_samples, uint32_t *hist)
-{
-    const uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (s >= n_samples) return;
-    uint64_t h = ((uint64_t)s + 1u) * 0x9E3779B97F4A7C15ull;
-    h ^= h >> 29;
-    h *= 0xBF58476D1CE4E5B9ull;
-    h ^= h >> 32;
-    const uint32_t i = (uint32_t)(h % n_rows);
-    uint32_t j = (uint32_t)((h >> 20) % n_cols);
-    if (self_mode && j == i) j = (j + 1u) % n_cols;
-    uint32_t lead = 0u;
-    for (uint32_t t = 0; t < nk && t < 8u; ++t) {
-        const uint64_t *a = rows_ref + (((uint64_t)i * nk + t) * ss64) * BBITS;
-        const uint64_t *b = cols_ref + (((uint64_t)j * nk + t) * ss64) * BBITS;
-        uint32_t m = 0u;
-        for (uint32_t c = lane; c < ss64; c += 64u) {
-            uint64_t differ = 0ull;
-#pragma unroll
-            for (uint32_t pl = 0; pl < (uint32_t)BBITS; ++pl) differ |= a[(uint64_t)c * BBITS + pl] ^ b[(uint64_t)c * BBITS + pl];
-            m += (uint32_t)__popcll(~differ);
-        }
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) m += (uint32_t)__shfl_xor((int)m, sh);
-        if (m == 0u) break;
-        ++lead;
-    }
-    if (lane == 0u) atomicAdd(&hist[lead], 1u);
-}
-
-hipError_t launch_early_break_sample(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t n_rows, uint32_t n_cols, uint32_t nk,
-                                     uint32_t ss64, uint32_t self_mode, uint32_t n_samples, uint32_t *hist, hipStream_t stream)
-{
-    if (n_samples == 0 || n_rows == 0 || n_cols == 0) return hipSuccess;
-    hipLaunchKernelGGL(early_break_sample_kernel, dim3((n_samples * 64u + 255u) / 256u), dim3(256), 0, stream, rows_ref, cols_ref, n_rows,
-                       n_cols, nk, ss64, self_mode, n_samples, hist);
-    return hipGetLastError();
-}
-
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream)
 {
     if (args.n_pairs == 0) return hipSuccess;

@@ -204,6 +204,17 @@ __global__ __launch_bounds__(LANES *WAVES_PER_WG, OCC != 0 ? OCC : (TIGHT ? (R >
     if (jb0 >= g.n_jblocks) return;
     if (a0 >= g.row_end) return;
     if (g.self_mode && a0 >= (jg + 1u) * JL * 64u - 1u) return;   // tile entirely on/below the diagonal
+    if constexpr (KSL && MODE == MODE_COUNTS && !FUSE) {
+        // EARLY BREAK DECIDED PER BLOCK (PairArgs::block_ke): this workgroup counts k index kk0 of its tile; the tile's block of
+        // sample ids may want fewer lengths than the launch carries planes for
+        if (g.block_ke != nullptr) {
+            const uint32_t r_last = min(a0 + (uint32_t)R, g.row_end) - 1u;
+            const uint32_t bc = (jb0 * 64u) >> g.blk_shift_c;
+            const uint32_t ke_a = g.block_ke[(size_t)(a0 >> g.blk_shift_r) * g.blk_cols + bc];
+            const uint32_t ke_b = g.block_ke[(size_t)(r_last >> g.blk_shift_r) * g.blk_cols + bc];
+            if (kk0 >= max(ke_a, ke_b)) return;
+        }
+    }
     // HALF TILES (2 columns per lane).  A 64-column block of the tile that holds no pair of the launch is
     // not walked: block 0 of a tile that straddles the diagonal when every column of it is <= the
     // tile's first row (self mode: 4 of the 8 diagonal row tiles of every column group at 16 rows, 2 of
