@@ -182,6 +182,9 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     free_plans(ctx);
+    for (hipEvent_t ev : ctx->eb_events) {
+        if (ev) (void)hipEventDestroy(ev);
+    }
     if (ctx->eb_counter) (void)hipFree(ctx->eb_counter);
     if (ctx->sampler_buf) (void)hipFree(ctx->sampler_buf);
     if (ctx->sampler_count) (void)hipFree(ctx->sampler_count);
@@ -379,8 +382,12 @@ Knobs read_knobs()
     k.knn_panel = env_int("SKL_KNN_PANEL", 0);
     k.knn_sparse = env_int("SKL_KNN_SPARSE", 1) != 0;
     k.early_break = (int)std::min(7ll, std::max(0ll, env_int("SKL_EARLY_BREAK", 1)));
-    k.epilogue_span = std::max(0ll, env_int("SKL_EPILOGUE_SPAN", 0));
     k.epilogue_r5 = env_int("SKL_EPILOGUE_R5", 0) != 0;
+    k.eb_pipeline = env_int("SKL_EB_PIPELINE", 1) != 0;
+    k.eb_pipeline_min = std::max(2ll, env_int("SKL_EB_PIPELINE_MIN", 64ll << 20));
+    k.eb_worklist_min = env_int("SKL_EB_WORKLIST_MIN", 2ll << 20);
+    k.eb_worklist_cap = std::max(0ll, env_int("SKL_EB_WORKLIST_CAP", 0));
+    k.counts_u16 = env_int("SKL_COUNTS_U16", 1) != 0;
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
@@ -1217,20 +1224,70 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // of equal pair count, each into its slice of the destination -- only sketches beyond 65 535 bins or more than 6
         // k-mer lengths come here with that many pairs)
         const size_t nkw = eb_lengths > 0 ? (size_t)eb_lengths : rows->nk;   // k-mer lengths the pair kernel counts (block by block: planes)
-        if (pairs * nkw * sizeof(uint32_t) > COUNTS_SCRATCH_MAX && r1 - r0 > 1) {
-            uint64_t mid = r0 + (r1 - r0) / 2;
-            if (self_mode) {   // the row that splits the pairs evenly
-                uint64_t lo = r0 + 1, hi = r1 - 1;
-                while (lo < hi) {
-                    const uint64_t m = (lo + hi) / 2;
-                    if (self_rows_pairs(r0, m, n_cols) * 2 < pairs) lo = m + 1; else hi = m;
+        // U16 COUNTS (round 6): sketches of up to 1 023 chunks count at most 65 472 bins per length, so a launch without
+        // chunk slices (no plane to add into) parks its counts as u16: half the scratch traffic of the stream
+        const bool tiny = pairs * nkw < 2ull * 4ull * (uint64_t)ctx->n_cu * 2048ull;   // (launches that may be tail-sliced keep u32: slices ADD into a plane)
+        const bool cnt_u16 = sliced && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS && !tiny && ctx->knobs.k_slices <= 1 && ctx->knobs.counts_u16;
+        const size_t cnt_bytes = cnt_u16 ? sizeof(uint16_t) : sizeof(uint32_t);
+        // BAND PIPELINE (round 6).  The counts scratch is bounded, and a call whose counts do not fit is computed in row bands of
+        // equal pair count.  From 64 Mi pairs on the bands are also what hides the epilogue: band i's epilogue (+ completion
+        // of the pairs still in the running) is memory-bound, band i + 1's counts kernel is bound by the vector ALUs, so they
+        // run side by side -- counts kernels on the context's stream, epilogues on its second stream, two counts buffers.
+        if (!ctx->eb_in_pipeline && r1 - r0 > 1 &&
+            (pairs * nkw * cnt_bytes > COUNTS_SCRATCH_MAX || (early && ctx->knobs.eb_pipeline && pairs >= (uint64_t)ctx->knobs.eb_pipeline_min))) {
+            const uint64_t fit = std::max<uint64_t>(1, COUNTS_SCRATCH_MAX / (nkw * cnt_bytes));
+            const uint64_t want = early && ctx->knobs.eb_pipeline ? std::max<uint64_t>((uint64_t)ctx->knobs.eb_pipeline_min / 2, pairs / 8) : fit;
+            const uint64_t n_bands = (pairs + std::min(fit, want) - 1) / std::min(fit, want);
+            std::vector<uint64_t> cuts(1, r0);
+            for (uint64_t b = 1; b < n_bands; ++b) {
+                const uint64_t target = pairs * b / n_bands;   // pairs before the cut
+                uint64_t cut;
+                if (self_mode) {   // the first row whose predecessors hold at least `target` pairs
+                    uint64_t lo = cuts.back() + 1, hi = r1 - 1;
+                    while (lo < hi) {
+                        const uint64_t m = (lo + hi) / 2;
+                        if (self_rows_pairs(r0, m, n_cols) < target) lo = m + 1; else hi = m;
+                    }
+                    cut = lo;
+                } else {
+                    cut = r0 + (target + n_cols - 1) / n_cols;
                 }
-                mid = lo;
+                cut = std::min<uint64_t>(std::max<uint64_t>(cut, cuts.back() + 1), r1 - 1);
+                if (cut > cuts.back()) cuts.push_back(cut);
             }
-            SKL_TRY(dense_band(ctx, rows, cols, p, mode, jout, self_mode, r0, mid, dst_dev));
-            const uint64_t base_mid = self_mode ? cond_index(mid, mid + 1, n_cols) : mid * n_cols;
-            return dense_band(ctx, rows, cols, p, mode, jout, self_mode, mid, r1, (char *)dst_dev + (base_mid - base) * 2 * sizeof(float));
+            cuts.push_back(r1);
+            const bool overlap = early && ctx->knobs.eb_pipeline && cuts.size() > 2;
+            if (overlap && !ctx->eb_events[0]) {
+                for (auto &ev : ctx->eb_events) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            }
+            ctx->eb_in_pipeline = true;
+            int rc = SKL_OK;
+            for (size_t b = 0; b + 1 < cuts.size() && rc == SKL_OK; ++b) {
+                const int buf = (int)(b & 1);
+                ctx->eb_pipe_buf = overlap ? buf : 0;
+                ctx->eb_pipe_overlap = overlap;
+                // (the epilogue that read this counts buffer two bands ago must be done before the counts kernel rewrites it)
+                if (overlap && b >= 2) {
+                    const hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->eb_events[2 + buf], 0);
+                    if (e != hipSuccess) rc = fail(SKL_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+                }
+                const uint64_t base_b = self_mode ? cond_index(cuts[b], cuts[b] + 1, n_cols) : cuts[b] * n_cols;
+                if (rc == SKL_OK) rc = dense_band(ctx, rows, cols, p, mode, jout, self_mode, cuts[b], cuts[b + 1], (char *)dst_dev + (base_b - base) * 2 * sizeof(float));
+            }
+            ctx->eb_in_pipeline = false;
+            ctx->eb_pipe_overlap = false;
+            ctx->eb_pipe_buf = 0;
+            if (overlap) {   // the output belongs to the context's stream again
+                for (int buf = 0; buf < 2; ++buf) {
+                    const hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->eb_events[2 + buf], 0);
+                    if (e != hipSuccess && rc == SKL_OK) rc = fail(SKL_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+                }
+                if (rc == SKL_OK) ctx->last_kernel += "; " + std::to_string(cuts.size() - 1) + " row bands, each band's epilogue beside the next band's counts kernel";
+            }
+            return rc;
         }
+        const bool piped = ctx->eb_in_pipeline && ctx->eb_pipe_overlap;
+        hipStream_t epi_stream = piped ? ctx->aux_stream : ctx->stream;
         PairArgs g;
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
         if (early) {
@@ -1280,8 +1337,10 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             tail_slices_eff = slice_plan((uint32_t)rows->ss64, 2u, &tail_chunks_eff);
         }
         const bool two_planes = tail;
-        const size_t plane_bytes = pairs * nkw * sizeof(uint32_t);
-        SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(two_planes ? 2u : 1u, k_slices), &counts, 1));
+        const bool u16_now = cnt_u16 && !tail && k_slices == 1u;
+        const size_t plane_bytes = pairs * nkw * (u16_now ? sizeof(uint16_t) : sizeof(uint32_t));
+        SKL_TRY(ctx_scratch(ctx, plane_bytes * std::max(two_planes ? 2u : 1u, k_slices), &counts, piped && ctx->eb_pipe_buf ? 15 : 1));
+        g.cnt_u16 = u16_now ? 1u : 0u;
         if (sliced) {   // k-major scratch: coalesced stores from the (tile, k[, chunk slice]) workgroups
             g.cnt_pair_stride = 1;
             g.cnt_k_stride = pairs;
@@ -1369,10 +1428,31 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             }
         }
         e.min_alive = rows->min_alive;
-        {   // groups of 64 pairs per wave: enough waves to fill the chip twice over, at most 16 groups
-            const uint64_t units = (pairs + 63) / 64, slots = (uint64_t)ctx->n_cu * 4ull * 4ull;
-            const long long forced_span = ctx->knobs.epilogue_span;
-            e.span = forced_span > 0 ? (uint32_t)std::min(64ll, forced_span) : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, units / (2 * slots)));
+        e.cnt_u16 = g.cnt_u16;
+        // WORK LIST: from 2 Mi pairs on the pairs still in the running are parked and a second launch completes them, grouped by
+        // row (below that a second launch costs more than it saves: completed on the spot).  4 096 sub-lists, room for ~16 % of
+        // the pairs (a sub-list that fills up completes its surplus on the spot); counters: two arrays that alternate.
+        if (early && pairs >= (uint64_t)std::max(0ll, ctx->knobs.eb_worklist_min) && pairs < (1ull << 32) && e.n_slices == 1u && !e.rezero_plane1) {
+            constexpr uint32_t SUBS = 4096;
+            const long long forced_cap = ctx->knobs.eb_worklist_cap;
+            const uint32_t cap = forced_cap > 0 ? (uint32_t)forced_cap : (uint32_t)std::max<uint64_t>(64, (pairs * 16 / 100 / SUBS + 31) / 32 * 32);
+            void *wl = nullptr, *wc = nullptr;
+            SKL_TRY(ctx_scratch(ctx, (size_t)SUBS * cap * sizeof(uint4), &wl, 16));
+            const size_t had = ctx->scratch_bytes[17];
+            SKL_TRY(ctx_scratch(ctx, 2 * SUBS * sizeof(uint32_t), &wc, 17));
+            if (ctx->scratch_bytes[17] != had) {
+                HIP_TRY(hipMemsetAsync(wc, 0, 2 * SUBS * sizeof(uint32_t), ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));   // (once per context: whichever stream uses the counters first finds them zero)
+                ctx->eb_wl_toggle = 0;
+            }
+            e.wl = (uint4 *)wl;
+            e.wl_subs = SUBS;
+            e.wl_cap = cap;
+            e.wl_count = (uint32_t *)wc + (size_t)ctx->eb_wl_toggle * SUBS;
+            e.wl_zero = (uint32_t *)wc + (size_t)(ctx->eb_wl_toggle ^ 1) * SUBS;
+            ctx->eb_wl_toggle ^= 1;
+            e.wl_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, pairs / (48ull << 20)));
+            ctx->last_kernel += " (work list, completed grouped by row)";
         }
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
@@ -1392,13 +1472,19 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.tolerance = g.tolerance;
         e.kf = rows->d_kf;
         e.out = (float *)dst_dev;
+        if (piped) {   // this band's epilogue on the second stream, behind its counts kernel
+            HIP_TRY(hipEventRecord(ctx->eb_events[ctx->eb_pipe_buf], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(epi_stream, ctx->eb_events[ctx->eb_pipe_buf], 0));
+        }
 #ifdef SKL_AB
-        if (ctx->knobs.epilogue_r5 && !eb_mixed && !(early && (e.has_comp || rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS))) {
+        if (ctx->knobs.epilogue_r5 && !eb_mixed && !e.cnt_u16 && !(early && (e.has_comp || rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS))) {
             if (!early) e.nk_total = 0;
-            HIP_TRY(launch_coreacc_epilogue(e, ctx->stream));   // round 5's epilogue: alive pairs completed where they are found (A/B timing)
+            e.wl = nullptr;
+            HIP_TRY(launch_coreacc_epilogue(e, epi_stream));   // round 5's epilogue: alive pairs completed where they are found (A/B timing)
         } else
 #endif
-        HIP_TRY(launch_coreacc_epilogue_rows(e, ctx->stream));
+        HIP_TRY(launch_coreacc_epilogue_r6(e, epi_stream));
+        if (piped) HIP_TRY(hipEventRecord(ctx->eb_events[2 + ctx->eb_pipe_buf], epi_stream));
         // (an empty launch, or one another kernel took, leaves plane 1 not known to be zero)
         if (two_planes && ctx->last_tail) ctx->clean_plane1 = plane1_clean;
         return SKL_OK;

@@ -262,12 +262,15 @@ __device__ __forceinline__ uint64_t pair_out_index(const PairArgs &g, uint32_t i
 
 // MODE_COUNTS: samebits of k index kk (jaccard.rs:15-25) over `bins` bins (the whole sketch, or one
 // chunk slice of it: pair_kslice.hip, k_slices)
+// (U16_OK: the forms whose launches may park u16 records -- PairArgs::cnt_u16 -- carry the run-time choice)
+template <bool U16_OK = false>
 __device__ __forceinline__ void store_count(const PairArgs &g, uint32_t i, uint32_t jcol,
                                             uint32_t kk, uint32_t bins, uint32_t mismatches)
 {
     if (pair_valid(g, i, jcol)) {
-        ((uint32_t *)g.out)[pair_out_index(g, i, jcol) * g.cnt_pair_stride + kk * g.cnt_k_stride] =
-            bins - mismatches;
+        const uint64_t at = pair_out_index(g, i, jcol) * g.cnt_pair_stride + kk * g.cnt_k_stride;
+        if (U16_OK && g.cnt_u16) ((uint16_t *)g.out)[at] = (uint16_t)(bins - mismatches);
+        else ((uint32_t *)g.out)[at] = bins - mismatches;
     }
 }
 

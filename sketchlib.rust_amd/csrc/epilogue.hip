@@ -4,16 +4,20 @@
 // Reference: core_acc_dist, src/distances/jaccard.rs:61-101.  The loop over the k-mer lengths leaves at the first one whose
 // ln J lies below the tolerance (:89-91) -- J = 0 for a pair that shares no more bins than chance (expected_samebits,
 // :26-31) -- and a fit over fewer than three lengths is (1, 1) (:117).  The pair kernel therefore counts only the first
-// `ke` lengths of a block of pairs (pair_kslice.hip, k-sliced MODE_COUNTS), and this kernel
-//   1. runs the reference's loop over those counts for every pair: a pair that leaves inside them is finished at once;
-//   2. parks the pairs STILL IN THE RUNNING in LDS lists (one per wave), which the workgroup then completes together:
-//      the four waves share the lists evenly, a wave takes its entries in pair order -- consecutive entries are columns of
-//      one row -- holds the ROW sample's slice of the next length in registers across them, and reads each column
-//      sample's slice as ONE contiguous run (lane l the l-th half chunk of 7 planes; the two halves of a chunk meet by
-//      DPP): the form pair_cand.hip measured at 0.88 of the HBM peak;
-//   3. finishes those pairs one per lane, all at once: the same sums in the same order as the reference.
-// Round 5 completed a pair where it was found -- a whole wave re-reading BOTH samples' slices per pair, 64 lanes 112
-// bytes apart, the other pairs of the wave waiting: 21-31 % of every core/accessory step.
+// `ke` lengths of a block of pairs (pair_kslice.hip, k-sliced MODE_COUNTS), and
+//   * coreacc_epilogue_kernel (one thread per pair, a pure stream: 4-16 bytes of counts in, 8 bytes out) runs the
+//     reference's loop over those counts: a pair that leaves inside them is finished at once; a pair STILL IN THE RUNNING is
+//     appended to a WORK LIST in global memory -- 4 096 sub-lists keyed by (row, column stripe), so that a sub-list holds
+//     runs of columns of one row -- or, for launches too small to be worth a second kernel (and when a sub-list is full),
+//     completed on the spot by its wave;
+//   * coreacc_completion_kernel walks the sub-lists: a wave takes 32 entries, holds the ROW sample's slice of the next
+//     length in registers across the entries that share the row, reads each column sample's slice as ONE contiguous run
+//     (lane l the l-th half chunk of 7 planes; the two halves of a chunk meet by DPP: the form pair_cand.hip measured at 0.88
+//     of the HBM peak), and finishes its entries one per lane: the same sums in the same order as the reference.
+// Round 5 completed every such pair where it was found -- a whole wave re-reading BOTH samples' slices, 64 lanes 112 bytes
+// apart, the wave's other pairs waiting: 21-31 % of every core/accessory step.  A first round-6 form that
+// completed the pairs inside the epilogue (LDS lists per workgroup) halved the completions' time and lost it again on the
+// stream: 128 registers and 24 KB of LDS where the plain epilogue runs at 5 waves per SIMD (profiles/r06_epilogue_forms.md).
 //
 // The break test is the reference's: y < tolerance with y = ln J.  Without a completeness correction y is a function of
 // the bin-match count alone and non-decreasing in it, so the test is `count < min_alive` (the host finds min_alive in the
@@ -27,15 +31,9 @@ namespace skl {
 
 namespace {
 
-constexpr uint32_t EB_CAP = 128;       // alive pairs a wave parks before its workgroup completes them
 constexpr uint32_t EB_MAXK = 8;        // k-mer lengths of an early-break launch (the driver refuses more)
 constexpr uint32_t EB_NONE = 0xFFFFFFFFu;
-
-struct EbLists {                        // LDS of one workgroup: one list per wave
-    uint32_t i[4][EB_CAP], j[4][EB_CAP], slot[4][EB_CAP], ke[4][EB_CAP];
-    uint32_t same[4][EB_CAP][EB_MAXK];  // bin-match count per k-mer length: the first ke from the pair kernel, the rest from the completion
-    uint32_t count[4];
-};
+constexpr uint32_t EB_WAVE_ENTRIES = 32;   // work-list entries a wave of the completion kernel takes at a time
 
 // row i's condensed start, inverted: the (i, position in row i) of flat index `flat` (distance_matrix.rs:46-51 with the
 // f64 guess fixed up by a search, as coreacc_epilogue_kernel has always done)
@@ -77,13 +75,6 @@ struct EbSums {
         n += 1.0;
     }
 };
-
-// (one copy per kernel: the regression -- f64 divisions, square roots, exp -- inlined at both of its sites took the kernel
-// past 128 registers)
-__device__ __noinline__ float2 eb_regress(double xsum, double ysum, double xysum, double xsquaresum, double ysquaresum, double n)
-{
-    return simple_linear_regression_dev(xsum, ysum, xysum, xsquaresum, ysquaresum, n);
-}
 
 #define SKL_DPP_ADD(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
 
@@ -162,271 +153,218 @@ __device__ __forceinline__ uint32_t eb_same_bins(const uint64_t *rows_ref, const
 
 // Entry e of wave w_src's list, completed by the calling wave: the counts of the lengths from its ke on, up to and including
 // the one that ends the reference's loop (jaccard.rs:89-91).
-struct EbCompleteArgs {                 // what the completion needs of EpilogueArgs (passed by value: registers)
-    const uint64_t *rows_ref, *cols_ref;
-    const double *compA, *compB, *ytab;
-    double cutoff, tolerance;
-    uint32_t nk_total, ss64, min_alive;
-    int32_t log_variant;
-};
-
-template <int TRIPS, bool COMP>
-__device__ __forceinline__ void eb_complete(const EbCompleteArgs &g, EbLists &L, uint32_t w_src, uint32_t e, EbRow<TRIPS> &row, uint32_t lane)
+// the (i, j) of flat pair index `flat` of the launch's pair space
+__device__ __forceinline__ void eb_pair_of(const EpilogueArgs &g, uint64_t flat, uint32_t &i, uint32_t &j)
 {
-    const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.i[w_src][e]);
-    const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.j[w_src][e]);
-    const uint32_t ke = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.ke[w_src][e]);
-    double c1 = 0.0, c2 = 0.0;
-    if constexpr (COMP) {
-        c1 = g.compA[i];
-        c2 = g.compB[j];
-    }
-    for (uint32_t t = ke; t < g.nk_total; ++t) {
-        // (the row's slice is kept for the first of the remaining lengths, where four completions of five end)
-        const uint32_t same = eb_same_bins<TRIPS>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, row, i, j, t, t == ke, lane);
-        if (lane == 0u) L.same[w_src][e][t] = same;
-        bool stop;
-        if (!COMP && g.min_alive != EB_NONE) stop = same < g.min_alive;
-        else if constexpr (COMP) stop = glibc_log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff), g.log_variant) < g.tolerance;
-        else stop = g.ytab[same <= g.ss64 * 64u ? same : g.ss64 * 64u] < g.tolerance;
-        if (stop) break;   // (wave-uniform)
+    if (g.self_mode) {
+        uint32_t pos;
+        eb_locate_self(flat, g.n_total, i, pos);
+        j = i + 1u + pos;
+    } else {
+        i = (uint32_t)(flat / g.nB_cols);
+        j = (uint32_t)(flat % g.nB_cols);
     }
 }
 
-// Entries [e_lo, e_hi) of the workgroup's concatenated lists (c0, c1, c2: the lengths of the first three; `shared` = false: of
-// wave w_own's list alone), completed by the calling wave.  Not inlined: its registers -- the row slice, a column slice in
-// flight -- are then allotted apart from the kernel's other phases.
-template <int TRIPS, bool COMP>
-__device__ __noinline__ void eb_complete_range(EbCompleteArgs g, EbLists *L, uint32_t e_lo, uint32_t e_hi, uint32_t c0, uint32_t c1, uint32_t c2,
-                                               uint32_t w_own, bool shared)
+// does the reference's loop leave at a length with this bin-match count?  (jaccard.rs:88-91; wave-uniform where `same` is)
+template <bool COMP>
+__device__ __forceinline__ bool eb_stops(const EpilogueArgs &g, uint32_t same, double c1, double c2)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    EbRow<TRIPS> row;
-    for (uint32_t e = e_lo; e < e_hi; ++e) {
-        uint32_t w_src = w_own, idx = e;
-        if (shared && idx >= c0) {
-            idx -= c0;
-            w_src = 1;
-            if (idx >= c1) {
-                idx -= c1;
-                w_src = 2;
-                if (idx >= c2) {
-                    idx -= c2;
-                    w_src = 3;
-                }
-            }
-        }
-        eb_complete<TRIPS, COMP>(g, *L, w_src, idx, row, lane);
-    }
-}
-
-// a wave's LDS writes (list entries, completed counts) before its other lanes read them
-__device__ __forceinline__ void eb_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (!COMP && g.min_alive != EB_NONE) return same < g.min_alive;
+    return eb_lnj<COMP>(g, same, c1, c2) < g.tolerance;
 }
 
 }  // namespace
 
-// One wave = 64 x span consecutive pairs of the launch's flat order (consecutive columns of a row, then the next row).
-template <int TRIPS, bool COMP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void coreacc_epilogue_rows_kernel(const EpilogueArgs g)
+// One thread per pair of the launch.
+template <bool COMP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 5, COMP ? 4 : 5))) void coreacc_epilogue_kernel_r6(const EpilogueArgs g)
 {
-    __shared__ EbLists L;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t wave_p0 = ((uint64_t)blockIdx.x * 4u + wave) * 64ull * g.span;
+    const uint64_t p_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool early = g.nk_total > g.nk || g.block_ke != nullptr;   // (pairs may be left in the running)
-    const bool need_ij = early || COMP;
+    if (early && g.wl_zero != nullptr && p_raw < g.wl_subs) g.wl_zero[p_raw] = 0u;   // the NEXT launch's counters (see kernels.h)
+    if (p_raw >= g.n_pairs && !early) return;   // (early break: every lane of a wave stays, the on-the-spot completion is cooperative)
+    const bool in_range = p_raw < g.n_pairs;
+    const uint64_t p = in_range ? p_raw : g.n_pairs - 1;   // (lanes past the end shadow the last pair and store nothing)
     const uint32_t maxnbits = g.ss64 * 64u;
-    uint32_t i0 = 0, pos0 = 0;
-    if (need_ij && wave_p0 < g.n_pairs) {
-        const uint64_t flat = wave_p0 + g.out_base;
-        if (g.self_mode) {
-            eb_locate_self(flat, g.n_total, i0, pos0);
-        } else {
-            i0 = (uint32_t)(flat / g.nB_cols);
-            pos0 = (uint32_t)(flat % g.nB_cols);
+    uint32_t i = 0, j = 0, ke = g.nk;
+    double c1 = 0.0, c2 = 0.0;
+    if (COMP || g.block_ke != nullptr) {
+        eb_pair_of(g, p + g.out_base, i, j);
+        if constexpr (COMP) {
+            c1 = g.compA[i];
+            c2 = g.compB[j];
+        }
+        if (g.block_ke != nullptr) ke = g.block_ke[(size_t)(i >> g.blk_shift_r) * g.blk_cols + (j >> g.blk_shift_c)];
+    }
+    const uint64_t cnt0 = p * g.pair_stride;
+    EbSums s;
+    // The reference's loop leaves at the first k-mer length whose ln J is below the tolerance (jaccard.rs:89-91), so a literal
+    // loop is a chain of 2 nk dependent loads (count, then table entry).  The counts of up to KB k-mer lengths and their table
+    // entries are therefore loaded up front, independent of each other; the sums then stop at the same length as before.
+    constexpr uint32_t KB = 8;
+    bool stopped = false;
+    for (uint32_t t0 = 0; t0 < g.nk; t0 += KB) {
+        uint32_t same[KB];
+        double yt[KB];
+#pragma unroll
+        for (uint32_t u = 0; u < KB; ++u) {
+            const uint32_t t = t0 + u;
+            same[u] = 0u;
+            if (t < g.nk) {
+                if (t < ke) {
+                    same[u] = eb_count_at(g, cnt0 + (uint64_t)t * g.k_stride);
+                    for (uint32_t sl = 1; sl < g.n_slices; ++sl) same[u] += eb_count_at(g, cnt0 + ((uint64_t)sl * g.nk + t) * g.k_stride);
+                    // (a pair still in the running is taken up again from plane 0: it gets the sum)
+                    if (early && g.n_slices > 1u && in_range) g.counts[cnt0 + (uint64_t)t * g.k_stride] = same[u];
+                }
+                // plane 1 goes back to zero for the next tail-sliced launch, whether or not k index t is used
+                if (g.rezero_plane1 && in_range) g.counts[cnt0 + ((uint64_t)g.nk + t) * g.k_stride] = 0u;   // (a lane that shadows the last pair must not clear what that pair's own lane has yet to read)
+            }
+        }
+        if constexpr (!COMP) {
+#pragma unroll
+            for (uint32_t u = 0; u < KB; ++u) yt[u] = g.ytab[same[u] <= maxnbits ? same[u] : maxnbits];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < KB; ++u) {
+            const uint32_t t = t0 + u;
+            if (t >= ke || t >= g.nk || stopped) continue;
+            double y;
+            if constexpr (COMP) y = eb_lnj<true>(g, same[u], c1, c2);
+            else y = yt[u];
+            if (y < g.tolerance) {   // jaccard.rs:89-91: break
+                stopped = true;
+                continue;
+            }
+            s.add(g.kf[t], y);
         }
     }
-    // the (i, j) of the pair `slot` positions behind the wave's first
-    auto pair_at = [&](uint32_t slot, uint32_t &i, uint32_t &j) {
-        if (g.self_mode) {
-            uint32_t pos = pos0 + slot, len = g.n_total - 1u - i0;
-            i = i0;
-            while (pos >= len) {
-                pos -= len;
-                ++i;
-                --len;
-            }
-            j = i + 1u + pos;
-        } else {
-            const uint64_t at = (uint64_t)pos0 + slot;
-            i = i0 + (uint32_t)(at / g.nB_cols);
-            j = (uint32_t)(at % g.nB_cols);
-        }
-    };
-    uint32_t parked = 0;                // pairs this wave has parked in all
-    uint32_t it = 0;
-    bool last;
-    // A wave walks its groups of 64 pairs until they end (`last`) or its list may not hold another group's alive pairs; then
-    // the parked pairs are completed and finished -- after the last group by the whole workgroup together, before (a list
-    // that filled up: closely related samples the block's sample did not show) by the wave alone.
-    do {
-        uint32_t count = 0;             // entries of this wave's list
-        for (; it < g.span && count + 64u <= EB_CAP; ++it) {
-            const uint64_t p0_it = wave_p0 + (uint64_t)it * 64u;
-            if (p0_it >= g.n_pairs) {   // (wave-uniform)
-                it = g.span;
-                break;
-            }
-            const uint32_t slot = it * 64u + lane;
-            const uint64_t p = p0_it + lane;
-            const bool in_range = p < g.n_pairs;
-            uint32_t i = 0, j = 0, ke = g.nk;
-            double c1 = 0.0, c2 = 0.0;
-            if (in_range && (COMP || g.block_ke != nullptr)) {
-                pair_at(slot, i, j);
-                if constexpr (COMP) {
-                    c1 = g.compA[i];
-                    c2 = g.compB[j];
+    if (!early) {
+        ((float2 *)g.out)[p] = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+        return;
+    }
+    bool alive = in_range && !stopped && ke < g.nk_total;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (__ballot(alive) != 0ull) {      // (wave-uniform)
+        if (alive && !(COMP || g.block_ke != nullptr)) eb_pair_of(g, p + g.out_base, i, j);
+        if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(__ballot(alive)));   // (1 024 slots: a million adds to ONE address queue up)
+        if (g.wl != nullptr) {
+            // WORK LIST: sub-list (row mod 512, column stripe of 1 024 mod 8); the lanes of a wave that go to the same sub-list
+            // reserve their places with ONE add
+            const uint32_t sub = (((i & 511u) << 3) | ((j >> 10) & 7u)) & (g.wl_subs - 1u);
+            uint64_t todo = __ballot(alive);
+            while (todo != 0ull) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t sub_l = (uint32_t)__shfl((int)sub, leader);
+                const uint64_t peers = __ballot(alive && sub == sub_l) & todo;
+                uint32_t base = 0u;
+                if ((int)lane == leader) base = atomicAdd(&g.wl_count[sub_l], (uint32_t)__popcll(peers));
+                base = (uint32_t)__shfl((int)base, leader);
+                if ((peers >> lane) & 1ull) {
+                    const uint32_t at = base + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                    if (at < g.wl_cap) {
+                        g.wl[(size_t)sub_l * g.wl_cap + at] = make_uint4((uint32_t)p, i, j, ke);
+                        alive = false;          // parked: the completion kernel finishes it
+                    }                           // (else: the sub-list is full -- completed here, below)
                 }
-                if (g.block_ke != nullptr) ke = g.block_ke[(size_t)(i >> g.blk_shift_r) * g.blk_cols + (j >> g.blk_shift_c)];
+                todo &= ~peers;
+            }
+        }
+    }
+    // ON THE SPOT (launches too small for a second kernel; a full sub-list): the pairs of this wave still in the running, one
+    // after the other -- all 64 lanes count the bins the pair shares at the next length, until the reference's break
+    uint64_t todo = __ballot(alive);
+    while (todo != 0ull) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t i_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)i, l)), j_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)j, l));
+        const uint32_t ke_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ke, l));
+        double c1_l = 0.0, c2_l = 0.0;
+        if constexpr (COMP) {
+            c1_l = g.compA[i_l];
+            c2_l = g.compB[j_l];
+        }
+        EbRow<0> none;
+        for (uint32_t t = ke_l; t < g.nk_total; ++t) {
+            const uint32_t same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_l, j_l, t, false, lane);
+            if (eb_stops<COMP>(g, same, c1_l, c2_l)) break;   // (wave-uniform)
+            if ((int)lane == l) s.add(g.kf[t], eb_lnj<COMP>(g, same, c1, c2));
+        }
+    }
+    if (in_range && (alive || stopped || ke >= g.nk_total)) {
+        ((float2 *)g.out)[p] = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+    }
+}
+
+namespace {
+struct EbWaveResults {                  // LDS of one workgroup of the completion kernel
+    uint32_t same[4][EB_WAVE_ENTRIES][EB_MAXK];
+};
+}  // namespace
+
+// The work list, completed: see the head of this file.  Wave w of the launch walks sub-list w / wl_waves, chunks of 32 entries
+// (w mod wl_waves, + wl_waves, ...).
+template <int TRIPS, bool COMP>
+__global__ __launch_bounds__(256) void coreacc_completion_kernel(const EpilogueArgs g)
+{
+    __shared__ EbWaveResults R;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t w = blockIdx.x * 4u + wave;
+    const uint32_t sub = w / g.wl_waves, first = w - sub * g.wl_waves;
+    if (sub >= g.wl_subs) return;
+    const uint32_t count = min(g.wl_count[sub], g.wl_cap);
+    EbRow<TRIPS> row;
+    for (uint32_t c = first * EB_WAVE_ENTRIES; c < count; c += g.wl_waves * EB_WAVE_ENTRIES) {
+        const uint32_t n_e = min(EB_WAVE_ENTRIES, count - c);
+        uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < n_e) mine = g.wl[(size_t)sub * g.wl_cap + c + lane];
+        if (lane < n_e) {
+#pragma unroll
+            for (uint32_t t = 0; t < EB_MAXK; ++t) R.same[wave][lane][t] = EB_NONE;
+        }
+        for (uint32_t e = 0; e < n_e; ++e) {
+            const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)e), j = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)e);
+            const uint32_t ke = (uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)e);
+            double c1 = 0.0, c2 = 0.0;
+            if constexpr (COMP) {
+                c1 = g.compA[i];
+                c2 = g.compB[j];
+            }
+            for (uint32_t t = ke; t < g.nk_total; ++t) {
+                // (the row's slice is kept for the first of the remaining lengths, where four completions of five end)
+                const uint32_t same = eb_same_bins<TRIPS>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, row, i, j, t, t == ke, lane);
+                if (lane == 0u) R.same[wave][e][t] = same;
+                if (eb_stops<COMP>(g, same, c1, c2)) break;   // (wave-uniform) jaccard.rs:89-91
+            }
+        }
+        // (the wave's own LDS writes, read back by its other lanes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < n_e) {
+            const uint64_t p = mine.x;
+            double c1 = 0.0, c2 = 0.0;
+            if constexpr (COMP) {
+                c1 = g.compA[mine.y];
+                c2 = g.compB[mine.z];
             }
             EbSums s;
-            bool stopped = !in_range;
-            // The reference's loop is a chain of 2 nk dependent loads when taken literally (count, then table entry): the
-            // counts of up to KB lengths and their table entries are loaded up front, independent of each other; the sums
-            // then stop where the reference's do.
-            constexpr uint32_t KB = 8;
-            uint32_t first_same[KB];
-            for (uint32_t t0 = 0; t0 < g.nk; t0 += KB) {
-                uint32_t same[KB];
-#pragma unroll
-                for (uint32_t u = 0; u < KB; ++u) {
-                    const uint32_t t = t0 + u;
-                    same[u] = 0u;
-                    if (t < g.nk && in_range) {
-                        if (t < ke) {
-                            same[u] = eb_count_at(g, p * g.pair_stride + (uint64_t)t * g.k_stride);
-                            for (uint32_t sl = 1; sl < g.n_slices; ++sl) same[u] += eb_count_at(g, p * g.pair_stride + ((uint64_t)sl * g.nk + t) * g.k_stride);
-                        }
-                        // plane 1 goes back to zero for the next tail-sliced launch, whether or not k index t is used
-                        if (g.rezero_plane1) g.counts[p * g.pair_stride + ((uint64_t)g.nk + t) * g.k_stride] = 0u;
-                    }
-                    if (t0 == 0u) first_same[u] = same[u];
-                }
-                if constexpr (!COMP) {
-                    double yt[KB];
-#pragma unroll
-                    for (uint32_t u = 0; u < KB; ++u) yt[u] = g.ytab[same[u] <= maxnbits ? same[u] : maxnbits];
-#pragma unroll
-                    for (uint32_t u = 0; u < KB; ++u) {
-                        const uint32_t t = t0 + u;
-                        if (t >= ke || t >= g.nk || stopped) continue;
-                        if (yt[u] < g.tolerance) {   // jaccard.rs:89-91: break
-                            stopped = true;
-                            continue;
-                        }
-                        s.add(g.kf[t], yt[u]);
-                    }
-                } else {
 #pragma clang loop unroll(disable)
-                    for (uint32_t u = 0; u < KB; ++u) {
-                        const uint32_t t = t0 + u;
-                        if (t >= ke || t >= g.nk || stopped) break;
-                        uint32_t same_u = same[0];
-#pragma unroll
-                        for (uint32_t x = 1; x < KB; ++x) same_u = u == x ? same[x] : same_u;
-                        const double y = eb_lnj<COMP>(g, same_u, c1, c2);
-                        if (y < g.tolerance) {
-                            stopped = true;
-                            break;
-                        }
-                        s.add(g.kf[t], y);
-                    }
-                }
+            for (uint32_t t = 0; t < g.nk_total; ++t) {
+                uint32_t same;
+                if (t < mine.w) same = eb_count_at(g, p * g.pair_stride + (uint64_t)t * g.k_stride);   // (summed into plane 0 by the epilogue where there were slices)
+                else same = R.same[wave][lane][t];
+                if (same == EB_NONE) break;
+                const double y = eb_lnj<COMP>(g, same, c1, c2);
+                if (y < g.tolerance) break;   // jaccard.rs:89-91
+                s.add(g.kf[t], y);
             }
-            const bool alive = early && in_range && !stopped && ke < g.nk_total;
-            if (in_range && !alive) ((float2 *)g.out)[p] = eb_regress(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
-            if (!early) continue;
-            const uint64_t mask = __ballot(alive);
-            if (mask == 0ull) continue;     // (wave-uniform)
-            if (alive) {
-                if (!(COMP || g.block_ke != nullptr)) pair_at(slot, i, j);
-                const uint32_t e = count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                L.i[wave][e] = i;
-                L.j[wave][e] = j;
-                L.slot[wave][e] = slot;
-                L.ke[wave][e] = ke;
-#pragma unroll
-                for (uint32_t t = 0; t < EB_MAXK; ++t) L.same[wave][e][t] = t < ke ? first_same[t] : EB_NONE;
-            }
-            count += (uint32_t)__popcll(mask);
+            ((float2 *)g.out)[p] = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
         }
-        if (!early) return;
-        last = it >= g.span;
-        parked += count;
-        // completion: after the last group the four waves take equal shares of the workgroup's concatenated lists, each
-        // its entries in list order (a wave's list is in pair order: runs of columns of one row)
-        uint32_t c0 = 0, c1_ = 0, c2_ = 0, e_lo = 0, e_hi = count, w_own = wave;
-        if (last) {
-            if (lane == 0u) L.count[wave] = count;
-            __syncthreads();
-            c0 = L.count[0];
-            c1_ = L.count[1];
-            c2_ = L.count[2];
-            const uint32_t total = c0 + c1_ + c2_ + L.count[3];
-            e_lo = (uint32_t)(((uint64_t)total * wave) >> 2);
-            e_hi = (uint32_t)(((uint64_t)total * (wave + 1u)) >> 2);
-            w_own = 0u;
-        } else {
-            eb_wave_sync();
-        }
-        if (e_hi > e_lo) {
-            EbCompleteArgs ca;
-            ca.rows_ref = g.rows_ref;
-            ca.cols_ref = g.cols_ref;
-            ca.compA = g.compA;
-            ca.compB = g.compB;
-            ca.ytab = g.ytab;
-            ca.cutoff = g.cutoff;
-            ca.tolerance = g.tolerance;
-            ca.nk_total = g.nk_total;
-            ca.ss64 = g.ss64;
-            ca.min_alive = g.min_alive;
-            ca.log_variant = g.log_variant;
-            eb_complete_range<TRIPS, COMP>(ca, &L, e_lo, e_hi, c0, c1_, c2_, w_own, last);
-        }
-        if (last) __syncthreads();
-        else eb_wave_sync();
-        // the parked pairs, one per lane: the reference's loop over the counts of every length looked at
-        for (uint32_t q0 = 0; q0 < count; q0 += 64u) {
-            const uint32_t q = q0 + lane;
-            if (q < count) {
-                const uint32_t i = L.i[wave][q], j = L.j[wave][q];
-                double c1 = 0.0, c2 = 0.0;
-                if constexpr (COMP) {
-                    c1 = g.compA[i];
-                    c2 = g.compB[j];
-                }
-                EbSums s;
-#pragma clang loop unroll(disable)
-                for (uint32_t t = 0; t < g.nk_total; ++t) {
-                    const uint32_t same = L.same[wave][q][t];
-                    if (same == EB_NONE) break;
-                    const double y = eb_lnj<COMP>(g, same, c1, c2);
-                    if (y < g.tolerance) break;   // jaccard.rs:89-91
-                    s.add(g.kf[t], y);
-                }
-                ((float2 *)g.out)[wave_p0 + L.slot[wave][q]] = eb_regress(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
-            }
-        }
-        if (!last) eb_wave_sync();      // (the list is rewritten by the next groups)
-    } while (!last);
-    if (g.alive_count != nullptr && parked != 0u && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], parked);   // (1 024 slots: adds to ONE address queue up)
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // One wave per (block, sample): see EbSampleArgs (kernels.h).
@@ -479,8 +417,6 @@ __global__ __launch_bounds__(256) void early_break_sample_kernel(const EbSampleA
     if (lane == 0u) atomicAdd(&g.hist[(size_t)blk * 9u + lead], 1u);
 }
 
-#undef SKL_DPP_ADD
-
 hipError_t launch_early_break_sample(const EbSampleArgs &args, hipStream_t stream)
 {
     const uint64_t waves = (uint64_t)args.blk_rows * args.blk_cols * args.samples;
@@ -491,24 +427,29 @@ hipError_t launch_early_break_sample(const EbSampleArgs &args, hipStream_t strea
     return hipGetLastError();
 }
 
-hipError_t launch_coreacc_epilogue_rows(const EpilogueArgs &args_in, hipStream_t stream)
+#undef SKL_DPP_ADD
+
+hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stream)
 {
-    EpilogueArgs args = args_in;
     if (args.n_pairs == 0) return hipSuccess;
-    if (args.span == 0u) args.span = 1u;
-    if (args.nk_total != 0u && args.nk_total > EB_MAXK && (args.nk_total > args.nk || args.block_ke != nullptr)) return hipErrorInvalidValue;
-    const uint64_t per_wg = 256ull * args.span;
-    const uint64_t blocks = (args.n_pairs + per_wg - 1) / per_wg;
+    const bool early = args.nk_total > args.nk || args.block_ke != nullptr;
+    if (early && args.nk_total > EB_MAXK) return hipErrorInvalidValue;
+    if (args.wl != nullptr && (args.wl_subs == 0u || (args.wl_subs & (args.wl_subs - 1u)) != 0u || args.n_pairs >= (1ull << 32))) return hipErrorInvalidValue;
+    const uint64_t blocks = (std::max<uint64_t>(args.n_pairs, early && args.wl_zero ? args.wl_subs : 0u) + 255) / 256;
     if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 gr((unsigned)blocks), bl(256);
-    const bool early = args.nk_total > args.nk || args.block_ke != nullptr;
-    const uint32_t trips = early ? (args.ss64 + 31u) / 32u : 0u;   // trips of 32 chunks the row slice is kept for (0: not kept)
-#define SKL_EPI_LAUNCH(T)                                                                                               \
-    do {                                                                                                                \
-        if (args.has_comp) hipLaunchKernelGGL((coreacc_epilogue_rows_kernel<T, true>), gr, bl, 0, stream, args);        \
-        else hipLaunchKernelGGL((coreacc_epilogue_rows_kernel<T, false>), gr, bl, 0, stream, args);                     \
+    if (args.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, 0, stream, args);
+    else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, 0, stream, args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !early || args.wl == nullptr) return e;
+    // the work list: wl_waves waves per sub-list
+    const dim3 gc((args.wl_subs * args.wl_waves + 3u) / 4u);
+#define SKL_EPI_LAUNCH(T)                                                                                            \
+    do {                                                                                                             \
+        if (args.has_comp) hipLaunchKernelGGL((coreacc_completion_kernel<T, true>), gc, bl, 0, stream, args);        \
+        else hipLaunchKernelGGL((coreacc_completion_kernel<T, false>), gc, bl, 0, stream, args);                     \
     } while (0)
-    switch (trips) {
+    switch ((args.ss64 + 31u) / 32u) {   // trips of 32 chunks the row slice is kept for (beyond 4: not kept)
         case 1: SKL_EPI_LAUNCH(1); break;
         case 2: SKL_EPI_LAUNCH(2); break;
         case 3: SKL_EPI_LAUNCH(3); break;

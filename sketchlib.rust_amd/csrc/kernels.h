@@ -70,6 +70,7 @@ struct PairArgs {
     // MODE_COUNTS record layout: count of (pair p, k index kk) at out[p*cnt_pair_stride + kk*cnt_k_stride]
     // ([pair][k] for the public bin-match calls, k-major for the internal counts scratch)
     uint64_t cnt_pair_stride, cnt_k_stride;
+    uint32_t cnt_u16;             // MODE_COUNTS: the records are u16 (k-sliced launches without chunk slices, sketches of up to 1 023 chunks)
     uint32_t k_sliced;            // host-side request: one workgroup per (tile, k-mer length)
     uint32_t slice_chunks;        // chunks per chunk slice (k_slices / tail_slices > 1): a multiple of 8; the last slice takes what is
                                   // left, so any sketch size can be cut (slice_plan(); 0: ss64 / slices, the even split)
@@ -234,9 +235,15 @@ struct EpilogueArgs {
     uint32_t nk_total;
     const uint64_t *rows_ref, *cols_ref;
     uint32_t *alive_count;      // 1 024 words, slot blockIdx & 1023 += pairs completed here (diagnostic; may be null)
-    // Round 6 (epilogue.hip, coreacc_epilogue_rows_kernel): a wave takes `span` groups of 64 consecutive pairs and the
-    // workgroup completes its alive pairs together, grouped by row.
-    uint32_t span;              // 64-pair groups per wave (0: 1)
+    // Round 6 (epilogue.hip): the pairs still in the running go to a WORK LIST that coreacc_completion_kernel walks, grouped
+    // by row.  wl: wl_subs sub-lists (a power of two) of wl_cap entries (pair index of the launch, row sample, column sample,
+    // lengths counted); wl_count[sub]: entries appended (may exceed wl_cap: the pairs beyond it were completed on the spot);
+    // wl_zero: the counters of the NEXT launch on this stream, zeroed by this launch's first threads (two arrays alternate: the
+    // completion kernel that read the other one has finished before this launch starts); wl_waves: waves per sub-list of the
+    // completion launch.  wl == null: every pair still in the running is completed on the spot by its wave.
+    uint4 *wl;
+    uint32_t *wl_count, *wl_zero;
+    uint32_t wl_subs, wl_cap, wl_waves;
     uint32_t min_alive;         // no completeness correction: ln J(count) < tolerance <=> count < min_alive (0xFFFFFFFF: ask ytab)
     uint32_t cnt_u16;           // 1: the counts are u16 records (sketches of up to 1 023 chunks, no chunk slices)
     // EARLY BREAK DECIDED PER BLOCK: block_ke[(i >> blk_shift_r) * blk_cols + (j >> blk_shift_c)] = k-mer lengths the pair kernel
@@ -246,7 +253,8 @@ struct EpilogueArgs {
     uint32_t blk_shift_r, blk_shift_c, blk_cols;
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
-hipError_t launch_coreacc_epilogue_rows(const EpilogueArgs &args, hipStream_t stream);   // core/accessory records only (epilogue.hip)
+// core/accessory records only, round 6 (epilogue.hip): the stream + (work list given) the completion launch behind it
+hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stream);
 // EARLY BREAK in the one-evaluation core/accessory self kNN (capi_knn.cpp): a row band's view of the columns was counted at
 // its first `nk` k-mer lengths (k-major counts, counts[t * n_pairs + row * nB + c]); this launch turns them into the band's
 // (core, acc) records -- completing the pairs still in the running like coreacc_epilogue_kernel -- and does what the fused

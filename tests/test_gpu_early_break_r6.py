@@ -58,8 +58,12 @@ def test_expected_samebits_nonzero_product_library(oracle, skl, gpu_ctx, n, ss64
     got = skl.self_dists_all(gpu_ctx, g, g.set_k())
     after = gpu_ctx.early_break_stats()
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), np.argwhere(got != exp)[:5]
-    assert "early break: " in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
-    assert after[0] - before[0] == n * (n - 1) // 2 and after[1] > before[1]
+    # (at 1 023 chunks a random pair shares Poisson(4) bins per length against an expectation of 3: 57 % pass each test, a
+    # tenth of the pairs would still be in the running after four lengths -- the sample says so and every length is counted)
+    took = ss64 <= 512
+    assert ("early break: " in gpu_ctx.last_kernel()) == took, gpu_ctx.last_kernel()
+    if took:
+        assert after[0] - before[0] == n * (n - 1) // 2 and after[1] > before[1]
     part = skl.self_dists_rows(gpu_ctx, g, g.set_k(), 29, n - 41)
     lo = 29 * n - 29 * 30 // 2
     assert np.array_equal(part.view(np.uint32), exp[lo:lo + part.shape[0]].view(np.uint32))
@@ -67,7 +71,7 @@ def test_expected_samebits_nonzero_product_library(oracle, skl, gpu_ctx, n, ss64
     nr = n - 60
     g_u = gpu_ctx.sketches(bins[:nr], nr, KMERS, ss64)
     got_u = skl.self_dists_all(gpu_ctx, g_u, g_u.set_k())
-    assert "early break: " in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
+    assert ("early break: " in gpu_ctx.last_kernel()) == took, gpu_ctx.last_kernel()
     keep = np.array([i * n - i * (i + 1) // 2 + j - 1 - i for i in range(nr) for j in range(i + 1, nr)])
     assert np.array_equal(got_u.view(np.uint32), exp[keep].view(np.uint32))
     g_q = gpu_ctx.sketches(bins[nr - 100:], n - nr + 100, KMERS, ss64)
@@ -95,15 +99,13 @@ def test_expected_samebits_nonzero_forced_lengths(oracle, skl, gpu_ctx, monkeypa
     part = skl.self_dists_rows(gpu_ctx, g, g.set_k(), 100, 250)
     lo = 100 * n - 100 * 101 // 2
     assert np.array_equal(part.view(np.uint32), exp[lo:lo + part.shape[0]].view(np.uint32))
-    g_r, g_q = gpu_ctx.sketches(bins[:170], 170, KMERS, ss64), gpu_ctx.sketches(bins[170:], n - 170, KMERS, ss64)
-    o_r, o_q = oracle.Sketches(bins[:170], 170, KMERS, ss64), oracle.Sketches(bins[170:], n - 170, KMERS, ss64)
-    # (170 x (n - 170) < 65 536 pairs is below the early break's floor: a cross matrix large enough takes it)
+    # (a cross matrix of at least 65 536 pairs -- the early break's floor: queries = the samples from 70 on)
+    g_q, o_q = gpu_ctx.sketches(bins[70:], n - 70, KMERS, ss64), oracle.Sketches(bins[70:], n - 70, KMERS, ss64)
     cross = skl.cross_dists_all(gpu_ctx, g, g_q, g.set_k())
     assert "early break: %d of 5" % lengths in gpu_ctx.last_kernel()
     assert np.array_equal(cross.view(np.uint32), oracle.cross_dists_all(o, o_q, oracle.COREACC, threads=8).view(np.uint32))
-    for x in (g, g_r, g_q):
+    for x in (g, g_q):
         x.close()
-    del o_r
 
 
 @pytest.mark.parametrize("ties", ["reference", "canonical"])
@@ -112,7 +114,7 @@ def test_symmetric_knn_bands_where_chance_matches_are_expected(oracle, skl, gpu_
     """The one-evaluation core/accessory self kNN over several row bands (the bands' own early-break epilogue) at
     expected_samebits >= 1: ids, order and both distances = the oracle's."""
     n = 330
-    bins = _mixed(n, KMERS, ss64, n_random=n - 90, seed=17)
+    bins = _mixed(n, KMERS, ss64, n_random=n - 30, seed=17)
     o, g = oracle.Sketches(bins, n, KMERS, ss64), gpu_ctx.sketches(bins, n, KMERS, ss64)
     set_switch("SKL_KNN_BAND_ROWS", band_rows)
     gpu_ctx.set_knn_ties(skl.TIES_REFERENCE if ties == "reference" else skl.TIES_CANONICAL)
@@ -126,18 +128,21 @@ def test_symmetric_knn_bands_where_chance_matches_are_expected(oracle, skl, gpu_
                                 ties=oracle.TIES_RUST_HEAP if ties == "reference" else oracle.TIES_CANONICAL, threads=8)
     assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
     assert np.array_equal(d0.view(np.uint32), exp["d0"].view(np.uint32)) and np.array_equal(d1.view(np.uint32), exp["d1"].view(np.uint32))
-    assert "early break: " in gpu_ctx.last_kernel() and after[0] > before[0] and after[1] > before[1]
+    # (at 512 chunks -- Poisson(2) chance matches against an expectation of 2 -- whether three lengths pay is a close call the
+    # sample may decide either way; at 256 and 300 it is not)
+    if ss64 <= 300:
+        assert "early break: " in gpu_ctx.last_kernel() and after[0] > before[0] and after[1] > before[1]
     g.close()
 
 
-@pytest.mark.parametrize("world,ss64,band_rows,knn", [(3, 256, 64, 5), (2, 512, 96, 12)])
+@pytest.mark.parametrize("world,ss64,band_rows,knn", [(3, 256, 64, 5), (2, 300, 96, 12)])
 def test_column_windows_where_chance_matches_are_expected(oracle, skl, gpu_ctx, world, ss64, band_rows, knn):
     """skl_self_dists_knn_window (heaps that travel through column windows), core/accessory keys, expected_samebits >= 1."""
     import torch
     from sketchlib.rust_amd import multi_gpu
 
     n = 330
-    bins = _mixed(n, KMERS, ss64, n_random=n - 90, seed=19)
+    bins = _mixed(n, KMERS, ss64, n_random=n - 30, seed=19)
     o, g = oracle.Sketches(bins, n, KMERS, ss64), gpu_ctx.sketches(bins, n, KMERS, ss64)
     p = g.set_k()
     heaps = skl.knn_heaps_alloc(n, knn, True, torch.device("cuda", 0))
@@ -267,5 +272,44 @@ def test_the_early_break_is_decided_block_by_block(oracle, skl, gpu_ctx, sizes, 
     g_q, o_q = gpu_ctx.sketches(bins[h:], n - h, KMERS, ss64), oracle.Sketches(bins[h:], n - h, KMERS, ss64)
     cross = skl.cross_dists_all(gpu_ctx, g, g_q, g.set_k())
     assert np.array_equal(cross.view(np.uint32), oracle.cross_dists_all(o, o_q, oracle.COREACC, threads=8).view(np.uint32))
+    g.close()
+    g_q.close()
+
+
+@pytest.mark.ab_library
+@pytest.mark.parametrize("cap", [0, 32])
+@pytest.mark.parametrize("n,ss64,comp", [(700, 64, False), (600, 32, True), (500, 157, False), (320, 300, False)])
+def test_work_list_and_band_pipeline_forced_on_small_inputs(oracle, skl, gpu_ctx, monkeypatch, n, ss64, comp, cap):
+    """The forms large calls take, forced onto inputs the oracle can check whole (A/B build): every pair still in the running
+    through the WORK LIST and the completion kernel (SKL_EB_WORKLIST_MIN=0) -- with sub-lists of 32 entries, so that most of
+    them overflow and complete their surplus on the spot -- u16 counts, and the call cut into overlapping row bands, each
+    band's epilogue on the second stream (SKL_EB_PIPELINE_MIN)."""
+    bins = _mixed(n, KMERS, ss64, n_random=n - 200, n_clusters=2, seed=37)
+    cvec = np.random.default_rng(3).uniform(0.5, 1.0, n) if comp else None
+    o = oracle.Sketches(bins, n, KMERS, ss64, completeness=cvec)
+    exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
+    monkeypatch.setenv("SKL_EARLY_BREAK", "3")
+    monkeypatch.setenv("SKL_EB_WORKLIST_MIN", "0")
+    monkeypatch.setenv("SKL_EB_WORKLIST_CAP", str(cap))
+    monkeypatch.setenv("SKL_TAIL_SLICES", "0")       # (chunk slices keep u32 counts and the on-the-spot completion)
+    gpu_ctx.reload_env()
+    g = gpu_ctx.sketches(bins, n, KMERS, ss64, completeness=cvec)
+
+    def check(got, want):
+        if comp:
+            assert np.max(np.abs(got.astype(np.float64) - want.astype(np.float64))) <= 1e-6
+        else:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got != want)[:5]
+
+    check(skl.self_dists_all(gpu_ctx, g, g.set_k()), exp)
+    assert "work list" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
+    monkeypatch.setenv("SKL_EB_PIPELINE_MIN", "30000")
+    gpu_ctx.reload_env()
+    check(skl.self_dists_all(gpu_ctx, g, g.set_k()), exp)
+    assert "row bands, each band's epilogue beside the next band's counts kernel" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
+    g_q = gpu_ctx.sketches(bins[150:], n - 150, KMERS, ss64, completeness=None if cvec is None else cvec[150:])
+    o_q = oracle.Sketches(bins[150:], n - 150, KMERS, ss64, completeness=None if cvec is None else cvec[150:])
+    check(skl.cross_dists_all(gpu_ctx, g, g_q, g.set_k()), oracle.cross_dists_all(o, o_q, oracle.COREACC, threads=8))
+    assert "row bands" in gpu_ctx.last_kernel()
     g.close()
     g_q.close()
