@@ -1,6 +1,6 @@
 """Round 6: timings of the dense core/accessory calls around the early break (capi.cpp early_break_plan, csrc/epilogue.hip), with the
 library as loaded -- SKL_LIBRARY=<A/B build> with SKL_EPILOGUE_R5=1 (round 5's epilogue), SKL_EARLY_BREAK=0 (every length
-counted) or SKL_EB_PIPELINE=0 / SKL_EB_WORKLIST_MIN=<huge> / SKL_COUNTS_U16=0 for the comparisons.  One JSON line per case; `--cases a,b,...` selects."""
+counted) or SKL_EB_PIPELINE=0 / SKL_COUNTS_U16=0 for the comparisons.  One JSON line per case; `--cases a,b,...` selects."""
 import argparse
 import json
 import os
@@ -20,7 +20,7 @@ cases = set(args.cases.split(","))
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 K5 = [15, 19, 23, 27, 31]
-tag = {k: os.environ.get(k) for k in ("SKL_LIBRARY", "SKL_EPILOGUE_R5", "SKL_EARLY_BREAK", "SKL_EB_PIPELINE", "SKL_EB_WORKLIST_MIN", "SKL_COUNTS_U16") if os.environ.get(k)}
+tag = {k: os.environ.get(k) for k in ("SKL_LIBRARY", "SKL_EPILOGUE_R5", "SKL_EARLY_BREAK", "SKL_EB_PIPELINE", "SKL_COUNTS_U16") if os.environ.get(k)}
 
 
 def time_self(name, bins, n, kmers, ss64, reps, comp=None, cutoff=0.64):

@@ -385,8 +385,6 @@ Knobs read_knobs()
     k.epilogue_r5 = env_int("SKL_EPILOGUE_R5", 0) != 0;
     k.eb_pipeline = env_int("SKL_EB_PIPELINE", 1) != 0;
     k.eb_pipeline_min = std::max(2ll, env_int("SKL_EB_PIPELINE_MIN", 64ll << 20));
-    k.eb_worklist_min = env_int("SKL_EB_WORKLIST_MIN", 2ll << 20);
-    k.eb_worklist_cap = std::max(0ll, env_int("SKL_EB_WORKLIST_CAP", 0));
     k.counts_u16 = env_int("SKL_COUNTS_U16", 1) != 0;
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
@@ -979,9 +977,13 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 // else every length.  A database that is half one species therefore takes the early break between the species and skips
 // it within (round 5 decided once per slab pair).  Blocks of one mind give a plain launch; otherwise the pair kernel's
 // (tile, k index) workgroups look their block up and leave when k index >= its ke.
-constexpr double EB_COST = 24.0;
+// EB_COST, measured (profiles/r06_early_break_forced_lengths.md: whole calls with 2 / 3 lengths forced, T(3) - T(2) = one length's
+// kernel time - EB_COST x the difference of the alive shares): 15-22 at 2 048 and 4 096 bins.  Beyond 65 535 bins a completion
+// is a run of thousands of dependent trips of one wave and comes to ~60: there the early break is taken only where hardly a
+// pair stays in the running.
+constexpr double EB_COST = 20.0, EB_COST_BIG = 60.0;
 constexpr uint32_t EB_BLOCKS_MAX = 64;      // blocks per side
-constexpr uint32_t EB_SAMPLES_MIN = 64;     // sampled pairs per block
+constexpr uint32_t EB_SAMPLES_MIN = 128;    // sampled pairs per block
 constexpr uint32_t EB_SAMPLES_TOTAL = 4096; // ... and at least this many in all
 
 static std::atomic<uint64_t> g_next_gen{1};
@@ -1002,24 +1004,36 @@ void free_plans(skl_ctx *ctx)
 }
 
 // ke of {2, 3, 4} with the lowest modelled cost for a histogram of `total` sampled pairs (hist[m]: pairs that pass the test at
-// exactly their first m lengths), or 0 when counting every length is cheaper
-static int best_lengths(const uint32_t *hist, uint32_t total, size_t nk, double *share_out, int only = 0)
+// exactly their first m lengths), or 0 when counting every length is cheaper.  `prior` (9 shares, or null) and its weight:
+// the block's estimate is pulled towards the pooled sample of the blocks that take the early break -- 128 pairs a block cannot
+// tell a 5 % share from a 9 % one, ten thousand can -- so that only a block that really differs decides differently.
+static int best_lengths(const uint32_t *hist, uint32_t total, size_t nk, double eb_cost, double *share_out, const double *prior = nullptr,
+                        double weight = 0.0, int preferred = 0)
 {
     int best_ke = 0;
-    double best = 0.9 * (double)nk;
+    double best = 0.9 * (double)nk, cost_of[5] = {0, 0, 0, 0, 0};
     if (total == 0) return 0;
     // (two lengths decide nothing by themselves -- a fit needs three -- but a pair that fails the test at one of them is
     // decided all the same: (1, 1); ke = 2 leaves more pairs to complete and pays where few share a bin at all: 2 048 bins)
     for (int ke = 2; ke <= 4 && ke < (int)nk; ++ke) {
-        if (only && ke != only) continue;
-        uint32_t still = 0;
-        for (int m = ke; m <= 8; ++m) still += hist[m];
-        const double share = (double)still / (double)total, cost = (double)ke + EB_COST * share;
+        double still = 0.0, prior_still = 0.0;
+        for (int m = ke; m <= 8; ++m) {
+            still += hist[m];
+            if (prior) prior_still += prior[m];
+        }
+        const double share = (still + weight * prior_still) / ((double)total + weight), cost = (double)ke + eb_cost * share;
+        cost_of[ke] = cost;
         if (cost <= best) {
             best = cost;
             best_ke = ke;
             if (share_out) *share_out = share;
         }
+    }
+    // (the blocks' common choice stands unless this block's own is clearly better: the costs of 2 and 3 lengths are often a
+    // quarter of a length apart, and a plan whose blocks disagree pays for its table)
+    if (preferred >= 2 && preferred <= 4 && preferred < (int)nk && best_ke != preferred && cost_of[preferred] <= 0.9 * (double)nk &&
+        cost_of[preferred] <= best + 0.5) {
+        best_ke = preferred;
     }
     return best_ke;
 }
@@ -1115,33 +1129,35 @@ int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches 
             pooled_n += hist[(size_t)b * 9 + m];
         }
     }
-    plan->lengths = best_lengths(pooled, pooled_n, rows->nk, &plan->alive_share);
+    const double eb_cost = rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS ? EB_COST_BIG : EB_COST;
+    plan->lengths = best_lengths(pooled, pooled_n, rows->nk, eb_cost, &plan->alive_share);
     if (live_blocks > 1) {
-        // per block.  Pass 1: every block's own best; pass 2: the blocks that take the early break agree on the ke that is best
-        // for their POOLED sample (64 pairs a block cannot tell 2 from 3 lengths; 10 000 can) wherever it pays for them too.
+        // per block.  Pass 1: every block's own sample decides whether it takes the early break at all; pass 2: the blocks that
+        // do are pooled, and every block decides again with its estimate pulled towards that pool (weight: one block's sample).
         const uint8_t all = (uint8_t)rows->nk;
         std::vector<uint8_t> ke(n_blocks, all);
-        uint32_t cold[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cold_n = 0;
+        std::vector<uint32_t> tot(n_blocks, 0u);
+        double cold[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cold_n = 0.0;
         for (uint32_t b = 0; b < n_blocks; ++b) {
-            uint32_t tot = 0;
-            for (int m = 0; m <= 8; ++m) tot += hist[(size_t)b * 9 + m];
-            const int own = best_lengths(&hist[(size_t)b * 9], tot, rows->nk, nullptr);
-            if (own > 0) {
-                ke[b] = (uint8_t)own;
+            for (int m = 0; m <= 8; ++m) tot[b] += hist[(size_t)b * 9 + m];
+            if (best_lengths(&hist[(size_t)b * 9], tot[b], rows->nk, eb_cost, nullptr) > 0) {
                 for (int m = 0; m <= 8; ++m) cold[m] += hist[(size_t)b * 9 + m];
-                cold_n += tot;
+                cold_n += tot[b];
             }
         }
-        const int common = best_lengths(cold, cold_n, rows->nk, nullptr);
+        int common = 0;
+        if (cold_n > 0.0) {
+            uint32_t cold_u[9];
+            for (int m = 0; m <= 8; ++m) cold_u[m] = (uint32_t)std::min(cold[m], 4.0e9);
+            common = best_lengths(cold_u, (uint32_t)std::min(cold_n, 4.0e9), rows->nk, eb_cost, nullptr);
+            for (int m = 0; m <= 8; ++m) cold[m] /= cold_n;
+        }
         bool differ = false;
         uint8_t first = 0;
         for (uint32_t b = 0; b < n_blocks; ++b) {
             if (self_mode && b % plan->blk_cols < b / plan->blk_cols) continue;   // below the diagonal: no pair
-            if (ke[b] != all && common > 0) {
-                uint32_t tot = 0;
-                for (int m = 0; m <= 8; ++m) tot += hist[(size_t)b * 9 + m];
-                if (best_lengths(&hist[(size_t)b * 9], tot, rows->nk, nullptr, common) == common) ke[b] = (uint8_t)common;
-            }
+            const int own = best_lengths(&hist[(size_t)b * 9], tot[b], rows->nk, eb_cost, nullptr, cold_n > 0.0 ? cold : nullptr, cold_n > 0.0 ? (double)samples : 0.0, common);
+            ke[b] = own > 0 ? (uint8_t)own : all;
             if (first == 0) first = ke[b];
             else if (ke[b] != first) differ = true;
         }
@@ -1429,31 +1445,6 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         }
         e.min_alive = rows->min_alive;
         e.cnt_u16 = g.cnt_u16;
-        // WORK LIST: from 2 Mi pairs on the pairs still in the running are parked and a second launch completes them, grouped by
-        // row (below that a second launch costs more than it saves: completed on the spot).  4 096 sub-lists, room for ~16 % of
-        // the pairs (a sub-list that fills up completes its surplus on the spot); counters: two arrays that alternate.
-        if (early && pairs >= (uint64_t)std::max(0ll, ctx->knobs.eb_worklist_min) && pairs < (1ull << 32) && e.n_slices == 1u && !e.rezero_plane1) {
-            constexpr uint32_t SUBS = 4096;
-            const long long forced_cap = ctx->knobs.eb_worklist_cap;
-            const uint32_t cap = forced_cap > 0 ? (uint32_t)forced_cap : (uint32_t)std::max<uint64_t>(64, (pairs * 16 / 100 / SUBS + 31) / 32 * 32);
-            void *wl = nullptr, *wc = nullptr;
-            SKL_TRY(ctx_scratch(ctx, (size_t)SUBS * cap * sizeof(uint4), &wl, 16));
-            const size_t had = ctx->scratch_bytes[17];
-            SKL_TRY(ctx_scratch(ctx, 2 * SUBS * sizeof(uint32_t), &wc, 17));
-            if (ctx->scratch_bytes[17] != had) {
-                HIP_TRY(hipMemsetAsync(wc, 0, 2 * SUBS * sizeof(uint32_t), ctx->stream));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));   // (once per context: whichever stream uses the counters first finds them zero)
-                ctx->eb_wl_toggle = 0;
-            }
-            e.wl = (uint4 *)wl;
-            e.wl_subs = SUBS;
-            e.wl_cap = cap;
-            e.wl_count = (uint32_t *)wc + (size_t)ctx->eb_wl_toggle * SUBS;
-            e.wl_zero = (uint32_t *)wc + (size_t)(ctx->eb_wl_toggle ^ 1) * SUBS;
-            ctx->eb_wl_toggle ^= 1;
-            e.wl_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, pairs / (48ull << 20)));
-            ctx->last_kernel += " (work list, completed grouped by row)";
-        }
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
         e.rezero_plane1 = sliced && ctx->last_tail ? 1u : 0u;
@@ -1479,7 +1470,6 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
 #ifdef SKL_AB
         if (ctx->knobs.epilogue_r5 && !eb_mixed && !e.cnt_u16 && !(early && (e.has_comp || rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS))) {
             if (!early) e.nk_total = 0;
-            e.wl = nullptr;
             HIP_TRY(launch_coreacc_epilogue(e, epi_stream));   // round 5's epilogue: alive pairs completed where they are found (A/B timing)
         } else
 #endif

@@ -64,8 +64,6 @@ struct Knobs {
                                       // sample of the pairs says it pays; 2..7 forced with that many lengths counted (tests).  Results identical.
     bool eb_pipeline = true;          // A/B build, SKL_EB_PIPELINE=0: the row bands of a large early-break call run one after the other on one stream
     long long eb_pipeline_min = 64ll << 20;  // A/B build, SKL_EB_PIPELINE_MIN: pairs from which an early-break call is cut into overlapping row bands (tests force it low)
-    long long eb_worklist_min = 2ll << 20;   // A/B build, SKL_EB_WORKLIST_MIN: pairs from which the pairs still in the running go to the work list
-    long long eb_worklist_cap = 0;    // A/B build, SKL_EB_WORKLIST_CAP: entries per sub-list forced (tests: a full sub-list completes its surplus on the spot)
     bool counts_u16 = true;           // A/B build, SKL_COUNTS_U16=0: the counts scratch keeps u32 records
     bool epilogue_r5 = false;         // A/B build, SKL_EPILOGUE_R5=1: round 5's epilogue (alive pairs completed where they are found; timing)
     bool knn_sparse = true;           // A/B build, SKL_KNN_SPARSE=0: tiles that survive the probe are walked whole (results identical)
@@ -110,9 +108,9 @@ struct skl_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // grow-only scratch
-    void *scratch[18] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits,
+    void *scratch[16] = {};   // 0/3: key bands, 1: counts, 2: kNN staging, 4/5: turned key bands (symmetric kNN), 6: its row flags (2 x n u32), 7: its block bits,
                               // 8: tile-pruning bounds (n u32), 9: bits of the turned bands, 10: pruning counters, 11: arrival counters of the fused epilogue, 12-14: GPU sketching (packed bases, signs, small arrays), 15: second counts band (early break of the core/accessory kNN)
-    size_t scratch_bytes[18] = {};   // ... 16: work list of the early break (epilogue.hip), 17: its counters (2 x 4 096 u32)
+    size_t scratch_bytes[16] = {};
     uint32_t *pinned = nullptr;         // pinned host ring of the sketching upload (two batches of packed bases; grow-only)
     uint64_t pinned_words = 0;
     size_t fuse_counter_k = 0;          // k-mer lengths the arrival counters of slot 11 count modulo (fused epilogue)
@@ -148,7 +146,6 @@ struct skl_ctx {
     bool eb_in_pipeline = false, eb_pipe_overlap = false;
     int eb_pipe_buf = 0;
     hipEvent_t eb_events[4] = {nullptr, nullptr, nullptr, nullptr};   // counts of buffer b done / epilogue of buffer b done
-    int eb_wl_toggle = 0;                  // which of the two work-list counter arrays the next launch appends to
     std::vector<EbPlan *> eb_plans;        // early-break decisions of the last few slab pairs (newest last)
     const EbPlan *eb_last_plan = nullptr;  // the plan of the last dense core/accessory call (skl_ctx_early_break_blocks)
     uint64_t knn_tiles = 0, knn_tiles_pruned = 0;   // tile pruning of the last self kNN call (skl_ctx_knn_prune_stats)

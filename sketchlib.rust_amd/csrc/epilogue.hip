@@ -5,19 +5,18 @@
 // ln J lies below the tolerance (:89-91) -- J = 0 for a pair that shares no more bins than chance (expected_samebits,
 // :26-31) -- and a fit over fewer than three lengths is (1, 1) (:117).  The pair kernel therefore counts only the first
 // `ke` lengths of a block of pairs (pair_kslice.hip, k-sliced MODE_COUNTS), and
-//   * coreacc_epilogue_kernel (one thread per pair, a pure stream: 4-16 bytes of counts in, 8 bytes out) runs the
-//     reference's loop over those counts: a pair that leaves inside them is finished at once; a pair STILL IN THE RUNNING is
-//     appended to a WORK LIST in global memory -- 4 096 sub-lists keyed by (row, column stripe), so that a sub-list holds
-//     runs of columns of one row -- or, for launches too small to be worth a second kernel (and when a sub-list is full),
-//     completed on the spot by its wave;
-//   * coreacc_completion_kernel walks the sub-lists: a wave takes 32 entries, holds the ROW sample's slice of the next
-//     length in registers across the entries that share the row, reads each column sample's slice as ONE contiguous run
-//     (lane l the l-th half chunk of 7 planes; the two halves of a chunk meet by DPP: the form pair_cand.hip measured at 0.88
-//     of the HBM peak), and finishes its entries one per lane: the same sums in the same order as the reference.
-// Round 5 completed every such pair where it was found -- a whole wave re-reading BOTH samples' slices, 64 lanes 112 bytes
-// apart, the wave's other pairs waiting: 21-31 % of every core/accessory step.  A first round-6 form that
-// completed the pairs inside the epilogue (LDS lists per workgroup) halved the completions' time and lost it again on the
-// stream: 128 registers and 24 KB of LDS where the plain epilogue runs at 5 waves per SIMD (profiles/r06_epilogue_forms.md).
+// coreacc_epilogue_kernel_r6 (one thread per pair, a pure stream: 4-16 bytes of counts in, 8 bytes out) runs the reference's
+// loop over those counts: a pair that leaves inside them is finished at once; a pair STILL IN THE RUNNING is completed on the
+// spot by its wave -- all 64 lanes count the bins the pair shares at the next length, each sample's slice read as ONE
+// contiguous run (lane l the l-th half chunk of 7 planes, 56 bytes; the two halves of a chunk meet by DPP: the form
+// pair_cand.hip measured at 0.88 of the HBM peak), until the reference's break.
+// Round 5 read the two slices a lane per chunk, 64 lanes 112 bytes apart, and asked the ln J table after every length; this
+// form tests the count itself (below) and is 5-13 % faster on whole calls (profiles/r06_epilogue_forms.md).  Two forms that
+// set the completions apart were built and measured SLOWER than completing on the spot, and are gone again: per-workgroup
+// LDS lists completed row by row inside the epilogue (the completions halve, the stream loses it again: 128 registers and 24
+// KB of LDS where the plain epilogue runs at 5 waves per SIMD), and a work list in global memory walked by a second kernel
+// with the row's slice held in registers (n = 16 000: 22.4 against 18.7 ms -- the completions are bound by the column
+// slices' bytes either way, and on the spot they overlap with the other waves' streaming for free).
 //
 // The break test is the reference's: y < tolerance with y = ln J.  Without a completeness correction y is a function of
 // the bin-match count alone and non-decreasing in it, so the test is `count < min_alive` (the host finds min_alive in the
@@ -33,7 +32,6 @@ namespace {
 
 constexpr uint32_t EB_MAXK = 8;        // k-mer lengths of an early-break launch (the driver refuses more)
 constexpr uint32_t EB_NONE = 0xFFFFFFFFu;
-constexpr uint32_t EB_WAVE_ENTRIES = 32;   // work-list entries a wave of the completion kernel takes at a time
 
 // row i's condensed start, inverted: the (i, position in row i) of flat index `flat` (distance_matrix.rs:46-51 with the
 // f64 guess fixed up by a search, as coreacc_epilogue_kernel has always done)
@@ -182,7 +180,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
 {
     const uint64_t p_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool early = g.nk_total > g.nk || g.block_ke != nullptr;   // (pairs may be left in the running)
-    if (early && g.wl_zero != nullptr && p_raw < g.wl_subs) g.wl_zero[p_raw] = 0u;   // the NEXT launch's counters (see kernels.h)
     if (p_raw >= g.n_pairs && !early) return;   // (early break: every lane of a wave stays, the on-the-spot completion is cooperative)
     const bool in_range = p_raw < g.n_pairs;
     const uint64_t p = in_range ? p_raw : g.n_pairs - 1;   // (lanes past the end shadow the last pair and store nothing)
@@ -246,34 +243,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     }
     bool alive = in_range && !stopped && ke < g.nk_total;
     const uint32_t lane = threadIdx.x & 63u;
-    if (__ballot(alive) != 0ull) {      // (wave-uniform)
+    const uint64_t alive_mask = __ballot(alive);
+    if (alive_mask != 0ull) {           // (wave-uniform)
         if (alive && !(COMP || g.block_ke != nullptr)) eb_pair_of(g, p + g.out_base, i, j);
-        if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(__ballot(alive)));   // (1 024 slots: a million adds to ONE address queue up)
-        if (g.wl != nullptr) {
-            // WORK LIST: sub-list (row mod 512, column stripe of 1 024 mod 8); the lanes of a wave that go to the same sub-list
-            // reserve their places with ONE add
-            const uint32_t sub = (((i & 511u) << 3) | ((j >> 10) & 7u)) & (g.wl_subs - 1u);
-            uint64_t todo = __ballot(alive);
-            while (todo != 0ull) {
-                const int leader = __builtin_ctzll(todo);
-                const uint32_t sub_l = (uint32_t)__shfl((int)sub, leader);
-                const uint64_t peers = __ballot(alive && sub == sub_l) & todo;
-                uint32_t base = 0u;
-                if ((int)lane == leader) base = atomicAdd(&g.wl_count[sub_l], (uint32_t)__popcll(peers));
-                base = (uint32_t)__shfl((int)base, leader);
-                if ((peers >> lane) & 1ull) {
-                    const uint32_t at = base + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-                    if (at < g.wl_cap) {
-                        g.wl[(size_t)sub_l * g.wl_cap + at] = make_uint4((uint32_t)p, i, j, ke);
-                        alive = false;          // parked: the completion kernel finishes it
-                    }                           // (else: the sub-list is full -- completed here, below)
-                }
-                todo &= ~peers;
-            }
-        }
+        if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(alive_mask));   // (1 024 slots: a million adds to ONE address queue up)
     }
-    // ON THE SPOT (launches too small for a second kernel; a full sub-list): the pairs of this wave still in the running, one
-    // after the other -- all 64 lanes count the bins the pair shares at the next length, until the reference's break
+    // the pairs of this wave still in the running, one after the other -- all 64 lanes count the bins the pair shares at the next
+    // length, until the reference's break
     uint64_t todo = __ballot(alive);
     while (todo != 0ull) {
         const int l = __builtin_ctzll(todo);
@@ -294,76 +270,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     }
     if (in_range && (alive || stopped || ke >= g.nk_total)) {
         ((float2 *)g.out)[p] = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
-    }
-}
-
-namespace {
-struct EbWaveResults {                  // LDS of one workgroup of the completion kernel
-    uint32_t same[4][EB_WAVE_ENTRIES][EB_MAXK];
-};
-}  // namespace
-
-// The work list, completed: see the head of this file.  Wave w of the launch walks sub-list w / wl_waves, chunks of 32 entries
-// (w mod wl_waves, + wl_waves, ...).
-template <int TRIPS, bool COMP>
-__global__ __launch_bounds__(256) void coreacc_completion_kernel(const EpilogueArgs g)
-{
-    __shared__ EbWaveResults R;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t w = blockIdx.x * 4u + wave;
-    const uint32_t sub = w / g.wl_waves, first = w - sub * g.wl_waves;
-    if (sub >= g.wl_subs) return;
-    const uint32_t count = min(g.wl_count[sub], g.wl_cap);
-    EbRow<TRIPS> row;
-    for (uint32_t c = first * EB_WAVE_ENTRIES; c < count; c += g.wl_waves * EB_WAVE_ENTRIES) {
-        const uint32_t n_e = min(EB_WAVE_ENTRIES, count - c);
-        uint4 mine = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < n_e) mine = g.wl[(size_t)sub * g.wl_cap + c + lane];
-        if (lane < n_e) {
-#pragma unroll
-            for (uint32_t t = 0; t < EB_MAXK; ++t) R.same[wave][lane][t] = EB_NONE;
-        }
-        for (uint32_t e = 0; e < n_e; ++e) {
-            const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)e), j = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)e);
-            const uint32_t ke = (uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)e);
-            double c1 = 0.0, c2 = 0.0;
-            if constexpr (COMP) {
-                c1 = g.compA[i];
-                c2 = g.compB[j];
-            }
-            for (uint32_t t = ke; t < g.nk_total; ++t) {
-                // (the row's slice is kept for the first of the remaining lengths, where four completions of five end)
-                const uint32_t same = eb_same_bins<TRIPS>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, row, i, j, t, t == ke, lane);
-                if (lane == 0u) R.same[wave][e][t] = same;
-                if (eb_stops<COMP>(g, same, c1, c2)) break;   // (wave-uniform) jaccard.rs:89-91
-            }
-        }
-        // (the wave's own LDS writes, read back by its other lanes)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane < n_e) {
-            const uint64_t p = mine.x;
-            double c1 = 0.0, c2 = 0.0;
-            if constexpr (COMP) {
-                c1 = g.compA[mine.y];
-                c2 = g.compB[mine.z];
-            }
-            EbSums s;
-#pragma clang loop unroll(disable)
-            for (uint32_t t = 0; t < g.nk_total; ++t) {
-                uint32_t same;
-                if (t < mine.w) same = eb_count_at(g, p * g.pair_stride + (uint64_t)t * g.k_stride);   // (summed into plane 0 by the epilogue where there were slices)
-                else same = R.same[wave][lane][t];
-                if (same == EB_NONE) break;
-                const double y = eb_lnj<COMP>(g, same, c1, c2);
-                if (y < g.tolerance) break;   // jaccard.rs:89-91
-                s.add(g.kf[t], y);
-            }
-            ((float2 *)g.out)[p] = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -434,29 +340,11 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
     if (args.n_pairs == 0) return hipSuccess;
     const bool early = args.nk_total > args.nk || args.block_ke != nullptr;
     if (early && args.nk_total > EB_MAXK) return hipErrorInvalidValue;
-    if (args.wl != nullptr && (args.wl_subs == 0u || (args.wl_subs & (args.wl_subs - 1u)) != 0u || args.n_pairs >= (1ull << 32))) return hipErrorInvalidValue;
-    const uint64_t blocks = (std::max<uint64_t>(args.n_pairs, early && args.wl_zero ? args.wl_subs : 0u) + 255) / 256;
+    const uint64_t blocks = (args.n_pairs + 255) / 256;
     if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 gr((unsigned)blocks), bl(256);
     if (args.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, 0, stream, args);
     else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, 0, stream, args);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !early || args.wl == nullptr) return e;
-    // the work list: wl_waves waves per sub-list
-    const dim3 gc((args.wl_subs * args.wl_waves + 3u) / 4u);
-#define SKL_EPI_LAUNCH(T)                                                                                            \
-    do {                                                                                                             \
-        if (args.has_comp) hipLaunchKernelGGL((coreacc_completion_kernel<T, true>), gc, bl, 0, stream, args);        \
-        else hipLaunchKernelGGL((coreacc_completion_kernel<T, false>), gc, bl, 0, stream, args);                     \
-    } while (0)
-    switch ((args.ss64 + 31u) / 32u) {   // trips of 32 chunks the row slice is kept for (beyond 4: not kept)
-        case 1: SKL_EPI_LAUNCH(1); break;
-        case 2: SKL_EPI_LAUNCH(2); break;
-        case 3: SKL_EPI_LAUNCH(3); break;
-        case 4: SKL_EPI_LAUNCH(4); break;
-        default: SKL_EPI_LAUNCH(0); break;
-    }
-#undef SKL_EPI_LAUNCH
     return hipGetLastError();
 }
 

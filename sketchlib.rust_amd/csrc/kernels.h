@@ -235,15 +235,6 @@ struct EpilogueArgs {
     uint32_t nk_total;
     const uint64_t *rows_ref, *cols_ref;
     uint32_t *alive_count;      // 1 024 words, slot blockIdx & 1023 += pairs completed here (diagnostic; may be null)
-    // Round 6 (epilogue.hip): the pairs still in the running go to a WORK LIST that coreacc_completion_kernel walks, grouped
-    // by row.  wl: wl_subs sub-lists (a power of two) of wl_cap entries (pair index of the launch, row sample, column sample,
-    // lengths counted); wl_count[sub]: entries appended (may exceed wl_cap: the pairs beyond it were completed on the spot);
-    // wl_zero: the counters of the NEXT launch on this stream, zeroed by this launch's first threads (two arrays alternate: the
-    // completion kernel that read the other one has finished before this launch starts); wl_waves: waves per sub-list of the
-    // completion launch.  wl == null: every pair still in the running is completed on the spot by its wave.
-    uint4 *wl;
-    uint32_t *wl_count, *wl_zero;
-    uint32_t wl_subs, wl_cap, wl_waves;
     uint32_t min_alive;         // no completeness correction: ln J(count) < tolerance <=> count < min_alive (0xFFFFFFFF: ask ytab)
     uint32_t cnt_u16;           // 1: the counts are u16 records (sketches of up to 1 023 chunks, no chunk slices)
     // EARLY BREAK DECIDED PER BLOCK: block_ke[(i >> blk_shift_r) * blk_cols + (j >> blk_shift_c)] = k-mer lengths the pair kernel
@@ -253,7 +244,7 @@ struct EpilogueArgs {
     uint32_t blk_shift_r, blk_shift_c, blk_cols;
 };
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
-// core/accessory records only, round 6 (epilogue.hip): the stream + (work list given) the completion launch behind it
+// core/accessory records only, round 6 (epilogue.hip)
 hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stream);
 // EARLY BREAK in the one-evaluation core/accessory self kNN (capi_knn.cpp): a row band's view of the columns was counted at
 // its first `nk` k-mer lengths (k-major counts, counts[t * n_pairs + row * nB + c]); this launch turns them into the band's

@@ -277,21 +277,17 @@ def test_the_early_break_is_decided_block_by_block(oracle, skl, gpu_ctx, sizes, 
 
 
 @pytest.mark.ab_library
-@pytest.mark.parametrize("cap", [0, 32])
-@pytest.mark.parametrize("n,ss64,comp", [(700, 64, False), (600, 32, True), (500, 157, False), (320, 300, False)])
-def test_work_list_and_band_pipeline_forced_on_small_inputs(oracle, skl, gpu_ctx, monkeypatch, n, ss64, comp, cap):
-    """The forms large calls take, forced onto inputs the oracle can check whole (A/B build): every pair still in the running
-    through the WORK LIST and the completion kernel (SKL_EB_WORKLIST_MIN=0) -- with sub-lists of 32 entries, so that most of
-    them overflow and complete their surplus on the spot -- u16 counts, and the call cut into overlapping row bands, each
-    band's epilogue on the second stream (SKL_EB_PIPELINE_MIN)."""
+@pytest.mark.parametrize("n,ss64,comp", [(700, 64, False), (600, 32, True), (500, 157, False), (420, 300, False)])
+def test_band_pipeline_forced_on_small_inputs(oracle, skl, gpu_ctx, monkeypatch, n, ss64, comp):
+    """The form large calls take, forced onto inputs the oracle can check whole (A/B build, SKL_EB_PIPELINE_MIN): u16 counts, the
+    call cut into row bands, each band's epilogue on the second stream beside the next band's counts kernel."""
     bins = _mixed(n, KMERS, ss64, n_random=n - 200, n_clusters=2, seed=37)
     cvec = np.random.default_rng(3).uniform(0.5, 1.0, n) if comp else None
     o = oracle.Sketches(bins, n, KMERS, ss64, completeness=cvec)
     exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
     monkeypatch.setenv("SKL_EARLY_BREAK", "3")
-    monkeypatch.setenv("SKL_EB_WORKLIST_MIN", "0")
-    monkeypatch.setenv("SKL_EB_WORKLIST_CAP", str(cap))
-    monkeypatch.setenv("SKL_TAIL_SLICES", "0")       # (chunk slices keep u32 counts and the on-the-spot completion)
+    monkeypatch.setenv("SKL_TAIL_SLICES", "0")       # (chunk slices keep u32 counts)
+    monkeypatch.setenv("SKL_EB_PIPELINE_MIN", "30000")
     gpu_ctx.reload_env()
     g = gpu_ctx.sketches(bins, n, KMERS, ss64, completeness=cvec)
 
@@ -301,10 +297,6 @@ def test_work_list_and_band_pipeline_forced_on_small_inputs(oracle, skl, gpu_ctx
         else:
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got != want)[:5]
 
-    check(skl.self_dists_all(gpu_ctx, g, g.set_k()), exp)
-    assert "work list" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
-    monkeypatch.setenv("SKL_EB_PIPELINE_MIN", "30000")
-    gpu_ctx.reload_env()
     check(skl.self_dists_all(gpu_ctx, g, g.set_k()), exp)
     assert "row bands, each band's epilogue beside the next band's counts kernel" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
     g_q = gpu_ctx.sketches(bins[150:], n - 150, KMERS, ss64, completeness=None if cvec is None else cvec[150:])

@@ -112,8 +112,9 @@ def test_large_sketch_knn(oracle, skl, gpu_ctx, set_switch, tile32):
 
 
 def test_counts_scratch_is_bounded(oracle, skl, gpu_ctx):
-    """Core/accessory over a large sketch parks its bin-match counts in HBM: at most 4 GiB per launch, a bigger band is
-    computed in halves.  20 000 x 20 000 pairs x 3 k x 4 B = 4.8 GB -> two launches; spot-checked against the oracle."""
+    """Core/accessory over a large sketch parks its bin-match counts in HBM: at most 4 GiB per launch, a bigger call is
+    computed in row bands.  20 000 x 20 000 pairs x 3 k x 4 B = 4.8 GB -> at least two launches (round 6: eight bands of
+    50 M pairs, each band's epilogue beside the next band's counts kernel); spot-checked against the oracle."""
     import torch
 
     kmers, ss64, n = [17, 21, 25], 1024, 20000
@@ -128,7 +129,7 @@ def test_counts_scratch_is_bounded(oracle, skl, gpu_ctx):
     skl.cross_dists_all(gpu_ctx, g, g, g.set_k(), out=out)
     torch.cuda.synchronize()
     _ms, launches = gpu_ctx.kernel_ms()
-    assert launches == 2, launches
+    assert 2 <= launches <= 16, launches
     rng = np.random.default_rng(3)
     ii = np.concatenate([rng.integers(0, n, 60), [0, n // 2 - 1, n // 2, n - 1]])
     jj = np.concatenate([ii[:60] % 400 + 400 * rng.integers(0, 50, 60), [1, n // 2, n // 2 - 1, n - 2]])   # (cluster = id % 400)
