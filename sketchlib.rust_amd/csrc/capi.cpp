@@ -1311,6 +1311,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             g.cnt_pair_stride = nkw;
         }
         if (eb_mixed) {
+            g.xcd_interleave = 1;
             g.block_ke = plan->d_block_ke;
             g.blk_shift_r = plan->shift_r;
             g.blk_shift_c = plan->shift_c;

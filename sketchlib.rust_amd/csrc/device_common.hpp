@@ -216,7 +216,7 @@ __device__ __forceinline__ bool lookup_tile_at(const PairArgs &g, uint32_t xcd, 
                                                uint32_t &group, uint32_t &row_tile)
 {
     if (slot >= g.tiles_per_xcd) return false;
-    const uint32_t t = xcd * g.tiles_per_xcd + slot;
+    const uint32_t t = g.xcd_interleave ? ((((slot >> 5) << g.xcd_shift) + xcd) << 5) + (slot & 31u) : xcd * g.tiles_per_xcd + slot;
     if (t >= g.n_active_tiles) return false;
     if (!g.self_mode) {
         tile_in_supergroup_cross(g, t, group, row_tile);

@@ -52,6 +52,9 @@ struct PairArgs {
     // group by column group and each XCD takes one contiguous eighth of the numbering
     uint32_t n_active_tiles;
     uint32_t tiles_per_xcd;       // ceil(n_active_tiles / XCDs)
+    uint32_t xcd_interleave;      // 1: the XCDs take the tile numbering in turns, 32 tiles at a time, instead of one contiguous share each
+                                  // (launches whose tiles differ in cost by REGION -- the early break decided per block: a contiguous
+                                  // share would give one XCD the blocks that count every length and another the ones that count two)
     uint32_t xcd_shift;           // log2 of the XCDs the device shows as one (SPX MI355X: 3; CPX: 0): workgroup b runs on XCD
                                   // b mod 2^xcd_shift (MI355X_MICROARCH.md), set by the C ABI from the device's CU count
     uint32_t n_groups;            // column groups

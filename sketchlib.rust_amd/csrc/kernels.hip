@@ -102,6 +102,7 @@ hipError_t plan_tiles(PairArgs &args, uint32_t rows_per_tile, uint32_t cols_per_
     args.n_active_tiles = (uint32_t)total;
     const uint64_t n_xcd = 1ull << args.xcd_shift;
     args.tiles_per_xcd = (uint32_t)((total + n_xcd - 1) / n_xcd);
+    if (args.xcd_interleave) args.tiles_per_xcd = (uint32_t)(((total + 31) / 32 + n_xcd - 1) / n_xcd * 32);   // whole blocks of 32 tiles, dealt in turns
     *grid_out = n_xcd * args.tiles_per_xcd;
     return hipSuccess;
 }

@@ -202,20 +202,29 @@ def test_early_break_with_a_completeness_correction(oracle, skl, gpu_ctx, n, ss6
         x.close()
 
 
-def test_early_break_beyond_65535_bins(oracle, skl, gpu_ctx):
-    """`sketch -s 100000` (sketchsize64 = 1 563: the segmented counts form): the first lengths are counted in segments, the
-    pairs still in the running are completed by the same epilogue (expected_samebits = 6)."""
+@pytest.mark.ab_library
+@pytest.mark.parametrize("lengths", [1, 3])
+def test_early_break_beyond_65535_bins(oracle, skl, gpu_ctx, monkeypatch, lengths):
+    """`sketch -s 100000` (sketchsize64 = 1 563: the segmented counts form, expected_samebits = 6).  Forced (3 lengths): the
+    first lengths are counted in segments, the pairs still in the running completed by the same epilogue, bit for bit.  Sampled
+    (1): between random sketches 44 % of the pairs pass each length's test (Poisson(6.1) > 6), a completion there is a run of
+    thousands of dependent trips -- the cost model says no, and every length is counted (profiles/r06_early_break_forced_lengths.md)."""
     n, ss64 = 300, 1563
     bins = _mixed(n, KMERS, ss64, n_random=n - 40, n_clusters=2, seed=29)
     o = oracle.Sketches(bins, n, KMERS, ss64)
     exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
     assert ((exp[:, 0] != 1.0) | (exp[:, 1] != 1.0)).sum() >= 100
+    monkeypatch.setenv("SKL_EARLY_BREAK", str(lengths))
+    gpu_ctx.reload_env()
     g = gpu_ctx.sketches(bins, n, KMERS, ss64)
     before = gpu_ctx.early_break_stats()
     got = skl.self_dists_all(gpu_ctx, g, g.set_k())
     after = gpu_ctx.early_break_stats()
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), np.argwhere(got != exp)[:5]
-    assert "early break: " in gpu_ctx.last_kernel() and after[1] > before[1]
+    if lengths == 3:
+        assert "early break: 3 of 5" in gpu_ctx.last_kernel() and after[1] > before[1]
+    else:
+        assert "early break" not in gpu_ctx.last_kernel()
     g.close()
 
 
