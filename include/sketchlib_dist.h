@@ -271,7 +271,9 @@ int skl_knn_merge_states(skl_ctx *ctx, size_t n_states, size_t rows, size_t knn,
 /* self_dists_knn in the REFERENCE's tie order over several devices, every pair evaluated once: the column-window pipeline.
  * A row's BinaryHeap must meet its candidates in ascending id (mod.rs:156-181), so partial heaps of disjoint candidate sets
  * cannot be merged -- but a heap can travel.  Participant r owns the column window [lo_r, hi_r) (windows ascending with r;
- * cut them at n * sqrt(r / R) so that the pair counts balance) and, for every row band b = rows [b * band_rows, ...) that
+ * cut them at n * sqrt(r / R) so that the pair counts balance, ROUNDED TO BAND BOUNDARIES: col_lo and col_hi must be multiples
+ * of band_rows -- col_hi may also be n -- or the call fails with SKL_ERR_INVALID_ARG: a window starting inside a band would
+ * lose candidates) and, for every row band b = rows [b * band_rows, ...) that
  * starts below hi_r, in ascending order, calls skl_self_dists_knn_window: the band's rows take the columns
  * [max(band start, lo_r), hi_r) as candidates, the window's rows below the band take the band's samples.  Before a band
  * whose rows lie below lo_r, participant r receives those rows' heaps from participant r - 1 (which has finished that band);

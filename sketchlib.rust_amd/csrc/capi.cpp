@@ -1243,7 +1243,8 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // U16 COUNTS (round 6): sketches of up to 1 023 chunks count at most 65 472 bins per length, so a launch without
         // chunk slices (no plane to add into) parks its counts as u16: half the scratch traffic of the stream
         const bool tiny = pairs * nkw < 2ull * 4ull * (uint64_t)ctx->n_cu * 2048ull;   // (launches that may be tail-sliced keep u32: slices ADD into a plane)
-        const bool cnt_u16 = sliced && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS && !tiny && ctx->knobs.k_slices <= 1 && ctx->knobs.counts_u16;
+        const bool cnt_u16 = sliced && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS && !tiny && ctx->knobs.k_slices <= 1 && ctx->knobs.counts_u16 &&
+                             !ctx->knobs.fuse_epilogue && !ctx->knobs.epilogue_r5;   // (the A/B build's older epilogues read u32)
         const size_t cnt_bytes = cnt_u16 ? sizeof(uint16_t) : sizeof(uint32_t);
         // BAND PIPELINE (round 6).  The counts scratch is bounded, and a call whose counts do not fit is computed in row bands of
         // equal pair count.  From 64 Mi pairs on the bands are also what hides the epilogue: band i's epilogue (+ completion
@@ -1469,7 +1470,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             HIP_TRY(hipStreamWaitEvent(epi_stream, ctx->eb_events[ctx->eb_pipe_buf], 0));
         }
 #ifdef SKL_AB
-        if (ctx->knobs.epilogue_r5 && !eb_mixed && !e.cnt_u16 && !(early && (e.has_comp || rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS))) {
+        if (ctx->knobs.epilogue_r5 && !eb_mixed && !(early && (e.has_comp || rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS))) {
             if (!early) e.nk_total = 0;
             HIP_TRY(launch_coreacc_epilogue(e, epi_stream));   // round 5's epilogue: alive pairs completed where they are found (A/B timing)
         } else

@@ -257,6 +257,21 @@ static int sketch_signs_impl(skl_ctx *ctx, const uint8_t *codes, const uint32_t 
                                 : "skl::nthash_binmin_kernel (256 window starts per thread, rolling canonical ntHash, atomicMin per bin)";
     HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // The sketching buffers belong to the context so that a run of sketch calls does not allocate per call -- but beyond 1 GiB
+    // they would sit in the way of what follows (the kNN drivers size their bands by the free memory): released, with the
+    // pinned ring.  (Both streams are idle here.)
+    if (ctx->scratch_bytes[12] + ctx->scratch_bytes[13] > (1ull << 30)) {
+        for (int slot : {12, 13}) {
+            if (ctx->scratch[slot]) HIP_TRY(hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        if (ctx->pinned) {
+            HIP_TRY(hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_words = 0;
+        }
+    }
     return SKL_OK;
 }
 

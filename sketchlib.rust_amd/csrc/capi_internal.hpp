@@ -148,6 +148,7 @@ struct skl_ctx {
     hipEvent_t eb_events[4] = {nullptr, nullptr, nullptr, nullptr};   // counts of buffer b done / epilogue of buffer b done
     std::vector<EbPlan *> eb_plans;        // early-break decisions of the last few slab pairs (newest last)
     const EbPlan *eb_last_plan = nullptr;  // the plan of the last dense core/accessory call (skl_ctx_early_break_blocks)
+    bool knn_prune_pending = false;        // the device counters (scratch slot 10) hold counts not yet read back
     uint64_t knn_tiles = 0, knn_tiles_pruned = 0;   // tile pruning of the last self kNN call (skl_ctx_knn_prune_stats)
     int knn_ties = SKL_KNN_TIES_REFERENCE;   // what self_dists_knn returns (mod.rs:133-224); skl_ctx_set_knn_ties(CANONICAL) opts out
     Knobs knobs;                        // environment switches as of skl_ctx_create

@@ -36,6 +36,41 @@ struct KnnState {
 
 // Rows per band of the symmetric drivers: about 8 bands per participant (7/16 of the pair
 // evaluations saved), each band at least 32 M pairs, four band buffers within `budget` bytes.
+// TILE-PRUNING COUNTERS (diagnostic): 1 024 slots of 4 words on the device (scratch slot 10), added to by the pair kernels of
+// every band of a call, read back LAZILY by skl_ctx_knn_prune_stats -- never on the launch path: the drivers that feed bands one
+// call at a time (column windows, column panels) must not stall the host once per call.
+static int prune_stats_reset(skl_ctx *ctx)
+{
+    ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    if (ctx->scratch[10] != nullptr) HIP_TRY(hipMemsetAsync(ctx->scratch[10], 0, 4096 * sizeof(uint32_t), ctx->stream));
+    return SKL_OK;
+}
+
+static int prune_stats_collect(skl_ctx *ctx)
+{
+    if (ctx->scratch[10] == nullptr || !ctx->knn_prune_pending) return SKL_OK;
+    std::vector<uint32_t> counted(4096, 0u);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+    HIP_TRY(hipMemcpy(counted.data(), ctx->scratch[10], counted.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tiles_sparse = 0;
+    for (size_t x = 0; x < 1024; ++x) {
+        ctx->knn_tiles_pruned += (uint64_t)counted[4 * x] + counted[4 * x + 1];
+        ctx->knn_tiles_probe_pruned += counted[4 * x];
+        ctx->knn_pruned_stages += counted[4 * x + 2];
+        ctx->knn_tiles_sparse += counted[4 * x + 3];
+    }
+    return SKL_OK;
+}
+
+// Bytes per pair and band buffer the symmetric drivers' budget counts: the record, and for core/accessory keys the share of
+// the early break's two counts buffers (up to 4 lengths x 2 bytes each against four band buffers: + 4 bytes per buffer).
+static size_t coreacc_rec_with_counts(const skl_sketches *s, const skl_dist_params *p)
+{
+    if (p->dist_type != SKL_DIST_COREACC) return sizeof(float);
+    return 2 * sizeof(float) + (s->nk >= 3 && s->nk <= 8 && fused_coreacc_ok(s) ? 4 : 0);
+}
+
 static size_t symmetric_band_rows(size_t n, size_t rec, size_t budget, size_t participants)
 {
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
@@ -163,10 +198,12 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
     if (prune) {
         void *pq = nullptr, *ps = nullptr;
         SKL_TRY(ctx_scratch(ctx, (n_rows + 64 + (is_cross ? n + 64 : 0)) * sizeof(uint32_t), &pq, 8));
+        const bool fresh = ctx->scratch[10] == nullptr;
         SKL_TRY(ctx_scratch(ctx, 4096 * sizeof(uint32_t), &ps, 10));
         prune_q = (uint32_t *)pq;
         prune_stats = (uint32_t *)ps;
-        HIP_TRY(hipMemsetAsync(prune_stats, 0, 4096 * sizeof(uint32_t), ctx->stream));
+        if (fresh) HIP_TRY(hipMemsetAsync(prune_stats, 0, 4096 * sizeof(uint32_t), ctx->stream));   // (afterwards: prune_stats_reset, at the start of a call)
+        ctx->knn_prune_pending = true;
         if (is_cross) HIP_TRY(hipMemsetAsync(prune_q + n_rows + 64, 0, (n + 64) * sizeof(uint32_t), ctx->stream));   // the columns have no lists: bound 0
     }
     hipStream_t topk_stream = overlap ? ctx->aux_stream : ctx->stream;
@@ -187,11 +224,19 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         (bands.size() > 1 || cross.lists_hold_knn)) {
         SKL_TRY(early_break_lengths(ctx, s, cs, 1, &eb_lengths));
         if (eb_lengths > 0) {
-            const size_t bytes = band_rows * n * (size_t)eb_lengths * sizeof(uint32_t);   // (the largest view a band can have)
-            SKL_TRY(ctx_scratch(ctx, bytes, &eb_counts[0], 1));
+            // (the band heights count these buffers in -- coreacc_rec_with_counts() -- but a band height the CALLER chose, or a
+            // device short of memory, must not fail the call: without the counts the bands take the fused kernel as before)
+            const size_t bytes = band_rows * n * (size_t)eb_lengths * sizeof(uint16_t);   // (the largest view a band can have; u16 records: fused_coreacc_ok means at most 65 472 bins)
+            int rc = ctx_scratch(ctx, bytes, &eb_counts[0], 1);
             ctx->clean_plane1 = nullptr;   // (the counts scratch holds another layout now)
             eb_counts[1] = eb_counts[0];
-            if (overlap) SKL_TRY(ctx_scratch(ctx, bytes, &eb_counts[1], 15));
+            if (rc == SKL_OK && overlap) rc = ctx_scratch(ctx, bytes, &eb_counts[1], 15);
+            if (rc == SKL_ERR_OOM) {
+                (void)hipGetLastError();   // (cleared: the call goes on)
+                eb_lengths = 0;
+            } else if (rc != SKL_OK) {
+                return rc;
+            }
         }
     }
     const size_t jb_words = s->nk * s->ss64 * 7 * 64;   // uint4 per 64-column block of the lane slab
@@ -271,6 +316,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             c.cnt_k_stride = pairs_view;
             c.k_sliced = 1;
             c.k_slices = 1;
+            c.cnt_u16 = 1;
             c.out = counts;
             SKL_TRY(timed_pair_launch(ctx, c, MODE_COUNTS));
             memset(&e, 0, sizeof e);
@@ -303,6 +349,11 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             e.t_bits = g.t_bits;
             e.t_bits_stride = g.t_bits_stride;
             e.alive_count = ctx->eb_counter;
+            e.min_alive = s->min_alive;
+            e.cnt_u16 = 1;
+            // (bands ascend: the `it` bands before this one each gave band_rows candidates to every row the turned copy reaches,
+            // and their merges run before this launch on the same stream)
+            e.plain_marks_nothing = (cross.lists_hold_knn || it * band_rows >= knn) ? 1u : 0u;
             ctx->eb_pairs += pairs_view;
             ctx->last_kernel += " + early break: " + std::to_string(eb_lengths) + " of " + std::to_string(s->nk) + " k-mer lengths counted, the pairs still in the running completed by the band's epilogue";
         } else {
@@ -401,18 +452,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
         if (overlap) HIP_TRY(hipEventRecord(ctx->knn_topk_done[buf], topk_stream));
         ++it;
     }
-    if (prune) {   // (read back with the call's last synchronisation: skl_ctx_knn_prune_stats)
-        std::vector<uint32_t> counted(4096, 0u);
-        HIP_TRY(hipMemcpyAsync(counted.data(), prune_stats, counted.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (size_t x = 0; x < 1024; ++x) {
-            ctx->knn_tiles_pruned += (uint64_t)counted[4 * x] + counted[4 * x + 1];
-            ctx->knn_tiles_probe_pruned += counted[4 * x];
-            ctx->knn_pruned_stages += counted[4 * x + 2];
-            ctx->knn_tiles_sparse += counted[4 * x + 3];
-        }
-        ctx->knn_tile_stages = (s->ss64 + 3) / 4;   // stages of a whole 32 x 128 tile: 4 waves, one chunk each per stage
-    }
+    if (prune) ctx->knn_tile_stages = (s->ss64 + 3) / 4;   // stages of a whole 32 x 128 tile: 4 waves, one chunk each per stage
     if (overlap && it) {   // the states (and the band buffers) belong to the context's stream again
         HIP_TRY(hipEventRecord(ctx->knn_topk_done[0], topk_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->knn_topk_done[0], 0));
@@ -495,7 +535,7 @@ static int knn_rows_banded(skl_ctx *ctx, const skl_sketches *rows, const skl_ske
             cross.self_rows = self_mode != 0;
             cross.row_lo = r0;
             cross.row_hi = r1;
-            ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+            SKL_TRY(prune_stats_reset(ctx));
             for (size_t c0 = 0; c0 < n_cand; c0 += panel) {
                 SKL_TRY(knn_symmetric_bands(ctx, rows, p, knn, rows_per, bands, overlap && bands.size() > 1, pst, c0, std::min(n_cand, c0 + panel), cross));
             }
@@ -647,7 +687,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     if (symmetric) {
         size_t budget = band_bytes;
         if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, 32ull << 30));
-        const size_t want = forced_band_rows ? forced_band_rows : symmetric_band_rows(n_cand, rec, budget, 1);
+        const size_t want = forced_band_rows ? forced_band_rows : symmetric_band_rows(n_cand, coreacc_rec_with_counts(rows, p), budget, 1);
         if (want >= n_cand) symmetric = false;
         else band_rows = want;
     }
@@ -669,7 +709,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
         d_d0 = (float *)(d_idx + items);
         d_d1 = d_d0 + items;
     }
-    ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    SKL_TRY(prune_stats_reset(ctx));
     if (symmetric) {
         SKL_TRY(knn_self_symmetric(ctx, rows, p, knn, band_rows, overlap, d_idx, d_d0, d_d1));
     } else {
@@ -693,6 +733,7 @@ extern "C" int skl_ctx_knn_prune_stats(skl_ctx *ctx, uint64_t *tiles, uint64_t *
                                        uint64_t *stages_walked_in_pruned_tiles, uint64_t *tiles_sparse)
 {
     SKL_TRY(ctx_bind(ctx));
+    SKL_TRY(prune_stats_collect(ctx));
     if (tiles_sparse) *tiles_sparse = ctx->knn_tiles_sparse;
     if (tiles) *tiles = ctx->knn_tiles;
     if (tiles_pruned) *tiles_pruned = ctx->knn_tiles_pruned;
@@ -730,7 +771,7 @@ extern "C" int skl_self_dists_knn(skl_ctx *ctx, const skl_sketches *s, const skl
 extern "C" size_t skl_knn_band_rows(const skl_sketches *s, const skl_dist_params *p, size_t n_participants)
 {
     if (!s || !p || s->n == 0) return 0;
-    const size_t rec = p->dist_type == SKL_DIST_COREACC ? 2 * sizeof(float) : sizeof(float);
+    const size_t rec = coreacc_rec_with_counts(s, p);
     const long long forced = s->ctx->knobs.knn_band_rows;   // test knob (the same for every participant)
     if (forced > 0) return std::min<size_t>(s->n, (size_t)forced);
     // a fixed budget (no free-memory query): every participant must arrive at the same number
@@ -767,7 +808,7 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
     }
     KnnState st;
     SKL_TRY(knn_state_init(st, n, knn, coreacc, ctx->stream));
-    ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    SKL_TRY(prune_stats_reset(ctx));
     const bool overlap = ctx->knobs.knn_overlap && list.size() > 1;
     SKL_TRY(knn_symmetric_bands(ctx, s, p, knn, band_rows, list, overlap, st));
     const hipMemcpyKind kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -804,6 +845,11 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
     if (n < 2 || knn == 0 || knn > n - 1) return fail(SKL_ERR_INVALID_ARG, "knn=%zu must be in [1, %zu]", knn, n ? n - 1 : 0);
     if (knn > (size_t)REFHEAP_LDS_MAX) return fail(SKL_ERR_INVALID_ARG, "the travelling heaps live in LDS while they are fed: knn=%zu exceeds %u", knn, REFHEAP_LDS_MAX);
     if (band_rows == 0 || band * band_rows >= n || col_lo > col_hi || col_hi > n) return fail(SKL_ERR_INVALID_ARG, "row band / column window out of range");
+    // (a window that starts inside a band would give that band's rows turned candidates on this window's owner which the heaps
+    // arriving from the upstream participant then overwrite: candidates silently lost)
+    if (col_lo % band_rows != 0 || (col_hi % band_rows != 0 && col_hi != n)) {
+        return fail(SKL_ERR_INVALID_ARG, "column window [%zu, %zu) must be cut on band boundaries (multiples of band_rows = %zu; col_hi may equal n)", col_lo, col_hi, band_rows);
+    }
     if (!knn_symmetric_ok(s, p)) return fail(SKL_ERR_INVALID_ARG, "no one-evaluation kNN for this configuration; shard rows with skl_self_dists_knn_rows");
     KnnState st;
     st.borrowed = true;
@@ -813,7 +859,8 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
     st.h_len = h_len;
     st.thr = thr;
     const std::vector<uint32_t> one{(uint32_t)band};
-    ctx->knn_tiles = ctx->knn_tiles_sparse = ctx->knn_tiles_pruned = ctx->knn_tiles_probe_pruned = ctx->knn_pruned_stages = ctx->knn_tile_stages = 0;
+    // (the counters run on over the bands of a window: skl_ctx_knn_prune_stats reports everything since the last kNN
+    // call of another kind -- no read-back, no reset here: this call must not stall the hand-over of the heaps)
     KnnCross form;   // (the symmetric form)
     form.lists_hold_knn = band >= 1 && band_rows >= knn;   // (bands 0 .. band - 1 of this window, or the windows before it, have fed every list)
     return knn_symmetric_bands(ctx, s, p, knn, band_rows, one, false, st, col_lo, col_hi, form);

@@ -273,6 +273,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     }
 }
 
+// The early-break epilogue of a row band of the symmetric core/accessory self kNN: see EpilogueKnnArgs (kernels.h).
+// Thread (blockIdx.y, blockIdx.x * 256 + threadIdx.x) = (row of the band, view column): a wave is 64 consecutive columns of
+// one row, i.e. one of the 64-column blocks the row bits stand for (the view starts on a block boundary).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
+{
+    const uint32_t row = g.row_base + blockIdx.y, c_raw = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool in_range = c_raw < g.nB;
+    const uint32_t c = in_range ? c_raw : g.nB - 1u;          // (lanes past the row's end shadow its last pair and store nothing)
+    const uint64_t p = (uint64_t)row * g.nB + c;
+    const uint32_t maxnbits = g.ss64 * 64u;
+    EbSums s;
+    bool stopped = false;
+    for (uint32_t t = 0; t < g.nk; ++t) {                      // (g.nk is 2, 3 or 4: independent loads, then the reference's loop)
+        const uint64_t at = (uint64_t)t * g.n_pairs + p;
+        const uint32_t same = g.cnt_u16 ? (uint32_t)reinterpret_cast<const uint16_t *>(g.counts)[at] : g.counts[at];
+        const double y = g.ytab[same <= maxnbits ? same : maxnbits];
+        if (stopped) continue;
+        if (y < g.tolerance) {   // jaccard.rs:89-91: break
+            stopped = true;
+            continue;
+        }
+        s.add(g.kf[t], y);
+    }
+    // the pairs of this wave still in the running, one after the other: all 64 lanes count the bins the pair shares at the next
+    // length, each slice read as one contiguous run (eb_same_bins), until the reference's break
+    const bool alive = in_range && !stopped && g.nk_total > g.nk;
+    uint64_t todo = __ballot(alive);
+    if (g.alive_count != nullptr && todo != 0ull && lane == 0u) atomicAdd(&g.alive_count[(blockIdx.x + blockIdx.y * 7u) & 1023u], (uint32_t)__popcll(todo));   // (1 024 slots, as above)
+    const uint32_t i_s = g.row_sample0 + row;
+    while (todo != 0ull) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t j_l = g.col_sample0 + (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)c, l));
+        EbRow<0> none;
+        for (uint32_t t = g.nk; t < g.nk_total; ++t) {
+            const uint32_t same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_l, t, false, lane);
+            if (g.min_alive != EB_NONE ? same < g.min_alive : g.ytab[same <= maxnbits ? same : maxnbits] < g.tolerance) break;   // (wave-uniform)
+            if ((int)lane == l) s.add(g.kf[t], g.ytab[same <= maxnbits ? same : maxnbits]);
+        }
+    }
+    const float2 v = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+    // does this 64-column block bring the row anything below its knn-th best?  (the key is the core distance)  The merge reads
+    // the marked blocks of a row only, so an unmarked block's 64 records are not even stored.
+    bool store = in_range;
+    if (g.r_bits != nullptr) {
+        const uint32_t thr_ = g.r_thr[(size_t)row * g.r_thr_stride];
+        const bool marked = __ballot(in_range && sortable_bits(v.x) < thr_) != 0ull;
+        if (marked && lane == 0u) {
+            const uint32_t blk = c_raw >> 6;
+            atomicOr(&g.r_bits[(size_t)row * g.r_bits_stride + (blk >> 5)], 1u << (blk & 31u));
+        }
+        store = store && marked;
+    }
+    if (store) ((float2 *)g.out)[p] = v;
+    // the turned copy: pre-filled with (1, 1); everything else is stored, and marked where it beats the column's knn-th best.
+    // Once every list holds knn candidates (none above 1: plain_marks_nothing, the host knows) a (1, 1) marks nothing, so a
+    // wave of nothing but (1, 1) -- nearly every wave -- is done here: no look at its 64 columns' thresholds.
+    const bool plain = __float_as_uint(v.x) == 0x3F800000u && __float_as_uint(v.y) == 0x3F800000u;
+    const bool turn = in_range && c >= g.t_col_begin && !(plain && g.plain_marks_nothing);
+    if (g.out_t == nullptr || __ballot(turn) == 0ull) return;
+    if (turn) {
+        if (!plain) reinterpret_cast<float2 *>(g.out_t)[(size_t)(c - g.t_col_begin) * g.t_stride + row] = v;
+        if (g.t_flag != nullptr && sortable_bits(v.x) < g.t_thr[(size_t)c * g.t_thr_stride]) {
+            g.t_flag[c] = g.t_flag_value;
+            if (g.t_bits != nullptr) {
+                const uint32_t tb = row >> 5;
+                atomicOr(&g.t_bits[(size_t)c * g.t_bits_stride + (tb >> 5)], 1u << (tb & 31u));
+            }
+        }
+    }
+}
+
+hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t stream)
+{
+    if (args.rows == 0 || args.nB == 0) return hipSuccess;
+    for (uint32_t r0 = 0; r0 < args.rows; r0 += 32768u) {
+        EpilogueKnnArgs a = args;
+        a.row_base = r0;
+        hipLaunchKernelGGL(coreacc_epilogue_knn_kernel, dim3((args.nB + 255u) / 256u, std::min(32768u, args.rows - r0)), dim3(256), 0, stream, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // One wave per (block, sample): see EbSampleArgs (kernels.h).
 __global__ __launch_bounds__(256) void early_break_sample_kernel(const EbSampleArgs g)
 {

@@ -279,6 +279,9 @@ struct EpilogueKnnArgs {
     uint32_t *t_bits;
     uint32_t t_bits_stride;
     uint32_t *alive_count;
+    uint32_t min_alive;          // as EpilogueArgs::min_alive
+    uint32_t cnt_u16;            // 1: the counts are u16 records
+    uint32_t plain_marks_nothing;   // 1: every list the band meets holds knn candidates (keys <= 1), so a (1, 1) record can enter none
 };
 hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t stream);
 // EARLY BREAK, the driver's question before it counts only the first few k-mer lengths of a block of pairs: how many of them
