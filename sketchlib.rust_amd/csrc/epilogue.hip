@@ -274,72 +274,211 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
 }
 
 // The early-break epilogue of a row band of the symmetric core/accessory self kNN: see EpilogueKnnArgs (kernels.h).
-// Thread (blockIdx.y, blockIdx.x * 256 + threadIdx.x) = (row of the band, view column): a wave is 64 consecutive columns of
-// one row, i.e. one of the 64-column blocks the row bits stand for (the view starts on a block boundary).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
+// A wave = KNN_BLOCKS consecutive 64-column blocks of ONE row of the band (the blocks the row bits stand for; the view starts on a
+// block boundary), a lane one column of each.  This kernel runs BESIDE the next band's counts kernel, and every wave of it
+// that is resident displaces a wave of that kernel (which fills the register file by itself): what it costs is its waves'
+// residence time, i.e. the length of its chains of dependent loads (profiles/r06_cfg5_coreacc.md).  So
+//   A. the counts of all the wave's blocks are requested at once, and whether a pair leaves the reference's loop is decided
+//      on the counts themselves (min_alive): a block all of whose pairs left with fewer than three lengths -- nearly every
+//      block between unrelated genomes -- is (1, 1) throughout: no table look-up, no regression, and once every list is
+//      full no store and no mark either;
+//   B. the pairs still in the running -- of ALL the wave's blocks -- are completed one after the other with the NEXT pair's
+//      column slice already requested: the row's slice of the first length not counted is read once per wave (every pair of
+//      the wave shares the row) and each column slice is one contiguous run (eb_trip); the completed counts wait in LDS;
+//   C. block by block, the pairs that have a fit run the reference's sums and regression; records, marks, turned copy.
+// TRIPS: trips of 32 chunks of a slice (1 or 2: the row's slice and the next column's are kept in registers; 0: any sketch
+// size, nothing kept, nothing requested ahead).
+constexpr uint32_t KNN_BLOCKS = 4;
+constexpr uint32_t KNN_MAXKE = 4;
+constexpr uint32_t KNN_MAXEXT = 6;      // lengths beyond the counted ones (nk_total <= 8, nk >= 2)
+
+template <int TRIPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
 {
-    const uint32_t row = g.row_base + blockIdx.y, c_raw = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    const bool in_range = c_raw < g.nB;
-    const uint32_t c = in_range ? c_raw : g.nB - 1u;          // (lanes past the row's end shadow its last pair and store nothing)
-    const uint64_t p = (uint64_t)row * g.nB + c;
-    const uint32_t maxnbits = g.ss64 * 64u;
-    EbSums s;
-    bool stopped = false;
-    for (uint32_t t = 0; t < g.nk; ++t) {                      // (g.nk is 2, 3 or 4: independent loads, then the reference's loop)
-        const uint64_t at = (uint64_t)t * g.n_pairs + p;
-        const uint32_t same = g.cnt_u16 ? (uint32_t)reinterpret_cast<const uint16_t *>(g.counts)[at] : g.counts[at];
-        const double y = g.ytab[same <= maxnbits ? same : maxnbits];
-        if (stopped) continue;
-        if (y < g.tolerance) {   // jaccard.rs:89-91: break
-            stopped = true;
-            continue;
-        }
-        s.add(g.kf[t], y);
-    }
-    // the pairs of this wave still in the running, one after the other: all 64 lanes count the bins the pair shares at the next
-    // length, each slice read as one contiguous run (eb_same_bins), until the reference's break
-    const bool alive = in_range && !stopped && g.nk_total > g.nk;
-    uint64_t todo = __ballot(alive);
-    if (g.alive_count != nullptr && todo != 0ull && lane == 0u) atomicAdd(&g.alive_count[(blockIdx.x + blockIdx.y * 7u) & 1023u], (uint32_t)__popcll(todo));   // (1 024 slots, as above)
+    __shared__ uint16_t ext[4][KNN_BLOCKS][KNN_MAXEXT][64];   // completed bin-match counts of the pairs still in the running (0xFFFF: not looked at)
+    const uint32_t row = g.row_base + blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t c_wave = (blockIdx.x * 4u + wave) * (64u * KNN_BLOCKS);
+    if (c_wave >= g.nB) return;
+    const uint32_t maxnbits = g.ss64 * 64u, halves = g.ss64 * 2u;
     const uint32_t i_s = g.row_sample0 + row;
-    while (todo != 0ull) {
-        const int l = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t j_l = g.col_sample0 + (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)c, l));
-        EbRow<0> none;
-        for (uint32_t t = g.nk; t < g.nk_total; ++t) {
-            const uint32_t same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_l, t, false, lane);
-            if (g.min_alive != EB_NONE ? same < g.min_alive : g.ytab[same <= maxnbits ? same : maxnbits] < g.tolerance) break;   // (wave-uniform)
-            if ((int)lane == l) s.add(g.kf[t], g.ytab[same <= maxnbits ? same : maxnbits]);
+    uint32_t cnt[KNN_BLOCKS][KNN_MAXKE];
+#pragma unroll
+    for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+        const uint32_t c = min(c_wave + u * 64u + lane, g.nB - 1u);   // (lanes past the row's end shadow its last pair and store nothing)
+        const uint64_t p = (uint64_t)row * g.nB + c;
+#pragma unroll
+        for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
+            const uint64_t at = (uint64_t)t * g.n_pairs + p;
+            cnt[u][t] = t < g.nk ? (g.cnt_u16 ? (uint32_t)reinterpret_cast<const uint16_t *>(g.counts)[at] : g.counts[at]) : 0u;
         }
     }
-    const float2 v = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
-    // does this 64-column block bring the row anything below its knn-th best?  (the key is the core distance)  The merge reads
-    // the marked blocks of a row only, so an unmarked block's 64 records are not even stored.
-    bool store = in_range;
-    if (g.r_bits != nullptr) {
-        const uint32_t thr_ = g.r_thr[(size_t)row * g.r_thr_stride];
-        const bool marked = __ballot(in_range && sortable_bits(v.x) < thr_) != 0ull;
-        if (marked && lane == 0u) {
-            const uint32_t blk = c_raw >> 6;
-            atomicOr(&g.r_bits[(size_t)row * g.r_bits_stride + (blk >> 5)], 1u << (blk & 31u));
+    const bool by_count = g.min_alive != EB_NONE;
+    const uint32_t thr_row = g.r_bits != nullptr ? g.r_thr[(size_t)row * g.r_thr_stride] : 0u;
+    auto stops = [&](uint32_t same) { return by_count ? same < g.min_alive : g.ytab[same <= maxnbits ? same : maxnbits] < g.tolerance; };
+    // A. the reference's loop over the first g.nk lengths, on the counts: how many lengths pass before the first that does not
+    uint32_t passed[KNN_BLOCKS];
+    uint64_t alive_mask[KNN_BLOCKS];
+    uint32_t n_alive = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+        const bool in_range = c_wave + u * 64u + lane < g.nB;
+        passed[u] = 0;
+        bool stopped = false;
+#pragma unroll
+        for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
+            if (t < g.nk && !stopped) {
+                if (stops(cnt[u][t])) stopped = true;   // jaccard.rs:89-91: break
+                else ++passed[u];
+            }
         }
-        store = store && marked;
+        alive_mask[u] = __ballot(in_range && !stopped && g.nk_total > g.nk);
+        n_alive += (uint32_t)__popcll(alive_mask[u]);
     }
-    if (store) ((float2 *)g.out)[p] = v;
-    // the turned copy: pre-filled with (1, 1); everything else is stored, and marked where it beats the column's knn-th best.
-    // Once every list holds knn candidates (none above 1: plain_marks_nothing, the host knows) a (1, 1) marks nothing, so a
-    // wave of nothing but (1, 1) -- nearly every wave -- is done here: no look at its 64 columns' thresholds.
-    const bool plain = __float_as_uint(v.x) == 0x3F800000u && __float_as_uint(v.y) == 0x3F800000u;
-    const bool turn = in_range && c >= g.t_col_begin && !(plain && g.plain_marks_nothing);
-    if (g.out_t == nullptr || __ballot(turn) == 0ull) return;
-    if (turn) {
-        if (!plain) reinterpret_cast<float2 *>(g.out_t)[(size_t)(c - g.t_col_begin) * g.t_stride + row] = v;
-        if (g.t_flag != nullptr && sortable_bits(v.x) < g.t_thr[(size_t)c * g.t_thr_stride]) {
-            g.t_flag[c] = g.t_flag_value;
-            if (g.t_bits != nullptr) {
-                const uint32_t tb = row >> 5;
-                atomicOr(&g.t_bits[(size_t)c * g.t_bits_stride + (tb >> 5)], 1u << (tb & 31u));
+    // B. the pairs still in the running, in block order
+    if (n_alive != 0u) {                // (wave-uniform)
+        if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[(blockIdx.x + blockIdx.y * 7u) & 1023u], n_alive);   // (1 024 slots)
+#pragma unroll
+        for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+            if ((alive_mask[u] >> lane) & 1ull) {
+#pragma unroll
+                for (uint32_t x = 0; x < KNN_MAXEXT; ++x) ext[wave][u][x][lane] = 0xFFFFu;
+            }
+        }
+        const uint2 *pi = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_s * g.nk_total + g.nk) * g.ss64) * BBITS);
+        constexpr int KEPT = TRIPS > 0 ? TRIPS : 1;
+        uint2 a_row[KEPT][7], b_next[KEPT][7];
+        if constexpr (TRIPS > 0) {
+#pragma unroll
+            for (int tr = 0; tr < TRIPS; ++tr) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) a_row[tr][q] = (uint32_t)tr * 64u + lane < halves ? pi[((size_t)tr * 64u + lane) * 7 + q] : make_uint2(0u, 0u);
+            }
+        }
+        // (u, l) of the next pair still in the running at or after block u0, lane mask `m` of that block's remainder
+        uint32_t cur_u = 0;
+        uint64_t cur_m = alive_mask[0];
+        auto advance = [&](uint32_t &u_out, uint32_t &l_out) -> bool {
+            while (cur_m == 0ull) {
+                if (++cur_u >= KNN_BLOCKS) return false;
+                cur_m = cur_u == 1u ? alive_mask[1] : (cur_u == 2u ? alive_mask[2] : alive_mask[3]);
+            }
+            l_out = (uint32_t)__builtin_ctzll(cur_m);
+            cur_m &= cur_m - 1ull;
+            u_out = cur_u;
+            return true;
+        };
+        auto column_of = [&](uint32_t u, uint32_t l) {   // view column -> sample id (wave-uniform)
+            return g.col_sample0 + c_wave + u * 64u + l;
+        };
+        auto request = [&](uint32_t j) {                 // the column sample's slice of the first length not counted
+            if constexpr (TRIPS > 0) {
+                const uint2 *pj = reinterpret_cast<const uint2 *>(g.cols_ref + (((uint64_t)j * g.nk_total + g.nk) * g.ss64) * BBITS);
+#pragma unroll
+                for (int tr = 0; tr < TRIPS; ++tr) {
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) b_next[tr][q] = (uint32_t)tr * 64u + lane < halves ? pj[((size_t)tr * 64u + lane) * 7 + q] : make_uint2(0u, 0u);
+                }
+            }
+        };
+        uint32_t u_e = 0, l_e = 0, u_n = 0, l_n = 0;
+        bool have = advance(u_e, l_e);
+        if (have) request(column_of(u_e, l_e));
+        while (have) {
+            const uint32_t j_e = column_of(u_e, l_e);
+            uint32_t same;
+            if constexpr (TRIPS > 0) {
+                uint32_t part = 0;
+#pragma unroll
+                for (int tr = 0; tr < TRIPS; ++tr) {
+                    const uint32_t h = (uint32_t)tr * 64u + lane;
+                    uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+                        mlo = acc_mismatch<true>(mlo, a_row[tr][q].x, b_next[tr][q].x);
+                        mhi = acc_mismatch<true>(mhi, a_row[tr][q].y, b_next[tr][q].y);
+                    }
+                    mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                    mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
+                    part += ((lane & 1u) == 0u && h < halves) ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
+                }
+                // the next pair's slice is on its way while this one is summed up
+                const bool more = advance(u_n, l_n);
+                if (more) request(column_of(u_n, l_n));
+                same = maxnbits - eb_wave_sum(part);
+                have = more;
+            } else {
+                EbRow<0> none;
+                same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_e, g.nk, false, lane);
+                have = advance(u_n, l_n);
+            }
+            // the reference's loop from the first length not counted on (the later ones, reached by one pair in eight, are read when
+            // they are needed)
+            uint32_t t = g.nk;
+            for (;;) {
+                if (lane == l_e) ext[wave][u_e][t - g.nk][lane] = (uint16_t)same;   // (u_e: wave-uniform)
+                if (stops(same) || ++t >= g.nk_total) break;   // (wave-uniform) jaccard.rs:89-91
+                EbRow<0> none;
+                same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_e, t, false, lane);
+            }
+            u_e = u_n;
+            l_e = l_n;
+        }
+    }
+    // C. block by block: sums and regression where there is a fit, records, marks, the turned copy
+#pragma unroll
+    for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+        const uint32_t c_raw = c_wave + u * 64u + lane;
+        if (c_wave + u * 64u >= g.nB) break;                    // (wave-uniform)
+        const bool in_range = c_raw < g.nB;
+        const uint32_t c = in_range ? c_raw : g.nB - 1u;
+        const uint64_t p = (uint64_t)row * g.nB + c;
+        const bool alive = (alive_mask[u] >> lane) & 1ull;
+        const bool fit = in_range && (alive || passed[u] >= 3u);   // (fewer than three lengths: (1, 1), jaccard.rs:117)
+        float2 v = make_float2(1.0f, 1.0f);
+        if (__ballot(fit) != 0ull) {                            // (wave-uniform; rare between unrelated genomes)
+            EbSums s;
+#pragma unroll
+            for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
+                if (t < passed[u] && fit) s.add(g.kf[t], g.ytab[cnt[u][t] <= maxnbits ? cnt[u][t] : maxnbits]);
+            }
+            if (alive) {
+                for (uint32_t t = g.nk; t < g.nk_total; ++t) {
+                    const uint32_t same = ext[wave][u][t - g.nk][lane];
+                    if (same == 0xFFFFu) break;
+                    const double y = g.ytab[same <= maxnbits ? same : maxnbits];
+                    if (y < g.tolerance) break;                 // jaccard.rs:89-91
+                    s.add(g.kf[t], y);
+                }
+            }
+            if (fit) v = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+        }
+        // does this 64-column block bring the row anything below its knn-th best?  (the key is the core distance)  The merge
+        // reads the marked blocks of a row only, so an unmarked block's 64 records are not even stored.
+        bool store = in_range;
+        if (g.r_bits != nullptr) {
+            const bool marked = __ballot(in_range && sortable_bits(v.x) < thr_row) != 0ull;
+            if (marked && lane == 0u) {
+                const uint32_t blk = c_raw >> 6;
+                atomicOr(&g.r_bits[(size_t)row * g.r_bits_stride + (blk >> 5)], 1u << (blk & 31u));
+            }
+            store = store && marked;
+        }
+        if (store) ((float2 *)g.out)[p] = v;
+        // the turned copy: pre-filled with (1, 1); everything else is stored, and marked where it beats the column's knn-th
+        // best.  Once every list holds knn candidates (none above 1: plain_marks_nothing, the host knows) a (1, 1) marks
+        // nothing, so a block of nothing but (1, 1) -- nearly every block -- is done here: no look at its columns' thresholds.
+        const bool plain = __float_as_uint(v.x) == 0x3F800000u && __float_as_uint(v.y) == 0x3F800000u;
+        const bool turn = in_range && c >= g.t_col_begin && !(plain && g.plain_marks_nothing);
+        if (g.out_t == nullptr || __ballot(turn) == 0ull) continue;
+        if (turn) {
+            if (!plain) reinterpret_cast<float2 *>(g.out_t)[(size_t)(c - g.t_col_begin) * g.t_stride + row] = v;
+            if (g.t_flag != nullptr && sortable_bits(v.x) < g.t_thr[(size_t)c * g.t_thr_stride]) {
+                g.t_flag[c] = g.t_flag_value;
+                if (g.t_bits != nullptr) {
+                    const uint32_t tb = row >> 5;
+                    atomicOr(&g.t_bits[(size_t)c * g.t_bits_stride + (tb >> 5)], 1u << (tb & 31u));
+                }
             }
         }
     }
@@ -348,10 +487,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t stream)
 {
     if (args.rows == 0 || args.nB == 0) return hipSuccess;
+    if (args.nk > KNN_MAXKE) return hipErrorInvalidValue;
+    const uint32_t per_wg = 256u * KNN_BLOCKS;
     for (uint32_t r0 = 0; r0 < args.rows; r0 += 32768u) {
         EpilogueKnnArgs a = args;
         a.row_base = r0;
-        hipLaunchKernelGGL(coreacc_epilogue_knn_kernel, dim3((args.nB + 255u) / 256u, std::min(32768u, args.rows - r0)), dim3(256), 0, stream, a);
+        const dim3 gr((args.nB + per_wg - 1u) / per_wg, std::min(32768u, args.rows - r0)), bl(256);
+        if (args.ss64 <= 32u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<1>, gr, bl, 0, stream, a);
+        else if (args.ss64 <= 64u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<2>, gr, bl, 0, stream, a);
+        else hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<0>, gr, bl, 0, stream, a);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
