@@ -386,6 +386,7 @@ Knobs read_knobs()
     k.eb_pipeline = env_int("SKL_EB_PIPELINE", 1) != 0;
     k.eb_pipeline_min = std::max(2ll, env_int("SKL_EB_PIPELINE_MIN", 64ll << 20));
     k.counts_u16 = env_int("SKL_COUNTS_U16", 1) != 0;
+    k.eb_lds_rows = env_int("SKL_EB_LDS_ROWS", 1) != 0;
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
@@ -1447,6 +1448,9 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         }
         e.min_alive = rows->min_alive;
         e.cnt_u16 = g.cnt_u16;
+        // (the workgroup's row slices in LDS pay from ~8 completions per workgroup of 256 pairs on: n = 16 000 at 4 096 bins, 4.9 %
+        // still in the running: 18.0 against 18.7 ms; at 2 048 bins, 1.4 %: 30.8 against 27.3 -- profiles/r06_epilogue_forms.md)
+        e.lds_rows = ctx->knobs.eb_lds_rows && plan != nullptr && plan->alive_share >= 0.03 ? 1u : 0u;
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;
         e.rezero_plane1 = sliced && ctx->last_tail ? 1u : 0u;

@@ -64,6 +64,7 @@ struct Knobs {
                                       // sample of the pairs says it pays; 2..7 forced with that many lengths counted (tests).  Results identical.
     bool eb_pipeline = true;          // A/B build, SKL_EB_PIPELINE=0: the row bands of a large early-break call run one after the other on one stream
     long long eb_pipeline_min = 64ll << 20;  // A/B build, SKL_EB_PIPELINE_MIN: pairs from which an early-break call is cut into overlapping row bands (tests force it low)
+    bool eb_lds_rows = true;          // A/B build, SKL_EB_LDS_ROWS=0: completions read the row sample's slice from memory, not from the workgroup's LDS copy
     bool counts_u16 = true;           // A/B build, SKL_COUNTS_U16=0: the counts scratch keeps u32 records
     bool epilogue_r5 = false;         // A/B build, SKL_EPILOGUE_R5=1: round 5's epilogue (alive pairs completed where they are found; timing)
     bool knn_sparse = true;           // A/B build, SKL_KNN_SPARSE=0: tiles that survive the probe are walked whole (results identical)

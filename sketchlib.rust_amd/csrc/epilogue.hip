@@ -248,6 +248,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
         if (alive && !(COMP || g.block_ke != nullptr)) eb_pair_of(g, p + g.out_base, i, j);
         if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(alive_mask));   // (1 024 slots: a million adds to ONE address queue up)
     }
+    // ROWS IN LDS (g.lds_rows: launches with one ke for every pair, sketches whose two slices fit).  The 256 pairs of a workgroup
+    // are consecutive in the launch's flat order -- columns of one row, then of the next -- so if any of them is still in the
+    // running, the workgroup stages the slices (of the first length not counted) of its first pair's row and of the row behind
+    // it ONCE, and a completion reads only its column sample's slice from memory: half the L2 traffic of the completions.
+    extern __shared__ uint2 eb_lds_rows[];   // [2][2 ss64][7]
+    uint32_t i_wg = 0;
+    bool staged = false;
+    if (g.lds_rows) {                       // (workgroup-uniform; every thread is still here: see the top)
+        if (__syncthreads_or(alive ? 1 : 0)) {
+            uint32_t j_wg;
+            eb_pair_of(g, (uint64_t)blockIdx.x * blockDim.x + g.out_base, i_wg, j_wg);
+            const uint32_t per_row = g.ss64 * 14u;   // uint2 per slice
+            const uint2 *src = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_wg * g.nk_total + g.nk) * g.ss64) * BBITS);
+            const size_t next_row = (size_t)g.nk_total * g.ss64 * BBITS;   // uint2 between the same slice of consecutive samples
+            for (uint32_t x = threadIdx.x; x < 2u * per_row; x += blockDim.x) {
+                const uint32_t r = x >= per_row ? 1u : 0u;   // (the row slab ends in pad rows: row i_wg + 1 always exists)
+                eb_lds_rows[x] = src[(size_t)r * next_row + (x - r * per_row)];
+            }
+            __syncthreads();
+            staged = true;
+        }
+    }
     // the pairs of this wave still in the running, one after the other -- all 64 lanes count the bins the pair shares at the next
     // length, until the reference's break
     uint64_t todo = __ballot(alive);
@@ -263,7 +285,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
         }
         EbRow<0> none;
         for (uint32_t t = ke_l; t < g.nk_total; ++t) {
-            const uint32_t same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_l, j_l, t, false, lane);
+            uint32_t same;
+            if (staged && t == g.nk && i_l - i_wg < 2u) {   // the row's slice from LDS, the column's as one contiguous run
+                const uint32_t halves = g.ss64 * 2u;
+                const uint2 *a_lds = eb_lds_rows + (size_t)(i_l - i_wg) * g.ss64 * 14u;
+                const uint2 *pj = reinterpret_cast<const uint2 *>(g.cols_ref + (((uint64_t)j_l * g.nk_total + t) * g.ss64) * BBITS);
+                uint32_t part = 0;
+                for (uint32_t h0 = 0; h0 < halves; h0 += 64u) {
+                    const uint32_t h = h0 + lane;
+                    uint2 a[7];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) a[q] = h < halves ? a_lds[(size_t)h * 7 + q] : make_uint2(0u, 0u);
+                    part += eb_trip(a, pj, h, halves, lane);
+                }
+                same = g.ss64 * 64u - eb_wave_sum(part);
+            } else {
+                same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_l, j_l, t, false, lane);
+            }
             if (eb_stops<COMP>(g, same, c1_l, c2_l)) break;   // (wave-uniform)
             if ((int)lane == l) s.add(g.kf[t], eb_lnj<COMP>(g, same, c1, c2));
         }
@@ -572,8 +610,12 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
     const uint64_t blocks = (args.n_pairs + 255) / 256;
     if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 gr((unsigned)blocks), bl(256);
-    if (args.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, 0, stream, args);
-    else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, 0, stream, args);
+    EpilogueArgs a = args;
+    // the workgroup's two row slices in LDS: one ke for every pair (the slices are those of length index nk), up to 16 KB
+    const size_t lds = early && a.block_ke == nullptr && a.ss64 * 224ull <= 16384ull && a.lds_rows != 0u ? (size_t)a.ss64 * 224u : 0u;
+    a.lds_rows = lds != 0 ? 1u : 0u;
+    if (a.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, lds, stream, a);
+    else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, lds, stream, a);
     return hipGetLastError();
 }
 

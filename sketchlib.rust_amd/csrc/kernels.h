@@ -238,6 +238,7 @@ struct EpilogueArgs {
     uint32_t nk_total;
     const uint64_t *rows_ref, *cols_ref;
     uint32_t *alive_count;      // 1 024 words, slot blockIdx & 1023 += pairs completed here (diagnostic; may be null)
+    uint32_t lds_rows;          // host-side request (epilogue.hip): a workgroup with a pair still in the running stages its two row slices in LDS
     uint32_t min_alive;         // no completeness correction: ln J(count) < tolerance <=> count < min_alive (0xFFFFFFFF: ask ytab)
     uint32_t cnt_u16;           // 1: the counts are u16 records (sketches of up to 1 023 chunks, no chunk slices)
     // EARLY BREAK DECIDED PER BLOCK: block_ke[(i >> blk_shift_r) * blk_cols + (j >> blk_shift_c)] = k-mer lengths the pair kernel
