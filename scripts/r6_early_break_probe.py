@@ -78,6 +78,27 @@ if "species" in cases:
     per = 320
     parts = [synth.set_clustered_device(per, 5, 64, dev, n_clusters=1, keep=[0.97, 0.955, 0.94, 0.925, 0.91], seed=synth.SEED_R + 7 * s) for s in range(50)]
     time_self("n = 16 000 sorted by 50 species", torch.cat(parts), per * 50, K5, 64, 5)
+if "cfg3" in cases:    # BASELINE configs[2] at FULL size: 100 000 genomes all-vs-all, 4 096 bins, Set U (40 GB of output)
+    time_self("cfg3 FULL: n = 100 000 Set U", synth.set_u_device(100000, 5, 64, dev), 100000, K5, 64, 2)
+if "cfg4" in cases:    # BASELINE configs[3] at FULL size: 1 M clustered references x 10 000 queries, 2 048 bins (80 GB of output)
+    kmers, ss64, nr, nq = [13, 17, 21, 25, 29], 32, 1_000_000, 10_000
+    keep = [0.97, 0.955, 0.94, 0.925, 0.91]
+    g_r = ctx.sketches(synth.set_clustered_device(nr, 5, ss64, dev, cluster_size=200, keep=keep), nr, kmers, ss64)
+    g_q = ctx.sketches(synth.set_clustered_device(nq, 5, ss64, dev, keep=keep, first_sample=10_000_000, n_clusters=nr // 200), nq, kmers, ss64)
+    out = torch.zeros((nr, nq, 2), dtype=torch.float32, device=dev)
+    p4 = g_r.set_k()
+    capi.cross_dists_all(ctx, g_r, g_q, p4, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        capi.cross_dists_all(ctx, g_r, g_q, p4, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    print(json.dumps({"case": "cfg4 FULL: 1 000 000 x 10 000 clustered, 2 048 bins", "ms": round(dt * 1e3, 3), "pairs_per_s": nr * nq / dt, "kernel": ctx.last_kernel()[-150:],
+                      "pooled_lengths": ctx.early_break_blocks()["pooled_lengths"], "checksum": float(out.view(-1)[:2000000].double().sum().item()), **tag}), flush=True)
+    g_r.close()
+    g_q.close()
+    del out
 if "cross" in cases:
     # BASELINE configs[3] in small: 300 000 clustered references x 10 000 queries, 2 048 bins, k = 13 ... 29
     kmers, ss64, nr, nq = [13, 17, 21, 25, 29], 32, 300_000, 10_000

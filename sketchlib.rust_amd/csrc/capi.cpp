@@ -979,10 +979,20 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 // it within (round 5 decided once per slab pair).  Blocks of one mind give a plain launch; otherwise the pair kernel's
 // (tile, k index) workgroups look their block up and leave when k index >= its ke.
 // EB_COST, measured (profiles/r06_early_break_forced_lengths.md: whole calls with 2 / 3 lengths forced, T(3) - T(2) = one length's
-// kernel time - EB_COST x the difference of the alive shares): 15-22 at 2 048 and 4 096 bins.  Beyond 65 535 bins a completion
-// is a run of thousands of dependent trips of one wave and comes to ~60: there the early break is taken only where hardly a
-// pair stays in the running.
-constexpr double EB_COST = 20.0, EB_COST_BIG = 60.0;
+// kernel time - EB_COST x the difference of the alive shares): 15-22 while the column samples' slices of ONE k-mer length
+// (n_cols x sketchsize64 x 112 bytes) fit the 256 MB Infinity Cache -- a completion then reads its column slice from there --
+// and 37-40 when they do not (cfg 3: 717 MB) and every completion is a 7 KB gather from HBM.  Beyond 65 535 bins a
+// completion is a run of thousands of dependent trips of one wave and comes to ~60: there the early break is taken only
+// where hardly a pair stays in the running.
+constexpr double EB_COST = 20.0, EB_COST_HBM = 40.0, EB_COST_BIG = 60.0;
+static double eb_cost_of(const skl_sketches *rows, const skl_sketches *cols)
+{
+    if (rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS) return EB_COST_BIG;
+    const double slice_mb = (double)cols->n * (double)rows->ss64 * 112.0 / (1024.0 * 1024.0);
+    if (slice_mb <= 128.0) return EB_COST;
+    if (slice_mb >= 512.0) return EB_COST_HBM;
+    return EB_COST + (EB_COST_HBM - EB_COST) * (slice_mb - 128.0) / 384.0;
+}
 constexpr uint32_t EB_BLOCKS_MAX = 64;      // blocks per side
 constexpr uint32_t EB_SAMPLES_MIN = 128;    // sampled pairs per block
 constexpr uint32_t EB_SAMPLES_TOTAL = 4096; // ... and at least this many in all
@@ -1130,7 +1140,7 @@ int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches 
             pooled_n += hist[(size_t)b * 9 + m];
         }
     }
-    const double eb_cost = rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS ? EB_COST_BIG : EB_COST;
+    const double eb_cost = eb_cost_of(rows, cols);
     plan->lengths = best_lengths(pooled, pooled_n, rows->nk, eb_cost, &plan->alive_share);
     if (live_blocks > 1) {
         // per block.  Pass 1: every block's own sample decides whether it takes the early break at all; pass 2: the blocks that
@@ -1251,10 +1261,14 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // equal pair count.  From 64 Mi pairs on the bands are also what hides the epilogue: band i's epilogue (+ completion
         // of the pairs still in the running) is memory-bound, band i + 1's counts kernel is bound by the vector ALUs, so they
         // run side by side -- counts kernels on the context's stream, epilogues on its second stream, two counts buffers.
+        // (the side-by-side run costs the counts kernel about what it hides of the epilogue -- an epilogue wave displaces a wave of the
+        // counts kernel, which fills the register file by itself -- and pays only where the epilogue is heavy: from ~3 % of the
+        // pairs still in the running.  n = 16 000 at 4.9 %: 18.5 against 19.4 ms; cfg 3 at 1.1 %: 782 against 748 ms.)
+        const bool piping = early && ctx->knobs.eb_pipeline && (eb_mixed || (plan != nullptr && plan->alive_share >= 0.03) || ctx->knobs.early_break >= 2);
         if (!ctx->eb_in_pipeline && r1 - r0 > 1 &&
-            (pairs * nkw * cnt_bytes > COUNTS_SCRATCH_MAX || (early && ctx->knobs.eb_pipeline && pairs >= (uint64_t)ctx->knobs.eb_pipeline_min))) {
+            (pairs * nkw * cnt_bytes > COUNTS_SCRATCH_MAX || (piping && pairs >= (uint64_t)ctx->knobs.eb_pipeline_min))) {
             const uint64_t fit = std::max<uint64_t>(1, COUNTS_SCRATCH_MAX / (nkw * cnt_bytes));
-            const uint64_t want = early && ctx->knobs.eb_pipeline ? std::max<uint64_t>((uint64_t)ctx->knobs.eb_pipeline_min / 2, pairs / 8) : fit;
+            const uint64_t want = piping ? std::max<uint64_t>((uint64_t)ctx->knobs.eb_pipeline_min / 2, pairs / 8) : fit;
             const uint64_t n_bands = (pairs + std::min(fit, want) - 1) / std::min(fit, want);
             std::vector<uint64_t> cuts(1, r0);
             for (uint64_t b = 1; b < n_bands; ++b) {
@@ -1274,7 +1288,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
                 if (cut > cuts.back()) cuts.push_back(cut);
             }
             cuts.push_back(r1);
-            const bool overlap = early && ctx->knobs.eb_pipeline && cuts.size() > 2;
+            const bool overlap = piping && cuts.size() > 2;
             if (overlap && !ctx->eb_events[0]) {
                 for (auto &ev : ctx->eb_events) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             }
