@@ -286,6 +286,24 @@ int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, const skl_dis
                               size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
                               float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr);
 int skl_knn_heaps_clear(skl_ctx *ctx, size_t row_begin, size_t row_end, uint32_t *h_len, uint32_t *thr);
+/* The same pipeline DECOUPLED (round 6): no participant waits for another.  A BinaryHeap that starts EMPTY on a window takes a
+ * superset of what the row's true heap (the one that has met every earlier window) would take there -- its maximum is never
+ * lower, and push_heap pushes on `key < maximum` (mod.rs:41-48).  So every participant clears ALL its heaps, runs its window
+ * band by band with skl_self_dists_knn_window_logged, which also appends every candidate a heap takes to the row's ACCEPT LOG,
+ * in order: log_rec [n][log_cap] records of 1 float (the key) or 2 (CoreAcc: key, second distance), log_id [n][log_cap],
+ * log_len [n] (zeroed by the caller; it counts past log_cap -- an overflowed row's log is useless and the caller falls back
+ * to the travelling heaps; random candidate order takes ~knn (1 + ln(window / knn)) entries).  The row's true list is then
+ * skl_knn_heaps_replay of the participants' logs for that row in WINDOW ORDER into one empty heap (rows: the pointers are at
+ * the first of them; logs of participants that own no column of a row's candidates are empty), then skl_knn_heaps_finalize.
+ * Exactness: a candidate missing from a log was refused by a heap whose maximum was at least the true heap's.  What it
+ * costs: tile pruning sees only the window's own relatives (scripts/knn_pipeline_model.py). */
+int skl_self_dists_knn_window_logged(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                                     size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
+                                     float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr,
+                                     float *log_rec, uint32_t *log_id, uint32_t *log_len, size_t log_cap);
+int skl_knn_heaps_replay(skl_ctx *ctx, size_t rows, size_t knn, int coreacc, const float *log_rec, const uint32_t *log_id,
+                         const uint32_t *log_len, size_t log_cap, float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len,
+                         uint32_t *thr);
 /* For callers without a device runtime of their own (the C++ host layer sees only this header): device memory on the
  * context's device for the heap arrays above, and copies between it and host memory (to_device != 0: host -> device),
  * ordered with the context's stream and complete on return. */

@@ -84,6 +84,8 @@ def lib():
         L.sko_heap_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
         L.sko_heap_feed.restype = None
         L.sko_heap_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        L.sko_heap_feed_logged.restype = None
+        L.sko_heap_feed_logged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
         L.sko_heap_sorted.restype = None
         L.sko_heap_sorted.argtypes = [C.c_void_p, C.c_size_t]
         L.sko_cross_dists_knn.restype = C.c_long
@@ -190,12 +192,19 @@ class Heaps:
         self.items = np.zeros((n, knn + 1), dtype=SPARSE_DTYPE)
         self.len = np.zeros(n, dtype=np.uintp)
 
-    def feed(self, row, ids, keys, d1=None):
+    def feed(self, row, ids, keys, d1=None, log=False):
+        """push_heap over the candidates in the order given; log=True: -> bool array, which of them the heap took."""
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
         keys = np.ascontiguousarray(keys, dtype=np.float32)
         d1 = None if d1 is None else np.ascontiguousarray(d1, dtype=np.float32)
+        if log:
+            took = np.zeros(ids.size, dtype=np.uint8)
+            lib().sko_heap_feed_logged(self.items[row].ctypes.data, self.len[row:row + 1].ctypes.data, ids.ctypes.data, keys.ctypes.data,
+                                       None if d1 is None else d1.ctypes.data, ids.size, self.knn, took.ctypes.data)
+            return took.astype(bool)
         lib().sko_heap_feed(self.items[row].ctypes.data, self.len[row:row + 1].ctypes.data, ids.ctypes.data, keys.ctypes.data,
                             None if d1 is None else d1.ctypes.data, ids.size, self.knn)
+        return None
 
     def sorted_rows(self):
         out = self.items.copy()

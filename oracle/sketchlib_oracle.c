@@ -513,6 +513,25 @@ void sko_heap_feed(sko_sparse *heap, size_t *len, const uint64_t *ids, const flo
     *len = h.len;
 }
 
+/* ... and which of the candidates the heap TOOK (accepted[c] = 1: push_heap's condition held, mod.rs:42): the accept log of the
+ * decoupled column windows -- a heap that arrives later with more in it takes a subset of these. */
+void sko_heap_feed_logged(sko_sparse *heap, size_t *len, const uint64_t *ids, const float *keys, const float *d1, size_t n, size_t knn,
+                          uint8_t *accepted)
+{
+    heap_t h;
+    h.data = heap;
+    h.len = *len;
+    for (size_t c = 0; c < n; ++c) {
+        sko_sparse item;
+        item.idx = ids[c];
+        item.d0 = keys[c];
+        item.d1 = d1 ? d1[c] : 0.0f;
+        accepted[c] = (uint8_t)(h.len < knn || item.d0 < h.data[0].d0);
+        push_heap(&h, item, knn);
+    }
+    *len = h.len;
+}
+
 void sko_heap_sorted(sko_sparse *heap, size_t len)
 {
     heap_t h;

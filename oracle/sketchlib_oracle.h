@@ -101,6 +101,8 @@ size_t sko_heap_replay(const uint64_t *ids, const float *keys, size_t n, size_t 
 
 /* ... and resumable: heap[0 .. *len) is the BinaryHeap's array between calls (capacity knn + 1 items). */
 void sko_heap_feed(sko_sparse *heap, size_t *len, const uint64_t *ids, const float *keys, const float *d1, size_t n, size_t knn);
+void sko_heap_feed_logged(sko_sparse *heap, size_t *len, const uint64_t *ids, const float *keys, const float *d1, size_t n, size_t knn,
+                          uint8_t *accepted);
 void sko_heap_sorted(sko_sparse *heap, size_t len);
 
 /* mod.rs:133-224.  out: n*knn items, row-major (row i, neighbours ascending). */

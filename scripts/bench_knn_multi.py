@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--clustered", action="store_true", help="clustered sketches instead of Set U")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--ties", default="reference", choices=["reference", "canonical"])
+    ap.add_argument("--decoupled", action="store_true", help="reference ties: every rank runs its window against empty heaps and logs what "
+                    "they take; logs replayed in window order (multi_gpu.self_knn_once_reference_decoupled); falls back to the travelling heaps")
     args = ap.parse_args()
 
     import torch
@@ -61,7 +63,14 @@ def main():
     reference = args.ties == "reference"
     ctx.set_knn_ties(capi.TIES_REFERENCE if reference else capi.TIES_CANONICAL)
 
+    fell_back = [False]
+
     def knn_once():
+        if reference and args.decoupled:
+            res = multi_gpu.self_knn_once_reference_decoupled(ctx, sk, p, args.knn, rank, world, dist, device, host_staged=gloo)
+            if res is not None:
+                return res
+            fell_back[0] = True
         if reference:
             return multi_gpu.self_knn_once_reference(ctx, sk, p, args.knn, rank, world, dist, device, host_staged=gloo)
         return multi_gpu.self_knn_once(ctx, sk, p, args.knn, rank, world, dist, device)
@@ -86,7 +95,9 @@ def main():
     wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    line = {"mode": ("self kNN, every pair once, the reference's tie order: column windows, heaps travelling from rank to rank band by band"
+    line = {"mode": (("self kNN, every pair once, the reference's tie order: column windows against empty heaps, accept logs replayed in window order (decoupled)"
+                      if args.decoupled and not fell_back[0] else
+                      "self kNN, every pair once, the reference's tie order: column windows, heaps travelling from rank to rank band by band")
                      if reference else "self kNN, every pair once, canonical ties: row bands dealt over the ranks + all-to-all of partial states"),
             "ties": args.ties, "backend": "gloo (host-staged)" if gloo else "nccl",
             "n": args.n, "knn": args.knn, "sketchsize64": args.ss64, "keys": "core/acc" if args.coreacc else "jaccard k=21",

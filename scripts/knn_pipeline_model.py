@@ -4,8 +4,13 @@
 starts below its window's end in ascending order, and cannot start a band whose rows lie below its window before rank r - 1
 has finished that band.  A band's cost on a rank = its rows x the columns evaluated / the single-GPU pair rate.
 
-    python scripts/knn_pipeline_model.py [n] [band_rows] [world] [pairs_per_s]
+and of its DECOUPLED form (round 6; multi_gpu.self_knn_once_reference_decoupled): every rank runs the same bands of its window
+against heaps that start empty and waits for nobody -- it finishes after its own window's work -- then the accept logs
+(~knn (1 + ln(window / knn)) entries of 8 or 12 bytes per row and rank) cross the xGMI links once and are replayed.
+
+    python scripts/knn_pipeline_model.py [n] [band_rows] [world] [pairs_per_s] [knn]
 """
+import math
 import sys
 
 ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
@@ -36,8 +41,24 @@ def main():
         finish.append(t)
     single = n * (n - 1) / 2 / rate
     print(f"n = {n}, {world} ranks, windows {cuts}")
-    print(f"one GPU {single:.2f} s; perfect split {single / world:.2f} s; ranks finish at " + ", ".join(f"{x:.2f}" for x in finish) +
-          f" s -> speed-up {single / finish[-1]:.2f} x")
+    print(f"one GPU {single:.2f} s; perfect split {single / world:.2f} s")
+    print("travelling heaps: ranks finish at " + ", ".join(f"{x:.2f}" for x in finish) + f" s -> speed-up {single / finish[-1]:.2f} x")
+    # decoupled: a rank's own work only (the windows hold equal pair counts), then the logs: every rank sends the rows below its
+    # window's end their entries, each row receives from the ranks at or behind its own; one xGMI link per peer at 60 GB/s
+    # effective, and the replay of ~entries pushes per row at the heap kernels' measured ~1e9 pushes/s per GPU
+    knn = int(sys.argv[5]) if len(sys.argv) > 5 else 50
+    own = [sum((min(n, (b + 1) * band) - b * band) * (cuts[r + 1] - max(b * band, cuts[r])) for b in range(n_bands) if b * band < cuts[r + 1]) / rate
+           for r in range(world)]
+    entries = [knn * (1.0 + math.log(max(1.0, (cuts[r + 1] - cuts[r]) / knn))) for r in range(world)]
+    rec_bytes = 12.0
+    sent = [cuts[r + 1] * entries[r] * rec_bytes * (world - 1) / world for r in range(world)]          # what leaves rank r
+    exchange = max(sent) / ((world - 1) * 60e9) if world > 1 else 0.0
+    replay = (n / world) * sum(entries) / 1e9
+    total = max(own) + exchange + replay
+    print("decoupled windows: ranks finish their windows at " + ", ".join(f"{x:.2f}" for x in own) +
+          f" s; logs {max(entries):.0f} entries per row and rank, {max(sent) / 1e9:.2f} GB out of the busiest rank: exchange {exchange * 1e3:.0f} ms, "
+          f"replay {replay * 1e3:.0f} ms -> {total:.2f} s, speed-up {single / total:.2f} x"
+          " (before what the weaker pruning costs: a window's heaps see only that window's relatives)")
 
 
 if __name__ == "__main__":

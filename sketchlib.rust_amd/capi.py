@@ -63,6 +63,9 @@ _SIG = [
     ("skl_ctx_set_knn_ties", C.c_int, [_P, C.c_int]),
     ("skl_self_dists_knn_window", C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P]),
     ("skl_knn_heaps_clear", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, _P]),
+    ("skl_self_dists_knn_window_logged", C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P,
+                                                   _P, _P, _P, C.c_size_t]),
+    ("skl_knn_heaps_replay", C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_int, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P]),
     ("skl_knn_heaps_finalize", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     ("skl_device_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     ("skl_device_free", C.c_int, [_P, _P]),
@@ -498,6 +501,39 @@ def self_dists_knn_window(ctx, s, p, knn, band_rows, band, col_lo, col_hi, heaps
     ptr = lambda t: _ptr(t)[0]
     _check(load().skl_self_dists_knn_window(ctx._h, s._h, C.byref(p), knn, band_rows, band, col_lo, col_hi, ptr(heaps["h_key"]),
                                             ptr(heaps["h_id"]), ptr(heaps["h_d1"]), ptr(heaps["h_len"]), ptr(heaps["thr"])))
+
+
+def knn_logs_alloc(n, cap, coreacc, device):
+    """Accept logs of the decoupled column windows (skl_self_dists_knn_window_logged): device tensors for n rows, empty."""
+    import torch
+
+    return {"rec": torch.zeros((n, cap, 2 if coreacc else 1), dtype=torch.float32, device=device),
+            "id": torch.zeros((n, cap), dtype=torch.int32, device=device),
+            "len": torch.zeros((n,), dtype=torch.int32, device=device), "cap": cap}
+
+
+def self_dists_knn_window_logged(ctx, s, p, knn, band_rows, band, col_lo, col_hi, heaps, logs):
+    """skl_self_dists_knn_window_logged: as self_dists_knn_window, and every candidate a heap takes is appended to the row's log."""
+    ptr = lambda t: _ptr(t)[0]
+    _check(load().skl_self_dists_knn_window_logged(ctx._h, s._h, C.byref(p), knn, band_rows, band, col_lo, col_hi, ptr(heaps["h_key"]),
+                                                   ptr(heaps["h_id"]), ptr(heaps["h_d1"]), ptr(heaps["h_len"]), ptr(heaps["thr"]),
+                                                   ptr(logs["rec"]), ptr(logs["id"]), ptr(logs["len"]), logs["cap"]))
+
+
+def knn_heaps_replay(ctx, heaps, r0, r1, knn, rec, ids, lens):
+    """skl_knn_heaps_replay: the heaps of rows [r0, r1) (of `heaps`, arrays over all rows) are fed the logged candidates
+    rec [r1 - r0, cap, 1 | 2] f32 / ids [r1 - r0, cap] i32 / lens [r1 - r0] i32 (device tensors), each row's in the order logged."""
+    if r1 <= r0:
+        return
+    coreacc = heaps["h_d1"] is not None
+    cap = int(rec.shape[1])
+    if cap == 0:
+        return
+    rec, ids, lens = rec.contiguous(), ids.contiguous(), lens.contiguous()
+    sl = lambda t: None if t is None else t[r0:r1]
+    ptr = lambda t: _ptr(t)[0]
+    _check(load().skl_knn_heaps_replay(ctx._h, r1 - r0, knn, int(coreacc), ptr(rec), ptr(ids), ptr(lens), cap, ptr(sl(heaps["h_key"])),
+                                       ptr(sl(heaps["h_id"])), ptr(sl(heaps["h_d1"])), ptr(sl(heaps["h_len"])), ptr(sl(heaps["thr"]))))
 
 
 def knn_heaps_finalize(ctx, heaps, r0, r1, knn, ani=False):

@@ -24,6 +24,10 @@ struct KnnState {
     float *h_key = nullptr, *h_d1 = nullptr;
     uint32_t *h_id = nullptr, *h_len = nullptr, *thr = nullptr;
     bool borrowed = false;   // the arrays belong to the caller (skl_self_dists_knn_window)
+    // accept log of the heap replays (skl_self_dists_knn_window_logged; RefHeapMergeArgs::log_*), the caller's arrays
+    float *log_rec = nullptr;
+    uint32_t *log_id = nullptr, *log_len = nullptr;
+    uint32_t log_cap = 0;
     ~KnnState()
     {
         if (borrowed) return;
@@ -379,6 +383,10 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             m.h_d1 = st.h_d1;
             m.h_len = st.h_len;
             m.thr = st.thr;
+            m.log_rec = st.log_rec;
+            m.log_id = st.log_id;
+            m.log_len = st.log_len;
+            m.log_cap = st.log_cap;
             m.force_workgroup_form = ctx->knobs.refheap_wave ? 0u : 1u;
             // rows below the band FIRST: for them the band's samples are the next candidates in ascending id, and their
             // own band comes later; then the band's own rows (columns [b0, n) minus themselves: everything below b0 reached
@@ -833,9 +841,10 @@ extern "C" int skl_self_dists_knn_partial(skl_ctx *ctx, const skl_sketches *s, c
 // where every heap ends.  The heaps of rows [b0, b1) are handed on as soon as the band is done, so the participants work one
 // band behind each other.  This call is one band on one participant; the caller owns the heap arrays (device memory, the
 // RefHeap layout of skl_knn_heaps_*: h_key / h_id / h_d1 [n][knn], h_len [n], thr [n]) and moves row slices between devices.
-extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
-                                         size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
-                                         float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr)
+static int knn_window_impl(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                           size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
+                           float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr,
+                           float *log_rec, uint32_t *log_id, uint32_t *log_len, size_t log_cap)
 {
     SKL_TRY(check_params(s, s, p));
     SKL_TRY(ctx_bind(ctx));
@@ -858,6 +867,10 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
     st.h_d1 = h_d1;
     st.h_len = h_len;
     st.thr = thr;
+    st.log_rec = log_rec;
+    st.log_id = log_id;
+    st.log_len = log_len;
+    st.log_cap = (uint32_t)log_cap;
     const std::vector<uint32_t> one{(uint32_t)band};
     // (the counters run on over the bands of a window: skl_ctx_knn_prune_stats reports everything since the last kNN
     // call of another kind -- no read-back, no reset here: this call must not stall the hand-over of the heaps)
@@ -867,6 +880,57 @@ extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, co
 }
 
 // Empty heaps (h_len = 0, thr = "not full") for rows [row_begin, row_end) of caller-owned state arrays.
+extern "C" int skl_self_dists_knn_window(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                                         size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
+                                         float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr)
+{
+    return knn_window_impl(ctx, s, p, knn, band_rows, band, col_lo, col_hi, h_key, h_id, h_d1, h_len, thr, nullptr, nullptr, nullptr, 0);
+}
+
+// DECOUPLED COLUMN WINDOWS (round 6).  The travelling heaps make participant r wait for r - 1.  A heap that starts EMPTY on a
+// window takes a superset of what the row's true heap -- the one that has already met every earlier window -- would take
+// there (its maximum is never lower, and push_heap's test is `key < maximum`, mod.rs:41-48), so every participant can run its
+// window against empty heaps at once and LOG what they take, in order; the row's true list is then the replay of the logs in
+// window order (skl_knn_heaps_replay): a candidate missing from a log was refused by a heap with a higher maximum, so the true
+// heap refuses it too, and the logged ones reach it in the order the reference would have shown them.
+extern "C" int skl_self_dists_knn_window_logged(skl_ctx *ctx, const skl_sketches *s, const skl_dist_params *p, size_t knn,
+                                                size_t band_rows, size_t band, size_t col_lo, size_t col_hi,
+                                                float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len, uint32_t *thr,
+                                                float *log_rec, uint32_t *log_id, uint32_t *log_len, size_t log_cap)
+{
+    if (!log_rec || !log_id || !log_len || log_cap == 0 || log_cap >= (1ull << 31)) return fail(SKL_ERR_INVALID_ARG, "accept-log pointers / capacity");
+    return knn_window_impl(ctx, s, p, knn, band_rows, band, col_lo, col_hi, h_key, h_id, h_d1, h_len, thr, log_rec, log_id, log_len, log_cap);
+}
+
+extern "C" int skl_knn_heaps_replay(skl_ctx *ctx, size_t rows, size_t knn, int coreacc, const float *log_rec, const uint32_t *log_id,
+                                    const uint32_t *log_len, size_t log_cap, float *h_key, uint32_t *h_id, float *h_d1, uint32_t *h_len,
+                                    uint32_t *thr)
+{
+    SKL_TRY(ctx_bind(ctx));
+    if (rows == 0) return SKL_OK;
+    if (!log_rec || !log_id || !log_len || !h_key || !h_id || !h_len || !thr || (coreacc && !h_d1)) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (knn == 0 || knn > (size_t)REFHEAP_LDS_MAX || log_cap == 0 || log_cap >= (1ull << 31) || rows >= (1ull << 31)) return fail(SKL_ERR_INVALID_ARG, "knn / capacity / rows out of range");
+    RefHeapMergeArgs m;
+    memset(&m, 0, sizeof m);
+    m.keys = log_rec;
+    m.stride2 = coreacc ? 2u : 1u;
+    m.key_stride = (uint64_t)log_cap * m.stride2;
+    m.rows = (uint32_t)rows;
+    m.cols = (uint32_t)log_cap;
+    m.self_id_base = 0xFFFFFFFFu;   // (a log never holds the row itself)
+    m.knn = (uint32_t)knn;
+    m.h_key = h_key;
+    m.h_id = h_id;
+    m.h_d1 = h_d1;
+    m.h_len = h_len;
+    m.thr = thr;
+    m.cand_ids = log_id;
+    m.row_cols = log_len;
+    m.force_workgroup_form = ctx->knobs.refheap_wave ? 0u : 1u;
+    HIP_TRY(launch_refheap_merge(m, ctx->stream));
+    return SKL_OK;
+}
+
 extern "C" int skl_knn_heaps_clear(skl_ctx *ctx, size_t row_begin, size_t row_end, uint32_t *h_len, uint32_t *thr)
 {
     SKL_TRY(ctx_bind(ctx));

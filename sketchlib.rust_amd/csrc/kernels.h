@@ -450,6 +450,15 @@ struct RefHeapMergeArgs {
     const uint32_t *seg_bits; // as TopkMergeArgs::seg_bits
     uint32_t seg_bits_stride, seg_shift;
     uint32_t force_workgroup_form;   // 1: one workgroup per row whatever knn is (default: one WAVE per row up to 256 neighbours; A/B, tests)
+    // ACCEPT LOG (decoupled column windows, capi_knn.cpp): every candidate push_heap takes is appended, in order, to the row's
+    // log -- log_rec[row * log_cap + x] (stride2 floats: key[, second value]), log_id[row * log_cap + x]; log_len[row] counts on
+    // past log_cap (overflow: the caller checks); rows indexed like the heaps (state_row_base + r).  Null: no log.
+    float *log_rec;
+    uint32_t *log_id, *log_len;
+    uint32_t log_cap;
+    // EXPLICIT CANDIDATES (the replay of such logs): record q of row r stands for sample cand_ids[r * cols + q] (null: id_base + q),
+    // and row r has row_cols[r] records (null: cols; clamped to cols).
+    const uint32_t *cand_ids, *row_cols;
 };
 hipError_t launch_refheap_merge(const RefHeapMergeArgs &args, hipStream_t stream);
 hipError_t launch_refheap_finalize(const float *h_key, const uint32_t *h_id, const float *h_d1, const uint32_t *h_len, uint32_t rows,

@@ -552,8 +552,8 @@ struct RefHeap {
         set(pos, elt);
         sift_up(start, pos);
     }
-    // mod.rs:41-48
-    __device__ void push_heap(const Elt &item, uint32_t knn)
+    // mod.rs:41-48; -> whether the item entered the heap (the accept log of the decoupled column windows)
+    __device__ bool push_heap(const Elt &item, uint32_t knn)
     {
         if (len < knn || item.k < key[0]) {
             set(len, item);
@@ -566,7 +566,9 @@ struct RefHeap {
                     sift_down_to_bottom(0u);
                 }
             }
+            return true;
         }
+        return false;
     }
     __device__ void into_sorted()
     {
@@ -584,6 +586,25 @@ struct RefHeap {
 
 // Shared scratch of the replay kernels: the candidates that passed the pre-filter since the last drain, in order.
 constexpr uint32_t REFHEAP_CAP = 2048;
+// ACCEPT LOG (RefHeapMergeArgs::log_*): every candidate a row's heap takes is appended to the row's log, in order -- what a
+// heap that arrives LATER with the row's earlier candidates already in it has to be shown of this launch's candidates (it
+// takes a subset: its maximum is never higher).  One thread writes (the one that pushes); len counts past cap (overflow).
+struct RefHeapLog {
+    float *rec = nullptr;
+    uint32_t *id = nullptr;
+    uint32_t cap = 0, len = 0, stride2 = 1;
+    __device__ __forceinline__ void add(const RefHeap::Elt &e)
+    {
+        if (rec == nullptr) return;
+        if (len < cap) {
+            rec[(size_t)len * stride2] = e.k;
+            if (stride2 == 2u) rec[(size_t)len * 2u + 1u] = e.d;
+            id[len] = e.i;
+        }
+        ++len;
+    }
+};
+
 struct RefHeapShared {
     float cand_key[REFHEAP_CAP], cand_d1[REFHEAP_CAP];
     uint32_t cand_id[REFHEAP_CAP];
@@ -598,7 +619,8 @@ struct RefHeapShared {
 // few bits), such stretches are not read.  sh.len / sh.thr describe the heap on entry and on return (whole workgroup).
 template <class IdOf>
 __device__ __forceinline__ void refheap_feed(RefHeap &h, RefHeapShared &sh, const float *keys, uint32_t stride2, uint32_t cols,
-                                             uint32_t knn, const IdOf &id_of, const uint32_t *bits, uint32_t seg_shift = 6u)
+                                             uint32_t knn, const IdOf &id_of, const uint32_t *bits, uint32_t seg_shift = 6u,
+                                             RefHeapLog *alog = nullptr)
 {
     constexpr uint32_t UNROLL = 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -606,7 +628,10 @@ __device__ __forceinline__ void refheap_feed(RefHeap &h, RefHeapShared &sh, cons
         if (tid == 0) {
             h.len = sh.len;
             const uint32_t m = sh.ncand;
-            for (uint32_t c = 0; c < m; ++c) h.push_heap(RefHeap::Elt{sh.cand_key[c], sh.cand_d1[c], sh.cand_id[c]}, knn);
+            for (uint32_t c = 0; c < m; ++c) {
+                const RefHeap::Elt e{sh.cand_key[c], sh.cand_d1[c], sh.cand_id[c]};
+                if (h.push_heap(e, knn) && alog != nullptr) alog->add(e);
+            }
             sh.len = h.len;
             sh.ncand = 0;
             sh.thr = h.len < knn ? __builtin_inff() : h.key[0];
@@ -780,12 +805,23 @@ __global__ __launch_bounds__(TOPK_THREADS) void refheap_merge_kernel(const RefHe
     __syncthreads();
     if (tid == 0) sh.thr = len0 < knn ? __builtin_inff() : h.key[0];
     __syncthreads();
-    refheap_feed(h, sh, g.keys + (size_t)row * g.key_stride, stride2, g.cols, knn,
+    RefHeapLog alog;   // (thread 0's copy is the one that counts)
+    if (g.log_rec != nullptr) {
+        alog.rec = g.log_rec + srow * g.log_cap * stride2;
+        alog.id = g.log_id + srow * g.log_cap;
+        alog.cap = g.log_cap;
+        alog.len = g.log_len[srow];
+        alog.stride2 = stride2;
+    }
+    const uint32_t cols = g.row_cols != nullptr ? min(g.cols, g.row_cols[row]) : g.cols;
+    const uint32_t *ids = g.cand_ids != nullptr ? g.cand_ids + (size_t)row * g.cols : nullptr;
+    refheap_feed(h, sh, g.keys + (size_t)row * g.key_stride, stride2, cols, knn,
                  [&](uint32_t q, uint32_t &id) {
-                     id = g.id_base + q;
+                     id = ids != nullptr ? ids[q] : g.id_base + q;
                      return id >= g.skip_below && id != self_id;
                  },
-                 g.seg_bits ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr, g.seg_shift != 0u ? g.seg_shift : 6u);
+                 g.seg_bits ? g.seg_bits + (size_t)row * g.seg_bits_stride : nullptr, g.seg_shift != 0u ? g.seg_shift : 6u, &alog);
+    if (tid == 0 && g.log_rec != nullptr) g.log_len[srow] = alog.len;
     const uint32_t len = sh.len;
     for (uint32_t x = tid; x < len; x += TOPK_THREADS) {
         g.h_key[srow * knn + x] = h.key[x];
@@ -815,9 +851,19 @@ __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMe
     const uint32_t row = blockIdx.x * 4u + wave;
     if (row >= g.rows) return;
     if (g.flag != nullptr && g.flag[row] != g.flag_value) return;
-    const uint32_t knn = g.knn, stride2 = g.stride2, cols = g.cols;
+    const uint32_t knn = g.knn, stride2 = g.stride2;
+    const uint32_t cols = g.row_cols != nullptr ? min(g.cols, g.row_cols[row]) : g.cols;
+    const uint32_t *ids = g.cand_ids != nullptr ? g.cand_ids + (size_t)row * g.cols : nullptr;
     const size_t srow = (size_t)(g.state_row_base + row);
     const uint32_t self_id = g.self_id_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : g.self_id_base + row;
+    RefHeapLog alog;   // (lane 0's copy is the one that counts)
+    if (g.log_rec != nullptr) {
+        alog.rec = g.log_rec + srow * g.log_cap * stride2;
+        alog.id = g.log_id + srow * g.log_cap;
+        alog.cap = g.log_cap;
+        alog.len = g.log_len[srow];
+        alog.stride2 = stride2;
+    }
     float *hm = heap_mem[wave];
     RefHeap h{hm, hm + (knn + 1u), reinterpret_cast<uint32_t *>(hm + 2u * (knn + 1u)), 0u, stride2 == 2u};
     auto wave_sync = [] {   // orders this wave's LDS traffic as the program states it
@@ -838,7 +884,10 @@ __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMe
         wave_sync();
         if (lane == 0u) {
             h.len = len;
-            for (uint32_t c = 0; c < ncand; ++c) h.push_heap(RefHeap::Elt{cand_key[wave][c], cand_d1[wave][c], cand_id[wave][c]}, knn);
+            for (uint32_t c = 0; c < ncand; ++c) {
+                const RefHeap::Elt e{cand_key[wave][c], cand_d1[wave][c], cand_id[wave][c]};
+                if (h.push_heap(e, knn)) alog.add(e);
+            }
             len = h.len;
             thr = h.len < knn ? __builtin_inff() : h.key[0];
         }
@@ -881,7 +930,7 @@ __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMe
         for (uint32_t j = 0; j < UNROLL; ++j) {
             if (!((mask >> j) & 1u)) continue;
             const uint32_t q = q0 + j * 64u + lane;
-            const uint32_t id = g.id_base + q;
+            const uint32_t id = ids != nullptr ? ids[min(q, cols - 1u)] : g.id_base + q;
             const bool open = len < knn;
             const bool take = q < cols && ((lane_ok >> j) & 1u) != 0u && id >= g.skip_below && id != self_id && (open || k[j] < thr);
             const uint64_t votes = __ballot(take);
@@ -898,6 +947,7 @@ __global__ __launch_bounds__(256) void refheap_merge_wave_kernel(const RefHeapMe
         }
     }
     if (ncand != 0u) drain();
+    if (lane == 0u && g.log_rec != nullptr) g.log_len[srow] = alog.len;
     if (dirty) {
         for (uint32_t x = lane; x < len; x += 64u) {
             g.h_key[srow * knn + x] = h.key[x];
@@ -941,7 +991,7 @@ __global__ __launch_bounds__(256) void topk_refheap_wave_kernel(const RefHeapArg
         wave_sync();
         if (lane == 0u) {
             h.len = len;
-            for (uint32_t c = 0; c < ncand; ++c) h.push_heap(RefHeap::Elt{cand_key[wave][c], cand_d1[wave][c], cand_id[wave][c]}, knn);
+            for (uint32_t c = 0; c < ncand; ++c) (void)h.push_heap(RefHeap::Elt{cand_key[wave][c], cand_d1[wave][c], cand_id[wave][c]}, knn);
             len = h.len;
             thr = h.len < knn ? __builtin_inff() : h.key[0];
         }

@@ -433,3 +433,101 @@ def self_knn_once_reference(ctx, sk, p, knn, rank, world, dist, device, band_row
         if t is not None and r1 > r0:
             dist.recv(t, src=world - 1)
     return r0, r1, idx.to(device), d0.to(device), (d1.to(device) if d1 is not None else None)
+
+
+def self_knn_once_reference_decoupled(ctx, sk, p, knn, rank, world, dist, device, band_rows=None, stage=None, replay=None, finalize=None,
+                                      heaps=None, logs=None, log_cap=None, host_staged=False):
+    """Self kNN in the reference's tie order over `world` ranks, every pair evaluated once, NO RANK WAITING FOR ANOTHER:
+    -> (row0, row1, idx, d0, d1) for this rank's row shard (device tensors; even_row_bounds), or None when some row's accept log
+    overflowed (then call self_knn_once_reference, the travelling heaps).  Every rank must call it.
+
+    A BinaryHeap that starts EMPTY on a column window takes a superset of what the row's true heap takes there (its maximum is
+    never lower; push_heap pushes on key < maximum, mod.rs:41-48).  So rank r runs ITS window [lo_r, hi_r) -- every row band
+    that starts below hi_r, the same calls as the travelling form -- against heaps it has cleared itself, logging per row what
+    the heaps take, in order (skl_self_dists_knn_window_logged); row x's true list is the replay of its logs in rank order into
+    one empty heap (skl_knn_heaps_replay) on the rank whose shard holds x.  Ranks exchange logs, not heaps: one all-to-all of
+    (lengths, records) per pair of ranks after the windows, nothing during them.
+
+    `stage(band, lo, hi, heaps, logs)`, `replay(heaps, r0, r1, rec, ids, lens)` and `finalize(heaps, r0, r1)` default to the
+    library's calls; the CPU tests of the protocol pass oracle-backed ones.  host_staged: messages through host memory (gloo)."""
+    import torch
+
+    from . import capi
+
+    n = sk.n
+    coreacc = p.dist_type == capi.COREACC
+    if band_rows is None:
+        band_rows = capi.knn_band_rows(sk, p, world)
+    n_bands = (n + band_rows - 1) // band_rows
+    cuts = knn_window_cuts(n, band_rows, world)
+    lo, hi = cuts[rank:rank + 2]
+    if log_cap is None:
+        log_cap = max(64, 16 * knn)
+    if heaps is None:
+        heaps = capi.knn_heaps_alloc(n, knn, coreacc, device)
+    if logs is None:
+        logs = capi.knn_logs_alloc(n, log_cap, coreacc, device)
+    if stage is None:
+        def stage(band, lo_, hi_, h, lg):
+            capi.self_dists_knn_window_logged(ctx, sk, p, knn, band_rows, band, lo_, hi_, h, lg)
+    if replay is None:
+        def replay(h, r0, r1, rec, ids, lens):
+            capi.knn_heaps_replay(ctx, h, r0, r1, knn, rec, ids, lens)
+    if finalize is None:
+        def finalize(h, r0, r1):
+            return capi.knn_heaps_finalize(ctx, h, r0, r1, knn, ani=bool(p.ani))
+    comm = torch.device("cpu") if host_staged else device
+    # 1. this rank's window against its own empty heaps, every band that holds a pair of it
+    for band in range(n_bands):
+        if band * band_rows >= hi:
+            break
+        stage(band, lo, hi, heaps, logs)
+    # 2. did every log hold?  (one number per rank; an overflow anywhere sends everybody to the travelling form)
+    worst = torch.tensor([int(logs["len"][:hi].max()) if hi > 0 else 0], dtype=torch.int64, device=comm)
+    if world > 1:
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    if int(worst.item()) > log_cap:
+        return None
+    # 3. logs to the ranks that finalise the rows: rank s holds candidates of the rows below hi_s
+    bounds = even_row_bounds(n, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    width = 2 if coreacc else 1
+    sends, mine = [], None
+    for d in range(world):
+        a, b = bounds[d], min(bounds[d + 1], hi)
+        if b <= a:
+            continue
+        lens = logs["len"][a:b].to(torch.int32)
+        m = max(1, int(lens.max()))
+        rec = logs["rec"][a:b, :m].contiguous()
+        ids = logs["id"][a:b, :m].contiguous()
+        if d == rank:
+            mine = (a, b, lens, rec, ids)
+            continue
+        head = torch.tensor([m], dtype=torch.int32, device=comm)
+        for t in (head, lens.to(comm), rec.to(comm), ids.to(comm)):
+            sends.append((dist.isend(t, dst=d), t))
+    # 4. replay in rank (= window) order into empty heaps of this rank's rows
+    final = {k: (None if v is None else torch.zeros_like(v[r0:r1])) for k, v in heaps.items()}
+    final["thr"] = torch.full_like(heaps["thr"][r0:r1], -1)
+    for s_rank in range(world):
+        a, b = r0, min(r1, cuts[s_rank + 1])
+        if b <= a:
+            continue
+        if s_rank == rank:
+            _a, _b, lens, rec, ids = mine
+        else:
+            head = torch.empty((1,), dtype=torch.int32, device=comm)
+            dist.recv(head, src=s_rank)
+            m = int(head.item())
+            lens = torch.empty((b - a,), dtype=torch.int32, device=comm)
+            rec = torch.empty((b - a, m, width), dtype=torch.float32, device=comm)
+            ids = torch.empty((b - a, m), dtype=torch.int32, device=comm)
+            for t in (lens, rec, ids):
+                dist.recv(t, src=s_rank)
+            lens, rec, ids = lens.to(device), rec.to(device), ids.to(device)
+        replay(final, 0, b - a, rec, ids, lens)
+    for work, _buf in sends:
+        work.wait()
+    idx, d0, d1 = finalize(final, 0, r1 - r0)
+    return r0, r1, idx, d0, d1

@@ -176,3 +176,15 @@ def test_knn_reference_order_travelling_heaps_with_several_ranks_on_the_one_gpu(
     line = _torchrun_world(world, args + (["--coreacc"] if coreacc else []), port)
     assert line["n_gpus"] == world and line["ties"] == "reference" and "travelling" in line["mode"]
     assert line["shard_equals_row_by_row"] is True
+
+
+@pytest.mark.parametrize("world,coreacc,port", [(1, False, 29641), (2, True, 29643), (3, False, 29645), (4, True, 29647)])
+def test_knn_reference_order_decoupled_windows_with_several_ranks_on_the_one_gpu(gpu_ctx, world, coreacc, port):
+    """The same lists with no rank waiting for another (round 6): every rank runs its column window against heaps it has cleared
+    itself, logs what they take (skl_self_dists_knn_window_logged), the logs are exchanged and replayed in window order
+    (skl_knn_heaps_replay; multi_gpu.self_knn_once_reference_decoupled) -- all ranks on the box's one GPU over gloo: rank 0's
+    row shard equals the single-device row-by-row replay of the same rows (ids, order, distances)."""
+    args = ["scripts/bench_knn_multi.py", "--samples", "12000", "--knn", "20", "--clustered", "--check", "--ties", "reference", "--decoupled"]
+    line = _torchrun_world(world, args + (["--coreacc"] if coreacc else []), port) if world > 1 else _torchrun(args + (["--coreacc"] if coreacc else []), port)
+    assert line["n_gpus"] == world and line["ties"] == "reference" and "decoupled" in line["mode"]
+    assert line["shard_equals_row_by_row"] is True

@@ -316,3 +316,48 @@ def test_reference_order_over_column_windows(oracle, skl, gpu_ctx, monkeypatch, 
     if dist == "coreacc":
         assert np.array_equal(d1.cpu().numpy(), exp["d1"])
     g.close()
+
+
+@pytest.mark.parametrize("coreacc", [False, True])
+@pytest.mark.parametrize("world,band_rows,knn,cap", [(1, 64, 7, 64), (3, 64, 5, 64), (2, 96, 40, 256), (5, 48, 12, 128), (3, 64, 300, 1024)])
+def test_decoupled_column_windows_logs_replayed_in_window_order(oracle, skl, gpu_ctx, world, band_rows, knn, cap, coreacc):
+    """skl_self_dists_knn_window_logged + skl_knn_heaps_replay (round 6): every participant's window run against heaps that START
+    EMPTY, one participant after the other on the one device, each with its own heaps and accept logs; the replay of the logs in
+    window order into one empty heap per row gives the oracle's whole-row BinaryHeap replay -- ids, order, both distances --
+    for the one-wave and (knn = 300) the one-workgroup form of the heap kernels, with exact ties in the data."""
+    import torch
+    from sketchlib.rust_amd import multi_gpu
+
+    kmers, ss64, n = [15, 19, 23, 27, 31], 16, 700
+    bins = synth.set_r(n, kmers, ss64, n_clusters=4)
+    bins[40] = bins[7]
+    bins[399] = bins[7]
+    bins[400] = bins[7]
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    p = g.set_k() if coreacc else g.set_k(23)
+    dev = torch.device("cuda", 0)
+    cuts = multi_gpu.knn_window_cuts(n, band_rows, world)
+    logs = []
+    for r in range(world):
+        heaps = skl.knn_heaps_alloc(n, knn, coreacc, dev)
+        lg = skl.knn_logs_alloc(n, cap, coreacc, dev)
+        for band in range((n + band_rows - 1) // band_rows):
+            if band * band_rows >= cuts[r + 1]:
+                break
+            skl.self_dists_knn_window_logged(gpu_ctx, g, p, knn, band_rows, band, cuts[r], cuts[r + 1], heaps, lg)
+        gpu_ctx.synchronize()
+        assert int(lg["len"].max()) <= cap, "the test's logs are meant to hold"
+        assert int(lg["len"][cuts[r + 1]:].sum()) == 0       # rows behind the window meet none of its pairs
+        logs.append(lg)
+    final = skl.knn_heaps_alloc(n, knn, coreacc, dev)
+    for lg in logs:
+        m = max(1, int(lg["len"].max()))
+        skl.knn_heaps_replay(gpu_ctx, final, 0, n, knn, lg["rec"][:, :m].contiguous(), lg["id"][:, :m].contiguous(), lg["len"])
+    idx, d0, d1 = skl.knn_heaps_finalize(gpu_ctx, final, 0, n, knn)
+    gpu_ctx.synchronize()
+    exp = oracle.self_dists_knn(o, knn, oracle.COREACC if coreacc else oracle.JACCARD, 0 if coreacc else 2, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint64), exp["idx"]), np.argwhere(idx.cpu().numpy() != exp["idx"])[:5]
+    assert np.array_equal(d0.cpu().numpy().view(np.uint32), exp["d0"].view(np.uint32))
+    if coreacc:
+        assert np.array_equal(d1.cpu().numpy().view(np.uint32), exp["d1"].view(np.uint32))
+    g.close()

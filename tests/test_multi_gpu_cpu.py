@@ -227,6 +227,7 @@ from oracle import oracle as O
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 mode = sys.argv[1]
+form = sys.argv[2] if len(sys.argv) > 2 else "travelling"     # travelling | decoupled | overflow
 n, kmers, ss64, knn, band_rows = 131, [17, 21, 25], 4, 7, 16
 bins = synth.set_r(n, kmers, ss64, n_clusters=3)
 bins[40] = bins[7]; bins[99] = bins[7]; bins[100] = bins[7]       # exact ties inside a cluster
@@ -261,8 +262,19 @@ def store_row(h, row, hp):
     if coreacc:
         h["h_d1"][row, :m] = torch.from_numpy(hp.items["d1"][0, :m].copy())
 
-def stage(band, lo, hi, h):
-    # stand-in for skl_self_dists_knn_window (the GPU half), from the oracle's distances and its resumable BinaryHeap
+def log_taken(lg, row, took, ids, keys, d1):
+    # append what the heap took, in order (skl_self_dists_knn_window_logged's accept log; the length counts past the capacity)
+    for c in np.flatnonzero(took):
+        m = int(lg["len"][row])
+        if m < lg["cap"]:
+            lg["rec"][row, m, 0] = float(keys[c])
+            if coreacc:
+                lg["rec"][row, m, 1] = float(d1[c])
+            lg["id"][row, m] = int(ids[c])
+        lg["len"][row] = m + 1
+
+def stage(band, lo, hi, h, lg=None):
+    # stand-in for skl_self_dists_knn_window[_logged] (the GPU half), from the oracle's distances and its resumable BinaryHeap
     b0, b1 = band * band_rows, min(n, (band + 1) * band_rows)
     c_first, t_first = max(b0, lo), max(b1, lo)
     if c_first >= hi:
@@ -271,15 +283,31 @@ def stage(band, lo, hi, h):
     evaluated[0] += sum(1 for i in range(b0, b1) for j in range(c_first, hi) if i < j)
     for j in range(t_first, hi):            # the window's rows below the band: the band's samples, ascending
         hp = load_row(h, j)
-        hp.feed(0, np.arange(b0, b1), D[:, j - c_first, 0], D[:, j - c_first, 1] if coreacc else None)
+        ids_, k_, d_ = np.arange(b0, b1), D[:, j - c_first, 0], (D[:, j - c_first, 1] if coreacc else None)
+        took = hp.feed(0, ids_, k_, d_, log=lg is not None)
+        if lg is not None:
+            log_taken(lg, j, took, ids_, k_, d_)
         store_row(h, j, hp)
     for i in range(b0, b1):                 # the band's own rows: the window's columns from max(b0, lo) on, minus themselves
         cols = np.array([c for c in range(c_first, hi) if c != i], dtype=np.int64)
         if cols.size == 0:
             continue
         hp = load_row(h, i)
-        hp.feed(0, cols, D[i - b0, cols - c_first, 0], D[i - b0, cols - c_first, 1] if coreacc else None)
+        k_, d_ = D[i - b0, cols - c_first, 0], (D[i - b0, cols - c_first, 1] if coreacc else None)
+        took = hp.feed(0, cols, k_, d_, log=lg is not None)
+        if lg is not None:
+            log_taken(lg, i, took, cols, k_, d_)
         store_row(h, i, hp)
+
+def replay(h, r0, r1, rec, ids, lens):
+    # stand-in for skl_knn_heaps_replay: rows [r0, r1) of h take their logged candidates in the order logged
+    for r in range(r0, r1):
+        m = int(lens[r - r0])
+        if m == 0:
+            continue
+        hp = load_row(h, r)
+        hp.feed(0, ids[r - r0, :m].numpy().astype(np.int64), rec[r - r0, :m, 0].numpy(), rec[r - r0, :m, 1].numpy() if coreacc else None)
+        store_row(h, r, hp)
 
 def finalize(h, r0, r1):
     idx = torch.zeros((r1 - r0, knn), dtype=torch.int64); d0 = torch.zeros((r1 - r0, knn)); d1 = torch.zeros((r1 - r0, knn)) if coreacc else None
@@ -294,8 +322,28 @@ def finalize(h, r0, r1):
 heaps = {"h_key": torch.zeros((n, knn)), "h_id": torch.zeros((n, knn), dtype=torch.int32),
          "h_d1": torch.zeros((n, knn)) if coreacc else None, "h_len": torch.zeros((n,), dtype=torch.int32),
          "thr": torch.full((n,), -1, dtype=torch.int32)}
-r0, r1, idx, d0, d1 = multi_gpu.self_knn_once_reference(None, SK, P, knn, rank, world, dist, torch.device("cpu"),
-                                                        band_rows=band_rows, stage=stage, finalize=finalize, heaps=heaps)
+def new_logs(cap):
+    return {"rec": torch.zeros((n, cap, 2 if coreacc else 1)), "id": torch.zeros((n, cap), dtype=torch.int32),
+            "len": torch.zeros((n,), dtype=torch.int32), "cap": cap}
+if form == "travelling":
+    res = multi_gpu.self_knn_once_reference(None, SK, P, knn, rank, world, dist, torch.device("cpu"),
+                                            band_rows=band_rows, stage=stage, finalize=finalize, heaps=heaps)
+else:
+    # the decoupled form: every rank its own window against empty heaps, logs exchanged, replayed in window order
+    cap = 3 if form == "overflow" else 64
+    res = multi_gpu.self_knn_once_reference_decoupled(None, SK, P, knn, rank, world, dist, torch.device("cpu"), band_rows=band_rows,
+                                                      stage=stage, replay=replay, finalize=finalize, heaps=heaps, logs=new_logs(cap),
+                                                      log_cap=cap, host_staged=True)
+    if form == "overflow":
+        assert res is None, "a log of 3 entries cannot hold what a heap of 7 takes"
+        evaluated[0] = 0
+        for k in heaps:
+            if heaps[k] is not None:
+                heaps[k].zero_()
+        heaps["thr"].fill_(-1)
+        res = multi_gpu.self_knn_once_reference(None, SK, P, knn, rank, world, dist, torch.device("cpu"),
+                                                band_rows=band_rows, stage=stage, finalize=finalize, heaps=heaps)
+r0, r1, idx, d0, d1 = res
 exp = O.self_dists_knn(s, knn, dtype, k_idx, False, ties=O.TIES_RUST_HEAP)
 assert (r0, r1) == tuple(multi_gpu.even_row_bounds(n, world)[rank:rank + 2])
 assert np.array_equal(idx.numpy().astype(np.uint64), exp["idx"][r0:r1]), (rank, "ids / order differ from the reference's heap")
@@ -311,6 +359,28 @@ print("HEAPS_OK", rank)
 dist.barrier()
 dist.destroy_process_group()
 """ % ROOT
+
+
+@pytest.mark.parametrize("form", ["decoupled", "overflow"])
+@pytest.mark.parametrize("mode", ["jaccard", "coreacc"])
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+def test_gloo_reference_order_decoupled_windows(oracle, tmp_path, world, mode, form):
+    """The same lists with NO rank waiting for another (round 6): every rank runs its column window against heaps that start
+    empty and logs what they take; a row's true list is the replay of its logs in window order on the rank that finalises it
+    (multi_gpu.self_knn_once_reference_decoupled).  ids, order, both distances = the oracle's whole-row BinaryHeap replay;
+    every pair evaluated exactly once; a log too short for what a heap takes sends every rank back to the travelling heaps."""
+    if form == "overflow" and world == 4:
+        pytest.skip("one overflow case per world size up to 3 is enough")
+    script = tmp_path / "heap_worker.py"
+    script.write_text(HEAP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+         "--master-addr", "127.0.0.1", "--master-port", str(29600 + world + (10 if mode == "coreacc" else 0) + (20 if form == "overflow" else 0)),
+         str(script), mode, form],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert res.stdout.count("HEAPS_OK") == world
 
 
 @pytest.mark.parametrize("mode", ["jaccard", "coreacc"])
