@@ -522,7 +522,8 @@ def self_dists_knn_window_logged(ctx, s, p, knn, band_rows, band, col_lo, col_hi
 
 def knn_heaps_replay(ctx, heaps, r0, r1, knn, rec, ids, lens):
     """skl_knn_heaps_replay: the heaps of rows [r0, r1) (of `heaps`, arrays over all rows) are fed the logged candidates
-    rec [r1 - r0, cap, 1 | 2] f32 / ids [r1 - r0, cap] i32 / lens [r1 - r0] i32 (device tensors), each row's in the order logged."""
+    rec [r1 - r0, cap, 1 | 2] f32 / ids [r1 - r0, cap] i32 / lens [r1 - r0] i32 (device tensors), each row's in the order logged.
+    The call is asynchronous on the CONTEXT's stream: tensors made on another stream must be complete (and stay alive) until it ran."""
     if r1 <= r0:
         return
     coreacc = heaps["h_d1"] is not None

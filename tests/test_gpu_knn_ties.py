@@ -352,7 +352,10 @@ def test_decoupled_column_windows_logs_replayed_in_window_order(oracle, skl, gpu
     final = skl.knn_heaps_alloc(n, knn, coreacc, dev)
     for lg in logs:
         m = max(1, int(lg["len"].max()))
-        skl.knn_heaps_replay(gpu_ctx, final, 0, n, knn, lg["rec"][:, :m].contiguous(), lg["id"][:, :m].contiguous(), lg["len"])
+        rec, ids = lg["rec"][:, :m].contiguous(), lg["id"][:, :m].contiguous()
+        torch.cuda.synchronize()      # (torch cuts the logs on ITS stream; the session's context runs on a stream of its own)
+        skl.knn_heaps_replay(gpu_ctx, final, 0, n, knn, rec, ids, lg["len"])
+        gpu_ctx.synchronize()
     idx, d0, d1 = skl.knn_heaps_finalize(gpu_ctx, final, 0, n, knn)
     gpu_ctx.synchronize()
     exp = oracle.self_dists_knn(o, knn, oracle.COREACC if coreacc else oracle.JACCARD, 0 if coreacc else 2, False, ties=oracle.TIES_RUST_HEAP, threads=8)
