@@ -510,6 +510,110 @@ SparseDistanceMatrix self_dists_knn(DeviceSet &devs, const MultiSketch &sketches
     // [cut[d], cut[d + 1]), evaluates the pairs whose column lies in it band by band (skl_self_dists_knn_window), and hands each
     // band's heaps to device d + 1 as soon as the band is done; the last device ends up with every row's final heap.  Decided up
     // front: nothing is uploaded for a form the configuration does not have.
+    // DECOUPLED WINDOWS first (round 6; the header's skl_self_dists_knn_window_logged): every device runs its column window against
+    // heaps it has cleared itself and logs what they take; no device waits for another.  The logs pass through host memory
+    // (this layer sees only the C ABI), so the form is taken while they fit comfortably -- 16 knn entries per row and device --
+    // and falls through to the travelling heaps when a log overflows or the logs would not fit.
+    if (skl_ctx_get_knn_ties(devs[0].ctx()) == SKL_KNN_TIES_REFERENCE && knn <= 2048 && n >= 2) {
+        const size_t W = devs.size();
+        const bool coreacc = p.dist_type == SKL_DIST_COREACC;
+        const size_t rec_w = coreacc ? 2 : 1, cap = std::max<size_t>(64, 16 * knn);
+        const char *off = std::getenv("SKL_KNN_DECOUPLED");   // (=0: the travelling heaps, for tests and A/B timing)
+        if (!(off && off[0] == '0') && n * cap * (rec_w + 1) * 4 <= (4ull << 30)) {
+            struct DevMem {
+                skl_ctx *c;
+                void *p = nullptr;
+                DevMem(skl_ctx *ctx_, size_t bytes) : c(ctx_) { check(skl_device_malloc(c, bytes, &p)); }
+                ~DevMem() { skl_device_free(c, p); }
+                DevMem(const DevMem &) = delete;
+                DevMem &operator=(const DevMem &) = delete;
+            };
+            std::vector<std::vector<float>> log_rec(W);
+            std::vector<std::vector<uint32_t>> log_id(W), log_len(W);
+            std::vector<size_t> cut;
+            size_t band_rows = 0;
+            std::mutex plan_m;
+            std::atomic<bool> give_up{false};
+            for_each_device(devs, [&](size_t d) {
+                Slab s(devs[d], sketches, completeness_vec);
+                skl_ctx *ctx = devs[d].ctx();
+                {
+                    std::lock_guard<std::mutex> g(plan_m);
+                    if (band_rows == 0) {   // (every device arrives at the same plan)
+                        band_rows = skl_knn_band_rows(s.h, &p, W);
+                        if (band_rows == 0) throw std::runtime_error("skl_knn_band_rows failed");
+                        cut.assign(1, 0);
+                        for (size_t r = 1; r < W; ++r) {   // n * sqrt(r / W) on band boundaries: equal pair counts
+                            const size_t c = (size_t)std::llround((double)n * std::sqrt((double)r / (double)W) / (double)band_rows) * band_rows;
+                            cut.push_back(std::min(std::max(c, cut.back()), n));
+                        }
+                        cut.push_back(n);
+                    }
+                }
+                const size_t lo = cut[d], hi = cut[d + 1];
+                if (hi == 0) return;
+                DevMem h_key(ctx, n * knn * 4), h_id(ctx, n * knn * 4), h_d1(ctx, coreacc ? n * knn * 4 : 4), h_len(ctx, n * 4), thr(ctx, n * 4);
+                DevMem l_rec(ctx, hi * cap * rec_w * 4), l_id(ctx, hi * cap * 4), l_len(ctx, hi * 4);
+                check(skl_knn_heaps_clear(ctx, 0, n, (uint32_t *)h_len.p, (uint32_t *)thr.p));
+                {
+                    const std::vector<uint32_t> zeros(hi, 0u);
+                    check(skl_device_memcpy(ctx, l_len.p, zeros.data(), hi * 4, 1));
+                }
+                const size_t n_bands = (n + band_rows - 1) / band_rows;
+                for (size_t band = 0; band < n_bands && !give_up; ++band) {
+                    if (band * band_rows >= hi) break;
+                    // (the log arrays cover rows [0, hi): no row at or behind the window's end meets a pair of it)
+                    const int r = skl_self_dists_knn_window_logged(ctx, s.h, &p, knn, band_rows, band, lo, hi, (float *)h_key.p, (uint32_t *)h_id.p,
+                                                                   coreacc ? (float *)h_d1.p : nullptr, (uint32_t *)h_len.p, (uint32_t *)thr.p,
+                                                                   (float *)l_rec.p, (uint32_t *)l_id.p, (uint32_t *)l_len.p, cap);
+                    if (r == SKL_ERR_INVALID_ARG && band == 0) {   // no one-evaluation form for this configuration
+                        give_up = true;
+                        return;
+                    }
+                    check(r);
+                }
+                log_len[d].resize(hi);
+                check(skl_device_memcpy(ctx, log_len[d].data(), l_len.p, hi * 4, 0));
+                for (const uint32_t v : log_len[d]) {
+                    if (v > cap) give_up = true;   // an overflowed log is useless: the travelling heaps below
+                }
+                if (give_up) return;
+                log_rec[d].resize(hi * cap * rec_w);
+                log_id[d].resize(hi * cap);
+                check(skl_device_memcpy(ctx, log_rec[d].data(), l_rec.p, hi * cap * rec_w * 4, 0));
+                check(skl_device_memcpy(ctx, log_id[d].data(), l_id.p, hi * cap * 4, 0));
+            });
+            if (!give_up) {
+                // every device replays the logs of ITS row shard in window order into empty heaps, and sorts them
+                for_each_device(devs, [&](size_t d) {
+                    const size_t r0 = b[d], r1 = b[d + 1], rows = r1 - r0;
+                    if (rows == 0) return;
+                    skl_ctx *ctx = devs[d].ctx();
+                    DevMem h_key(ctx, rows * knn * 4), h_id(ctx, rows * knn * 4), h_d1(ctx, coreacc ? rows * knn * 4 : 4), h_len(ctx, rows * 4), thr(ctx, rows * 4);
+                    DevMem u_rec(ctx, rows * cap * rec_w * 4), u_id(ctx, rows * cap * 4), u_len(ctx, rows * 4);
+                    check(skl_knn_heaps_clear(ctx, 0, rows, (uint32_t *)h_len.p, (uint32_t *)thr.p));
+                    for (size_t src = 0; src < W; ++src) {
+                        const size_t a = r0, e = std::min(r1, cut[src + 1]);
+                        if (e <= a) continue;   // (rows at or behind window src's end: nothing of it)
+                        check(skl_device_memcpy(ctx, u_rec.p, log_rec[src].data() + a * cap * rec_w, (e - a) * cap * rec_w * 4, 1));
+                        check(skl_device_memcpy(ctx, u_id.p, log_id[src].data() + a * cap, (e - a) * cap * 4, 1));
+                        check(skl_device_memcpy(ctx, u_len.p, log_len[src].data() + a, (e - a) * 4, 1));
+                        check(skl_knn_heaps_replay(ctx, e - a, knn, coreacc ? 1 : 0, (const float *)u_rec.p, (const uint32_t *)u_id.p, (const uint32_t *)u_len.p, cap,
+                                                   (float *)h_key.p, (uint32_t *)h_id.p, coreacc ? (float *)h_d1.p : nullptr, (uint32_t *)h_len.p, (uint32_t *)thr.p));
+                    }
+                    DevMem o_idx(ctx, rows * knn * 8), o_d0(ctx, rows * knn * 4), o_d1(ctx, coreacc ? rows * knn * 4 : 4);
+                    check(skl_knn_heaps_finalize(ctx, rows, knn, (const float *)h_key.p, (const uint32_t *)h_id.p, coreacc ? (const float *)h_d1.p : nullptr,
+                                                 (const uint32_t *)h_len.p, p.ani, (uint64_t *)o_idx.p, (float *)o_d0.p, coreacc ? (float *)o_d1.p : nullptr));
+                    check(skl_device_memcpy(ctx, idx.data() + r0 * knn, o_idx.p, rows * knn * 8, 0));
+                    check(skl_device_memcpy(ctx, d0.data() + r0 * knn, o_d0.p, rows * knn * 4, 0));
+                    if (coreacc) check(skl_device_memcpy(ctx, d1.data() + r0 * knn, o_d1.p, rows * knn * 4, 0));
+                });
+                SparseDistanceMatrix out = assemble_knn(dist_type, knn, idx.data(), d0.data(), d1.data(), idx.size());
+                out.ref_names = sketch_names(sketches);
+                return out;
+            }
+        }
+    }
     if (skl_ctx_get_knn_ties(devs[0].ctx()) == SKL_KNN_TIES_REFERENCE && knn <= 2048 && n >= 2) {
         const size_t W = devs.size();
         const bool coreacc = p.dist_type == SKL_DIST_COREACC;

@@ -233,13 +233,16 @@ def test_multi_context_synthetic(gpu_ctx, tmp_path):
     # several bands per device: every pair is evaluated once across the devices, the partial
     # top-k states are merged shard by shard (single-k and core/accessory keys)
     # (--knn-ties canonical: row bands dealt over the devices + merged partial states; the default, reference rule: column
-    # windows per device and heaps that travel from device to device band by band -- either way every pair once and the
-    # same text whatever the partition)
+    # windows per device -- round 6: every device against heaps it cleared itself, accept logs replayed in window order;
+    # SKL_KNN_DECOUPLED=0: heaps that travel from device to device band by band -- either way every pair once and the same
+    # text whatever the partition)
     for flags in (("--knn", "10"), ("--knn", "7", "-k", "23"), ("--knn", "7", "-k", "23", "--ani")):
         for ties in ((), ("--knn-ties", "canonical")):
             want = run(prefix, *flags, *ties)
             for devices in ("0,0", "0,0,0,0,0"):
                 assert run(prefix, *flags, *ties, "--devices", devices, env={"SKL_KNN_BAND_ROWS": "16"}) == want
+                if not ties:
+                    assert run(prefix, *flags, "--devices", devices, env={"SKL_KNN_BAND_ROWS": "16", "SKL_KNN_DECOUPLED": "0"}) == want
 
 
 # ---- `sketchlib inverted precluster`, as tests/inverted.rs drives it ----
