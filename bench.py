@@ -243,8 +243,9 @@ def valu_block(pairs_per_launch, avg_kernel_s, nk, ss64, clock, counted=None):
     if counted != nk:
         blk["frac_as_if_every_length_were_counted"] = blk["frac"] * nk / counted
         blk["early_break"] = (f"the pair kernel counted the first {counted} of {nk} k-mer lengths (core_acc_dist leaves its loop at the first "
-                              "length without a shared bin, jaccard.rs:89-91, and fewer than three lengths give (1, 1), :117); the few "
-                              "pairs still in the running are completed by the epilogue launch; same (core, acc) bit for bit")
+                              "length whose ln J is below the tolerance -- no more shared bins than chance, jaccard.rs:26-31, :89-91 -- and fewer "
+                              "than three lengths give (1, 1), :117); the pairs still in the running are completed by the epilogue launch, each "
+                              "slice read as one contiguous run (csrc/epilogue.hip); same (core, acc) bit for bit")
     if clock and clock.get("ghz", 0) > 0:
         blk["in_kernel_clock"] = clock
         blk["frac_at_in_kernel_clock"] = achieved / (VALU_PEAK_LANE_OPS * clock["ghz"] / DATASHEET_CLOCK_GHZ)
@@ -725,11 +726,12 @@ def main():
                     "k_mer_lengths_counted_for_every_pair": counted_lengths(kernel_name, nk), "of": nk,
                     "pairs_in_the_timed_region": eb_after[0] - eb_before[0],
                     "of_them_completed_one_by_one": eb_after[1] - eb_before[1],
-                    "what": "core_acc_dist leaves its loop at the first k-mer length without a shared bin (jaccard.rs:89-91) and fewer "
-                            "than three lengths give (1, 1) (:117): the pair kernel counts the first few lengths for every pair, the "
-                            "epilogue completes the pairs still in the running; taken when a sample of the pairs says it pays "
-                            "(DESIGN.md 4.2; the A/B build's SKL_EARLY_BREAK=0 counts every length: 3.4e9 pairs/s here); results "
-                            "bit-identical (tests/test_gpu_early_break.py)"},
+                    "what": "core_acc_dist leaves its loop at the first k-mer length whose ln J is below the tolerance (no more shared bins "
+                            "than chance, jaccard.rs:26-31, :89-91) and fewer than three lengths give (1, 1) (:117): the pair kernel counts "
+                            "the first few lengths of a block of the pair space, the epilogue completes the pairs still in the running; "
+                            "decided block by block from a sample of the pairs (DESIGN.md 4.2; the A/B build's SKL_EARLY_BREAK=0 counts "
+                            "every length: 3.2e9 pairs/s here, profiles/r06_early_break_forced_lengths.md); results bit-identical "
+                            "(tests/test_gpu_early_break.py, tests/test_gpu_early_break_r6.py)"},
                 **(verified or {}),
                 **({"cold_pairs_per_s": cold["pairs_per_s"], "cold": cold} if cold else {}),
                 **({"n1_same_workload": n1_same} if n1_same else {}),
