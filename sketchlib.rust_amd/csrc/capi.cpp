@@ -1061,7 +1061,7 @@ int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches 
     }
     const bool has_comp = rows->d_comp != nullptr && cols->d_comp != nullptr;
     for (const EbPlan *p : ctx->eb_plans) {
-        if (p->rows_gen == rows->gen && p->cols_gen == cols->gen && p->self_mode == self_mode && (!has_comp || p->cutoff == cutoff)) {
+        if (p->rows_gen == rows->gen && p->cols_gen == cols->gen && p->self_mode == self_mode && p->knob == knob && (!has_comp || p->cutoff == cutoff)) {
             *out = p;
             return SKL_OK;
         }
@@ -1071,8 +1071,14 @@ int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches 
     plan->cols_gen = cols->gen;
     plan->self_mode = self_mode;
     plan->cutoff = cutoff;
+    plan->knob = knob;
     auto keep = [&]() {
-        if (ctx->eb_plans.size() >= 8) {   // (nothing in flight reads an old plan's table: the sample below synchronises the stream)
+        if (ctx->eb_plans.size() >= 8) {
+            // (nothing in flight may still read the oldest plan's table: the streams are drained before it goes)
+            if (ctx->eb_plans.front()->d_block_ke != nullptr) {
+                (void)hipStreamSynchronize(ctx->stream);
+                if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+            }
             if (ctx->eb_last_plan == ctx->eb_plans.front()) ctx->eb_last_plan = nullptr;
             free_plan(ctx->eb_plans.front());
             ctx->eb_plans.erase(ctx->eb_plans.begin());

@@ -93,7 +93,7 @@ SKL_INTERNAL Knobs read_knobs();
 // caller's const slab.
 struct EbPlan {
     uint64_t rows_gen = 0, cols_gen = 0;
-    int self_mode = 0;
+    int self_mode = 0, knob = 1;        // (knob: SKL_EARLY_BREAK as of the decision -- the A/B build may change it between calls)
     double cutoff = 0.0;                // completeness cutoff the sample was taken with (a correction changes ln J)
     int lengths = 0;                    // pooled decision: lengths to count (0: all of them, no early break)
     double alive_share = 0.0;           // sampled share of the pairs still in the running after them
