@@ -315,6 +315,20 @@ int skl_ctx_get_knn_ties(const skl_ctx *ctx);   /* SKL_KNN_TIES_* of the context
 int skl_knn_heaps_finalize(skl_ctx *ctx, size_t rows, size_t knn, const float *h_key, const uint32_t *h_id, const float *h_d1,
                            const uint32_t *h_len, int ani, uint64_t *out_idx, float *out_d0, float *out_d1);
 
+/* Assembling a dense matrix that several devices of ONE process computed in row bands (skl_self_dists_rows /
+ * skl_cross_dists_rows with device outputs) on the first context's device, over xGMI: "the N x N pair space block-partitioned
+ * across the GPUs of one node with a RCCL gather to assemble the output matrix" (the reference has one address space and no
+ * counterpart).  ctxs[d] made band_dev[d] (band_bytes[d] bytes, device memory of ITS device, produced on ITS stream); the bands
+ * land at dst_dev_root + dst_offsets[d] on ctxs[0]'s device: the root's own band by a copy inside its HBM, the others by
+ * grouped ncclSend / ncclRecv in messages of at most 1 GiB, each send behind the kernels of its context's stream, the receives
+ * on the root's stream.  Asynchronous: skl_ctx_synchronize(ctxs[0]) completes it.  One context per device (RCCL takes one rank
+ * per device: a device listed twice is SKL_ERR_INVALID_ARG).  librccl.so.1 is looked up at run time; the communicators of a
+ * device list are made once per process.  loopback_through_rccl != 0 with ONE context sends that band to itself through RCCL
+ * (what a one-GPU box can test of the transport).  The torch.distributed rendering (one process per GPU) is
+ * sketchlib.rust_amd/multi_gpu.py. */
+int skl_gather_bands_rccl(skl_ctx *const *ctxs, size_t n_ctx, const void *const *band_dev, const size_t *band_bytes,
+                          void *dst_dev_root, const size_t *dst_offsets, int loopback_through_rccl);
+
 /* The same with the candidate lists built on the device as well: skq holds the index sketch
  * (u16 bins, `.skq` layout [sample][sketch_size]) of every sample of `s`, row i = sample i (the
  * caller applies the .ski -> .skd order map); candidates of i = samples sharing at least one

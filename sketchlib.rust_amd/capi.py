@@ -65,6 +65,7 @@ _SIG = [
     ("skl_knn_heaps_clear", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, _P]),
     ("skl_self_dists_knn_window_logged", C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P,
                                                    _P, _P, _P, C.c_size_t]),
+    ("skl_gather_bands_rccl", C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, C.c_int]),
     ("skl_knn_heaps_replay", C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_int, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P]),
     ("skl_knn_heaps_finalize", C.c_int, [_P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     ("skl_device_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
@@ -501,6 +502,17 @@ def self_dists_knn_window(ctx, s, p, knn, band_rows, band, col_lo, col_hi, heaps
     ptr = lambda t: _ptr(t)[0]
     _check(load().skl_self_dists_knn_window(ctx._h, s._h, C.byref(p), knn, band_rows, band, col_lo, col_hi, ptr(heaps["h_key"]),
                                             ptr(heaps["h_id"]), ptr(heaps["h_d1"]), ptr(heaps["h_len"]), ptr(heaps["thr"])))
+
+
+def gather_bands_rccl(ctxs, bands, dst, offsets_bytes, loopback_through_rccl=False):
+    """skl_gather_bands_rccl: device tensors bands[d] (made on ctxs[d]'s device and stream) land at byte offsets offsets_bytes[d]
+    of the device tensor `dst` on ctxs[0]'s device; asynchronous on the contexts' streams."""
+    n = len(ctxs)
+    handles = (_P * n)(*[c._h for c in ctxs])
+    ptrs = (_P * n)(*[_ptr(b)[0] for b in bands])
+    sizes = (C.c_size_t * n)(*[b.numel() * b.element_size() for b in bands])
+    offs = (C.c_size_t * n)(*[int(o) for o in offsets_bytes])
+    _check(load().skl_gather_bands_rccl(handles, n, ptrs, sizes, _ptr(dst)[0], offs, int(bool(loopback_through_rccl))))
 
 
 def knn_logs_alloc(n, cap, coreacc, device):

@@ -596,3 +596,116 @@ extern "C" int skl_self_dists_knn_shared_bins(skl_ctx *ctx, const skl_sketches *
     return knn_from_device_csr(ctx, s, p, knn, offsets.data(), (const uint64_t *)d_off.p, (const uint32_t *)d_cand.p,
                                true, out_idx, out_d0);
 }
+
+
+// ---------------------------------------------------------------------------
+// RCCL gather of row bands computed on several devices of one process ("grouped ncclSend/ncclRecv to root
+// for unequal counts").  The reference has no counterpart (one address space); BASELINE.json's north star names it: "a RCCL
+// gather over xGMI to assemble the output matrix".  The library is looked up at run time (librccl.so.1: part of ROCm, but the
+// product library must load without it); the communicators of a device list are made once per process and kept.
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+namespace {
+struct RcclApi {
+    ncclResult_t (*comm_init_all)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*group_start)() = nullptr;
+    ncclResult_t (*group_end)() = nullptr;
+    ncclResult_t (*send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*error_string)(ncclResult_t) = nullptr;
+    bool ok = false;
+    RcclApi()
+    {
+        for (const char *lib : {"librccl.so.1", "librccl.so"}) {
+            void *h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+            if (!h) continue;
+            comm_init_all = reinterpret_cast<decltype(comm_init_all)>(dlsym(h, "ncclCommInitAll"));
+            comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+            group_start = reinterpret_cast<decltype(group_start)>(dlsym(h, "ncclGroupStart"));
+            group_end = reinterpret_cast<decltype(group_end)>(dlsym(h, "ncclGroupEnd"));
+            send = reinterpret_cast<decltype(send)>(dlsym(h, "ncclSend"));
+            recv = reinterpret_cast<decltype(recv)>(dlsym(h, "ncclRecv"));
+            error_string = reinterpret_cast<decltype(error_string)>(dlsym(h, "ncclGetErrorString"));
+            ok = comm_init_all && comm_destroy && group_start && group_end && send && recv && error_string;
+            if (ok) return;
+        }
+    }
+    static const RcclApi &get()
+    {
+        static const RcclApi api;
+        return api;
+    }
+};
+
+std::mutex g_rccl_mutex;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;   // device list -> one communicator per entry (kept for the process)
+}  // namespace
+
+#define RCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        const ncclResult_t r_ = (expr);                                                         \
+        if (r_ != ncclSuccess) return fail(SKL_ERR_HIP, "%s: %s", #expr, api.error_string(r_)); \
+    } while (0)
+
+extern "C" int skl_gather_bands_rccl(skl_ctx *const *ctxs, size_t n_ctx, const void *const *band_dev, const size_t *band_bytes,
+                                     void *dst_dev_root, const size_t *dst_offsets, int loopback_through_rccl)
+{
+    if (!ctxs || n_ctx == 0 || !band_dev || !band_bytes || !dst_dev_root || !dst_offsets) return fail(SKL_ERR_INVALID_ARG, "null argument");
+    if (n_ctx > 64) return fail(SKL_ERR_INVALID_ARG, "at most 64 devices");
+    std::vector<int> devs(n_ctx);
+    for (size_t d = 0; d < n_ctx; ++d) {
+        if (!ctxs[d]) return fail(SKL_ERR_INVALID_ARG, "null context");
+        devs[d] = ctxs[d]->device;
+        for (size_t e = 0; e < d; ++e) {
+            if (devs[e] == devs[d]) return fail(SKL_ERR_INVALID_ARG, "skl_gather_bands_rccl: device %d listed twice (RCCL takes one rank per device)", devs[d]);
+        }
+    }
+    skl_ctx *root = ctxs[0];
+    SKL_TRY(ctx_bind(root));
+    // the root's own band: a copy inside its HBM (or, on request, through RCCL to itself: the one-device test of the transport)
+    const bool use_rccl = n_ctx > 1 || loopback_through_rccl;
+    if (!use_rccl) {
+        if (band_bytes[0]) HIP_TRY(hipMemcpyAsync((char *)dst_dev_root + dst_offsets[0], band_dev[0], band_bytes[0], hipMemcpyDeviceToDevice, root->stream));
+        return SKL_OK;
+    }
+    const RcclApi &api = RcclApi::get();
+    if (!api.ok) return fail(SKL_ERR_HIP, "librccl.so.1 not found: the RCCL gather is not available on this host");
+    std::vector<ncclComm_t> comms;
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        auto it = g_rccl_comms.find(devs);
+        if (it == g_rccl_comms.end()) {
+            std::vector<ncclComm_t> fresh(n_ctx);
+            RCCL_TRY(api.comm_init_all(fresh.data(), (int)n_ctx, devs.data()));
+            it = g_rccl_comms.emplace(devs, std::move(fresh)).first;
+        }
+        comms = it->second;
+    }
+    if (n_ctx > 1 && band_bytes[0]) {
+        HIP_TRY(hipMemcpyAsync((char *)dst_dev_root + dst_offsets[0], band_dev[0], band_bytes[0], hipMemcpyDeviceToDevice, root->stream));
+    }
+    // messages of at most 1 GiB (a cfg-3 band is 5-20 GB), every message of a round in ONE group: rank d sends on its context's
+    // stream -- behind the kernels that made the band -- and the root receives on its own
+    constexpr size_t MSG = 1ull << 30;
+    size_t longest = 0;
+    for (size_t d = n_ctx > 1 ? 1 : 0; d < n_ctx; ++d) longest = std::max(longest, band_bytes[d]);
+    for (size_t off = 0; off < longest; off += MSG) {
+        RCCL_TRY(api.group_start());
+        for (size_t d = n_ctx > 1 ? 1 : 0; d < n_ctx; ++d) {
+            if (off >= band_bytes[d]) continue;
+            const size_t cnt = std::min(MSG, band_bytes[d] - off);
+            HIP_TRY(hipSetDevice(devs[d]));
+            RCCL_TRY(api.send((const char *)band_dev[d] + off, cnt, ncclUint8, 0, comms[d], ctxs[d]->stream));
+            HIP_TRY(hipSetDevice(devs[0]));
+            RCCL_TRY(api.recv((char *)dst_dev_root + dst_offsets[d] + off, cnt, ncclUint8, (int)d, comms[0], root->stream));
+        }
+        RCCL_TRY(api.group_end());
+    }
+    HIP_TRY(hipSetDevice(devs[0]));
+    return SKL_OK;
+}

@@ -188,3 +188,36 @@ def test_knn_reference_order_decoupled_windows_with_several_ranks_on_the_one_gpu
     line = _torchrun_world(world, args + (["--coreacc"] if coreacc else []), port) if world > 1 else _torchrun(args + (["--coreacc"] if coreacc else []), port)
     assert line["n_gpus"] == world and line["ties"] == "reference" and "decoupled" in line["mode"]
     assert line["shard_equals_row_by_row"] is True
+
+
+def test_c_abi_rccl_gather_of_row_bands_with_one_device(oracle, skl, gpu_ctx):
+    """skl_gather_bands_rccl (the C ABI's rendering of "a RCCL gather over xGMI to assemble the output matrix"): two row bands of
+    a self matrix computed with device outputs, assembled on the root (a) by the root's own copy and (b) THROUGH RCCL -- the
+    band sent to itself, grouped ncclSend / ncclRecv on the context's stream, the one-GPU test of the transport; the
+    assembled matrix is the oracle's.  A device listed twice is refused (RCCL takes one rank per device)."""
+    import numpy as np
+    import torch
+    from sketchlib.rust_amd import synth
+
+    kmers, ss64, n = [15, 19, 23, 27, 31], 16, 400
+    bins = synth.set_r(n, kmers, ss64, n_clusters=8)
+    o, g = oracle.Sketches(bins, n, kmers, ss64), gpu_ctx.sketches(bins, n, kmers, ss64)
+    exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
+    dev = torch.device("cuda", 0)
+    cut = 150
+    first = cut * n - cut * (cut + 1) // 2                      # pairs of rows [0, cut)
+    b0 = torch.zeros((first, 2), dtype=torch.float32, device=dev)
+    b1 = torch.zeros((exp.shape[0] - first, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    skl.self_dists_rows(gpu_ctx, g, g.set_k(), 0, cut, out=b0)
+    skl.self_dists_rows(gpu_ctx, g, g.set_k(), cut, n, out=b1)
+    for loopback in (False, True):
+        full = torch.full((exp.shape[0], 2), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        skl.gather_bands_rccl([gpu_ctx], [b0], full, [0], loopback_through_rccl=loopback)
+        skl.gather_bands_rccl([gpu_ctx], [b1], full, [first * 8], loopback_through_rccl=loopback)
+        gpu_ctx.synchronize()
+        assert np.array_equal(full.cpu().numpy().view(np.uint32), exp.view(np.uint32)), loopback
+    with pytest.raises(skl.SklError):
+        skl.gather_bands_rccl([gpu_ctx, gpu_ctx], [b0, b1], full, [0, first * 8])
+    g.close()
