@@ -165,6 +165,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    if (ctx->epi_stream) (void)hipStreamSynchronize(ctx->epi_stream);
     // slabs die with their context; their handles become inert
     const std::set<skl_sketches *> owned = ctx->sketches;
     for (skl_sketches *s : owned) free_sketches_locked(s);
@@ -194,6 +195,7 @@ extern "C" int skl_ctx_destroy(skl_ctx *ctx)
     if (ctx->tile_scratch.staged) (void)hipEventDestroy(ctx->tile_scratch.staged);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->epi_stream) (void)hipStreamDestroy(ctx->epi_stream);
     for (int x = 0; x < 2; ++x) {
         if (ctx->knn_pair_done[x]) (void)hipEventDestroy(ctx->knn_pair_done[x]);
         if (ctx->knn_topk_done[x]) (void)hipEventDestroy(ctx->knn_topk_done[x]);
@@ -1077,7 +1079,7 @@ int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches 
             // (nothing in flight may still read the oldest plan's table: the streams are drained before it goes)
             if (ctx->eb_plans.front()->d_block_ke != nullptr) {
                 (void)hipStreamSynchronize(ctx->stream);
-                if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+                if (ctx->epi_stream) (void)hipStreamSynchronize(ctx->epi_stream);
             }
             if (ctx->eb_last_plan == ctx->eb_plans.front()) ctx->eb_last_plan = nullptr;
             free_plan(ctx->eb_plans.front());
@@ -1325,7 +1327,10 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             return rc;
         }
         const bool piped = ctx->eb_in_pipeline && ctx->eb_pipe_overlap;
-        hipStream_t epi_stream = piped ? ctx->aux_stream : ctx->stream;
+        // (a stream of its own: the banded host output copies band i back on aux_stream while band i + 1 is computed, and must not
+        // queue behind that band's epilogues)
+        if (piped && !ctx->epi_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->epi_stream, hipStreamNonBlocking));
+        hipStream_t epi_stream = piped ? ctx->epi_stream : ctx->stream;
         PairArgs g;
         SKL_TRY(fill_args(rows, cols, p, MODE_COUNTS, 0, &g));
         if (early) {

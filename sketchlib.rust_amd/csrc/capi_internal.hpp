@@ -116,6 +116,7 @@ struct skl_ctx {
     uint64_t pinned_words = 0;
     size_t fuse_counter_k = 0;          // k-mer lengths the arrival counters of slot 11 count modulo (fused epilogue)
     hipStream_t aux_stream = nullptr;   // top-k of band i runs here while band i+1 is computed
+    hipStream_t epi_stream = nullptr;   // band pipeline of the early break (capi.cpp dense_band): band i's epilogue beside band i+1's counts kernel
     // band pipelines (kNN: pair kernel -> top-k; dense to host: pair kernel -> D2H copy):
     // "producer finished buffer b" / "consumer finished buffer b"
     hipEvent_t knn_pair_done[2] = {nullptr, nullptr}, knn_topk_done[2] = {nullptr, nullptr};
@@ -143,7 +144,7 @@ struct skl_ctx {
     uint64_t knn_pruned_stages = 0, knn_tile_stages = 0;   // ... stages the pruned tiles had walked / stages of a whole tile
     uint32_t *eb_counter = nullptr;        // device word: pairs the early-break epilogue completed (skl_ctx_early_break_stats)
     uint64_t eb_pairs = 0;                 // ... out of this many pairs of early-break launches since the context was made
-    // band pipeline of a large early-break call (capi.cpp dense_band): counts kernels on `stream`, epilogues on `aux_stream`
+    // band pipeline of a large early-break call (capi.cpp dense_band): counts kernels on `stream`, epilogues on `epi_stream`
     bool eb_in_pipeline = false, eb_pipe_overlap = false;
     int eb_pipe_buf = 0;
     hipEvent_t eb_events[4] = {nullptr, nullptr, nullptr, nullptr};   // counts of buffer b done / epilogue of buffer b done
