@@ -608,6 +608,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_name = ctx.last_kernel()
     eb_after = ctx.early_break_stats()
+    eb_plan = ctx.early_break_blocks()
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -724,6 +725,7 @@ def main():
                 "output_checksum_first_1e8_pairs": checksum,
                 "early_break": {
                     "k_mer_lengths_counted_for_every_pair": counted_lengths(kernel_name, nk), "of": nk,
+                    "decided_over_blocks_of_sample_ids": list(eb_plan["blocks"]), "blocks_disagree": eb_plan["mixed"],
                     "pairs_in_the_timed_region": eb_after[0] - eb_before[0],
                     "of_them_completed_one_by_one": eb_after[1] - eb_before[1],
                     "what": "core_acc_dist leaves its loop at the first k-mer length whose ln J is below the tolerance (no more shared bins "
