@@ -181,8 +181,7 @@ def test_early_break_with_a_completeness_correction(oracle, skl, gpu_ctx, n, ss6
     before = gpu_ctx.early_break_stats()
     got = skl.self_dists_all(gpu_ctx, g, p)
     after = gpu_ctx.early_break_stats()
-    assert "early break: " in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
-    assert after[0] - before[0] == n * (n - 1) // 2 and after[1] > before[1]
+    name = gpu_ctx.last_kernel()
     assert np.max(np.abs(got.astype(np.float64) - exp.astype(np.float64))) <= 1e-6
     assert np.array_equal(np.isnan(got), np.isnan(exp))
     nr = n // 2
@@ -200,6 +199,10 @@ def test_early_break_with_a_completeness_correction(oracle, skl, gpu_ctx, n, ss6
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
     for x in (g, g_r, g_q):
         x.close()
+    # (what the default dispatch does, asserted LAST: under scripts/forced_switch_suites.sh every parity assertion above must
+    # hold whatever the switches make of the dispatch)
+    assert "early break: " in name, name
+    assert after[0] - before[0] == n * (n - 1) // 2 and after[1] > before[1]
 
 
 @pytest.mark.ab_library
