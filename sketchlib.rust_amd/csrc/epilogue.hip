@@ -178,21 +178,43 @@ __device__ __forceinline__ bool eb_stops(const EpilogueArgs &g, uint32_t same, d
 template <bool COMP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 5, COMP ? 4 : 5))) void coreacc_epilogue_kernel_r6(const EpilogueArgs g)
 {
-    const uint64_t p_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool early = g.nk_total > g.nk || g.block_ke != nullptr;   // (pairs may be left in the running)
-    if (p_raw >= g.n_pairs && !early) return;   // (early break: every lane of a wave stays, the on-the-spot completion is cooperative)
-    const bool in_range = p_raw < g.n_pairs;
-    const uint64_t p = in_range ? p_raw : g.n_pairs - 1;   // (lanes past the end shadow the last pair and store nothing)
     const uint32_t maxnbits = g.ss64 * 64u;
     uint32_t i = 0, j = 0, ke = g.nk;
+    bool in_range, have_ij = false;
+    uint64_t p;
+    if (g.blocked) {
+        // BLOCKED ORDER (early-break launches whose column slices do not fit the Infinity Cache): the pair space is walked in
+        // blocks of 256 rows x 256 columns, a workgroup = one row's 256 columns of a block, the 256 workgroups of a block
+        // consecutive ON ONE XCD (blockIdx mod XCDs is the XCD, MI355X_MICROARCH.md).  A completion reads its column sample's
+        // slice; in the flat order (a row after the other, all its columns) a slice's next reader comes a whole row later and
+        // every completion is a 7 KB gather from HBM.  Here the block's 256 column slices (1.8 MB at 4 096 bins) stay in that
+        // XCD's 4 MB L2 while the block's rows pass.
+        const uint32_t xcd = blockIdx.x & ((1u << g.xcd_shift) - 1u), slot = blockIdx.x >> g.xcd_shift;
+        const uint32_t blk = ((slot >> 8) << g.xcd_shift) + xcd;
+        if (blk >= g.blk_rb * g.blk_cb) return;                    // (workgroup-uniform)
+        const uint32_t rb = blk / g.blk_cb, cb = blk - rb * g.blk_cb;
+        i = g.row_begin + rb * 256u + (slot & 255u);
+        j = cb * 256u + threadIdx.x;
+        if (i >= g.row_end || (g.self_mode && cb * 256u + 255u <= i)) return;   // (workgroup-uniform: no pair of the launch in this row of the block)
+        in_range = j < g.nB_cols && (!g.self_mode || j > i);
+        have_ij = true;
+        p = in_range ? (g.self_mode ? square_to_condensed_dev(i, j, g.n_total) : (uint64_t)i * g.nB_cols + j) - g.out_base : 0ull;   // (lanes without a pair shadow pair 0 and store nothing)
+    } else {
+        const uint64_t p_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (p_raw >= g.n_pairs && !early) return;   // (early break: every lane of a wave stays, the completion below is cooperative)
+        in_range = p_raw < g.n_pairs;
+        p = in_range ? p_raw : g.n_pairs - 1;       // (lanes past the end shadow the last pair and store nothing)
+    }
     double c1 = 0.0, c2 = 0.0;
     if (COMP || g.block_ke != nullptr) {
-        eb_pair_of(g, p + g.out_base, i, j);
+        if (!have_ij) eb_pair_of(g, p + g.out_base, i, j);
+        have_ij = true;
         if constexpr (COMP) {
             c1 = g.compA[i];
-            c2 = g.compB[j];
+            c2 = g.compB[min(j, g.nB_cols - 1u)];
         }
-        if (g.block_ke != nullptr) ke = g.block_ke[(size_t)(i >> g.blk_shift_r) * g.blk_cols + (j >> g.blk_shift_c)];
+        if (g.block_ke != nullptr) ke = g.block_ke[(size_t)(i >> g.blk_shift_r) * g.blk_cols + (min(j, g.nB_cols - 1u) >> g.blk_shift_c)];
     }
     const uint64_t cnt0 = p * g.pair_stride;
     EbSums s;
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t alive_mask = __ballot(alive);
     if (alive_mask != 0ull) {           // (wave-uniform)
-        if (alive && !(COMP || g.block_ke != nullptr)) eb_pair_of(g, p + g.out_base, i, j);
+        if (alive && !have_ij) eb_pair_of(g, p + g.out_base, i, j);
         if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(alive_mask));   // (1 024 slots: a million adds to ONE address queue up)
     }
     // ROWS IN LDS (g.lds_rows: launches with one ke for every pair, sketches whose two slices fit).  The 256 pairs of a workgroup
@@ -258,7 +280,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     if (g.lds_rows) {                       // (workgroup-uniform; every thread is still here: see the top)
         if (__syncthreads_or(alive ? 1 : 0)) {
             uint32_t j_wg;
-            eb_pair_of(g, (uint64_t)blockIdx.x * blockDim.x + g.out_base, i_wg, j_wg);
+            if (g.blocked) i_wg = i;      // (blocked order: the workgroup's one row)
+            else eb_pair_of(g, (uint64_t)blockIdx.x * blockDim.x + g.out_base, i_wg, j_wg);
             const uint32_t per_row = g.ss64 * 14u;   // uint2 per slice
             const uint2 *src = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_wg * g.nk_total + g.nk) * g.ss64) * BBITS);
             const size_t next_row = (size_t)g.nk_total * g.ss64 * BBITS;   // uint2 between the same slice of consecutive samples
@@ -334,8 +357,9 @@ template <int TRIPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
 {
     __shared__ uint16_t ext[4][KNN_BLOCKS][KNN_MAXEXT][64];   // completed bin-match counts of the pairs still in the running (0xFFFF: not looked at)
-    const uint32_t row = g.row_base + blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t row = g.row_base + blockIdx.y;
     const uint32_t c_wave = (blockIdx.x * 4u + wave) * (64u * KNN_BLOCKS);
     if (c_wave >= g.nB) return;
     const uint32_t maxnbits = g.ss64 * 64u, halves = g.ss64 * 2u;
@@ -607,10 +631,17 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
     if (args.n_pairs == 0) return hipSuccess;
     const bool early = args.nk_total > args.nk || args.block_ke != nullptr;
     if (early && args.nk_total > EB_MAXK) return hipErrorInvalidValue;
-    const uint64_t blocks = (args.n_pairs + 255) / 256;
+    EpilogueArgs a = args;
+    uint64_t blocks = (args.n_pairs + 255) / 256;
+    if (!early) a.blocked = 0u;
+    if (a.blocked) {   // blocks of 256 rows x 256 columns, 256 workgroups each, dealt to the XCDs whole
+        a.blk_rb = (a.row_end - a.row_begin + 255u) / 256u;
+        a.blk_cb = (a.nB_cols + 255u) / 256u;
+        const uint64_t n_blk = (uint64_t)a.blk_rb * a.blk_cb, n_xcd = 1ull << a.xcd_shift;
+        blocks = ((n_blk + n_xcd - 1) / n_xcd * 256ull) << a.xcd_shift;
+    }
     if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 gr((unsigned)blocks), bl(256);
-    EpilogueArgs a = args;
     // the workgroup's two row slices in LDS: one ke for every pair (the slices are those of length index nk), up to 16 KB
     const size_t lds = early && a.block_ke == nullptr && a.ss64 * 224ull <= 16384ull && a.lds_rows != 0u ? (size_t)a.ss64 * 224u : 0u;
     a.lds_rows = lds != 0 ? 1u : 0u;

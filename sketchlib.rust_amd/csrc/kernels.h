@@ -238,6 +238,10 @@ struct EpilogueArgs {
     uint32_t nk_total;
     const uint64_t *rows_ref, *cols_ref;
     uint32_t *alive_count;      // 1 024 words, slot blockIdx & 1023 += pairs completed here (diagnostic; may be null)
+    // BLOCKED ORDER (epilogue.hip, early-break launches): workgroups walk the pair space in blocks of 256 rows x 256 columns kept
+    // on one XCD each, so that the column slices the completions read are reused from that XCD's L2.  row_end: one past the
+    // launch's last row; blk_rb / blk_cb: set by the launcher
+    uint32_t blocked, row_end, xcd_shift, blk_rb, blk_cb;
     uint32_t lds_rows;          // host-side request (epilogue.hip): a workgroup with a pair still in the running stages its two row slices in LDS
     uint32_t min_alive;         // no completeness correction: ln J(count) < tolerance <=> count < min_alive (0xFFFFFFFF: ask ytab)
     uint32_t cnt_u16;           // 1: the counts are u16 records (sketches of up to 1 023 chunks, no chunk slices)

@@ -317,3 +317,37 @@ def test_band_pipeline_forced_on_small_inputs(oracle, skl, gpu_ctx, monkeypatch,
     assert "row bands" in gpu_ctx.last_kernel()
     g.close()
     g_q.close()
+
+
+@pytest.mark.ab_library
+@pytest.mark.parametrize("lengths", [2, 3])
+@pytest.mark.parametrize("n,ss64,comp", [(700, 64, False), (601, 32, True), (530, 16, False), (420, 300, False)])
+def test_blocked_epilogue_order_forced_on_small_inputs(oracle, skl, gpu_ctx, monkeypatch, n, ss64, comp, lengths):
+    """SKL_EB_BLOCKED=1 (A/B build): the early break's epilogue walking the pair space in blocks of 256 x 256 pairs, each block on
+    one XCD -- what the library does by itself when the column samples' slices of one k-mer length outgrow the Infinity Cache
+    (cfg 3) -- on inputs the oracle checks whole: self matrix (ragged last blocks, the diagonal), a row range, a cross matrix."""
+    bins = _mixed(n, KMERS, ss64, n_random=n - 200, n_clusters=2, seed=41)
+    cvec = np.random.default_rng(3).uniform(0.5, 1.0, n) if comp else None
+    o = oracle.Sketches(bins, n, KMERS, ss64, completeness=cvec)
+    exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
+    monkeypatch.setenv("SKL_EARLY_BREAK", str(lengths))
+    monkeypatch.setenv("SKL_EB_BLOCKED", "1")
+    gpu_ctx.reload_env()
+    g = gpu_ctx.sketches(bins, n, KMERS, ss64, completeness=cvec)
+
+    def check(got, want):
+        if comp:
+            assert np.max(np.abs(got.astype(np.float64) - want.astype(np.float64))) <= 1e-6
+        else:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got != want)[:5]
+
+    check(skl.self_dists_all(gpu_ctx, g, g.set_k()), exp)
+    assert "blocks of 256 x 256" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
+    part = skl.self_dists_rows(gpu_ctx, g, g.set_k(), 131, n - 57)
+    lo = 131 * n - 131 * 132 // 2
+    check(part, exp[lo:lo + part.shape[0]])
+    g_q = gpu_ctx.sketches(bins[150:], n - 150, KMERS, ss64, completeness=None if cvec is None else cvec[150:])
+    o_q = oracle.Sketches(bins[150:], n - 150, KMERS, ss64, completeness=None if cvec is None else cvec[150:])
+    check(skl.cross_dists_all(gpu_ctx, g, g_q, g.set_k()), oracle.cross_dists_all(o, o_q, oracle.COREACC, threads=8))
+    g.close()
+    g_q.close()
