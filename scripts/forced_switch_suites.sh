@@ -20,8 +20,8 @@ for e in "SKL_TILE32_MIN=0" "SKL_TILE32_MIN=-1" "SKL_TAIL_MAX_PCT=100000000 SKL_
          "SKL_TAIL_MAX_PCT=100000000 SKL_TAIL_SLICES=8 SKL_TILE32_MIN=0 SKL_GROUP_SPAN=3" \
          "SKL_ROUND_PRIORITY=0 SKL_KNN_ROW_FLAGS=0" "SKL_XCDS=1 SKL_CAND_ROW_ORDER=0" "SKL_XCDS=4 SKL_TILE32_MIN=0" \
          "SKL_EARLY_BREAK=3" "SKL_EARLY_BREAK=4 SKL_TILE32_MIN=0" "SKL_EARLY_BREAK=2" "SKL_EARLY_BREAK=0 SKL_KNN_SPARSE=0" \
-         "SKL_EARLY_BREAK=2 SKL_EB_PIPELINE_MIN=30000 SKL_TAIL_SLICES=0" "SKL_EARLY_BREAK=3 SKL_EB_LDS_ROWS=0 SKL_COUNTS_U16=0 SKL_TILE32_MIN=0" \
-         "SKL_EPILOGUE_R5=1 SKL_EB_PIPELINE=0"; do
+         "SKL_EARLY_BREAK=2 SKL_EB_PIPELINE=1 SKL_EB_PIPELINE_MIN=30000 SKL_TAIL_SLICES=0" "SKL_EARLY_BREAK=3 SKL_EB_LDS_ROWS=0 SKL_COUNTS_U16=0 SKL_TILE32_MIN=0" \
+         "SKL_EPILOGUE_R5=1" "SKL_EARLY_BREAK=2 SKL_EB_BLOCKED=1 SKL_EB_BLK_ROW_SHIFT=6"; do
   I=$((I + 1))
   if [ "$I" -lt "$FIRST" ] || [ "$I" -gt "$LAST" ]; then continue; fi
   echo "== $e"

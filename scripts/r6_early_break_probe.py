@@ -20,7 +20,7 @@ cases = set(args.cases.split(","))
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 K5 = [15, 19, 23, 27, 31]
-tag = {k: os.environ.get(k) for k in ("SKL_LIBRARY", "SKL_EPILOGUE_R5", "SKL_EARLY_BREAK", "SKL_EB_PIPELINE", "SKL_COUNTS_U16", "SKL_EB_LDS_ROWS", "SKL_EB_BLOCKED") if os.environ.get(k)}
+tag = {k: os.environ.get(k) for k in ("SKL_LIBRARY", "SKL_EPILOGUE_R5", "SKL_EARLY_BREAK", "SKL_EB_PIPELINE", "SKL_COUNTS_U16", "SKL_EB_LDS_ROWS", "SKL_EB_BLOCKED", "SKL_EB_BLK_ROW_SHIFT") if os.environ.get(k)}
 
 
 def time_self(name, bins, n, kmers, ss64, reps, comp=None, cutoff=0.64):
@@ -78,6 +78,9 @@ if "species" in cases:
     per = 320
     parts = [synth.set_clustered_device(per, 5, 64, dev, n_clusters=1, keep=[0.97, 0.955, 0.94, 0.925, 0.91], seed=synth.SEED_R + 7 * s) for s in range(50)]
     time_self("n = 16 000 sorted by 50 species", torch.cat(parts), per * 50, K5, 64, 5)
+for nn in (8000, 12000, 20000, 24000, 30000, 40000, 60000):   # where does the blocked epilogue order start to pay?  (column slices of one length: 205 / 273 / 410 MB)
+    if ("u%d" % nn) in cases:
+        time_self("n = %d Set U, 4 096 bins" % nn, synth.set_u_device(nn, 5, 64, dev), nn, K5, 64, 3)
 if "cfg3" in cases:    # BASELINE configs[2] at FULL size: 100 000 genomes all-vs-all, 4 096 bins, Set U (40 GB of output)
     time_self("cfg3 FULL: n = 100 000 Set U", synth.set_u_device(100000, 5, 64, dev), 100000, K5, 64, 2)
 if "cfg4" in cases:    # BASELINE configs[3] at FULL size: 1 M clustered references x 10 000 queries, 2 048 bins (80 GB of output)

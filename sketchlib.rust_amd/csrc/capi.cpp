@@ -385,11 +385,12 @@ Knobs read_knobs()
     k.knn_sparse = env_int("SKL_KNN_SPARSE", 1) != 0;
     k.early_break = (int)std::min(7ll, std::max(0ll, env_int("SKL_EARLY_BREAK", 1)));
     k.epilogue_r5 = env_int("SKL_EPILOGUE_R5", 0) != 0;
-    k.eb_pipeline = env_int("SKL_EB_PIPELINE", 1) != 0;
+    k.eb_pipeline = env_int("SKL_EB_PIPELINE", 0) != 0;
     k.eb_pipeline_min = std::max(2ll, env_int("SKL_EB_PIPELINE_MIN", 64ll << 20));
     k.counts_u16 = env_int("SKL_COUNTS_U16", 1) != 0;
     k.eb_lds_rows = env_int("SKL_EB_LDS_ROWS", 1) != 0;
     k.eb_blocked = (int)env_int("SKL_EB_BLOCKED", -1);
+    k.eb_blk_row_shift = (int)env_int("SKL_EB_BLK_ROW_SHIFT", 10);
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
     k.refheap_wave = env_int("SKL_REFHEAP_WAVE", 1) != 0;
     k.knn_row_flags = env_int("SKL_KNN_ROW_FLAGS", 1) != 0;
@@ -982,22 +983,23 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 // it within (round 5 decided once per slab pair).  Blocks of one mind give a plain launch; otherwise the pair kernel's
 // (tile, k index) workgroups look their block up and leave when k index >= its ke.
 // EB_COST, measured (profiles/r06_early_break_forced_lengths.md: whole calls with 2 / 3 lengths forced, T(3) - T(2) = one length's
-// kernel time - EB_COST x the difference of the alive shares): 15-22.  While the column samples' slices of ONE k-mer length
-// (n_cols x sketchsize64 x 112 bytes) fit the 256 MB Infinity Cache a completion reads its column slice from there; when
-// they do not (cfg 3: 717 MB) the epilogue walks the pairs in blocks of 256 x 256 kept on one XCD each, whose column slices
-// stay in that XCD's L2 (eb_blocked_order: in the flat order every completion is a 7 KB gather from HBM and EB_COST is 37-40:
-// cfg 3 at two lengths 827 ms flat, 667 ms blocked).  Beyond 65 535 bins a completion is a run of thousands of dependent trips
-// of one wave and comes to ~60: there the early break is taken only where hardly a pair stays in the running.
+// kernel time - EB_COST x the difference of the alive shares): 15-22.  Beyond 65 535 bins a completion is a run of thousands of
+// dependent trips of one wave and comes to ~60: there the early break is taken only where hardly a pair stays in the running.
 constexpr double EB_COST = 20.0, EB_COST_BIG = 60.0;
 static double eb_cost_of(const skl_sketches *rows, const skl_sketches *)
 {
     return rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS ? EB_COST_BIG : EB_COST;
 }
-bool eb_blocked_order(const skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols)
+// BLOCKED EPILOGUE ORDER (epilogue.hip): the early break's epilogue walks the pairs in blocks of 1 024 rows x 256 columns, each
+// block on one XCD, whose L2 then holds the block's 256 column slices while its rows pass -- instead of the launch's flat order
+// (a row after the other, all its columns), in which a slice's next reader comes a whole row later and every completion is a
+// gather from the Infinity Cache or, once the slices of one length outgrow it (cfg 3: 717 MB), from HBM.  Pays where many
+// pairs stay in the running and the launch is large: at 4.9 % alive n = 12 000 / 16 000 / 24 000 / 60 000 / 100 000:
+// 10.3 -> 9.9, 18.3 -> 17.2, 41.0 -> 38.0, 266 -> 234, 827 -> 595 ms; at 1.4 % alive (2 048 bins) +1 %: not taken.
+bool eb_blocked_order(const skl_ctx *ctx, const skl_sketches *rows, const EbPlan *plan, uint64_t pairs)
 {
     if (ctx->knobs.eb_blocked >= 0) return ctx->knobs.eb_blocked != 0;   // (A/B build: forced)
-    const double slice_mb = (double)cols->n * (double)rows->ss64 * 112.0 / (1024.0 * 1024.0);
-    return slice_mb > 256.0 && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS;
+    return plan != nullptr && plan->alive_share >= 0.03 && pairs >= (48ull << 20) && rows->ss64 <= (size_t)KSLICE_MAX_U16_CHUNKS;
 }
 
 constexpr uint32_t EB_BLOCKS_MAX = 64;      // blocks per side
@@ -1277,8 +1279,10 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // (the side-by-side run costs the counts kernel about what it hides of the epilogue -- an epilogue wave displaces a wave of the
         // counts kernel, which fills the register file by itself -- and pays only where the epilogue is heavy: from ~3 % of the
         // pairs still in the running.  n = 16 000 at 4.9 %: 18.5 against 19.4 ms; cfg 3 at 1.1 %: 782 against 748 ms.)
-        // (not with the blocked epilogue order either -- cfg 3 at two lengths: 667 ms alone, 703 ms piped)
-        const bool blocked = early && eb_blocked_order(ctx, rows, cols);
+        // Since the blocked epilogue order (eb_blocked_order) covers that regime better -- n = 16 000: 17.2 ms blocked, 18.3-18.8
+        // piped; cfg 3 at two lengths: 595 blocked, 703 both, 775 piped -- the pipeline is off unless asked for (A/B build,
+        // SKL_EB_PIPELINE=1; tests/test_gpu_early_break_r6.py keeps it exact).
+        const bool blocked = early && eb_blocked_order(ctx, rows, plan, pairs);
         const bool piping = early && !blocked && ctx->knobs.eb_pipeline &&
                             (eb_mixed || (plan != nullptr && plan->alive_share >= 0.03) || ctx->knobs.early_break >= 2);
         if (!ctx->eb_in_pipeline && r1 - r0 > 1 &&
@@ -1483,8 +1487,9 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         e.cnt_u16 = g.cnt_u16;
         e.row_end = (uint32_t)r1;
         e.xcd_shift = ctx_xcd_shift(ctx);
-        e.blocked = early && eb_blocked_order(ctx, rows, cols) ? 1u : 0u;
-        if (e.blocked) ctx->last_kernel += " (epilogue in blocks of 256 x 256 pairs per XCD)";
+        e.blocked = early && eb_blocked_order(ctx, rows, plan, pairs) ? 1u : 0u;
+        e.blk_row_shift = (uint32_t)ctx->knobs.eb_blk_row_shift;
+        if (e.blocked) ctx->last_kernel += " (epilogue in blocks of 1 024 x 256 pairs per XCD)";
         // (the workgroup's row slices in LDS pay from ~8 completions per workgroup of 256 pairs on: n = 16 000 at 4 096 bins, 4.9 %
         // still in the running: 18.0 against 18.7 ms; at 2 048 bins, 1.4 %: 30.8 against 27.3 -- profiles/r06_epilogue_forms.md)
         e.lds_rows = ctx->knobs.eb_lds_rows && plan != nullptr && plan->alive_share >= 0.03 ? 1u : 0u;

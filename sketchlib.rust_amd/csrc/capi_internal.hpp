@@ -62,9 +62,10 @@ struct Knobs {
     bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
     int early_break = 1;              // A/B build, SKL_EARLY_BREAK: 0 core/accessory launches count every k-mer length; 1 (default) the early break where a
                                       // sample of the pairs says it pays; 2..7 forced with that many lengths counted (tests).  Results identical.
-    bool eb_pipeline = true;          // A/B build, SKL_EB_PIPELINE=0: the row bands of a large early-break call run one after the other on one stream
+    bool eb_pipeline = false;         // A/B build, SKL_EB_PIPELINE=1: the row bands of a large early-break call overlap (band i's epilogue beside band i + 1's counts kernel; superseded by the blocked epilogue order)
     long long eb_pipeline_min = 64ll << 20;  // A/B build, SKL_EB_PIPELINE_MIN: pairs from which an early-break call is cut into overlapping row bands (tests force it low)
     int eb_blocked = -1;              // A/B build, SKL_EB_BLOCKED=0|1: the early break's epilogue walks the pairs in flat order / in 256 x 256 blocks per XCD (-1: by the size of the column slices)
+    int eb_blk_row_shift = 10;        // A/B build, SKL_EB_BLK_ROW_SHIFT: rows per block (log2) of the blocked epilogue
     bool eb_lds_rows = true;          // A/B build, SKL_EB_LDS_ROWS=0: completions read the row sample's slice from memory, not from the workgroup's LDS copy
     bool counts_u16 = true;           // A/B build, SKL_COUNTS_U16=0: the counts scratch keeps u32 records
     bool epilogue_r5 = false;         // A/B build, SKL_EPILOGUE_R5=1: round 5's epilogue (alive pairs completed where they are found; timing)
@@ -205,9 +206,8 @@ SKL_INTERNAL bool fused_coreacc_ok(const skl_sketches *s);
 // *plan = null: not applicable (fewer than 3 or more than 8 k-mer lengths, a tiny pair space, switched off)
 SKL_INTERNAL int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols, int self_mode, double cutoff,
                                   const EbPlan **plan);
-// does the early break's epilogue walk the pairs in blocks kept on one XCD each?  (capi.cpp: when the column samples' slices of one
-// k-mer length do not fit the Infinity Cache)
-SKL_INTERNAL bool eb_blocked_order(const skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols);
+// does the early break's epilogue walk the pairs in blocks kept on one XCD each?  (capi.cpp: large launches with many pairs still in the running)
+SKL_INTERNAL bool eb_blocked_order(const skl_ctx *ctx, const skl_sketches *rows, const EbPlan *plan, uint64_t pairs);
 // ... its pooled form, for the kNN drivers: k-mer lengths the pair kernel should count (0: all of them)
 SKL_INTERNAL int early_break_lengths(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols, int self_mode, int *lengths);
 // operand / epilogue fields common to every launch: `rows` is the scalar operand (A), `cols` the lane operand (B)

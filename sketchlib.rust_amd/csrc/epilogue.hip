@@ -185,16 +185,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     uint64_t p;
     if (g.blocked) {
         // BLOCKED ORDER (early-break launches whose column slices do not fit the Infinity Cache): the pair space is walked in
-        // blocks of 256 rows x 256 columns, a workgroup = one row's 256 columns of a block, the 256 workgroups of a block
-        // consecutive ON ONE XCD (blockIdx mod XCDs is the XCD, MI355X_MICROARCH.md).  A completion reads its column sample's
+        // blocks of 1 024 rows x 256 columns (cfg 3: 128 / 256 / 512 / 1 024 rows: 614 / 607 / 599 / 595 ms), a workgroup = one
+        // row's 256 columns of a block, the workgroups of a block consecutive ON ONE XCD (blockIdx mod XCDs is the XCD, MI355X_MICROARCH.md).  A completion reads its column sample's
         // slice; in the flat order (a row after the other, all its columns) a slice's next reader comes a whole row later and
         // every completion is a 7 KB gather from HBM.  Here the block's 256 column slices (1.8 MB at 4 096 bins) stay in that
         // XCD's 4 MB L2 while the block's rows pass.
         const uint32_t xcd = blockIdx.x & ((1u << g.xcd_shift) - 1u), slot = blockIdx.x >> g.xcd_shift;
-        const uint32_t blk = ((slot >> 8) << g.xcd_shift) + xcd;
+        const uint32_t rs = g.blk_row_shift, lb = slot >> rs;      // rows per block = 1 << rs; lb: this XCD's lb-th block
+        const uint32_t blk = (lb << g.xcd_shift) + xcd;          // blocks dealt to the XCDs in turns, column block fastest
         if (blk >= g.blk_rb * g.blk_cb) return;                    // (workgroup-uniform)
         const uint32_t rb = blk / g.blk_cb, cb = blk - rb * g.blk_cb;
-        i = g.row_begin + rb * 256u + (slot & 255u);
+        i = g.row_begin + (rb << rs) + (slot & ((1u << rs) - 1u));
         j = cb * 256u + threadIdx.x;
         if (i >= g.row_end || (g.self_mode && cb * 256u + 255u <= i)) return;   // (workgroup-uniform: no pair of the launch in this row of the block)
         in_range = j < g.nB_cols && (!g.self_mode || j > i);
@@ -285,7 +286,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
             const uint32_t per_row = g.ss64 * 14u;   // uint2 per slice
             const uint2 *src = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_wg * g.nk_total + g.nk) * g.ss64) * BBITS);
             const size_t next_row = (size_t)g.nk_total * g.ss64 * BBITS;   // uint2 between the same slice of consecutive samples
-            for (uint32_t x = threadIdx.x; x < 2u * per_row; x += blockDim.x) {
+            const uint32_t staged_rows = g.blocked ? 1u : 2u;   // (blocked order: the workgroup's pairs are one row's)
+            for (uint32_t x = threadIdx.x; x < staged_rows * per_row; x += blockDim.x) {
                 const uint32_t r = x >= per_row ? 1u : 0u;   // (the row slab ends in pad rows: row i_wg + 1 always exists)
                 eb_lds_rows[x] = src[(size_t)r * next_row + (x - r * per_row)];
             }
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
         EbRow<0> none;
         for (uint32_t t = ke_l; t < g.nk_total; ++t) {
             uint32_t same;
-            if (staged && t == g.nk && i_l - i_wg < 2u) {   // the row's slice from LDS, the column's as one contiguous run
+            if (staged && t == g.nk && i_l - i_wg < (g.blocked ? 1u : 2u)) {   // the row's slice from LDS, the column's as one contiguous run
                 const uint32_t halves = g.ss64 * 2u;
                 const uint2 *a_lds = eb_lds_rows + (size_t)(i_l - i_wg) * g.ss64 * 14u;
                 const uint2 *pj = reinterpret_cast<const uint2 *>(g.cols_ref + (((uint64_t)j_l * g.nk_total + t) * g.ss64) * BBITS);
@@ -634,11 +636,14 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
     EpilogueArgs a = args;
     uint64_t blocks = (args.n_pairs + 255) / 256;
     if (!early) a.blocked = 0u;
-    if (a.blocked) {   // blocks of 256 rows x 256 columns, 256 workgroups each, dealt to the XCDs whole
-        a.blk_rb = (a.row_end - a.row_begin + 255u) / 256u;
+    if (a.blocked) {   // blocks of (1 << blk_row_shift) rows x 256 columns, one workgroup per row of a block, dealt to the XCDs whole
+        if (a.blk_row_shift < 5u || a.blk_row_shift > 12u) a.blk_row_shift = 10u;
+        const uint32_t br = 1u << a.blk_row_shift;
+        a.blk_rb = (a.row_end - a.row_begin + br - 1u) / br;
         a.blk_cb = (a.nB_cols + 255u) / 256u;
-        const uint64_t n_blk = (uint64_t)a.blk_rb * a.blk_cb, n_xcd = 1ull << a.xcd_shift;
-        blocks = ((n_blk + n_xcd - 1) / n_xcd * 256ull) << a.xcd_shift;
+        const uint64_t n_xcd = 1ull << a.xcd_shift;
+        const uint64_t per_xcd = ((uint64_t)a.blk_rb * a.blk_cb + n_xcd - 1) / n_xcd;
+        blocks = (per_xcd * br) << a.xcd_shift;
     }
     if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
     const dim3 gr((unsigned)blocks), bl(256);

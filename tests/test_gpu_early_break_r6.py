@@ -299,6 +299,7 @@ def test_band_pipeline_forced_on_small_inputs(oracle, skl, gpu_ctx, monkeypatch,
     exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
     monkeypatch.setenv("SKL_EARLY_BREAK", "3")
     monkeypatch.setenv("SKL_TAIL_SLICES", "0")       # (chunk slices keep u32 counts)
+    monkeypatch.setenv("SKL_EB_PIPELINE", "1")
     monkeypatch.setenv("SKL_EB_PIPELINE_MIN", "30000")
     gpu_ctx.reload_env()
     g = gpu_ctx.sketches(bins, n, KMERS, ss64, completeness=cvec)
@@ -332,6 +333,7 @@ def test_blocked_epilogue_order_forced_on_small_inputs(oracle, skl, gpu_ctx, mon
     exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
     monkeypatch.setenv("SKL_EARLY_BREAK", str(lengths))
     monkeypatch.setenv("SKL_EB_BLOCKED", "1")
+    monkeypatch.setenv("SKL_EB_BLK_ROW_SHIFT", "7" if n % 2 else "10")     # (several row blocks at these sizes / one)
     gpu_ctx.reload_env()
     g = gpu_ctx.sketches(bins, n, KMERS, ss64, completeness=cvec)
 
@@ -342,7 +344,7 @@ def test_blocked_epilogue_order_forced_on_small_inputs(oracle, skl, gpu_ctx, mon
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got != want)[:5]
 
     check(skl.self_dists_all(gpu_ctx, g, g.set_k()), exp)
-    assert "blocks of 256 x 256" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
+    assert "pairs per XCD" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
     part = skl.self_dists_rows(gpu_ctx, g, g.set_k(), 131, n - 57)
     lo = 131 * n - 131 * 132 // 2
     check(part, exp[lo:lo + part.shape[0]])
