@@ -985,17 +985,21 @@ static uint32_t choose_k_slices(const skl_ctx *ctx, size_t ss64)
 // EB_COST, measured (profiles/r06_early_break_forced_lengths.md: whole calls with 2 / 3 lengths forced, T(3) - T(2) = one length's
 // kernel time - EB_COST x the difference of the alive shares): 15-22.  Beyond 65 535 bins a completion is a run of thousands of
 // dependent trips of one wave and comes to ~60: there the early break is taken only where hardly a pair stays in the running.
-constexpr double EB_COST = 20.0, EB_COST_BIG = 60.0;
-static double eb_cost_of(const skl_sketches *rows, const skl_sketches *)
+// Pair spaces large enough for the blocked epilogue order (below) complete a pair for ~12-15: cfg 3 with 2 / 3 lengths 642 / 733
+// ms, n = 16 000 17.2 / 19.3.
+constexpr double EB_COST = 20.0, EB_COST_BLOCKED = 12.0, EB_COST_BIG = 60.0;
+static double eb_cost_of(const skl_sketches *rows, const skl_sketches *cols, int self_mode)
 {
-    return rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS ? EB_COST_BIG : EB_COST;
+    if (rows->ss64 > (size_t)KSLICE_MAX_U16_CHUNKS) return EB_COST_BIG;
+    const uint64_t pairs = self_mode ? (uint64_t)rows->n * (rows->n - 1) / 2 : (uint64_t)rows->n * cols->n;
+    return pairs >= (48ull << 20) ? EB_COST_BLOCKED : EB_COST;
 }
 // BLOCKED EPILOGUE ORDER (epilogue.hip): the early break's epilogue walks the pairs in blocks of 1 024 rows x 256 columns, each
 // block on one XCD, whose L2 then holds the block's 256 column slices while its rows pass -- instead of the launch's flat order
 // (a row after the other, all its columns), in which a slice's next reader comes a whole row later and every completion is a
 // gather from the Infinity Cache or, once the slices of one length outgrow it (cfg 3: 717 MB), from HBM.  Pays where many
 // pairs stay in the running and the launch is large: at 4.9 % alive n = 12 000 / 16 000 / 24 000 / 60 000 / 100 000:
-// 10.3 -> 9.9, 18.3 -> 17.2, 41.0 -> 38.0, 266 -> 234, 827 -> 595 ms; at 1.4 % alive (2 048 bins) +1 %: not taken.
+// 10.3 -> 9.9, 18.3 -> 17.2, 41.0 -> 38.0, 266 -> 234, 827 -> 642 ms; at 1.4 % alive (2 048 bins) +1 %: not taken.
 bool eb_blocked_order(const skl_ctx *ctx, const skl_sketches *rows, const EbPlan *plan, uint64_t pairs)
 {
     if (ctx->knobs.eb_blocked >= 0) return ctx->knobs.eb_blocked != 0;   // (A/B build: forced)
@@ -1155,7 +1159,7 @@ int early_break_plan(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches 
             pooled_n += hist[(size_t)b * 9 + m];
         }
     }
-    const double eb_cost = eb_cost_of(rows, cols);
+    const double eb_cost = eb_cost_of(rows, cols, self_mode);
     plan->lengths = best_lengths(pooled, pooled_n, rows->nk, eb_cost, &plan->alive_share);
     if (live_blocks > 1) {
         // per block.  Pass 1: every block's own sample decides whether it takes the early break at all; pass 2: the blocks that
@@ -1280,7 +1284,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // counts kernel, which fills the register file by itself -- and pays only where the epilogue is heavy: from ~3 % of the
         // pairs still in the running.  n = 16 000 at 4.9 %: 18.5 against 19.4 ms; cfg 3 at 1.1 %: 782 against 748 ms.)
         // Since the blocked epilogue order (eb_blocked_order) covers that regime better -- n = 16 000: 17.2 ms blocked, 18.3-18.8
-        // piped; cfg 3 at two lengths: 595 blocked, 703 both, 775 piped -- the pipeline is off unless asked for (A/B build,
+        // piped; cfg 3 at two lengths: 642 blocked, 775 piped -- the pipeline is off unless asked for (A/B build,
         // SKL_EB_PIPELINE=1; tests/test_gpu_early_break_r6.py keeps it exact).
         const bool blocked = early && eb_blocked_order(ctx, rows, plan, pairs);
         const bool piping = early && !blocked && ctx->knobs.eb_pipeline &&

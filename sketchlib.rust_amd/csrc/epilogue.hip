@@ -185,16 +185,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     uint64_t p;
     if (g.blocked) {
         // BLOCKED ORDER (early-break launches whose column slices do not fit the Infinity Cache): the pair space is walked in
-        // blocks of 1 024 rows x 256 columns (cfg 3: 128 / 256 / 512 / 1 024 rows: 614 / 607 / 599 / 595 ms), a workgroup = one
+        // blocks of 1 024 rows x 256 columns (cfg 3: 256 / 512 / 1 024 / 2 048 rows: 659 / 649 / 642 / 639 ms), a workgroup = one
         // row's 256 columns of a block, the workgroups of a block consecutive ON ONE XCD (blockIdx mod XCDs is the XCD, MI355X_MICROARCH.md).  A completion reads its column sample's
         // slice; in the flat order (a row after the other, all its columns) a slice's next reader comes a whole row later and
         // every completion is a 7 KB gather from HBM.  Here the block's 256 column slices (1.8 MB at 4 096 bins) stay in that
         // XCD's 4 MB L2 while the block's rows pass.
-        const uint32_t xcd = blockIdx.x & ((1u << g.xcd_shift) - 1u), slot = blockIdx.x >> g.xcd_shift;
+        const uint32_t wg = blockIdx.x + g.wg_base;              // (a launch carries at most 2^31 work-items: wg_base, a multiple of the XCDs)
+        const uint32_t xcd = wg & ((1u << g.xcd_shift) - 1u), slot = wg >> g.xcd_shift;
         const uint32_t rs = g.blk_row_shift, lb = slot >> rs;      // rows per block = 1 << rs; lb: this XCD's lb-th block
         const uint32_t blk = (lb << g.xcd_shift) + xcd;          // blocks dealt to the XCDs in turns, column block fastest
         if (blk >= g.blk_rb * g.blk_cb) return;                    // (workgroup-uniform)
-        const uint32_t rb = blk / g.blk_cb, cb = blk - rb * g.blk_cb;
+        const uint32_t rb = blk / g.blk_cb, cb = g.blk_cb0 + (blk - rb * g.blk_cb);   // (self mode: the column blocks left of the launch's first row hold no pair)
         i = g.row_begin + (rb << rs) + (slot & ((1u << rs) - 1u));
         j = cb * 256u + threadIdx.x;
         if (i >= g.row_end || (g.self_mode && cb * 256u + 255u <= i)) return;   // (workgroup-uniform: no pair of the launch in this row of the block)
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
         have_ij = true;
         p = in_range ? (g.self_mode ? square_to_condensed_dev(i, j, g.n_total) : (uint64_t)i * g.nB_cols + j) - g.out_base : 0ull;   // (lanes without a pair shadow pair 0 and store nothing)
     } else {
-        const uint64_t p_raw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t p_raw = ((uint64_t)blockIdx.x + g.wg_base) * blockDim.x + threadIdx.x;
         if (p_raw >= g.n_pairs && !early) return;   // (early break: every lane of a wave stays, the completion below is cooperative)
         in_range = p_raw < g.n_pairs;
         p = in_range ? p_raw : g.n_pairs - 1;       // (lanes past the end shadow the last pair and store nothing)
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
         if (__syncthreads_or(alive ? 1 : 0)) {
             uint32_t j_wg;
             if (g.blocked) i_wg = i;      // (blocked order: the workgroup's one row)
-            else eb_pair_of(g, (uint64_t)blockIdx.x * blockDim.x + g.out_base, i_wg, j_wg);
+            else eb_pair_of(g, ((uint64_t)blockIdx.x + g.wg_base) * blockDim.x + g.out_base, i_wg, j_wg);
             const uint32_t per_row = g.ss64 * 14u;   // uint2 per slice
             const uint2 *src = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_wg * g.nk_total + g.nk) * g.ss64) * BBITS);
             const size_t next_row = (size_t)g.nk_total * g.ss64 * BBITS;   // uint2 between the same slice of consecutive samples
@@ -640,19 +641,26 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
         if (a.blk_row_shift < 5u || a.blk_row_shift > 12u) a.blk_row_shift = 10u;
         const uint32_t br = 1u << a.blk_row_shift;
         a.blk_rb = (a.row_end - a.row_begin + br - 1u) / br;
-        a.blk_cb = (a.nB_cols + 255u) / 256u;
+        a.blk_cb0 = a.self_mode ? (a.row_begin + 1u) / 256u : 0u;
+        a.blk_cb = (a.nB_cols + 255u) / 256u - a.blk_cb0;
         const uint64_t n_xcd = 1ull << a.xcd_shift;
         const uint64_t per_xcd = ((uint64_t)a.blk_rb * a.blk_cb + n_xcd - 1) / n_xcd;
         blocks = (per_xcd * br) << a.xcd_shift;
+        if (blocks >= (1ull << 32)) return hipErrorInvalidValue;
     }
-    if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
-    const dim3 gr((unsigned)blocks), bl(256);
-    // the workgroup's two row slices in LDS: one ke for every pair (the slices are those of length index nk), up to 16 KB
     const size_t lds = early && a.block_ke == nullptr && a.ss64 * 224ull <= 16384ull && a.lds_rows != 0u ? (size_t)a.ss64 * 224u : 0u;
     a.lds_rows = lds != 0 ? 1u : 0u;
-    if (a.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, lds, stream, a);
-    else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, lds, stream, a);
-    return hipGetLastError();
+    // (a dispatch packet counts WORK-ITEMS in 32 bits: 2^23 workgroups of 256 per launch at most)
+    constexpr uint64_t MAX_WG = 1ull << 23;
+    for (uint64_t w0 = 0; w0 < blocks; w0 += MAX_WG) {
+        a.wg_base = (uint32_t)w0;
+        const dim3 gr((unsigned)std::min(MAX_WG, blocks - w0)), bl(256);
+        if (a.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, lds, stream, a);
+        else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, lds, stream, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace skl
