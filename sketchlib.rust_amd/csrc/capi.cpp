@@ -389,6 +389,8 @@ Knobs read_knobs()
     k.eb_pipeline_min = std::max(2ll, env_int("SKL_EB_PIPELINE_MIN", 64ll << 20));
     k.counts_u16 = env_int("SKL_COUNTS_U16", 1) != 0;
     k.eb_lds_rows = env_int("SKL_EB_LDS_ROWS", 1) != 0;
+    k.eb_ahead = env_int("SKL_EB_AHEAD", 1) != 0;
+    k.eb_lean = env_int("SKL_EB_LEAN", 1) != 0;
     k.eb_blocked = (int)env_int("SKL_EB_BLOCKED", -1);
     k.eb_blk_row_shift = (int)env_int("SKL_EB_BLK_ROW_SHIFT", 10);
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;
@@ -1496,6 +1498,8 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         if (e.blocked) ctx->last_kernel += " (epilogue in blocks of 1 024 x 256 pairs per XCD)";
         // (the workgroup's row slices in LDS pay from ~8 completions per workgroup of 256 pairs on: n = 16 000 at 4 096 bins, 4.9 %
         // still in the running: 18.0 against 18.7 ms; at 2 048 bins, 1.4 %: 30.8 against 27.3 -- profiles/r06_epilogue_forms.md)
+        e.ahead = ctx->knobs.eb_ahead ? 1u : 0u;
+        e.lean = ctx->knobs.eb_lean ? 1u : 0u;
         e.lds_rows = ctx->knobs.eb_lds_rows && plan != nullptr && plan->alive_share >= 0.03 ? 1u : 0u;
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;

@@ -172,6 +172,94 @@ __device__ __forceinline__ bool eb_stops(const EpilogueArgs &g, uint32_t same, d
     return eb_lnj<COMP>(g, same, c1, c2) < g.tolerance;
 }
 
+// THE FIRST LENGTH NOT COUNTED, for all the pairs of a wave that are still in the running (bit l of `mask`: lane l's pair), with
+// the column slices requested ONE TRIP AHEAD.  Completing the pairs one after the other leaves a wave with one trip of 3.5 KB
+// in flight, then a reduction, then the next request: the completions are bound by that chain, not by the L2 the blocked
+// order serves them from (9 TB/s where MI355X_MICROARCH.md's gather reads 17-19).  Here trip n + 1 (the same pair's next
+// run, or the next pair's first) is requested before trip n is counted, two register sets in turns; the row's slice
+// comes from the workgroup's LDS copy (row_off: 0 / 1, which of the staged rows).  Every request is unconditional (lanes
+// past the slice's end re-read its last half chunk and count nothing), so that the wait before a trip is counted stands for
+// the OLDER request only.  Returns, in lane l of a pair, the bins the pair shares at length index g.nk.
+struct EbTripIt {
+    uint64_t mask;
+    uint32_t l, trip;
+    __device__ __forceinline__ explicit EbTripIt(uint64_t m) : mask(m), l((uint32_t)__builtin_ctzll(m)), trip(0u) {}
+    __device__ __forceinline__ bool valid() const { return mask != 0ull; }
+    __device__ __forceinline__ void advance(uint32_t trips)
+    {
+        if (++trip == trips) {
+            trip = 0u;
+            mask &= mask - 1ull;
+            l = mask != 0ull ? (uint32_t)__builtin_ctzll(mask) : 0u;
+        }
+    }
+};
+
+__device__ __forceinline__ void eb_request_cols(uint2 (&b)[7], const uint2 *cols_t, size_t sample_stride, uint32_t j, const EbTripIt &it, uint32_t halves, uint32_t lane)
+{
+    const uint32_t j_l = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)it.l);
+    const uint32_t h = min(it.trip * 64u + lane, halves - 1u);
+    const uint2 *pj = cols_t + (size_t)j_l * sample_stride + (size_t)h * 7;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) b[q] = pj[q];
+}
+
+__device__ __forceinline__ void eb_count_trip(const uint2 (&b)[7], const uint2 *lds_rows, uint32_t row_off, const EbTripIt &it, uint32_t ss64, uint32_t lane,
+                                              uint32_t &part, uint32_t &result)
+{
+    const uint32_t halves = ss64 * 2u, trips = (halves + 63u) >> 6;
+    const uint32_t r_l = (uint32_t)__builtin_amdgcn_readlane((int)row_off, (int)it.l);
+    const uint32_t h_raw = it.trip * 64u + lane, h = min(h_raw, halves - 1u);
+    const uint2 *pa = lds_rows + (size_t)r_l * ss64 * 14u + (size_t)h * 7;
+    uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const uint2 a = pa[q];
+        mlo = acc_mismatch<true>(mlo, a.x, b[q].x);
+        mhi = acc_mismatch<true>(mhi, a.y, b[q].y);
+    }
+    mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+    mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
+    part += ((lane & 1u) == 0u && h_raw < halves) ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
+    if (it.trip + 1u == trips) {   // (wave-uniform) the pair's last trip
+        const uint32_t same = ss64 * 64u - eb_wave_sum(part);
+        if (lane == it.l) result = same;
+        part = 0u;
+    }
+}
+
+__device__ __forceinline__ uint32_t eb_first_length_ahead(const EpilogueArgs &g, uint64_t mask, uint32_t j, uint32_t row_off, const uint2 *lds_rows, uint32_t lane)
+{
+    const uint32_t halves = g.ss64 * 2u, trips = (halves + 63u) >> 6;
+    const size_t sample_stride = (size_t)g.nk_total * g.ss64 * BBITS;   // uint2 between the same slice of consecutive samples
+    const uint2 *cols_t = reinterpret_cast<const uint2 *>(g.cols_ref) + (size_t)g.nk * g.ss64 * BBITS;
+    uint2 b0[7], b1[7];
+    uint32_t part = 0u, result = 0u;
+    EbTripIt rq(mask), ct(mask);
+    uint32_t left = (uint32_t)__popcll(mask) * trips;   // trips not yet counted; b0 holds the first of them
+    eb_request_cols(b0, cols_t, sample_stride, j, rq, halves, lane);
+    rq.advance(trips);
+    // (one exit, nothing conditional around a request: a wait in this loop stands for the older of the two requests in flight)
+    while (left > 2u) {
+        eb_request_cols(b1, cols_t, sample_stride, j, rq, halves, lane);
+        rq.advance(trips);
+        eb_count_trip(b0, lds_rows, row_off, ct, g.ss64, lane, part, result);
+        ct.advance(trips);
+        eb_request_cols(b0, cols_t, sample_stride, j, rq, halves, lane);
+        rq.advance(trips);
+        eb_count_trip(b1, lds_rows, row_off, ct, g.ss64, lane, part, result);
+        ct.advance(trips);
+        left -= 2u;
+    }
+    if (left == 2u) eb_request_cols(b1, cols_t, sample_stride, j, rq, halves, lane);
+    eb_count_trip(b0, lds_rows, row_off, ct, g.ss64, lane, part, result);
+    if (left == 2u) {
+        ct.advance(trips);
+        eb_count_trip(b1, lds_rows, row_off, ct, g.ss64, lane, part, result);
+    }
+    return result;
+}
+
 }  // namespace
 
 // One thread per pair of the launch.
@@ -276,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     // are consecutive in the launch's flat order -- columns of one row, then of the next -- so if any of them is still in the
     // running, the workgroup stages the slices (of the first length not counted) of its first pair's row and of the row behind
     // it ONCE, and a completion reads only its column sample's slice from memory: half the L2 traffic of the completions.
-    extern __shared__ uint2 eb_lds_rows[];   // [2][2 ss64][7]
+    extern __shared__ __attribute__((aligned(16))) uint2 eb_lds_rows[];   // [2][2 ss64][7]
     uint32_t i_wg = 0;
     bool staged = false;
     if (g.lds_rows) {                       // (workgroup-uniform; every thread is still here: see the top)
@@ -298,12 +386,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     }
     // the pairs of this wave still in the running, one after the other -- all 64 lanes count the bins the pair shares at the next
     // length, until the reference's break
-    uint64_t todo = __ballot(alive);
+    bool more = alive;            // this lane's pair is still in the running, from length index t_first on
+    uint32_t t_first = ke;
+    if constexpr (!COMP) {
+        if (staged && g.ahead) {   // (workgroup-uniform) the first length not counted: every such pair of the wave, requests one trip ahead
+            const uint32_t row_off = i - i_wg;
+            const bool fast = alive && ke == g.nk && row_off < (g.blocked ? 1u : 2u);
+            const uint64_t fast_mask = __ballot(fast);
+            if (fast_mask != 0ull) {
+                const uint32_t same0 = eb_first_length_ahead(g, fast_mask, j, row_off, eb_lds_rows, lane);
+                if (fast) {
+                    const double y0 = g.ytab[same0 <= maxnbits ? same0 : maxnbits];
+                    if (g.min_alive != EB_NONE ? same0 < g.min_alive : y0 < g.tolerance) {
+                        more = false;                        // jaccard.rs:89-91: break
+                    } else {
+                        s.add(g.kf[g.nk], y0);
+                        t_first = g.nk + 1u;
+                        more = t_first < g.nk_total;
+                    }
+                }
+            }
+        }
+    }
+    uint64_t todo = __ballot(more);
     while (todo != 0ull) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1ull;
         const uint32_t i_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)i, l)), j_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)j, l));
-        const uint32_t ke_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)ke, l));
+        const uint32_t ke_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)t_first, l));
         double c1_l = 0.0, c2_l = 0.0;
         if constexpr (COMP) {
             c1_l = g.compA[i_l];
@@ -335,6 +445,146 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     if (in_range && (alive || stopped || ke >= g.nk_total)) {
         ((float2 *)g.out)[p] = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
     }
+}
+
+// THE LEAN FORM of the kernel above, for the launches that matter (one ke for every pair, no completeness correction, the
+// break decided on the count itself, NK = 2 ... 4 lengths counted).  The general kernel is bound by the instructions it issues,
+// not by memory: 273 vector + 393 scalar instructions per wave at cfg 4's sketch size, 697 + 850 at cfg 3's
+// (profiles/r06_epilogue_lean.md), most of them spent on pairs that end as (1, 1) -- table look-ups, f64 sums and a regression
+// with three divisions and three square roots for a pair whose fit has fewer than three points.  Here a pair that leaves the
+// reference's loop with fewer than three lengths (jaccard.rs:89-91, :117) is decided by NK integer compares and stored; the
+// pairs still in the running are completed as above (first length: requests one trip ahead from the LDS rows; later lengths one
+// after the other), their counts kept in registers; only a pair with three or more points looks its ln J up and runs the
+// reference's sums and regression, in the reference's order.  SLICED: u32 counts in n_slices planes (tail-sliced launches,
+// cfg 2), plane 1 re-zeroed; else u16 counts in one plane.
+template <bool SLICED, int NK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void coreacc_epilogue_lean_kernel(const EpilogueArgs g)
+{
+    constexpr int EXT = (int)EB_MAXK - NK;
+    const uint32_t maxnbits = g.ss64 * 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t i = 0, j = 0;
+    bool in_range, have_ij = false;
+    uint64_t p;
+    if (g.blocked) {   // (the blocked order of the kernel above)
+        const uint32_t wg = blockIdx.x + g.wg_base;
+        const uint32_t xcd = wg & ((1u << g.xcd_shift) - 1u), slot = wg >> g.xcd_shift;
+        const uint32_t rs = g.blk_row_shift, lb = slot >> rs;
+        const uint32_t blk = (lb << g.xcd_shift) + xcd;
+        if (blk >= g.blk_rb * g.blk_cb) return;
+        const uint32_t rb = blk / g.blk_cb, cb = g.blk_cb0 + (blk - rb * g.blk_cb);
+        i = g.row_begin + (rb << rs) + (slot & ((1u << rs) - 1u));
+        j = cb * 256u + threadIdx.x;
+        if (i >= g.row_end || (g.self_mode && cb * 256u + 255u <= i)) return;
+        in_range = j < g.nB_cols && (!g.self_mode || j > i);
+        have_ij = true;
+        p = in_range ? (g.self_mode ? square_to_condensed_dev(i, j, g.n_total) : (uint64_t)i * g.nB_cols + j) - g.out_base : 0ull;
+    } else {
+        const uint64_t p_raw = ((uint64_t)blockIdx.x + g.wg_base) * blockDim.x + threadIdx.x;
+        in_range = p_raw < g.n_pairs;
+        p = in_range ? p_raw : g.n_pairs - 1;       // (lanes past the end shadow the last pair and store nothing)
+    }
+    // the counted lengths: how many pass before the first that does not (jaccard.rs:89-91 on the counts: count < min_alive <=> ln J < tolerance)
+    uint32_t all[EB_MAXK];
+#pragma unroll
+    for (int t = 0; t < (int)EB_MAXK; ++t) all[t] = 0u;
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+        if constexpr (SLICED) {
+            all[t] = g.counts[p + (uint64_t)t * g.k_stride];
+            for (uint32_t sl = 1; sl < g.n_slices; ++sl) all[t] += g.counts[p + ((uint64_t)sl * NK + t) * g.k_stride];
+            if (g.rezero_plane1 && in_range) g.counts[p + ((uint64_t)NK + t) * g.k_stride] = 0u;   // plane 1 back to zero for the next tail-sliced launch
+        } else {
+            all[t] = (uint32_t)reinterpret_cast<const uint16_t *>(g.counts)[p + (uint64_t)t * g.k_stride];
+        }
+    }
+    uint32_t passed = 0;
+    bool run = true;
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+        run = run && all[t] >= g.min_alive;
+        passed += run ? 1u : 0u;
+    }
+    const bool alive = in_range && run;     // (NK < nk_total: the host sends nothing else here)
+    const uint64_t alive_mask = __ballot(alive);
+    if (alive_mask != 0ull) {           // (wave-uniform)
+        if (alive && !have_ij) eb_pair_of(g, p + g.out_base, i, j);
+        if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(alive_mask));
+    }
+    extern __shared__ __attribute__((aligned(16))) uint2 eb_lds_rows[];   // [2][2 ss64][7]: the workgroup's row slices of length index NK (see above)
+    uint32_t i_wg = 0;
+    bool staged = false;
+    if (g.lds_rows) {                       // (workgroup-uniform; every thread is still here)
+        if (__syncthreads_or(alive ? 1 : 0)) {
+            uint32_t j_wg;
+            if (g.blocked) i_wg = i;
+            else eb_pair_of(g, ((uint64_t)blockIdx.x + g.wg_base) * blockDim.x + g.out_base, i_wg, j_wg);
+            const uint32_t per_row = g.ss64 * 14u;
+            const uint2 *src = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_wg * g.nk_total + NK) * g.ss64) * BBITS);
+            const size_t next_row = (size_t)g.nk_total * g.ss64 * BBITS;
+            const uint32_t staged_rows = g.blocked ? 1u : 2u;
+            for (uint32_t x = threadIdx.x; x < staged_rows * per_row; x += blockDim.x) {
+                const uint32_t r = x >= per_row ? 1u : 0u;   // (the row slab ends in pad rows: row i_wg + 1 always exists)
+                eb_lds_rows[x] = src[(size_t)r * next_row + (x - r * per_row)];
+            }
+            __syncthreads();
+            staged = true;
+        }
+    }
+    if (alive_mask != 0ull) {
+        bool more = alive;
+        uint32_t u_first = 0;             // this lane's first length index beyond NK not yet counted
+        if (staged && g.ahead) {
+            const uint32_t row_off = i - i_wg;
+            const bool fast = alive && row_off < (g.blocked ? 1u : 2u);
+            const uint64_t fast_mask = __ballot(fast);
+            if (fast_mask != 0ull) {
+                const uint32_t same0 = eb_first_length_ahead(g, fast_mask, j, row_off, eb_lds_rows, lane);
+                if (fast) {
+                    if (same0 < g.min_alive) {
+                        more = false;                        // jaccard.rs:89-91: break
+                    } else {
+                        all[NK] = same0;
+                        ++passed;
+                        u_first = 1u;
+                        more = NK + 1u < g.nk_total;
+                    }
+                }
+            }
+        }
+        uint64_t todo = __ballot(more);
+        EbRow<0> none;
+        while (todo != 0ull) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t i_l = (uint32_t)__builtin_amdgcn_readlane((int)i, l), j_l = (uint32_t)__builtin_amdgcn_readlane((int)j, l);
+            const uint32_t u_l = (uint32_t)__builtin_amdgcn_readlane((int)u_first, l);
+#pragma unroll
+            for (int u = 0; u < EXT; ++u) {
+                if ((uint32_t)u < u_l) continue;                    // (wave-uniform)
+                if ((uint32_t)(NK + u) >= g.nk_total) break;
+                const uint32_t same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_l, j_l, (uint32_t)(NK + u), false, lane);
+                if (same < g.min_alive) break;                      // jaccard.rs:89-91: break (wave-uniform)
+                if ((int)lane == l) {
+                    all[NK + u] = same;
+                    ++passed;
+                }
+            }
+        }
+    }
+    float2 res = make_float2(1.0f, 1.0f);     // a fit over fewer than three lengths (jaccard.rs:117)
+    if (passed >= 3u) {
+        double yt[EB_MAXK];
+#pragma unroll
+        for (int t = 0; t < (int)EB_MAXK; ++t) yt[t] = (uint32_t)t < passed ? g.ytab[all[t] <= maxnbits ? all[t] : maxnbits] : 0.0;
+        EbSums s;
+#pragma unroll
+        for (int t = 0; t < (int)EB_MAXK; ++t) {
+            if ((uint32_t)t < passed) s.add(g.kf[t], yt[t]);        // jaccard.rs:92-97
+        }
+        res = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+    }
+    if (in_range) ((float2 *)g.out)[p] = res;
 }
 
 // The early-break epilogue of a row band of the symmetric core/accessory self kNN: see EpilogueKnnArgs (kernels.h).
@@ -650,12 +900,23 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
     }
     const size_t lds = early && a.block_ke == nullptr && a.ss64 * 224ull <= 16384ull && a.lds_rows != 0u ? (size_t)a.ss64 * 224u : 0u;
     a.lds_rows = lds != 0 ? 1u : 0u;
+    // the lean form: one ke for every pair, the break decided on the count, 2 ... 4 lengths counted, k-major counts (u16 in one plane, or
+    // u32 in the planes of a tail-sliced launch)
+    const bool lean = a.lean != 0u && early && a.block_ke == nullptr && !a.has_comp && a.min_alive != EB_NONE && a.nk >= 2u && a.nk <= 4u &&
+                      a.nk_total > a.nk && a.pair_stride == 1u && (a.cnt_u16 != 0u ? a.n_slices == 1u && a.rezero_plane1 == 0u : a.n_slices >= 1u);
     // (a dispatch packet counts WORK-ITEMS in 32 bits: 2^23 workgroups of 256 per launch at most)
     constexpr uint64_t MAX_WG = 1ull << 23;
     for (uint64_t w0 = 0; w0 < blocks; w0 += MAX_WG) {
         a.wg_base = (uint32_t)w0;
         const dim3 gr((unsigned)std::min(MAX_WG, blocks - w0)), bl(256);
-        if (a.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, lds, stream, a);
+        if (lean) {
+            const bool sl = a.cnt_u16 == 0u;
+            switch (a.nk) {
+            case 2: if (sl) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, 2>), gr, bl, lds, stream, a); else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, 2>), gr, bl, lds, stream, a); break;
+            case 3: if (sl) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, 3>), gr, bl, lds, stream, a); else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, 3>), gr, bl, lds, stream, a); break;
+            default: if (sl) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, 4>), gr, bl, lds, stream, a); else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, 4>), gr, bl, lds, stream, a); break;
+            }
+        } else if (a.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, lds, stream, a);
         else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, lds, stream, a);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
