@@ -1529,7 +1529,10 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
             HIP_TRY(launch_coreacc_epilogue(e, epi_stream));   // round 5's epilogue: alive pairs completed where they are found (A/B timing)
         } else
 #endif
-        HIP_TRY(launch_coreacc_epilogue_r6(e, epi_stream));
+        {
+            if (coreacc_epilogue_is_lean(e)) ctx->last_kernel += e.cnt_u16 ? " [lean epilogue]" : " [lean epilogue, sliced counts]";
+            HIP_TRY(launch_coreacc_epilogue_r6(e, epi_stream));
+        }
         if (piped) HIP_TRY(hipEventRecord(ctx->eb_events[2 + ctx->eb_pipe_buf], epi_stream));
         // (an empty launch, or one another kernel took, leaves plane 1 not known to be zero)
         if (two_planes && ctx->last_tail) ctx->clean_plane1 = plane1_clean;

@@ -159,8 +159,19 @@ __device__ __forceinline__ void eb_pair_of(const EpilogueArgs &g, uint64_t flat,
         eb_locate_self(flat, g.n_total, i, pos);
         j = i + 1u + pos;
     } else {
-        i = (uint32_t)(flat / g.nB_cols);
-        j = (uint32_t)(flat % g.nB_cols);
+        // (a 64-bit division is ~100 instructions for every wave that holds a pair still in the running: the quotient from the f64
+        // product -- flat < 2^53 is exact in a double -- put right by one step either way)
+        uint64_t q = (uint64_t)((double)flat * (1.0 / (double)g.nB_cols));
+        int64_t r = (int64_t)(flat - q * g.nB_cols);
+        if (r < 0) {
+            --q;
+            r += g.nB_cols;
+        } else if (r >= (int64_t)g.nB_cols) {
+            ++q;
+            r -= g.nB_cols;
+        }
+        i = (uint32_t)q;
+        j = (uint32_t)r;
     }
 }
 
@@ -749,8 +760,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         const uint32_t c = in_range ? c_raw : g.nB - 1u;
         const uint64_t p = (uint64_t)row * g.nB + c;
         const bool alive = (alive_mask[u] >> lane) & 1ull;
-        const bool fit = in_range && (alive || passed[u] >= 3u);   // (fewer than three lengths: (1, 1), jaccard.rs:117)
         float2 v = make_float2(1.0f, 1.0f);
+        if (by_count) {
+            // the lengths a pair still in the running passed beyond the counted ones, from the counts phase B left in LDS -- integer
+            // compares; a block none of whose pairs has three points (nearly every block: a pair that survives the counted lengths
+            // by chance leaves at the next) looks nothing up
+            uint32_t e[KNN_MAXEXT];
+            uint32_t n_ext = 0;
+            if (alive) {
+                bool run = true;
+#pragma unroll
+                for (uint32_t x = 0; x < KNN_MAXEXT; ++x) {
+                    e[x] = ext[wave][u][x][lane];
+                    run = run && e[x] != 0xFFFFu && e[x] >= g.min_alive;
+                    n_ext += run ? 1u : 0u;
+                }
+            }
+            const bool fit = in_range && passed[u] + n_ext >= 3u;   // (fewer than three lengths: (1, 1), jaccard.rs:117)
+            if (__ballot(fit) != 0ull) {                            // (wave-uniform)
+                double y[KNN_MAXKE], ye[KNN_MAXEXT];
+#pragma unroll
+                for (uint32_t t = 0; t < KNN_MAXKE; ++t) y[t] = fit && t < passed[u] ? g.ytab[cnt[u][t] <= maxnbits ? cnt[u][t] : maxnbits] : 0.0;
+#pragma unroll
+                for (uint32_t x = 0; x < KNN_MAXEXT; ++x) ye[x] = fit && x < n_ext ? g.ytab[e[x] <= maxnbits ? e[x] : maxnbits] : 0.0;
+                EbSums s;
+#pragma unroll
+                for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
+                    if (fit && t < passed[u]) s.add(g.kf[t], y[t]);
+                }
+#pragma unroll
+                for (uint32_t x = 0; x < KNN_MAXEXT; ++x) {
+                    if (fit && x < n_ext) s.add(g.kf[g.nk + x], ye[x]);
+                }
+                if (fit) v = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+            }
+        } else {
+        const bool fit = in_range && (alive || passed[u] >= 3u);   // (fewer than three lengths: (1, 1), jaccard.rs:117)
         if (__ballot(fit) != 0ull) {                            // (wave-uniform; rare between unrelated genomes)
             EbSums s;
 #pragma unroll
@@ -767,6 +812,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                 }
             }
             if (fit) v = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+        }
         }
         // does this 64-column block bring the row anything below its knn-th best?  (the key is the core distance)  The merge
         // reads the marked blocks of a row only, so an unmarked block's 64 records are not even stored.
@@ -807,6 +853,8 @@ hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t 
     for (uint32_t r0 = 0; r0 < args.rows; r0 += 32768u) {
         EpilogueKnnArgs a = args;
         a.row_base = r0;
+        // (gridDim.x rounded up to a multiple of the XCDs, so that a column group meets the same XCD in every row and finds its
+        // column slices in that L2: 2.51 s either way at n = 300 000 -- not where the completions' time goes; not kept)
         const dim3 gr((args.nB + per_wg - 1u) / per_wg, std::min(32768u, args.rows - r0)), bl(256);
         if (args.ss64 <= 32u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<1>, gr, bl, 0, stream, a);
         else if (args.ss64 <= 64u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<2>, gr, bl, 0, stream, a);
@@ -879,6 +927,15 @@ hipError_t launch_early_break_sample(const EbSampleArgs &args, hipStream_t strea
 
 #undef SKL_DPP_ADD
 
+// the lean form takes: one ke for every pair, no completeness correction, the break decided on the count, 2 ... 4 lengths counted, k-major
+// counts (u16 in one plane, or u32 in the planes of a tail-sliced launch)
+bool coreacc_epilogue_is_lean(const EpilogueArgs &a)
+{
+    const bool early = a.nk_total > a.nk || a.block_ke != nullptr;
+    return a.lean != 0u && early && a.block_ke == nullptr && !a.has_comp && a.min_alive != EB_NONE && a.nk >= 2u && a.nk <= 4u && a.nk_total > a.nk &&
+           a.nk_total <= EB_MAXK && a.pair_stride == 1u && (a.cnt_u16 != 0u ? a.n_slices == 1u && a.rezero_plane1 == 0u : a.n_slices >= 1u);
+}
+
 hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stream)
 {
     if (args.n_pairs == 0) return hipSuccess;
@@ -900,10 +957,7 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
     }
     const size_t lds = early && a.block_ke == nullptr && a.ss64 * 224ull <= 16384ull && a.lds_rows != 0u ? (size_t)a.ss64 * 224u : 0u;
     a.lds_rows = lds != 0 ? 1u : 0u;
-    // the lean form: one ke for every pair, the break decided on the count, 2 ... 4 lengths counted, k-major counts (u16 in one plane, or
-    // u32 in the planes of a tail-sliced launch)
-    const bool lean = a.lean != 0u && early && a.block_ke == nullptr && !a.has_comp && a.min_alive != EB_NONE && a.nk >= 2u && a.nk <= 4u &&
-                      a.nk_total > a.nk && a.pair_stride == 1u && (a.cnt_u16 != 0u ? a.n_slices == 1u && a.rezero_plane1 == 0u : a.n_slices >= 1u);
+    const bool lean = coreacc_epilogue_is_lean(a);
     // (a dispatch packet counts WORK-ITEMS in 32 bits: 2^23 workgroups of 256 per launch at most)
     constexpr uint64_t MAX_WG = 1ull << 23;
     for (uint64_t w0 = 0; w0 < blocks; w0 += MAX_WG) {

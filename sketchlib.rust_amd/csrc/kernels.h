@@ -258,6 +258,7 @@ struct EpilogueArgs {
 hipError_t launch_coreacc_epilogue(const EpilogueArgs &args, hipStream_t stream);
 // core/accessory records only, round 6 (epilogue.hip)
 hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stream);
+bool coreacc_epilogue_is_lean(const EpilogueArgs &args);   // will that launch take the lean kernel?
 // EARLY BREAK in the one-evaluation core/accessory self kNN (capi_knn.cpp): a row band's view of the columns was counted at
 // its first `nk` k-mer lengths (k-major counts, counts[t * n_pairs + row * nB + c]); this launch turns them into the band's
 // (core, acc) records -- completing the pairs still in the running like coreacc_epilogue_kernel -- and does what the fused

@@ -216,3 +216,22 @@ def test_register_budget_of_the_candidate_list_and_replay_kernels():
     for kernel in ("topk_refheap_wave_kernel", "refheap_merge_wave_kernel"):
         (vgpr, scratch, lds), = [v for k, v in meta.items() if kernel in k]
         assert scratch == 0 and vgpr <= 64 and lds <= 20 * 1024, (kernel, vgpr, scratch, lds)
+
+
+def test_register_budget_of_the_early_break_epilogues():
+    """The lean early-break epilogue (epilogue.hip coreacc_epilogue_lean_kernel<SLICED, NK>) is bound by the instructions it
+    issues and hides its loads behind other waves: all six forms must stay at 8 waves per SIMD (<= 64 VGPRs) without scratch;
+    the general kernel at 5 (<= 96; with a completeness correction 4: <= 128), the kNN bands' at 4 or better."""
+    import sketchlib.rust_amd as pkg
+
+    pkg.build_library()
+    meta = _kernel_metadata(pkg.library_path())
+    lean = {k: v for k, v in meta.items() if "coreacc_epilogue_lean_kernel" in k}
+    assert len(lean) == 6, sorted(lean)
+    for name, (vgpr, scratch, lds) in lean.items():
+        assert scratch == 0 and vgpr <= 64, (name, vgpr, scratch)
+    for name, (vgpr, scratch, lds) in meta.items():
+        if "coreacc_epilogue_kernel_r6<false>" in name:
+            assert scratch == 0 and vgpr <= 96, (name, vgpr, scratch)
+        if "coreacc_epilogue_kernel_r6<true>" in name or "coreacc_epilogue_knn_kernel" in name:
+            assert scratch == 0 and vgpr <= 128, (name, vgpr, scratch)

@@ -353,3 +353,40 @@ def test_blocked_epilogue_order_forced_on_small_inputs(oracle, skl, gpu_ctx, mon
     check(skl.cross_dists_all(gpu_ctx, g, g_q, g.set_k()), oracle.cross_dists_all(o, o_q, oracle.COREACC, threads=8))
     g.close()
     g_q.close()
+
+
+@pytest.mark.ab_library
+@pytest.mark.parametrize("lean", [1, 0])
+@pytest.mark.parametrize("lengths", [2, 3, 4])
+@pytest.mark.parametrize("n,ss64,tail", [(700, 64, True), (700, 64, False), (2100, 32, False), (2100, 16, False), (530, 16, True), (450, 73, False), (420, 300, False)])
+def test_lean_epilogue_against_the_general_one(oracle, skl, gpu_ctx, monkeypatch, n, ss64, tail, lengths, lean):
+    """The lean early-break epilogue (coreacc_epilogue_lean_kernel<SLICED, NK>: pairs that end as (1, 1) decided on their counts,
+    f64 work only for fits of three or more points, the first length not counted completed with requests a trip ahead from the LDS
+    rows) and the general kernel (SKL_EB_LEAN=0, A/B build) on the same inputs, both bit for bit against the oracle: 2 / 3 / 4
+    lengths counted; u32 counts (small launches, in one plane or in the planes of a tail-sliced launch) and u16 counts (from
+    4 Mi pair x length evaluations on: the cases of 2 100 genomes); sketch sizes of 1, 2 and 3 trips with the rows in LDS and one
+    beyond them (300 chunks); self matrix, a row range, a cross matrix."""
+    bins = _mixed(n, KMERS, ss64, n_random=n - 200, n_clusters=2, seed=43)
+    o = oracle.Sketches(bins, n, KMERS, ss64)
+    exp = oracle.self_dists_all(o, oracle.COREACC, threads=8).reshape(-1, 2)
+    monkeypatch.setenv("SKL_EARLY_BREAK", str(lengths))
+    monkeypatch.setenv("SKL_EB_LEAN", str(lean))
+    if not tail:
+        monkeypatch.setenv("SKL_TAIL_SLICES", "0")
+    gpu_ctx.reload_env()
+    g = gpu_ctx.sketches(bins, n, KMERS, ss64)
+    got = skl.self_dists_all(gpu_ctx, g, g.set_k())
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), np.argwhere(got != exp)[:5]
+    name = gpu_ctx.last_kernel()
+    part = skl.self_dists_rows(gpu_ctx, g, g.set_k(), 97, n - 33)
+    lo = 97 * n - 97 * 98 // 2
+    assert np.array_equal(part.view(np.uint32), exp[lo:lo + part.shape[0]].view(np.uint32))
+    g_q = gpu_ctx.sketches(bins[150:], n - 150, KMERS, ss64)
+    o_q = oracle.Sketches(bins[150:], n - 150, KMERS, ss64)
+    cross = skl.cross_dists_all(gpu_ctx, g, g_q, g.set_k())
+    assert np.array_equal(cross.view(np.uint32), oracle.cross_dists_all(o, o_q, oracle.COREACC, threads=8).view(np.uint32))
+    g.close()
+    g_q.close()
+    assert ("[lean epilogue" in name) == bool(lean), name
+    if lean and n >= 2000:
+        assert "[lean epilogue]" in name, name          # (u16 counts)
