@@ -518,18 +518,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     }
     const bool alive = in_range && run;     // (NK < nk_total: the host sends nothing else here)
     const uint64_t alive_mask = __ballot(alive);
+    // (i, j) in the flat order: the WORKGROUP's first pair is located once per wave (eb_pair_of: an f64 square root and its
+    // fix-ups in self mode, ~100 instructions), a lane's own pair follows from it by whole rows -- a workgroup's 256 pairs span two
+    // rows, a few more at the matrix' end -- instead of a second square root per wave
+    uint32_t i_wg = 0, j_wg = 0;
+    bool have_wg = false;
+    auto locate_wg = [&]() {
+        if (have_wg) return;
+        if (g.blocked) {
+            i_wg = i;
+        } else {
+            eb_pair_of(g, ((uint64_t)blockIdx.x + g.wg_base) * blockDim.x + g.out_base, i_wg, j_wg);
+        }
+        have_wg = true;
+    };
     if (alive_mask != 0ull) {           // (wave-uniform)
-        if (alive && !have_ij) eb_pair_of(g, p + g.out_base, i, j);
+        if (!have_ij) {
+            if (g.self_mode || g.nB_cols >= 64u) {
+                locate_wg();
+                if (alive) {
+                    if (g.self_mode) {
+                        uint32_t pos = j_wg - i_wg - 1u + threadIdx.x, len = g.n_total - 1u - i_wg, ii = i_wg;
+                        while (pos >= len) {
+                            pos -= len;
+                            ++ii;
+                            --len;
+                        }
+                        i = ii;
+                        j = ii + 1u + pos;
+                    } else {
+                        uint32_t jj = j_wg + threadIdx.x, ii = i_wg;
+                        while (jj >= g.nB_cols) {
+                            jj -= g.nB_cols;
+                            ++ii;
+                        }
+                        i = ii;
+                        j = jj;
+                    }
+                }
+            } else if (alive) {
+                eb_pair_of(g, p + g.out_base, i, j);
+            }
+        }
         if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[blockIdx.x & 1023u], (uint32_t)__popcll(alive_mask));
     }
     extern __shared__ __attribute__((aligned(16))) uint2 eb_lds_rows[];   // [2][2 ss64][7]: the workgroup's row slices of length index NK (see above)
-    uint32_t i_wg = 0;
     bool staged = false;
     if (g.lds_rows) {                       // (workgroup-uniform; every thread is still here)
         if (__syncthreads_or(alive ? 1 : 0)) {
-            uint32_t j_wg;
-            if (g.blocked) i_wg = i;
-            else eb_pair_of(g, ((uint64_t)blockIdx.x + g.wg_base) * blockDim.x + g.out_base, i_wg, j_wg);
+            locate_wg();
             const uint32_t per_row = g.ss64 * 14u;
             const uint2 *src = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_wg * g.nk_total + NK) * g.ss64) * BBITS);
             const size_t next_row = (size_t)g.nk_total * g.ss64 * BBITS;
