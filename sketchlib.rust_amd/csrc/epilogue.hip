@@ -139,12 +139,24 @@ __device__ __forceinline__ uint32_t eb_same_bins(const uint64_t *rows_ref, const
             return ss64 * 64u - eb_wave_sum(part);
         }
     }
+    // (every lane loads: those past the slices' end re-read the last half chunk and count nothing -- a load under `h < halves`
+    // is a branch around it, 8 of them per trip)
     for (uint32_t h0 = 0; h0 < halves; h0 += 64u) {
-        const uint32_t h = h0 + lane;
-        uint2 a[7];
+        const uint32_t h_raw = h0 + lane, h = min(h_raw, halves - 1u);
+        uint2 a[7], b[7];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) a[q] = h < halves ? pi[(size_t)h * 7 + q] : make_uint2(0u, 0u);
-        part += eb_trip(a, pj, h, halves, lane);
+        for (int q = 0; q < 7; ++q) a[q] = pi[(size_t)h * 7 + q];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) b[q] = pj[(size_t)h * 7 + q];
+        uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            mlo = acc_mismatch<true>(mlo, a[q].x, b[q].x);
+            mhi = acc_mismatch<true>(mhi, a[q].y, b[q].y);
+        }
+        mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+        mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
+        part += ((lane & 1u) == 0u && h_raw < halves) ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
     }
     return ss64 * 64u - eb_wave_sum(part);
 }
@@ -458,6 +470,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
     }
 }
 
+// (core, acc) of a pair with n_pts >= 3 points, from the bin-match counts of its first n_pts lengths: ln J looked up (all at once),
+// the reference's sums in the reference's order (jaccard.rs:92-97), the regression.  ONE copy per kernel (the regression alone
+// is ~600 instructions, and the callers meet it for one pair in a hundred or a thousand): the kNN bands' epilogue inlined it
+// four times and ran to 47 KB of code.
+__device__ __attribute__((noinline)) float2 eb_fit_of_counts(const double *ytab, const double *kf, uint32_t maxnbits, uint32_t n_pts, uint32_t c0, uint32_t c1,
+                                                             uint32_t c2, uint32_t c3, uint32_t c4, uint32_t c5, uint32_t c6, uint32_t c7)
+{
+    const uint32_t c[EB_MAXK] = {c0, c1, c2, c3, c4, c5, c6, c7};
+    double y[EB_MAXK];
+#pragma unroll
+    for (uint32_t t = 0; t < EB_MAXK; ++t) y[t] = t < n_pts ? ytab[c[t] <= maxnbits ? c[t] : maxnbits] : 0.0;
+    EbSums s;
+#pragma unroll
+    for (uint32_t t = 0; t < EB_MAXK; ++t) {
+        if (t < n_pts) s.add(kf[t], y[t]);
+    }
+    return simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+}
+
 // THE LEAN FORM of the kernel above, for the launches that matter (one ke for every pair, no completeness correction, the
 // break decided on the count itself, NK = 2 ... 4 lengths counted).  The general kernel is bound by the instructions it issues,
 // not by memory: 273 vector + 393 scalar instructions per wave at cfg 4's sketch size, 697 + 850 at cfg 3's
@@ -621,17 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
         }
     }
     float2 res = make_float2(1.0f, 1.0f);     // a fit over fewer than three lengths (jaccard.rs:117)
-    if (passed >= 3u) {
-        double yt[EB_MAXK];
-#pragma unroll
-        for (int t = 0; t < (int)EB_MAXK; ++t) yt[t] = (uint32_t)t < passed ? g.ytab[all[t] <= maxnbits ? all[t] : maxnbits] : 0.0;
-        EbSums s;
-#pragma unroll
-        for (int t = 0; t < (int)EB_MAXK; ++t) {
-            if ((uint32_t)t < passed) s.add(g.kf[t], yt[t]);        // jaccard.rs:92-97
-        }
-        res = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
-    }
+    if (passed >= 3u) res = eb_fit_of_counts(g.ytab, g.kf, maxnbits, passed, all[0], all[1], all[2], all[3], all[4], all[5], all[6], all[7]);
     if (in_range) ((float2 *)g.out)[p] = res;
 }
 
@@ -655,59 +676,79 @@ constexpr uint32_t KNN_MAXKE = 4;
 constexpr uint32_t KNN_MAXEXT = 6;      // lengths beyond the counted ones (nk_total <= 8, nk >= 2)
 
 template <int TRIPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS == 0 ? 8 : 5))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
 {
     __shared__ uint16_t ext[4][KNN_BLOCKS][KNN_MAXEXT][64];   // completed bin-match counts of the pairs still in the running (0xFFFF: not looked at)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t row = g.row_base + blockIdx.y;
     const uint32_t c_wave = (blockIdx.x * 4u + wave) * (64u * KNN_BLOCKS);
-    if (c_wave >= g.nB) return;
     const uint32_t maxnbits = g.ss64 * 64u, halves = g.ss64 * 2u;
     const uint32_t i_s = g.row_sample0 + row;
-    uint32_t cnt[KNN_BLOCKS][KNN_MAXKE];
-#pragma unroll
-    for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+    if (c_wave >= g.nB) return;
+    // the counts of block u's pairs at the counted lengths.  They are NOT kept across phase B: a register this kernel holds is a
+    // register the counts kernel beside it cannot have (that kernel fills the file with 4 waves of 128), and two waves of 64
+    // displace what one wave of 65 ... 128 does; the rare pair with a fit reads its counts again in phase C.
+    auto load_counts = [&](uint32_t u, uint32_t (&cn)[KNN_MAXKE]) {
         const uint32_t c = min(c_wave + u * 64u + lane, g.nB - 1u);   // (lanes past the row's end shadow its last pair and store nothing)
         const uint64_t p = (uint64_t)row * g.nB + c;
 #pragma unroll
         for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
             const uint64_t at = (uint64_t)t * g.n_pairs + p;
-            cnt[u][t] = t < g.nk ? (g.cnt_u16 ? (uint32_t)reinterpret_cast<const uint16_t *>(g.counts)[at] : g.counts[at]) : 0u;
+            cn[t] = t < g.nk ? (g.cnt_u16 ? (uint32_t)reinterpret_cast<const uint16_t *>(g.counts)[at] : g.counts[at]) : 0u;
         }
-    }
+    };
     const bool by_count = g.min_alive != EB_NONE;
     const uint32_t thr_row = g.r_bits != nullptr ? g.r_thr[(size_t)row * g.r_thr_stride] : 0u;
     auto stops = [&](uint32_t same) { return by_count ? same < g.min_alive : g.ytab[same <= maxnbits ? same : maxnbits] < g.tolerance; };
     // A. the reference's loop over the first g.nk lengths, on the counts: how many lengths pass before the first that does not
-    uint32_t passed[KNN_BLOCKS];
+    uint32_t passed_pk = 0;                 // passed[u] in byte u
     uint64_t alive_mask[KNN_BLOCKS];
     uint32_t n_alive = 0;
+    {
+        uint32_t cnt[KNN_BLOCKS][KNN_MAXKE];
 #pragma unroll
-    for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
-        const bool in_range = c_wave + u * 64u + lane < g.nB;
-        passed[u] = 0;
-        bool stopped = false;
+        for (uint32_t u = 0; u < KNN_BLOCKS; ++u) load_counts(u, cnt[u]);
+        if (by_count) {   // (the usual case, decided ONCE: integer compares and nothing else)
 #pragma unroll
-        for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
-            if (t < g.nk && !stopped) {
-                if (stops(cnt[u][t])) stopped = true;   // jaccard.rs:89-91: break
-                else ++passed[u];
+            for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+                const bool in_range = c_wave + u * 64u + lane < g.nB;
+                uint32_t passed = 0;
+                bool run = true;
+#pragma unroll
+                for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
+                    run = run && (t >= g.nk || cnt[u][t] >= g.min_alive);   // jaccard.rs:89-91: break
+                    passed += run && t < g.nk ? 1u : 0u;
+                }
+                passed_pk |= passed << (8u * u);
+                alive_mask[u] = __ballot(in_range && run && g.nk_total > g.nk);
+                n_alive += (uint32_t)__popcll(alive_mask[u]);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+                const bool in_range = c_wave + u * 64u + lane < g.nB;
+                uint32_t passed = 0;
+                bool stopped = false;
+#pragma unroll
+                for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
+                    if (t < g.nk && !stopped) {
+                        if (stops(cnt[u][t])) stopped = true;   // jaccard.rs:89-91: break
+                        else ++passed;
+                    }
+                }
+                passed_pk |= passed << (8u * u);
+                alive_mask[u] = __ballot(in_range && !stopped && g.nk_total > g.nk);
+                n_alive += (uint32_t)__popcll(alive_mask[u]);
             }
         }
-        alive_mask[u] = __ballot(in_range && !stopped && g.nk_total > g.nk);
-        n_alive += (uint32_t)__popcll(alive_mask[u]);
     }
-    // B. the pairs still in the running, in block order
+    // B. the pairs still in the running, in block order (pass_mask: those that passed the first length not counted -- their counts wait in LDS)
+    uint64_t pass_mask[KNN_BLOCKS];
+#pragma unroll
+    for (uint32_t u = 0; u < KNN_BLOCKS; ++u) pass_mask[u] = 0ull;
     if (n_alive != 0u) {                // (wave-uniform)
         if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[(blockIdx.x + blockIdx.y * 7u) & 1023u], n_alive);   // (1 024 slots)
-#pragma unroll
-        for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
-            if ((alive_mask[u] >> lane) & 1ull) {
-#pragma unroll
-                for (uint32_t x = 0; x < KNN_MAXEXT; ++x) ext[wave][u][x][lane] = 0xFFFFu;
-            }
-        }
         const uint2 *pi = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_s * g.nk_total + g.nk) * g.ss64) * BBITS);
         constexpr int KEPT = TRIPS > 0 ? TRIPS : 1;
         uint2 a_row[KEPT][7], b_next[KEPT][7];
@@ -718,74 +759,146 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                 for (int q = 0; q < 7; ++q) a_row[tr][q] = (uint32_t)tr * 64u + lane < halves ? pi[((size_t)tr * 64u + lane) * 7 + q] : make_uint2(0u, 0u);
             }
         }
-        // (u, l) of the next pair still in the running at or after block u0, lane mask `m` of that block's remainder
+        // (u, l) of the next pair still in the running: lane u of vm_lo / vm_hi holds block u's mask (a register array indexed by
+        // a running block number turned the walk into a scalar state machine of ~40 instructions per step)
+        uint32_t vm_lo = 0u, vm_hi = 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < KNN_BLOCKS; ++u) {
+            if (lane == u) {
+                vm_lo = (uint32_t)alive_mask[u];
+                vm_hi = (uint32_t)(alive_mask[u] >> 32);
+            }
+        }
         uint32_t cur_u = 0;
         uint64_t cur_m = alive_mask[0];
-        auto advance = [&](uint32_t &u_out, uint32_t &l_out) -> bool {
+        auto advance = [&](uint32_t &u_out, uint32_t &l_out) {   // (the caller counts: never called past the last pair)
             while (cur_m == 0ull) {
-                if (++cur_u >= KNN_BLOCKS) return false;
-                cur_m = cur_u == 1u ? alive_mask[1] : (cur_u == 2u ? alive_mask[2] : alive_mask[3]);
+                ++cur_u;
+                cur_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)vm_hi, (int)cur_u) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)vm_lo, (int)cur_u);
             }
             l_out = (uint32_t)__builtin_ctzll(cur_m);
             cur_m &= cur_m - 1ull;
             u_out = cur_u;
-            return true;
         };
         auto column_of = [&](uint32_t u, uint32_t l) {   // view column -> sample id (wave-uniform)
             return g.col_sample0 + c_wave + u * 64u + l;
         };
-        auto request = [&](uint32_t j) {                 // the column sample's slice of the first length not counted
-            if constexpr (TRIPS > 0) {
-                const uint2 *pj = reinterpret_cast<const uint2 *>(g.cols_ref + (((uint64_t)j * g.nk_total + g.nk) * g.ss64) * BBITS);
+        // the reference's loop from the first length not counted on, given that length's count (the later ones, reached by one pair
+        // in eight, are read when they are needed)
+        auto finish = [&](uint32_t same, uint32_t u_e, uint32_t l_e) {
+            // nearly every pair that survived the counted lengths by chance leaves here: nothing is written for it (it has
+            // g.nk points; phase C knows)
+            if (stops(same)) return;                           // (wave-uniform) jaccard.rs:89-91
+            const uint64_t bit = 1ull << l_e;
 #pragma unroll
-                for (int tr = 0; tr < TRIPS; ++tr) {
+            for (uint32_t u = 0; u < KNN_BLOCKS; ++u) pass_mask[u] |= u == u_e ? bit : 0ull;
+            if (lane == l_e) {
+                ext[wave][u_e][0][lane] = (uint16_t)same;       // (u_e: wave-uniform)
 #pragma unroll
-                    for (int q = 0; q < 7; ++q) b_next[tr][q] = (uint32_t)tr * 64u + lane < halves ? pj[((size_t)tr * 64u + lane) * 7 + q] : make_uint2(0u, 0u);
-                }
+                for (uint32_t x = 1; x < KNN_MAXEXT; ++x) ext[wave][u_e][x][lane] = 0xFFFFu;
             }
-        };
-        uint32_t u_e = 0, l_e = 0, u_n = 0, l_n = 0;
-        bool have = advance(u_e, l_e);
-        if (have) request(column_of(u_e, l_e));
-        while (have) {
             const uint32_t j_e = column_of(u_e, l_e);
-            uint32_t same;
-            if constexpr (TRIPS > 0) {
-                uint32_t part = 0;
-#pragma unroll
-                for (int tr = 0; tr < TRIPS; ++tr) {
-                    const uint32_t h = (uint32_t)tr * 64u + lane;
-                    uint32_t mlo = 0, mhi = 0;
-#pragma unroll
-                    for (int q = 0; q < 7; ++q) {
-                        mlo = acc_mismatch<true>(mlo, a_row[tr][q].x, b_next[tr][q].x);
-                        mhi = acc_mismatch<true>(mhi, a_row[tr][q].y, b_next[tr][q].y);
-                    }
-                    mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
-                    mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
-                    part += ((lane & 1u) == 0u && h < halves) ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
-                }
-                // the next pair's slice is on its way while this one is summed up
-                const bool more = advance(u_n, l_n);
-                if (more) request(column_of(u_n, l_n));
-                same = maxnbits - eb_wave_sum(part);
-                have = more;
-            } else {
-                EbRow<0> none;
-                same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_e, g.nk, false, lane);
-                have = advance(u_n, l_n);
-            }
-            // the reference's loop from the first length not counted on (the later ones, reached by one pair in eight, are read when
-            // they are needed)
-            uint32_t t = g.nk;
-            for (;;) {
-                if (lane == l_e) ext[wave][u_e][t - g.nk][lane] = (uint16_t)same;   // (u_e: wave-uniform)
-                if (stops(same) || ++t >= g.nk_total) break;   // (wave-uniform) jaccard.rs:89-91
+            for (uint32_t t = g.nk + 1u; t < g.nk_total; ++t) {
                 EbRow<0> none;
                 same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_e, t, false, lane);
+                if (stops(same)) break;                        // (wave-uniform)
+                if (lane == l_e) ext[wave][u_e][t - g.nk][lane] = (uint16_t)same;
             }
-            u_e = u_n;
-            l_e = l_n;
+        };
+        if constexpr (TRIPS == 1) {
+            // The next pair's slice is requested as soon as this one's registers are free (after the 14 bit operations, before the
+            // wave sum); every lane loads (those past the slice's end re-read its last half chunk and count nothing).  TWO register
+            // sets -- pair n + 1 requested before pair n is waited for -- were measured too: 2.53 s either way at n = 300 000,
+            // and 15 registers dearer.
+            const uint32_t h_c = min(lane, halves - 1u);
+            auto request1 = [&](uint2 (&bq)[7], uint32_t j) {
+                const uint2 *pj = reinterpret_cast<const uint2 *>(g.cols_ref + (((uint64_t)j * g.nk_total + g.nk) * g.ss64) * BBITS) + (size_t)h_c * 7;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) bq[q] = pj[q];
+            };
+            auto count_tail = [&](uint32_t mlo, uint32_t mhi) {
+                mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
+                const uint32_t part = ((lane & 1u) == 0u && lane < halves) ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
+                return maxnbits - eb_wave_sum(part);
+            };
+            uint2 b0[7];
+            uint32_t u0 = 0, l0 = 0, u1 = 0, l1 = 0;
+            uint32_t left = n_alive;                       // pairs not yet counted; b0 holds the first of them
+            advance(u0, l0);
+            request1(b0, column_of(u0, l0));
+            while (left > 1u) {
+                uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    mlo = acc_mismatch<true>(mlo, a_row[0][q].x, b0[q].x);
+                    mhi = acc_mismatch<true>(mhi, a_row[0][q].y, b0[q].y);
+                }
+                advance(u1, l1);                            // the next pair's slice is on its way while this one is summed up
+                request1(b0, column_of(u1, l1));
+                finish(count_tail(mlo, mhi), u0, l0);
+                u0 = u1;
+                l0 = l1;
+                --left;
+            }
+            {
+                uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    mlo = acc_mismatch<true>(mlo, a_row[0][q].x, b0[q].x);
+                    mhi = acc_mismatch<true>(mhi, a_row[0][q].y, b0[q].y);
+                }
+                finish(count_tail(mlo, mhi), u0, l0);
+            }
+        } else {
+            auto request = [&](uint32_t j) {                 // the column sample's slice of the first length not counted
+                if constexpr (TRIPS > 0) {
+                    const uint2 *pj = reinterpret_cast<const uint2 *>(g.cols_ref + (((uint64_t)j * g.nk_total + g.nk) * g.ss64) * BBITS);
+#pragma unroll
+                    for (int tr = 0; tr < TRIPS; ++tr) {
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) b_next[tr][q] = (uint32_t)tr * 64u + lane < halves ? pj[((size_t)tr * 64u + lane) * 7 + q] : make_uint2(0u, 0u);
+                    }
+                }
+            };
+            uint32_t u_e = 0, l_e = 0, u_n = 0, l_n = 0;
+            uint32_t left = n_alive;
+            advance(u_e, l_e);
+            request(column_of(u_e, l_e));
+            while (left != 0u) {
+                const uint32_t j_e = column_of(u_e, l_e);
+                uint32_t same;
+                --left;
+                if constexpr (TRIPS > 0) {
+                    uint32_t part = 0;
+#pragma unroll
+                    for (int tr = 0; tr < TRIPS; ++tr) {
+                        const uint32_t h = (uint32_t)tr * 64u + lane;
+                        uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) {
+                            mlo = acc_mismatch<true>(mlo, a_row[tr][q].x, b_next[tr][q].x);
+                            mhi = acc_mismatch<true>(mhi, a_row[tr][q].y, b_next[tr][q].y);
+                        }
+                        mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                        mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xF, 0xF, true);
+                        part += ((lane & 1u) == 0u && h < halves) ? (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi) : 0u;
+                    }
+                    // the next pair's slice is on its way while this one is summed up
+                    if (left != 0u) {
+                        advance(u_n, l_n);
+                        request(column_of(u_n, l_n));
+                    }
+                    same = maxnbits - eb_wave_sum(part);
+                } else {
+                    EbRow<0> none;
+                    same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_e, g.nk, false, lane);
+                    if (left != 0u) advance(u_n, l_n);
+                }
+                finish(same, u_e, l_e);
+                u_e = u_n;
+                l_e = l_n;
+            }
         }
     }
     // C. block by block: sums and regression where there is a fit, records, marks, the turned copy
@@ -797,59 +910,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         const uint32_t c = in_range ? c_raw : g.nB - 1u;
         const uint64_t p = (uint64_t)row * g.nB + c;
         const bool alive = (alive_mask[u] >> lane) & 1ull;
+        // a pair has a fit (three or more points, jaccard.rs:117) if its counted lengths gave three, or if it was still in the running
+        // and passed the first completed length (g.nk >= 2 counted ones + that one)
+        const bool ext_ok = alive && ((pass_mask[u] >> lane) & 1ull);
+        const uint32_t passed_u = (passed_pk >> (8u * u)) & 0xFFu;
+        const bool fit = in_range && (passed_u >= 3u || ext_ok);
+        const bool any_fit = __ballot(fit) != 0ull;
+        // NEARLY EVERY BLOCK: all 64 pairs are (1, 1), the row's list is full (a 1 marks nothing), so is every column's: nothing to
+        // store, nothing to mark
+        if (!any_fit && g.r_bits != nullptr && !(sortable_bits(1.0f) < thr_row) && (g.out_t == nullptr || g.plain_marks_nothing)) continue;
         float2 v = make_float2(1.0f, 1.0f);
-        if (by_count) {
-            // the lengths a pair still in the running passed beyond the counted ones, from the counts phase B left in LDS -- integer
-            // compares; a block none of whose pairs has three points (nearly every block: a pair that survives the counted lengths
-            // by chance leaves at the next) looks nothing up
+        if (any_fit) {
+            // the lengths passed beyond the counted ones, from the counts phase B left in LDS
             uint32_t e[KNN_MAXEXT];
             uint32_t n_ext = 0;
-            if (alive) {
+#pragma unroll
+            for (uint32_t x = 0; x < KNN_MAXEXT; ++x) e[x] = 0u;
+            if (ext_ok) {
                 bool run = true;
 #pragma unroll
                 for (uint32_t x = 0; x < KNN_MAXEXT; ++x) {
                     e[x] = ext[wave][u][x][lane];
-                    run = run && e[x] != 0xFFFFu && e[x] >= g.min_alive;
+                    run = run && e[x] != 0xFFFFu && !stops(e[x]);
                     n_ext += run ? 1u : 0u;
                 }
             }
-            const bool fit = in_range && passed[u] + n_ext >= 3u;   // (fewer than three lengths: (1, 1), jaccard.rs:117)
-            if (__ballot(fit) != 0ull) {                            // (wave-uniform)
-                double y[KNN_MAXKE], ye[KNN_MAXEXT];
+            if (fit) {
+                // the pair's counts in length order: the counted ones, then the completed ones (g.nk is 2 ... 4)
+                uint32_t cn[KNN_MAXKE], cc[EB_MAXK];
+                load_counts(u, cn);
 #pragma unroll
-                for (uint32_t t = 0; t < KNN_MAXKE; ++t) y[t] = fit && t < passed[u] ? g.ytab[cnt[u][t] <= maxnbits ? cnt[u][t] : maxnbits] : 0.0;
+                for (uint32_t t = 0; t < EB_MAXK; ++t) {
+                    cc[t] = t < KNN_MAXKE ? cn[t < KNN_MAXKE ? t : 0u] : 0u;
 #pragma unroll
-                for (uint32_t x = 0; x < KNN_MAXEXT; ++x) ye[x] = fit && x < n_ext ? g.ytab[e[x] <= maxnbits ? e[x] : maxnbits] : 0.0;
-                EbSums s;
-#pragma unroll
-                for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
-                    if (fit && t < passed[u]) s.add(g.kf[t], y[t]);
+                    for (uint32_t x = 0; x < KNN_MAXEXT; ++x) {
+                        if (t == g.nk + x) cc[t] = e[x];
+                    }
                 }
-#pragma unroll
-                for (uint32_t x = 0; x < KNN_MAXEXT; ++x) {
-                    if (fit && x < n_ext) s.add(g.kf[g.nk + x], ye[x]);
-                }
-                if (fit) v = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+                v = eb_fit_of_counts(g.ytab, g.kf, maxnbits, passed_u + n_ext, cc[0], cc[1], cc[2], cc[3], cc[4], cc[5], cc[6], cc[7]);
             }
-        } else {
-        const bool fit = in_range && (alive || passed[u] >= 3u);   // (fewer than three lengths: (1, 1), jaccard.rs:117)
-        if (__ballot(fit) != 0ull) {                            // (wave-uniform; rare between unrelated genomes)
-            EbSums s;
-#pragma unroll
-            for (uint32_t t = 0; t < KNN_MAXKE; ++t) {
-                if (t < passed[u] && fit) s.add(g.kf[t], g.ytab[cnt[u][t] <= maxnbits ? cnt[u][t] : maxnbits]);
-            }
-            if (alive) {
-                for (uint32_t t = g.nk; t < g.nk_total; ++t) {
-                    const uint32_t same = ext[wave][u][t - g.nk][lane];
-                    if (same == 0xFFFFu) break;
-                    const double y = g.ytab[same <= maxnbits ? same : maxnbits];
-                    if (y < g.tolerance) break;                 // jaccard.rs:89-91
-                    s.add(g.kf[t], y);
-                }
-            }
-            if (fit) v = simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
-        }
         }
         // does this 64-column block bring the row anything below its knn-th best?  (the key is the core distance)  The merge
         // reads the marked blocks of a row only, so an unmarked block's 64 records are not even stored.
