@@ -20,7 +20,7 @@ cases = set(args.cases.split(","))
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 K5 = [15, 19, 23, 27, 31]
-tag = {k: os.environ.get(k) for k in ("SKL_LIBRARY", "SKL_EPILOGUE_R5", "SKL_EARLY_BREAK", "SKL_EB_PIPELINE", "SKL_COUNTS_U16", "SKL_EB_LDS_ROWS", "SKL_EB_BLOCKED", "SKL_EB_BLK_ROW_SHIFT") if os.environ.get(k)}
+tag = {k: os.environ.get(k) for k in ("SKL_LIBRARY", "SKL_EPILOGUE_R5", "SKL_EARLY_BREAK", "SKL_EB_PIPELINE", "SKL_COUNTS_U16", "SKL_EB_LDS_ROWS", "SKL_EB_BLOCKED", "SKL_EB_BLK_ROW_SHIFT", "SKL_EB_LEAN", "SKL_EB_AHEAD") if os.environ.get(k)}
 
 
 def time_self(name, bins, n, kmers, ss64, reps, comp=None, cutoff=0.64):

@@ -385,7 +385,7 @@ Knobs read_knobs()
     k.knn_sparse = env_int("SKL_KNN_SPARSE", 1) != 0;
     k.early_break = (int)std::min(7ll, std::max(0ll, env_int("SKL_EARLY_BREAK", 1)));
     k.epilogue_r5 = env_int("SKL_EPILOGUE_R5", 0) != 0;
-    k.eb_pipeline = env_int("SKL_EB_PIPELINE", 0) != 0;
+    k.eb_pipeline = (int)env_int("SKL_EB_PIPELINE", -1);
     k.eb_pipeline_min = std::max(2ll, env_int("SKL_EB_PIPELINE_MIN", 64ll << 20));
     k.counts_u16 = env_int("SKL_COUNTS_U16", 1) != 0;
     k.eb_lds_rows = env_int("SKL_EB_LDS_ROWS", 1) != 0;
@@ -1289,8 +1289,20 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // piped; cfg 3 at two lengths: 642 blocked, 775 piped -- the pipeline is off unless asked for (A/B build,
         // SKL_EB_PIPELINE=1; tests/test_gpu_early_break_r6.py keeps it exact).
         const bool blocked = early && eb_blocked_order(ctx, rows, plan, pairs);
-        const bool piping = early && !blocked && ctx->knobs.eb_pipeline &&
-                            (eb_mixed || (plan != nullptr && plan->alive_share >= 0.03) || ctx->knobs.early_break >= 2);
+        // ROUND 6, LATE: with the lean epilogue (58 VGPRs, 8 waves per SIMD, a third of the instructions) the side-by-side run pays
+        // where it did not: 300 000 x 10 000 at 1.4 % still in the running 161.6 -> 154.0 ms, n = 30 000 at 2 048 bins 23.9 -> 23.2
+        // (profiles/r06_epilogue_lean.md) -- on by itself wherever that kernel runs in the flat order.
+        if (early) SKL_TRY(ensure_ytab(rows));   // (min_alive)
+        const bool lean_like = !eb_mixed && !(rows->d_comp && cols->d_comp) && rows->min_alive != 0xFFFFFFFFu && nkw >= 2 && nkw <= 4;
+        // (together with the blocked order it pays for the largest calls only: cfg 3 586 -> 575 ms, n = 40 000 95.4 -> 94.7, but
+        // n = 16 000 in 4 bands 15.5 -> 18.0: from 2^30 pairs)
+        bool piping = false;
+        if (early) {
+            const int pk = ctx->knobs.eb_pipeline;
+            if (pk == 1) piping = !blocked && (eb_mixed || (plan != nullptr && plan->alive_share >= 0.03) || ctx->knobs.early_break >= 2);
+            else if (pk == 2) piping = lean_like;
+            else if (pk == -1) piping = lean_like && (!blocked || pairs >= (1ull << 30));
+        }
         if (!ctx->eb_in_pipeline && r1 - r0 > 1 &&
             (pairs * nkw * cnt_bytes > COUNTS_SCRATCH_MAX || (piping && pairs >= (uint64_t)ctx->knobs.eb_pipeline_min))) {
             const uint64_t fit = std::max<uint64_t>(1, COUNTS_SCRATCH_MAX / (nkw * cnt_bytes));

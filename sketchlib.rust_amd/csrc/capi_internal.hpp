@@ -62,7 +62,7 @@ struct Knobs {
     bool fuse_epilogue = false;       // A/B build, SKL_FUSE_EPILOGUE=1: the core/accessory epilogue of plain k-sliced launches inside the pair kernel (results identical; slower: profiles/r05_fused_epilogue.md)
     int early_break = 1;              // A/B build, SKL_EARLY_BREAK: 0 core/accessory launches count every k-mer length; 1 (default) the early break where a
                                       // sample of the pairs says it pays; 2..7 forced with that many lengths counted (tests).  Results identical.
-    bool eb_pipeline = false;         // A/B build, SKL_EB_PIPELINE=1: the row bands of a large early-break call overlap (band i's epilogue beside band i + 1's counts kernel; superseded by the blocked epilogue order)
+    int eb_pipeline = -1;             // -1: the row bands of a large early-break call overlap (band i's epilogue beside band i + 1's counts kernel) where the lean epilogue runs in the flat order; A/B build, SKL_EB_PIPELINE=0 / 1 / 2: never / the old rule (general kernel too: from 3 % still in the running, or forced lengths; never with the blocked order) / wherever the lean kernel runs
     long long eb_pipeline_min = 64ll << 20;  // A/B build, SKL_EB_PIPELINE_MIN: pairs from which an early-break call is cut into overlapping row bands (tests force it low)
     int eb_blocked = -1;              // A/B build, SKL_EB_BLOCKED=0|1: the early break's epilogue walks the pairs in flat order / in 256 x 256 blocks per XCD (-1: by the size of the column slices)
     int eb_blk_row_shift = 10;        // A/B build, SKL_EB_BLK_ROW_SHIFT: rows per block (log2) of the blocked epilogue
