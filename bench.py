@@ -810,7 +810,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
     def set_timing_every(v):
         ctx.timing_enable(v)
 
-    def timed(launch, w, s, interval_us, separate_clock_pass=False, clock=True):
+    def timed(launch, w, s, interval_us, separate_clock_pass=False, clock=True, plain_first=True):
         """-> wall per step, PAIR-kernel seconds per step (every launch bracketed), launches, clock.  The clock sampler
         runs beside the bracketed launches -- or, for launches short enough that the late event timestamps of a
         two-queue device matter (~10 us each), in a second pass of its own without brackets, which then also gives the
@@ -820,8 +820,6 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
             launch()
         ctx.synchronize()
         est = (time.perf_counter() - t1) / max(w, 1) * s if w else 60.0
-        set_timing_every(1)
-        ctx.timing_reset()
         wall = [0.0]
 
         def run():
@@ -831,13 +829,25 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
             ctx.synchronize()
             wall[0] = (time.perf_counter() - t1) / s
 
+        # the WALL time first, the library as a caller gets it: no event brackets, no sampler beside it (round 6: large
+        # early-break calls run in row bands over two streams, and a sampler wave on a third queue next to event records
+        # on both made the bracketed pass 4 x slower than the call is -- cfg 3 2.49 s against 0.56 s)
+        wall_plain = None
+        if plain_first:
+            set_timing_every(0)
+            run()
+            wall_plain = wall[0]
+        set_timing_every(1)
+        ctx.timing_reset()
         clk = sampled(ctx, run, interval_us, expect_s=est, enabled=sampler and clock and not separate_clock_pass)
+        if wall_plain is None:
+            wall_plain = wall[0]
         kms, nl = ctx.kernel_ms()
         if sampler and clock and separate_clock_pass:
             set_timing_every(0)
             clk = sampled(ctx, run, interval_us, expect_s=est)
             set_timing_every(1)
-        return wall[0], kms / 1e3 / s, nl, clk
+        return wall_plain, kms / 1e3 / s, nl, clk
 
     if "setR" in which:
         # Set R: the same workload on related genomes (Set U returns (1, 1) for ~99 % of the pairs)
@@ -923,7 +933,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
             # (not sampled: the kNN driver allocates and frees band buffers inside the call -- device-wide synchronisations
             # that would wait for the sampler)
             ctx.set_knn_ties(capi.TIES_CANONICAL)   # (the library's default is the reference's order: timed below, beside this one)
-            wall, ksec, n_launch, clk = timed(knn_call, 1, 1, 500, clock=False)   # (one untimed call first: it allocates the band buffers)
+            wall, ksec, n_launch, clk = timed(knn_call, 1, 1, 500, clock=False, plain_first=False)   # (one untimed call first: it allocates the band buffers)
             idx, d0, _d1 = res[0]
             prune5 = ctx.knn_prune_stats(full=True)
             assert idx.shape == (nr, knn) and bool(np.all(np.diff(d0, axis=1) >= 0)) and not np.any(idx == np.arange(nr, dtype=np.uint64)[:, None])
@@ -998,7 +1008,7 @@ def secondary_legs(torch, np, capi, synth, ctx, device, which, sampler=True, cpu
             def knn_ca_call():
                 res[0] = capi.self_dists_knn(ctx, g_r, p5c, knn)
 
-            wall, ksec, n_launch, clk = timed(knn_ca_call, 0, 1, 500, clock=False)
+            wall, ksec, n_launch, clk = timed(knn_ca_call, 0, 1, 500, clock=False, plain_first=False)
             idx, d0, d1 = res[0]
             assert idx.shape == (nr, knn) and bool(np.all(np.diff(d0, axis=1) >= 0)) and not np.any(idx == np.arange(nr, dtype=np.uint64)[:, None])
             for i in (0, 77_777, nr - 1):     # three rows: the dense path's (core, acc) row pushed through the oracle's BinaryHeap
