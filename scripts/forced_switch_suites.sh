@@ -8,9 +8,9 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 # (round 5: "A/B only" switches -- SKL_ROUND_PRIORITY, SKL_KNN_ROW_FLAGS, SKL_CAND_ROW_ORDER ... -- are read by the A/B library
-# alone, so the whole suite runs against that build: the product library + the switches; round 6: settings 13-18 force the band
-# pipeline onto small inputs, the early break without LDS rows / u16 counts, round 5's epilogue, the blocked epilogue order, and
-# the general epilogue kernel where the lean one would run)
+# alone, so the whole suite runs against that build: the product library + the switches; round 6: settings 13-19 force the band
+# pipeline onto small inputs, the early break without LDS rows / u16 counts, round 5's epilogue, the blocked epilogue order, the
+# general epilogue kernel where the lean one would run, and the lean kernel in row bands on two streams)
 export SKL_LIBRARY="$R/sketchlib.rust_amd/csrc/_build_ab/libsketchlib_dist_hip.so"
 python3 -c "import sketchlib.rust_amd as pkg; pkg.build_ab_library()" || exit 1
 FIRST=${1:-1}
@@ -22,7 +22,8 @@ for e in "SKL_TILE32_MIN=0" "SKL_TILE32_MIN=-1" "SKL_TAIL_MAX_PCT=100000000 SKL_
          "SKL_ROUND_PRIORITY=0 SKL_KNN_ROW_FLAGS=0" "SKL_XCDS=1 SKL_CAND_ROW_ORDER=0" "SKL_XCDS=4 SKL_TILE32_MIN=0" \
          "SKL_EARLY_BREAK=3" "SKL_EARLY_BREAK=4 SKL_TILE32_MIN=0" "SKL_EARLY_BREAK=2" "SKL_EARLY_BREAK=0 SKL_KNN_SPARSE=0" \
          "SKL_EARLY_BREAK=2 SKL_EB_PIPELINE=1 SKL_EB_PIPELINE_MIN=30000 SKL_TAIL_SLICES=0" "SKL_EARLY_BREAK=3 SKL_EB_LDS_ROWS=0 SKL_COUNTS_U16=0 SKL_TILE32_MIN=0" \
-         "SKL_EPILOGUE_R5=1" "SKL_EARLY_BREAK=2 SKL_EB_BLOCKED=1 SKL_EB_BLK_ROW_SHIFT=6" "SKL_EB_LEAN=0 SKL_EB_AHEAD=0" "SKL_EARLY_BREAK=3 SKL_EB_LEAN=0"; do
+         "SKL_EPILOGUE_R5=1" "SKL_EARLY_BREAK=2 SKL_EB_BLOCKED=1 SKL_EB_BLK_ROW_SHIFT=6" "SKL_EB_LEAN=0 SKL_EB_AHEAD=0" "SKL_EARLY_BREAK=3 SKL_EB_LEAN=0" \
+         "SKL_EARLY_BREAK=2 SKL_EB_PIPELINE=2 SKL_EB_PIPELINE_MIN=30000 SKL_TAIL_SLICES=0"; do
   I=$((I + 1))
   if [ "$I" -lt "$FIRST" ] || [ "$I" -gt "$LAST" ]; then continue; fi
   echo "== $e"
