@@ -391,6 +391,7 @@ Knobs read_knobs()
     k.eb_lds_rows = env_int("SKL_EB_LDS_ROWS", 1) != 0;
     k.eb_ahead = env_int("SKL_EB_AHEAD", 1) != 0;
     k.eb_lean = env_int("SKL_EB_LEAN", 1) != 0;
+    k.knn_epi_blocked = (int)std::min(2ll, std::max(0ll, env_int("SKL_KNN_EPI_BLOCKED", 1)));
     k.eb_blocked = (int)env_int("SKL_EB_BLOCKED", -1);
     k.eb_blk_row_shift = (int)env_int("SKL_EB_BLK_ROW_SHIFT", 10);
     k.fuse_epilogue = env_int("SKL_FUSE_EPILOGUE", 0) != 0;

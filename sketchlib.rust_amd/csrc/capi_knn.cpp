@@ -354,6 +354,7 @@ static int knn_symmetric_bands(skl_ctx *ctx, const skl_sketches *s, const skl_di
             e.t_bits_stride = g.t_bits_stride;
             e.alive_count = ctx->eb_counter;
             e.min_alive = s->min_alive;
+            e.xcd_blocked = (uint32_t)ctx->knobs.knn_epi_blocked;
             e.cnt_u16 = 1;
             // (bands ascend: the `it` bands before this one each gave band_rows candidates to every row the turned copy reaches,
             // and their merges run before this launch on the same stream)

@@ -17,6 +17,9 @@
 // KB of LDS where the plain epilogue runs at 5 waves per SIMD), and a work list in global memory walked by a second kernel
 // with the row's slice held in registers (n = 16 000: 22.4 against 18.7 ms -- the completions are bound by the column
 // slices' bytes either way, and on the spot they overlap with the other waves' streaming for free).
+// Late in round 6 the counters showed what binds the kernel: the instructions it issues (profiles/r06_epilogue_lean.md).
+// Launches with one ke for every pair and no completeness correction -- all but block-by-block plans and completeness
+// vectors -- now go to coreacc_epilogue_lean_kernel (below); coreacc_epilogue_kernel_r6 keeps the general case.
 //
 // The break test is the reference's: y < tolerance with y = ln J.  Without a completeness correction y is a function of
 // the bin-match count alone and non-decreasing in it, so the test is `count < min_alive` (the host finds min_alive in the
@@ -107,38 +110,14 @@ __device__ __forceinline__ uint32_t eb_wave_sum(uint32_t part)
            (uint32_t)__builtin_amdgcn_readlane((int)part, 47) + (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
 }
 
-// The row sample's slice of ONE k-mer length, kept in registers across the alive columns of that row (TRIPS x 7 x 8 bytes
-// per lane: sketches of up to 32 x TRIPS chunks; TRIPS = 0: any size, nothing kept)
-template <int TRIPS>
-struct EbRow {
-    uint2 a[TRIPS > 0 ? TRIPS : 1][7];
-    uint32_t i = EB_NONE, t = EB_NONE;
-};
-
-template <int TRIPS>
-__device__ __forceinline__ uint32_t eb_same_bins(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t nk_total, uint32_t ss64,
-                                                 EbRow<TRIPS> &row, uint32_t i, uint32_t j, uint32_t t, bool keep, uint32_t lane)
+// Bins the pair (row sample i, column sample j) shares at k-mer length index t, counted by the whole wave.
+__device__ __forceinline__ uint32_t eb_same_bins(const uint64_t *rows_ref, const uint64_t *cols_ref, uint32_t nk_total, uint32_t ss64, uint32_t i, uint32_t j,
+                                                 uint32_t t, uint32_t lane)
 {
     const uint32_t halves = ss64 * 2u;
     const uint2 *pi = reinterpret_cast<const uint2 *>(rows_ref + (((uint64_t)i * nk_total + t) * ss64) * BBITS);
     const uint2 *pj = reinterpret_cast<const uint2 *>(cols_ref + (((uint64_t)j * nk_total + t) * ss64) * BBITS);
     uint32_t part = 0;
-    if constexpr (TRIPS > 0) {
-        if (keep) {
-            if (row.i != i || row.t != t) {   // (wave-uniform)
-#pragma unroll
-                for (int tr = 0; tr < TRIPS; ++tr) {
-#pragma unroll
-                    for (int q = 0; q < 7; ++q) row.a[tr][q] = (uint32_t)tr * 64u + lane < halves ? pi[((size_t)tr * 64u + lane) * 7 + q] : make_uint2(0u, 0u);
-                }
-                row.i = i;
-                row.t = t;
-            }
-#pragma unroll
-            for (int tr = 0; tr < TRIPS; ++tr) part += eb_trip(row.a[tr], pj, (uint32_t)tr * 64u + lane, halves, lane);
-            return ss64 * 64u - eb_wave_sum(part);
-        }
-    }
     // (every lane loads: those past the slices' end re-read the last half chunk and count nothing -- a load under `h < halves`
     // is a branch around it, 8 of them per trip)
     for (uint32_t h0 = 0; h0 < halves; h0 += 64u) {
@@ -161,8 +140,6 @@ __device__ __forceinline__ uint32_t eb_same_bins(const uint64_t *rows_ref, const
     return ss64 * 64u - eb_wave_sum(part);
 }
 
-// Entry e of wave w_src's list, completed by the calling wave: the counts of the lengths from its ke on, up to and including
-// the one that ends the reference's loop (jaccard.rs:89-91).
 // the (i, j) of flat pair index `flat` of the launch's pair space
 __device__ __forceinline__ void eb_pair_of(const EpilogueArgs &g, uint64_t flat, uint32_t &i, uint32_t &j)
 {
@@ -442,7 +419,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
             c1_l = g.compA[i_l];
             c2_l = g.compB[j_l];
         }
-        EbRow<0> none;
         for (uint32_t t = ke_l; t < g.nk_total; ++t) {
             uint32_t same;
             if (staged && t == g.nk && i_l - i_wg < (g.blocked ? 1u : 2u)) {   // the row's slice from LDS, the column's as one contiguous run
@@ -459,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMP ? 4 : 
                 }
                 same = g.ss64 * 64u - eb_wave_sum(part);
             } else {
-                same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_l, j_l, t, false, lane);
+                same = eb_same_bins(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, i_l, j_l, t, lane);
             }
             if (eb_stops<COMP>(g, same, c1_l, c2_l)) break;   // (wave-uniform)
             if ((int)lane == l) s.add(g.kf[t], eb_lnj<COMP>(g, same, c1, c2));
@@ -632,7 +608,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
             }
         }
         uint64_t todo = __ballot(more);
-        EbRow<0> none;
         while (todo != 0ull) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1ull;
@@ -642,7 +617,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
             for (int u = 0; u < EXT; ++u) {
                 if ((uint32_t)u < u_l) continue;                    // (wave-uniform)
                 if ((uint32_t)(NK + u) >= g.nk_total) break;
-                const uint32_t same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_l, j_l, (uint32_t)(NK + u), false, lane);
+                const uint32_t same = eb_same_bins(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, i_l, j_l, (uint32_t)(NK + u), lane);
                 if (same < g.min_alive) break;                      // jaccard.rs:89-91: break (wave-uniform)
                 if ((int)lane == l) {
                     all[NK + u] = same;
@@ -681,8 +656,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS ==
     __shared__ uint16_t ext[4][KNN_BLOCKS][KNN_MAXEXT][64];   // completed bin-match counts of the pairs still in the running (0xFFFF: not looked at)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t row = g.row_base + blockIdx.y;
-    const uint32_t c_wave = (blockIdx.x * 4u + wave) * (64u * KNN_BLOCKS);
+    // COLUMN-GROUP-MAJOR ORDER PER XCD (g.xcd_blocked; gridDim.x is a multiple of the XCDs then): the workgroups of the launch go to the
+    // XCDs in turns of their linear index; XCD x takes the column groups x, x + 8, ... one after the other, each for ALL the
+    // launch's rows before the next -- the group's 1 024 column slices (3.5 MB at 2 048 bins) stay in that XCD's L2 while the rows
+    // pass, and a slice read for one row's completion is found there by the ~30 other rows of the band that need it.  (Row-major, a
+    // slice's next reader comes ~67 rows later -- 1.5 % of the pairs are still in the running -- and by then the XCD has read
+    // 130 MB of other slices: every completion is an HBM gather.)
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (g.xcd_blocked) {
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
+        const uint32_t cg_l = slot / gridDim.y;
+        by = slot - cg_l * gridDim.y;
+        bx = cg_l * 8u + xcd;
+    }
+    const uint32_t row = g.row_base + by;
+    const uint32_t c_wave = (bx * 4u + wave) * (64u * KNN_BLOCKS);
     const uint32_t maxnbits = g.ss64 * 64u, halves = g.ss64 * 2u;
     const uint32_t i_s = g.row_sample0 + row;
     if (c_wave >= g.nB) return;
@@ -748,7 +736,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS ==
 #pragma unroll
     for (uint32_t u = 0; u < KNN_BLOCKS; ++u) pass_mask[u] = 0ull;
     if (n_alive != 0u) {                // (wave-uniform)
-        if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[(blockIdx.x + blockIdx.y * 7u) & 1023u], n_alive);   // (1 024 slots)
+        if (g.alive_count != nullptr && lane == 0u) atomicAdd(&g.alive_count[(bx + by * 7u) & 1023u], n_alive);   // (1 024 slots)
         const uint2 *pi = reinterpret_cast<const uint2 *>(g.rows_ref + (((uint64_t)i_s * g.nk_total + g.nk) * g.ss64) * BBITS);
         constexpr int KEPT = TRIPS > 0 ? TRIPS : 1;
         uint2 a_row[KEPT][7], b_next[KEPT][7];
@@ -799,8 +787,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS ==
             }
             const uint32_t j_e = column_of(u_e, l_e);
             for (uint32_t t = g.nk + 1u; t < g.nk_total; ++t) {
-                EbRow<0> none;
-                same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_e, t, false, lane);
+                same = eb_same_bins(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, i_s, j_e, t, lane);
                 if (stops(same)) break;                        // (wave-uniform)
                 if (lane == l_e) ext[wave][u_e][t - g.nk][lane] = (uint16_t)same;
             }
@@ -891,8 +878,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS ==
                     }
                     same = maxnbits - eb_wave_sum(part);
                 } else {
-                    EbRow<0> none;
-                    same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, none, i_s, j_e, g.nk, false, lane);
+                    same = eb_same_bins(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, i_s, j_e, g.nk, lane);
                     if (left != 0u) advance(u_n, l_n);
                 }
                 finish(same, u_e, l_e);
@@ -989,9 +975,12 @@ hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t 
     for (uint32_t r0 = 0; r0 < args.rows; r0 += 32768u) {
         EpilogueKnnArgs a = args;
         a.row_base = r0;
-        // (gridDim.x rounded up to a multiple of the XCDs, so that a column group meets the same XCD in every row and finds its
-        // column slices in that L2: 2.51 s either way at n = 300 000 -- not where the completions' time goes; not kept)
-        const dim3 gr((args.nB + per_wg - 1u) / per_wg, std::min(32768u, args.rows - r0)), bl(256);
+        // (gridDim.x rounded up to a multiple of the XCDs alone -- a column group on the same XCD in every row, rows still the slow
+        // index -- changed nothing: 2.51 s either way at n = 300 000; see the kernel for the order that goes with it)
+        uint32_t gx = (args.nB + per_wg - 1u) / per_wg;
+        a.xcd_blocked = a.xcd_blocked == 2u || (a.xcd_blocked == 1u && gx >= 32u) ? 1u : 0u;   // (narrow views: the padding to a multiple of 8 would be mostly empty workgroups; 2: forced, tests)
+        if (a.xcd_blocked) gx = (gx + 7u) & ~7u;
+        const dim3 gr(gx, std::min(32768u, args.rows - r0)), bl(256);
         if (args.ss64 <= 32u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<1>, gr, bl, 0, stream, a);
         else if (args.ss64 <= 64u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<2>, gr, bl, 0, stream, a);
         else hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<0>, gr, bl, 0, stream, a);
@@ -1037,10 +1026,9 @@ __global__ __launch_bounds__(256) void early_break_sample_kernel(const EbSampleA
         c2 = g.compB[j];
     }
     const uint32_t maxnbits = g.ss64 * 64u;
-    EbRow<0> none;
     uint32_t lead = 0u;
     for (uint32_t t = 0; t < g.nk && t < 8u; ++t) {
-        const uint32_t same = eb_same_bins<0>(g.rows_ref, g.cols_ref, g.nk, g.ss64, none, i, j, t, false, lane);
+        const uint32_t same = eb_same_bins(g.rows_ref, g.cols_ref, g.nk, g.ss64, i, j, t, lane);
         bool stop;
         if (g.has_comp) stop = glibc_log(jaccard_from_samebits_dev(same, g.ss64, true, c1, c2, g.cutoff), g.log_variant) < g.tolerance;
         else if (g.min_alive != EB_NONE) stop = same < g.min_alive;

@@ -266,6 +266,7 @@ bool coreacc_epilogue_is_lean(const EpilogueArgs &args);   // will that launch t
 // that holds a key below the row's knn-th best, and the TURNED copy.  The turned band is pre-filled with (1, 1) by the host
 // (a memset: what every pair that left the loop early is); only the other records are stored into it, with their marks.
 struct EpilogueKnnArgs {
+    uint32_t xcd_blocked;        // column-group-major order per XCD (epilogue.hip): 0 never, 1 from 32 column groups on, 2 always
     const uint32_t *counts;
     uint64_t n_pairs;            // rows * nB
     uint32_t rows, nB;           // the band's rows, the view's columns

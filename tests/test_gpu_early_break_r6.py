@@ -390,3 +390,27 @@ def test_lean_epilogue_against_the_general_one(oracle, skl, gpu_ctx, monkeypatch
     assert ("[lean epilogue" in name) == bool(lean), name
     if lean and n >= 2000:
         assert "[lean epilogue]" in name, name          # (u16 counts)
+
+
+@pytest.mark.ab_library
+@pytest.mark.parametrize("n,ss64,band_rows,knn,order", [(330, 256, 64, 7, 2), (9300, 16, 512, 20, 2), (9300, 16, 512, 20, 0)])
+def test_knn_band_epilogue_order(oracle, skl, gpu_ctx, set_switch, n, ss64, band_rows, knn, order):
+    """The kNN bands' early-break epilogue walks a launch column group by column group on each XCD (all the band's rows of one group
+    of 1 024 columns before the next, so that the group's column slices stay in that L2) from 32 column groups on;
+    SKL_KNN_EPI_BLOCKED=2 (A/B build) forces that order onto views the oracle can check whole -- one group padded to eight, and ten
+    groups of which the last is ragged, padded to sixteen -- and 0 the row-major order: ids, order and both distances = the oracle's."""
+    bins = _mixed(n, KMERS, ss64, n_random=n - 300, n_clusters=3, seed=29)
+    o, g = oracle.Sketches(bins, n, KMERS, ss64), gpu_ctx.sketches(bins, n, KMERS, ss64)
+    set_switch("SKL_KNN_BAND_ROWS", band_rows)
+    set_switch("SKL_KNN_EPI_BLOCKED", order)
+    set_switch("SKL_EARLY_BREAK", 2)
+    gpu_ctx.set_knn_ties(skl.TIES_REFERENCE)
+    try:
+        idx, d0, d1 = skl.self_dists_knn(gpu_ctx, g, g.set_k(), knn)
+    finally:
+        gpu_ctx.set_knn_ties(skl.TIES_CANONICAL)
+    exp = oracle.self_dists_knn(o, knn, oracle.COREACC, 0, False, ties=oracle.TIES_RUST_HEAP, threads=8)
+    assert "early break: 2 of 5" in gpu_ctx.last_kernel(), gpu_ctx.last_kernel()
+    assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
+    assert np.array_equal(d0.view(np.uint32), exp["d0"].view(np.uint32)) and np.array_equal(d1.view(np.uint32), exp["d1"].view(np.uint32))
+    g.close()
