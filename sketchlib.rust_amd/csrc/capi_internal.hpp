@@ -66,7 +66,7 @@ struct Knobs {
     long long eb_pipeline_min = 64ll << 20;  // A/B build, SKL_EB_PIPELINE_MIN: pairs from which an early-break call is cut into overlapping row bands (tests force it low)
     int eb_blocked = -1;              // A/B build, SKL_EB_BLOCKED=0|1: the early break's epilogue walks the pairs in flat order / in 256 x 256 blocks per XCD (-1: by the size of the column slices)
     int eb_blk_row_shift = 10;        // A/B build, SKL_EB_BLK_ROW_SHIFT: rows per block (log2) of the blocked epilogue
-    int knn_epi_blocked = 1;          // A/B build, SKL_KNN_EPI_BLOCKED=0 / 2: the kNN bands' early-break epilogue in row-major order / column-group-major per XCD whatever the view's width (default: from 32 768 columns; 2.52 -> 2.44 s at n = 300 000)
+    int knn_epi_blocked = 1;          // A/B build, SKL_KNN_EPI_BLOCKED=0 / 2: the kNN bands' early-break epilogue in row-major order / column-group-major per XCD whatever the view's width (default: from 16 384 columns; 2.52 -> 2.43 s at n = 300 000)
     bool eb_lean = true;              // A/B build, SKL_EB_LEAN=0: every early-break launch through the general epilogue kernel
     bool eb_ahead = true;             // A/B build, SKL_EB_AHEAD=0: completions one after the other, nothing requested ahead
     bool eb_lds_rows = true;          // A/B build, SKL_EB_LDS_ROWS=0: completions read the row sample's slice from memory, not from the workgroup's LDS copy

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS ==
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // COLUMN-GROUP-MAJOR ORDER PER XCD (g.xcd_blocked; gridDim.x is a multiple of the XCDs then): the workgroups of the launch go to the
     // XCDs in turns of their linear index; XCD x takes the column groups x, x + 8, ... one after the other, each for ALL the
-    // launch's rows before the next -- the group's 1 024 column slices (3.5 MB at 2 048 bins) stay in that XCD's L2 while the rows
+    // launch's rows before the next -- the group's 512 column slices (a workgroup = 2 waves x 256 columns; 1.75 MB at 2 048 bins) stay in that XCD's L2 while the rows
     // pass, and a slice read for one row's completion is found there by the ~30 other rows of the band that need it.  (Row-major, a
     // slice's next reader comes ~67 rows later -- 1.5 % of the pairs are still in the running -- and by then the XCD has read
     // 130 MB of other slices: every completion is an HBM gather.)
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS ==
         bx = cg_l * 8u + xcd;
     }
     const uint32_t row = g.row_base + by;
-    const uint32_t c_wave = (bx * 4u + wave) * (64u * KNN_BLOCKS);
+    const uint32_t c_wave = (bx * (blockDim.x >> 6) + wave) * (64u * KNN_BLOCKS);
     const uint32_t maxnbits = g.ss64 * 64u, halves = g.ss64 * 2u;
     const uint32_t i_s = g.row_sample0 + row;
     if (c_wave >= g.nB) return;
@@ -971,7 +971,8 @@ hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t 
 {
     if (args.rows == 0 || args.nB == 0) return hipSuccess;
     if (args.nk > KNN_MAXKE) return hipErrorInvalidValue;
-    const uint32_t per_wg = 256u * KNN_BLOCKS;
+    const uint32_t wg_threads = 128u;   // (2 waves = 512 columns = 1.75 MB of slices per column group at 2 048 bins; 4 waves: +0.4 %)
+    const uint32_t per_wg = wg_threads * KNN_BLOCKS;
     for (uint32_t r0 = 0; r0 < args.rows; r0 += 32768u) {
         EpilogueKnnArgs a = args;
         a.row_base = r0;
@@ -980,7 +981,7 @@ hipError_t launch_coreacc_epilogue_knn(const EpilogueKnnArgs &args, hipStream_t 
         uint32_t gx = (args.nB + per_wg - 1u) / per_wg;
         a.xcd_blocked = a.xcd_blocked == 2u || (a.xcd_blocked == 1u && gx >= 32u) ? 1u : 0u;   // (narrow views: the padding to a multiple of 8 would be mostly empty workgroups; 2: forced, tests)
         if (a.xcd_blocked) gx = (gx + 7u) & ~7u;
-        const dim3 gr(gx, std::min(32768u, args.rows - r0)), bl(256);
+        const dim3 gr(gx, std::min(32768u, args.rows - r0)), bl(wg_threads);
         if (args.ss64 <= 32u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<1>, gr, bl, 0, stream, a);
         else if (args.ss64 <= 64u) hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<2>, gr, bl, 0, stream, a);
         else hipLaunchKernelGGL(coreacc_epilogue_knn_kernel<0>, gr, bl, 0, stream, a);

@@ -396,9 +396,9 @@ def test_lean_epilogue_against_the_general_one(oracle, skl, gpu_ctx, monkeypatch
 @pytest.mark.parametrize("n,ss64,band_rows,knn,order", [(330, 256, 64, 7, 2), (9300, 16, 512, 20, 2), (9300, 16, 512, 20, 0)])
 def test_knn_band_epilogue_order(oracle, skl, gpu_ctx, set_switch, n, ss64, band_rows, knn, order):
     """The kNN bands' early-break epilogue walks a launch column group by column group on each XCD (all the band's rows of one group
-    of 1 024 columns before the next, so that the group's column slices stay in that L2) from 32 column groups on;
-    SKL_KNN_EPI_BLOCKED=2 (A/B build) forces that order onto views the oracle can check whole -- one group padded to eight, and ten
-    groups of which the last is ragged, padded to sixteen -- and 0 the row-major order: ids, order and both distances = the oracle's."""
+    of 512 columns before the next, so that the group's column slices stay in that L2) from 32 column groups on;
+    SKL_KNN_EPI_BLOCKED=2 (A/B build) forces that order onto views the oracle can check whole -- one group padded to eight, and nineteen
+    groups of which the last is ragged, padded to twenty-four -- and 0 the row-major order: ids, order and both distances = the oracle's."""
     bins = _mixed(n, KMERS, ss64, n_random=n - 300, n_clusters=3, seed=29)
     o, g = oracle.Sketches(bins, n, KMERS, ss64), gpu_ctx.sketches(bins, n, KMERS, ss64)
     set_switch("SKL_KNN_BAND_ROWS", band_rows)
