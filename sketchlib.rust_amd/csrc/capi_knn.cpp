@@ -687,7 +687,7 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
     band_rows = std::min(band_rows, r1 - r0);
     // The whole self matrix: evaluate each pair once (knn_self_symmetric) when that leaves bands
     // worth launching -- about 8 of them (7/16 of the pair evaluations saved), each at least 32 M
-    // pairs, within four band buffers of up to half the free HBM (<= 32 GiB) together.
+    // pairs, within four band buffers of up to half the free HBM (<= 32 GiB; core/accessory keys: <= 96 GiB) together.
     // (the reference's tie order depends on the ORDER candidates arrive in, ascending j for every row: the symmetric driver
     // delivers exactly that order, band by band, to a heap that lives in global memory between the bands; lists too long for
     // the LDS-resident running state go row by row)
@@ -695,7 +695,11 @@ static int knn_rows(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *
                      ctx->knobs.knn_symmetric;   // (SKL_KNN_SYMMETRIC=0: A/B against the row-by-row form)
     if (symmetric) {
         size_t budget = band_bytes;
-        if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, 32ull << 30));
+        // (core/accessory keys -- no tile pruning, whose thresholds want short bands -- take taller bands: the bands' epilogue
+        // finds a column group's slices in L2 for more rows, and there are fewer launches and heap replays: cfg 5 in
+        // core/accessory mode, 704 / 1 408 / 2 048 / 2 816 / 4 096 rows: 25.1 / 24.7 / 24.6 / 24.6 / 24.6 s)
+        const size_t budget_cap = p->dist_type == SKL_DIST_COREACC ? 96ull << 30 : 32ull << 30;
+        if (free_b) budget = std::max(budget, std::min<size_t>(free_b / 2, budget_cap));
         const size_t want = forced_band_rows ? forced_band_rows : symmetric_band_rows(n_cand, coreacc_rec_with_counts(rows, p), budget, 1);
         if (want >= n_cand) symmetric = false;
         else band_rows = want;

@@ -651,9 +651,9 @@ constexpr uint32_t KNN_MAXKE = 4;
 constexpr uint32_t KNN_MAXEXT = 6;      // lengths beyond the counted ones (nk_total <= 8, nk >= 2)
 
 template <int TRIPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, TRIPS == 0 ? 8 : 5))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, TRIPS == 0 ? 8 : 5))) void coreacc_epilogue_knn_kernel(const EpilogueKnnArgs g)
 {
-    __shared__ uint16_t ext[4][KNN_BLOCKS][KNN_MAXEXT][64];   // completed bin-match counts of the pairs still in the running (0xFFFF: not looked at)
+    __shared__ uint16_t ext[2][KNN_BLOCKS][KNN_MAXEXT][64];   // completed bin-match counts of the pairs still in the running (0xFFFF: not looked at)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // COLUMN-GROUP-MAJOR ORDER PER XCD (g.xcd_blocked; gridDim.x is a multiple of the XCDs then): the workgroups of the launch go to the
