@@ -799,6 +799,13 @@ extern "C" int skl_sketches_set_completeness(skl_sketches *s, const double *comp
     }
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
     HIP_TRY(hipMemcpy(s->d_comp, comp, s->n * sizeof(double), hipMemcpyHostToDevice));
+    s->comp_unit = true;
+    for (size_t x = 0; x < s->n; ++x) {
+        if (!(comp[x] > 0.0 && comp[x] <= 1.0)) {   // (NaN fails both)
+            s->comp_unit = false;
+            break;
+        }
+    }
     return SKL_OK;
 }
 
@@ -1294,7 +1301,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // where it did not: 300 000 x 10 000 at 1.4 % still in the running 161.6 -> 154.0 ms, n = 30 000 at 2 048 bins 23.9 -> 23.2
         // (profiles/r06_epilogue_lean.md) -- on by itself wherever that kernel runs in the flat order.
         if (early) SKL_TRY(ensure_ytab(rows));   // (min_alive)
-        const bool lean_like = !eb_mixed && !(rows->d_comp && cols->d_comp) && rows->min_alive != 0xFFFFFFFFu && nkw >= 2 && nkw <= 4;
+        const bool lean_like = !eb_mixed && (!(rows->d_comp && cols->d_comp) || (rows->comp_unit && cols->comp_unit)) && rows->min_alive != 0xFFFFFFFFu && nkw >= 2 && nkw <= 4;
         // (together with the blocked order it pays for the largest calls only: cfg 3 586 -> 575 ms, n = 40 000 95.4 -> 94.7, but
         // n = 16 000 in 4 bands 15.5 -> 18.0: from 2^30 pairs)
         bool piping = false;
@@ -1513,6 +1520,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // still in the running: 18.0 against 18.7 ms; at 2 048 bins, 1.4 %: 30.8 against 27.3 -- profiles/r06_epilogue_forms.md)
         e.ahead = ctx->knobs.eb_ahead ? 1u : 0u;
         e.lean = ctx->knobs.eb_lean ? 1u : 0u;
+        e.comp_lean = rows->d_comp && cols->d_comp && rows->comp_unit && cols->comp_unit ? 1u : 0u;
         e.lds_rows = ctx->knobs.eb_lds_rows && plan != nullptr && plan->alive_share >= 0.03 ? 1u : 0u;
         e.ss64 = (uint32_t)rows->ss64;
         e.n_slices = sliced ? ctx->last_count_planes : 1u;

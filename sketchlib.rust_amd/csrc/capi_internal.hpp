@@ -170,6 +170,7 @@ struct skl_sketches {
     uint64_t *d_rows = nullptr;  // reference layout + A_PAD_ROWS zero rows (scalar operand)
     uint4 *d_lanes = nullptr;    // lane-interleaved layout (vector operand), built on demand
     double *d_comp = nullptr;    // completeness or null
+    bool comp_unit = false;      // every completeness value is finite and in (0, 1] (what the lean early-break epilogue's integer tests need)
     double *d_ytab = nullptr;    // ln J table [64*ss64+1]
     double *d_kf = nullptr;      // k-mer lengths as f64 [nk]
     std::map<std::pair<int, size_t>, float *> d_dtab;  // (jout, k_idx) -> f32 table

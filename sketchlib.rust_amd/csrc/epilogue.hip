@@ -465,6 +465,36 @@ __device__ __attribute__((noinline)) float2 eb_fit_of_counts(const double *ytab,
     return simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
 }
 
+// ... the same with a completeness correction (jaccard.rs:36-41): J is scaled per pair, so ln J is the restated libm logarithm of each
+// point instead of a table entry
+__device__ __attribute__((noinline)) float2 eb_fit_of_counts_comp(const double *kf, uint32_t ss64, double c1, double c2, double cutoff, int log_variant, uint32_t n_pts,
+                                                                  uint32_t c0, uint32_t c1n, uint32_t c2n, uint32_t c3, uint32_t c4, uint32_t c5, uint32_t c6, uint32_t c7)
+{
+    const uint32_t c[EB_MAXK] = {c0, c1n, c2n, c3, c4, c5, c6, c7};
+    EbSums s;
+#pragma unroll 1
+    for (uint32_t t = 0; t < EB_MAXK; ++t) {
+        if (t < n_pts) s.add(kf[t], glibc_log(jaccard_from_samebits_dev(c[t], ss64, true, c1, c2, cutoff), log_variant));
+    }
+    return simple_linear_regression_dev(s.xsum, s.ysum, s.xysum, s.xsquaresum, s.ysquaresum, s.n);
+}
+
+// does a count pass the reference's test (jaccard.rs:88-91) under a completeness correction?  The correction divides J by
+// c1 c2 / (c1 + c2 - c1 c2) <= 1 for completeness values in (0, 1] (the host checks the vectors: EpilogueArgs::comp_lean), so a
+// count that passes uncorrected passes corrected, and a count at or below the chance level gives J = 0 either way; only the counts
+// in between -- none at most sketch sizes -- ask the logarithm.
+__device__ __attribute__((noinline)) bool eb_passes_comp_exact(uint32_t same, uint32_t ss64, double c1, double c2, double cutoff, int log_variant, double tolerance)
+{
+    return !(glibc_log(jaccard_from_samebits_dev(same, ss64, true, c1, c2, cutoff), log_variant) < tolerance);
+}
+
+__device__ __forceinline__ bool eb_passes_comp(const EpilogueArgs &g, uint32_t same, uint32_t expected, double c1, double c2)
+{
+    if (same >= g.min_alive) return true;
+    if (same <= expected) return false;
+    return eb_passes_comp_exact(same, g.ss64, c1, c2, g.cutoff, g.log_variant, g.tolerance);
+}
+
 // THE LEAN FORM of the kernel above, for the launches that matter (one ke for every pair, no completeness correction, the
 // break decided on the count itself, NK = 2 ... 4 lengths counted).  The general kernel is bound by the instructions it issues,
 // not by memory: 273 vector + 393 scalar instructions per wave at cfg 4's sketch size, 697 + 850 at cfg 3's
@@ -475,11 +505,12 @@ __device__ __attribute__((noinline)) float2 eb_fit_of_counts(const double *ytab,
 // after the other), their counts kept in registers; only a pair with three or more points looks its ln J up and runs the
 // reference's sums and regression, in the reference's order.  SLICED: u32 counts in n_slices planes (tail-sliced launches,
 // cfg 2), plane 1 re-zeroed; else u16 counts in one plane.
-template <bool SLICED, int NK>
+template <bool SLICED, int NK, bool COMP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void coreacc_epilogue_lean_kernel(const EpilogueArgs g)
 {
     constexpr int EXT = (int)EB_MAXK - NK;
     const uint32_t maxnbits = g.ss64 * 64u;
+    const uint32_t expected = maxnbits >> BBITS;   // (COMP) bins two unrelated sketches share by chance: J = 0 up to here
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t i = 0, j = 0;
     bool in_range, have_ij = false;
@@ -522,6 +553,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     for (int t = 0; t < NK; ++t) {
         run = run && all[t] >= g.min_alive;
         passed += run ? 1u : 0u;
+    }
+    bool ij_lane = false;                   // (COMP) this lane computed its own (i, j) already
+    if constexpr (COMP) {
+        // a count between the chance level and min_alive is decided by the pair's own completeness values: redo such a lane's walk exactly
+        bool unsure = false;
+        {
+            bool r = true;
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                if (r && all[t] < g.min_alive) {
+                    unsure = all[t] > expected;
+                    r = false;
+                }
+            }
+        }
+        unsure = unsure && in_range;
+        if (__ballot(unsure) != 0ull) {      // (rare; never where min_alive <= expected + 1)
+            if (unsure) {
+                if (!have_ij) eb_pair_of(g, p + g.out_base, i, j);
+                ij_lane = true;
+                const double c1 = g.compA[i], c2 = g.compB[j];
+                passed = 0;
+                run = true;
+#pragma unroll
+                for (int t = 0; t < NK; ++t) {
+                    run = run && eb_passes_comp(g, all[t], expected, c1, c2);
+                    passed += run ? 1u : 0u;
+                }
+            }
+        }
     }
     const bool alive = in_range && run;     // (NK < nk_total: the host sends nothing else here)
     const uint64_t alive_mask = __ballot(alive);
@@ -596,7 +657,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
             if (fast_mask != 0ull) {
                 const uint32_t same0 = eb_first_length_ahead(g, fast_mask, j, row_off, eb_lds_rows, lane);
                 if (fast) {
-                    if (same0 < g.min_alive) {
+                    bool pass0 = same0 >= g.min_alive;
+                    if constexpr (COMP) {
+                        if (!pass0 && same0 > expected) pass0 = eb_passes_comp(g, same0, expected, g.compA[i], g.compB[j]);
+                    }
+                    if (!pass0) {
                         more = false;                        // jaccard.rs:89-91: break
                     } else {
                         all[NK] = same0;
@@ -618,7 +683,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
                 if ((uint32_t)u < u_l) continue;                    // (wave-uniform)
                 if ((uint32_t)(NK + u) >= g.nk_total) break;
                 const uint32_t same = eb_same_bins(g.rows_ref, g.cols_ref, g.nk_total, g.ss64, i_l, j_l, (uint32_t)(NK + u), lane);
-                if (same < g.min_alive) break;                      // jaccard.rs:89-91: break (wave-uniform)
+                if constexpr (COMP) {
+                    if (same < g.min_alive && (same <= expected || !eb_passes_comp(g, same, expected, g.compA[i_l], g.compB[j_l]))) break;   // (wave-uniform)
+                } else {
+                    if (same < g.min_alive) break;                  // jaccard.rs:89-91: break (wave-uniform)
+                }
                 if ((int)lane == l) {
                     all[NK + u] = same;
                     ++passed;
@@ -627,7 +696,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
         }
     }
     float2 res = make_float2(1.0f, 1.0f);     // a fit over fewer than three lengths (jaccard.rs:117)
-    if (passed >= 3u) res = eb_fit_of_counts(g.ytab, g.kf, maxnbits, passed, all[0], all[1], all[2], all[3], all[4], all[5], all[6], all[7]);
+    if (passed >= 3u) {
+        if constexpr (COMP) {
+            if (!have_ij && !alive && !ij_lane) eb_pair_of(g, p + g.out_base, i, j);   // (a pair that left inside the counted lengths with three points)
+            res = eb_fit_of_counts_comp(g.kf, g.ss64, g.compA[i], g.compB[min(j, g.nB_cols - 1u)], g.cutoff, g.log_variant, passed, all[0], all[1], all[2], all[3], all[4],
+                                        all[5], all[6], all[7]);
+        } else {
+            res = eb_fit_of_counts(g.ytab, g.kf, maxnbits, passed, all[0], all[1], all[2], all[3], all[4], all[5], all[6], all[7]);
+        }
+    }
     if (in_range) ((float2 *)g.out)[p] = res;
 }
 
@@ -1052,12 +1129,24 @@ hipError_t launch_early_break_sample(const EbSampleArgs &args, hipStream_t strea
 
 #undef SKL_DPP_ADD
 
-// the lean form takes: one ke for every pair, no completeness correction, the break decided on the count, 2 ... 4 lengths counted, k-major
+template <int N>
+static void launch_lean_n(bool sliced, bool comp, dim3 gr, dim3 bl, size_t lds, hipStream_t stream, const EpilogueArgs &a)
+{
+    if (sliced) {
+        if (comp) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, N, true>), gr, bl, lds, stream, a);
+        else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, N, false>), gr, bl, lds, stream, a);
+    } else {
+        if (comp) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, N, true>), gr, bl, lds, stream, a);
+        else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, N, false>), gr, bl, lds, stream, a);
+    }
+}
+
+// the lean form takes: one ke for every pair, no completeness correction or one with every value in (0, 1], the break decided on the count, 2 ... 4 lengths counted, k-major
 // counts (u16 in one plane, or u32 in the planes of a tail-sliced launch)
 bool coreacc_epilogue_is_lean(const EpilogueArgs &a)
 {
     const bool early = a.nk_total > a.nk || a.block_ke != nullptr;
-    return a.lean != 0u && early && a.block_ke == nullptr && !a.has_comp && a.min_alive != EB_NONE && a.nk >= 2u && a.nk <= 4u && a.nk_total > a.nk &&
+    return a.lean != 0u && early && a.block_ke == nullptr && (!a.has_comp || a.comp_lean != 0u) && a.min_alive != EB_NONE && a.nk >= 2u && a.nk <= 4u && a.nk_total > a.nk &&
            a.nk_total <= EB_MAXK && a.pair_stride == 1u && (a.cnt_u16 != 0u ? a.n_slices == 1u && a.rezero_plane1 == 0u : a.n_slices >= 1u);
 }
 
@@ -1089,11 +1178,11 @@ hipError_t launch_coreacc_epilogue_r6(const EpilogueArgs &args, hipStream_t stre
         a.wg_base = (uint32_t)w0;
         const dim3 gr((unsigned)std::min(MAX_WG, blocks - w0)), bl(256);
         if (lean) {
-            const bool sl = a.cnt_u16 == 0u;
+            const bool sl = a.cnt_u16 == 0u, cm = a.has_comp != 0u;
             switch (a.nk) {
-            case 2: if (sl) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, 2>), gr, bl, lds, stream, a); else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, 2>), gr, bl, lds, stream, a); break;
-            case 3: if (sl) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, 3>), gr, bl, lds, stream, a); else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, 3>), gr, bl, lds, stream, a); break;
-            default: if (sl) hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<true, 4>), gr, bl, lds, stream, a); else hipLaunchKernelGGL((coreacc_epilogue_lean_kernel<false, 4>), gr, bl, lds, stream, a); break;
+            case 2: launch_lean_n<2>(sl, cm, gr, bl, lds, stream, a); break;
+            case 3: launch_lean_n<3>(sl, cm, gr, bl, lds, stream, a); break;
+            default: launch_lean_n<4>(sl, cm, gr, bl, lds, stream, a); break;
             }
         } else if (a.has_comp) hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<true>, gr, bl, lds, stream, a);
         else hipLaunchKernelGGL(coreacc_epilogue_kernel_r6<false>, gr, bl, lds, stream, a);

@@ -244,6 +244,7 @@ struct EpilogueArgs {
     uint32_t blocked, row_end, xcd_shift, blk_rb, blk_cb;
     uint32_t blk_row_shift;     // log2 of the rows per block (out of 5 ... 12: 10)
     uint32_t blk_cb0, wg_base;  // (launcher) first column block that holds a pair; workgroup offset of this launch (a launch carries < 2^32 work-items)
+    uint32_t comp_lean;         // 1: both completeness vectors lie in (0, 1] (checked on the host): the lean form's integer tests hold under the correction
     uint32_t lean;              // 1: launches the lean form can take go to it (epilogue.hip coreacc_epilogue_lean_kernel)
     uint32_t ahead;             // 1: with the row slices in LDS, the first length not counted is completed with the column slices requested a trip ahead
     uint32_t lds_rows;          // host-side request (epilogue.hip): a workgroup with a pair still in the running stages its two row slices in LDS

@@ -220,16 +220,19 @@ def test_register_budget_of_the_candidate_list_and_replay_kernels():
 
 def test_register_budget_of_the_early_break_epilogues():
     """The lean early-break epilogue (epilogue.hip coreacc_epilogue_lean_kernel<SLICED, NK>) is bound by the instructions it
-    issues and hides its loads behind other waves: all six forms must stay at 8 waves per SIMD (<= 64 VGPRs) without scratch;
+    issues and hides its loads behind other waves: the six forms without a completeness correction must stay at 8 waves per SIMD (<= 64 VGPRs) without scratch, the six with one at 5;
     the general kernel at 5 (<= 96; with a completeness correction 4: <= 128), the kNN bands' at 4 or better."""
     import sketchlib.rust_amd as pkg
 
     pkg.build_library()
     meta = _kernel_metadata(pkg.library_path())
     lean = {k: v for k, v in meta.items() if "coreacc_epilogue_lean_kernel" in k}
-    assert len(lean) == 6, sorted(lean)
+    assert len(lean) == 12, sorted(lean)
     for name, (vgpr, scratch, lds) in lean.items():
-        assert scratch == 0 and vgpr <= 64, (name, vgpr, scratch)
+        if name.rstrip().endswith("true>(skl::EpilogueArgs)"):   # <SLICED, NK, COMP = true>: calls the restated logarithm out of line
+            assert scratch <= 64 and vgpr <= 96, (name, vgpr, scratch)
+        else:
+            assert scratch == 0 and vgpr <= 64, (name, vgpr, scratch)
     for name, (vgpr, scratch, lds) in meta.items():
         if "coreacc_epilogue_kernel_r6<false>" in name:
             assert scratch == 0 and vgpr <= 96, (name, vgpr, scratch)

@@ -414,3 +414,46 @@ def test_knn_band_epilogue_order(oracle, skl, gpu_ctx, set_switch, n, ss64, band
     assert np.array_equal(idx, exp["idx"]), np.argwhere(idx != exp["idx"])[:5]
     assert np.array_equal(d0.view(np.uint32), exp["d0"].view(np.uint32)) and np.array_equal(d1.view(np.uint32), exp["d1"].view(np.uint32))
     g.close()
+
+
+@pytest.mark.ab_library
+@pytest.mark.parametrize("lean", [1, 0])
+@pytest.mark.parametrize("lengths", [2, 3, 4])
+@pytest.mark.parametrize("n,ss64,cutoff,unit", [(600, 64, 0.64, True), (500, 256, 0.3, True), (430, 300, 0.64, True), (520, 32, 0.5, False)])
+def test_lean_epilogue_with_a_completeness_correction(oracle, skl, gpu_ctx, monkeypatch, n, ss64, cutoff, unit, lengths, lean):
+    """The lean epilogue under a completeness correction (coreacc_epilogue_lean_kernel<.., COMP = true>): the correction divides J
+    by a factor <= 1 when every completeness value lies in (0, 1] -- the host checks the vectors -- so the integer tests stand (a
+    count that passes uncorrected passes corrected, a count at or below the chance level is J = 0 either way) and only the
+    counts in between (sketchsize64 256 and 300: expected_samebits = 1, min_alive above 2) ask the pair's own values.  A vector with
+    a value outside (0, 1] keeps the general kernel.  2 / 3 / 4 lengths forced (A/B build), against the oracle within the
+    completeness bar (1e-6), the same (1, 1) / NaN pattern; and the same call with SKL_EB_LEAN=0."""
+    bins = _mixed(n, KMERS, ss64, n_random=n - 150, n_clusters=3, seed=47)
+    rng = np.random.default_rng(9)
+    comp = rng.uniform(0.4, 1.0, n)
+    comp[::5] = 1.0
+    if not unit:
+        comp[3] = 1.25
+        comp[77] = 1.6
+    o = oracle.Sketches(bins, n, KMERS, ss64, completeness=comp)
+    exp = oracle.self_dists_all(o, oracle.COREACC, cutoff=cutoff, threads=8).reshape(-1, 2)
+    monkeypatch.setenv("SKL_EARLY_BREAK", str(lengths))
+    monkeypatch.setenv("SKL_EB_LEAN", str(lean))
+    gpu_ctx.reload_env()
+    g = gpu_ctx.sketches(bins, n, KMERS, ss64, completeness=comp)
+    p = g.set_k(cutoff=cutoff)
+    got = skl.self_dists_all(gpu_ctx, g, p)
+    name = gpu_ctx.last_kernel()
+    assert np.max(np.abs(got.astype(np.float64) - exp.astype(np.float64))) <= 1e-6
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert np.array_equal((got[:, 0] == 1.0) & (got[:, 1] == 1.0), (exp[:, 0] == 1.0) & (exp[:, 1] == 1.0))
+    nr = n // 3
+    g_r = gpu_ctx.sketches(bins[:nr], nr, KMERS, ss64, completeness=comp[:nr])
+    g_q = gpu_ctx.sketches(bins[nr:], n - nr, KMERS, ss64, completeness=comp[nr:])
+    o_r = oracle.Sketches(bins[:nr], nr, KMERS, ss64, completeness=comp[:nr])
+    o_q = oracle.Sketches(bins[nr:], n - nr, KMERS, ss64, completeness=comp[nr:])
+    cross = skl.cross_dists_all(gpu_ctx, g_r, g_q, g_r.set_k(cutoff=cutoff))
+    exp_c = oracle.cross_dists_all(o_r, o_q, oracle.COREACC, cutoff=cutoff, threads=8)
+    assert np.max(np.abs(cross.astype(np.float64) - exp_c.astype(np.float64))) <= 1e-6
+    for x in (g, g_r, g_q):
+        x.close()
+    assert ("[lean epilogue" in name) == bool(lean and unit), name

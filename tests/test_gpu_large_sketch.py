@@ -129,7 +129,6 @@ def test_counts_scratch_is_bounded(oracle, skl, gpu_ctx):
     skl.cross_dists_all(gpu_ctx, g, g, g.set_k(), out=out)
     torch.cuda.synchronize()
     _ms, launches = gpu_ctx.kernel_ms()
-    assert 2 <= launches <= 16, launches
     rng = np.random.default_rng(3)
     ii = np.concatenate([rng.integers(0, n, 60), [0, n // 2 - 1, n // 2, n - 1]])
     jj = np.concatenate([ii[:60] % 400 + 400 * rng.integers(0, 50, 60), [1, n // 2, n // 2 - 1, n - 2]])   # (cluster = id % 400)
@@ -144,3 +143,5 @@ def test_counts_scratch_is_bounded(oracle, skl, gpu_ctx):
         fitted += 0.0 < exp[0] < 1.0
     assert fitted >= 20
     g.close()
+    # (what the default dispatch does, asserted LAST: scripts/forced_switch_suites.sh)
+    assert 2 <= launches <= 16, launches
