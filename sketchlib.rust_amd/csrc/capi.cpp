@@ -1294,7 +1294,7 @@ int dense_band(skl_ctx *ctx, const skl_sketches *rows, const skl_sketches *cols,
         // counts kernel, which fills the register file by itself -- and pays only where the epilogue is heavy: from ~3 % of the
         // pairs still in the running.  n = 16 000 at 4.9 %: 18.5 against 19.4 ms; cfg 3 at 1.1 %: 782 against 748 ms.)
         // Since the blocked epilogue order (eb_blocked_order) covers that regime better -- n = 16 000: 17.2 ms blocked, 18.3-18.8
-        // piped; cfg 3 at two lengths: 642 blocked, 775 piped -- the pipeline is off unless asked for (A/B build,
+        // piped; cfg 3 at two lengths: 642 blocked, 775 piped -- the pipeline was off unless asked for (A/B build,
         // SKL_EB_PIPELINE=1; tests/test_gpu_early_break_r6.py keeps it exact).
         const bool blocked = early && eb_blocked_order(ctx, rows, plan, pairs);
         // ROUND 6, LATE: with the lean epilogue (58 VGPRs, 8 waves per SIMD, a third of the instructions) the side-by-side run pays

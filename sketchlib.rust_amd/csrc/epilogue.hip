@@ -18,8 +18,8 @@
 // with the row's slice held in registers (n = 16 000: 22.4 against 18.7 ms -- the completions are bound by the column
 // slices' bytes either way, and on the spot they overlap with the other waves' streaming for free).
 // Late in round 6 the counters showed what binds the kernel: the instructions it issues (profiles/r06_epilogue_lean.md).
-// Launches with one ke for every pair and no completeness correction -- all but block-by-block plans and completeness
-// vectors -- now go to coreacc_epilogue_lean_kernel (below); coreacc_epilogue_kernel_r6 keeps the general case.
+// Launches with one ke for every pair -- all but block-by-block plans and completeness vectors with a value outside (0, 1] --
+// now go to coreacc_epilogue_lean_kernel (below); coreacc_epilogue_kernel_r6 keeps the general case.
 //
 // The break test is the reference's: y < tolerance with y = ln J.  Without a completeness correction y is a function of
 // the bin-match count alone and non-decreasing in it, so the test is `count < min_alive` (the host finds min_alive in the
@@ -495,8 +495,8 @@ __device__ __forceinline__ bool eb_passes_comp(const EpilogueArgs &g, uint32_t s
     return eb_passes_comp_exact(same, g.ss64, c1, c2, g.cutoff, g.log_variant, g.tolerance);
 }
 
-// THE LEAN FORM of the kernel above, for the launches that matter (one ke for every pair, no completeness correction, the
-// break decided on the count itself, NK = 2 ... 4 lengths counted).  The general kernel is bound by the instructions it issues,
+// THE LEAN FORM of the kernel above, for the launches that matter (one ke for every pair, the break decided on the count
+// itself -- COMP: under a completeness correction with every value in (0, 1], see eb_passes_comp -- NK = 2 ... 4 lengths counted).  The general kernel is bound by the instructions it issues,
 // not by memory: 273 vector + 393 scalar instructions per wave at cfg 4's sketch size, 697 + 850 at cfg 3's
 // (profiles/r06_epilogue_lean.md), most of them spent on pairs that end as (1, 1) -- table look-ups, f64 sums and a regression
 // with three divisions and three square roots for a pair whose fit has fewer than three points.  Here a pair that leaves the
